@@ -1,0 +1,293 @@
+/*
+ * indelope_hip.h -- C ABI of the MI355X (gfx950) implementation of indelope's
+ * per-region hot path: slide-assembly (contig.nim), ksw2 contig->reference
+ * alignment (ksw2_extz2_sse.c) and the ref/alt k-mer tally (indelope.nim:283-311).
+ *
+ * Every entry point is plain C: pointers, sizes, POD structs.  No C++ or torch
+ * types cross this boundary.  All functions return 0 (IHP_OK) or a negative
+ * IHP_E_* code; nothing aborts or throws across the ABI.  `ksw_extz2_sse`
+ * keeps the reference's void signature (ksw2.h:54).
+ *
+ * Citations "file:line" are into the reference tree (brentp/indelope).
+ */
+#ifndef INDELOPE_HIP_H_
+#define INDELOPE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ errors */
+#define IHP_OK            0
+#define IHP_E_NODEVICE   (-1)  /* no gfx950 device / HIP runtime unusable       */
+#define IHP_E_HIP        (-2)  /* a HIP call failed (see ihp_last_hip_error)    */
+#define IHP_E_ARG        (-3)  /* bad argument (null pointer, negative size...) */
+#define IHP_E_NOMEM      (-4)  /* host or device allocation failed              */
+#define IHP_E_CAPACITY   (-5)  /* caller-provided buffer too small              */
+#define IHP_E_UNSUPPORTED (-6) /* parameter combination not implemented on GPU  */
+
+const char *ihp_strerror(int code);
+const char *ihp_last_hip_error(void);   /* text of the last failing HIP call    */
+const char *ihp_version(void);
+
+/* Bind the calling process to one GPU (one process per GPU).  Idempotent.     */
+int ihp_init(int device);
+int ihp_device_info(int *cu_count, int *wave_size, int64_t *hbm_bytes);
+void ihp_shutdown(void);
+
+/* ------------------------------------------------- ksw2 (L2b) : the FFI seam */
+/* ksw2.h:6-16 */
+#define KSW_NEG_INF        (-0x40000000)
+#define KSW_EZ_SCORE_ONLY  0x01
+#define KSW_EZ_RIGHT       0x02
+#define KSW_EZ_GENERIC_SC  0x04
+#define KSW_EZ_APPROX_MAX  0x08
+#define KSW_EZ_APPROX_DROP 0x10
+#define KSW_EZ_EXTZ_ONLY   0x40
+#define KSW_EZ_REV_CIGAR   0x80
+
+/* ksw2.h:22-30 / ksw2_c.nim:18-30 -- identical layout (48 bytes on LP64). */
+typedef struct {
+	uint32_t max:31, zdropped:1;
+	int max_q, max_t;
+	int mqe, mqe_t;
+	int mte, mte_q;
+	int score;
+	int m_cigar, n_cigar;
+	uint32_t *cigar;
+} ksw_extz_t;
+
+/*
+ * Symbol-compatible replacement of the reference's only native entry point
+ * (ksw2.h:54, bound by ksw2_c.nim:53-55, sole caller ksw2.nim:154-157).
+ * One alignment, computed by the HIP kernel.  `km` is ignored (always nil in
+ * the reference).  ez->cigar is (re)allocated with realloc and retained by the
+ * caller exactly as ksw2_extz2_sse.c:31-41 does.  On a HIP failure the call
+ * leaves ez reset (n_cigar 0, score KSW_NEG_INF) and records the error for
+ * ihp_last_hip_error().
+ */
+void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                   int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag,
+                   ksw_extz_t *ez);
+
+/* Scalar result fields of one alignment (ksw_extz_t minus the pointer).       */
+typedef struct {
+	int32_t max, zdropped;
+	int32_t max_q, max_t;
+	int32_t mqe, mqe_t;
+	int32_t mte, mte_q;
+	int32_t score;
+	int32_t n_cigar;
+} ihp_ez;
+
+/*
+ * Batched form of the same call: n independent (query,target) pairs, encoded
+ * 0..m-1 (ksw2.nim:129-132), concatenated; q_off/t_off have n+1 entries.
+ * Results: ez[n]; CIGARs (len<<4|op) concatenated in pair order into `cigar`
+ * (capacity cigar_cap words) with cigar_off[n+1].  IHP_E_CAPACITY if the
+ * CIGARs do not fit (cigar_off[n] then holds the required size).
+ */
+int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int64_t *q_off,
+                        const uint8_t *targets, const int64_t *t_off,
+                        int8_t m, const int8_t *mat, int8_t q, int8_t e,
+                        int w, int zdrop, int flag,
+                        ihp_ez *ez, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_off);
+
+/* ksw2.nim:129-132 (encode) and :135-140 (matrix): host helpers.              */
+void ihp_encode(const uint8_t *dna, int64_t n, uint8_t *out);
+void ihp_matrix(int8_t match, int8_t mismatch, int8_t out25[25]);
+
+/* --------------------------------------------- contig.nim (L2a) : Contig API */
+#define IHP_UNALIGNED INT64_MIN          /* contig.nim:27  `unaligned = low(int)` */
+
+/* contig.nim:7-15.  Caller-owned buffers; `cap` = elements allocated in both. */
+typedef struct {
+	uint8_t  *sequence;
+	uint32_t *support;
+	int64_t   len;
+	int64_t   cap;
+	int64_t   nreads;
+	int64_t   start;
+} ihp_contig;
+
+/* contig.nim:17 */
+typedef struct { int64_t qoff, toff; int32_t qbest; int32_t _pad; } ihp_correction;
+
+/* contig.nim:21.  `corrections` is caller-owned with capacity corr_cap.       */
+typedef struct {
+	int64_t matches, offset, mismatches;
+	int64_t n_corrections;
+	int64_t contig_i;
+	ihp_correction *corrections;
+	int64_t corr_cap;
+} ihp_match;
+
+/* allowable_mismatch_fn (contig.nim:25) cannot cross to the device as a
+ * closure; the two rules the reference ever passes are selectable.            */
+#define IHP_ALLOW_DEFAULT 0   /* contig.nim:44-47  */
+#define IHP_ALLOW_SUPPORT 1   /* contig.nim:287-290 (test rule `allow_test`)    */
+
+/* slide_align (contig.nim:70-141).  IHP_E_CAPACITY if corr_cap is too small
+ * (n_corrections then holds the required count).                             */
+int ihp_slide_align(const ihp_contig *q, const ihp_contig *t, int64_t min_overlap,
+                    int64_t max_mismatch, int allow_rule, ihp_match *out);
+/* insert(t,q,m) (contig.nim:156-222): mutates t AND q.  t->cap must hold the
+ * merged contig (IHP_E_CAPACITY otherwise, nothing modified).                 */
+int ihp_contig_insert(ihp_contig *t, ihp_contig *q, const ihp_match *m);
+/* trim(c,min_support) (contig.nim:49-68).                                     */
+int ihp_contig_trim(ihp_contig *c, int64_t min_support);
+
+/* ------------------------------------------------- k-mer tally (L2c, G1-G2) */
+/* One event: reads concatenated (ASCII), read_off[n+1], mapq[n].  Reads with
+ * mapq < min_mapq are skipped (indelope.nim:294).  counts = {ref_support,
+ * alt_support, both_found} (indelope.nim:301-311).  K <= 31.                  */
+int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64_t *read_off,
+                   const uint8_t *mapq, int32_t min_mapq, int32_t K,
+                   const char *ref_kmer, const char *alt_kmer, int32_t counts[3]);
+
+/* ------------------------------------------------ genotyper.nim (G3, host fp64) */
+#define IHP_GT_HOM_REF 0
+#define IHP_GT_HET     1
+#define IHP_GT_HOM_ALT 2
+#define IHP_GT_UNKNOWN 3
+typedef struct { int32_t gt; int32_t _pad; double gl[3]; } ihp_genotype_t;  /* genotyper.nim:14 */
+int    ihp_genotype(int64_t r, int64_t a, double error, ihp_genotype_t *out); /* :36-47 */
+double ihp_genotype_qual(const ihp_genotype_t *g);                            /* :22-29 */
+
+/* ------------------------------------------- batched per-region path (L3 ★) */
+/* Every default argument on the path (SURVEY.md §5 "Config / flags").         */
+typedef struct {
+	int32_t struct_size;          /* sizeof(ihp_params); checked                 */
+	double  min_overlap_pct;      /* 0.88   indelope.nim:157                     */
+	int32_t min_mapq_assemble;    /* 20     indelope.nim:157,164                 */
+	int32_t min_mapq_stop;        /* 5      indelope.nim:215 (qual <= 5 skipped) */
+	int32_t min_mapq_tally;       /* 10     indelope.nim:294                     */
+	int32_t trim_min_qual;        /* 15     indelope.nim:23                      */
+	int32_t combine_min_support;  /* 3      indelope.nim:176                     */
+	int32_t combine_min_overlap;  /* 65     contig.nim:224 (best_match default)  */
+	int32_t max_mismatch;         /* 0      contig.nim:243,254                   */
+	int32_t max_pre_contigs;      /* 20     indelope.nim:209                     */
+	int32_t min_ctg_len;          /* 74     indelope.nim:201 (CLI: 73)           */
+	int32_t min_reads;            /* 4      indelope.nim:201 (CLI: 3)            */
+	int32_t min_event_len;        /* 4      indelope.nim:201                     */
+	int32_t K;                    /* 27     indelope.nim:201                     */
+	int32_t max_events;           /* 4      indelope.nim:229                     */
+	int32_t ref_pad;              /* 50     indelope.nim:220                     */
+	int8_t  match, mismatch, gap_open, gap_ext; /* 1,-2,4,1  ksw2.nim:142        */
+	int32_t bw, zdrop, ksw_flag;  /* 50,400,0  indelope.nim:221                  */
+	double  error;                /* 1e-3   indelope.nim:379                     */
+} ihp_params;
+
+void ihp_params_default(ihp_params *p);
+
+/*
+ * One batch of candidate regions, flat caller-owned host buffers (what the
+ * BAM sweep's `roi` tuples -- indelope.nim:21 -- decode to).  Reads of region
+ * r are region_read_off[r] .. region_read_off[r+1]-1, in BAM order.
+ */
+typedef struct {
+	int32_t n_regions;
+	int64_t n_reads;
+	const int64_t *region_read_off;   /* [n_regions+1]                           */
+	const int64_t *read_off;          /* [n_reads+1] into bases / quals          */
+	const uint8_t *bases;             /* ASCII, Record.sequence                  */
+	const uint8_t *quals;             /* phred, Record.base_qualities; NULL = 255 */
+	const int64_t *read_start;        /* Record.start (0-based)                  */
+	const int64_t *read_stop;         /* Record.stop  (bam_endpos)               */
+	const uint8_t *mapq;              /* Record.qual                             */
+	const uint8_t *read_skip;         /* skippable(r) (indelope.nim:40-47); NULL = 0 */
+	const int64_t *ref_off;           /* [n_regions+1] into ref_bases            */
+	const uint8_t *ref_bases;         /* per-region slice of the chromosome      */
+	const int64_t *ref_origin;        /* [n_regions] genomic pos of slice[0]; window
+	                                     requests (indelope.nim:220) are clamped to
+	                                     the slice the way faidx clamps to a
+	                                     chromosome, and flagged IHP_ALN_REF_CLAMPED */
+} ihp_batch_in;
+
+/* event status: why the tally did or did not run for an alignment event.      */
+#define IHP_EV_TALLIED     0
+#define IHP_EV_SHORT       1   /* tloc.len < min_event_len     indelope.nim:234 */
+#define IHP_EV_SAME_KMER   2   /* indelope.nim:264                              */
+#define IHP_EV_LOW_CPLX    3   /* indelope.nim:266                              */
+#define IHP_EV_BUG_SAME    4   /* indelope.nim:268-275                          */
+#define IHP_EV_OOB         5   /* k-mer slice would index out of range (the
+                                  reference would raise/UB); never tallied      */
+#define IHP_EV_NON_ACGT    6   /* ref/alt k-mer holds a non-ACGT byte: `kmer`
+                                  package behaviour unpinned; never tallied     */
+
+typedef struct {
+	int64_t tstart, tstop;        /* target_locations(ctg.start) ksw2.nim:71-80  */
+	int64_t qstart, qstop;        /* query_locations()           ksw2.nim:82-91  */
+	uint32_t len;
+	uint8_t  type;                /* 0 Insertion, 1 Deletion     ksw2.nim:65-67  */
+	uint8_t  status;              /* IHP_EV_*                                    */
+	uint8_t  fallback_needed;     /* both_found > 0 (indelope.nim:313)           */
+	uint8_t  _pad;
+	int32_t  cf_offset;           /* `offset`, indelope.nim:243                  */
+	int32_t  ref_support, alt_support, both_found;   /* indelope.nim:285-311     */
+	char     ref_kmer[32], alt_kmer[32];             /* NUL padded               */
+	int32_t  gt;                  /* genotype(ref,alt,error) indelope.nim:379    */
+	double   gl[3];
+	double   qual;
+} ihp_event;
+
+/* per-contig alignment flags */
+#define IHP_ALN_DONE        1   /* align_to ran (passed indelope.nim:209-211)    */
+#define IHP_ALN_REF_CLAMPED 2   /* window request fell outside the given slice   */
+
+/*
+ * Results, allocated by the library (free with ihp_free_out).  Final contigs
+ * of region r are contig_off[r] .. contig_off[r+1]-1, in `combine` order.
+ */
+typedef struct {
+	int32_t  n_regions;
+	int64_t  n_contigs, n_events, n_cigar_words, n_bases;
+	int32_t *status;              /* [R] IHP_OK or IHP_E_*                       */
+	int32_t *n_contigs_pre;       /* [R] assemble's n_contigs, indelope.nim:171  */
+	int64_t *contig_off;          /* [R+1]                                       */
+	/* per final contig */
+	int64_t *ctg_start;           /* Contig.start                                */
+	int64_t *ctg_nreads;          /* Contig.nreads                               */
+	int64_t *ctg_seq_off;         /* [C+1] into ctg_seq / ctg_support            */
+	uint8_t *ctg_seq;
+	uint32_t *ctg_support;
+	int32_t *aln_flags;           /* IHP_ALN_*                                   */
+	int64_t *aln_ref_start;       /* window actually aligned to: start, length   */
+	int32_t *aln_ref_len;
+	ihp_ez  *aln_ez;
+	int64_t *cigar_off;           /* [C+1] into cigar (full CIGAR)               */
+	uint32_t *cigar;
+	int64_t *event_off;           /* [C+1] into events                           */
+	ihp_event *events;
+} ihp_batch_out;
+
+/* Host buffers in, host buffers out (upload + run + fetch).                   */
+int  ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out);
+void ihp_free_out(ihp_batch_out *out);
+
+/* The same in three steps, so a caller (or bench.py) can keep a batch resident
+ * in HBM: upload once, run any number of times, fetch results once.           */
+typedef struct ihp_batch ihp_batch;     /* opaque device-resident batch        */
+int  ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **b);
+int  ihp_batch_run(ihp_batch *b);                     /* async on the batch stream */
+int  ihp_batch_sync(ihp_batch *b);
+int  ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out);
+void ihp_batch_free(ihp_batch *b);
+/* Per-stage device time of the most recent ihp_batch_run+sync, from HIP events
+ * on the batch stream: ms[0] assemble, ms[1] ksw2, ms[2] tally, ms[3] total.  */
+int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);
+/* Fixed-size per-region summary record left on the device for the multi-GPU
+ * gather (one RCCL gather of these at the end).     */
+typedef struct {
+	int32_t status, n_contigs_pre, n_contigs, n_aligned, n_events, n_tallied;
+	int32_t ref_support, alt_support;     /* of the first tallied event, else -1 */
+} ihp_region_summary;
+/* Device pointer (valid until the next run/free) + count of the summaries.    */
+int  ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INDELOPE_HIP_H_ */

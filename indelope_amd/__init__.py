@@ -1,0 +1,86 @@
+"""indelope_amd -- MI355X (gfx950) implementation of indelope's per-region hot path.
+
+The package is a thin host layer over one C-ABI shared library
+(`indelope_amd/lib/libindelope_hip.so`, built from `indelope_amd/csrc/*.hip` by
+`indelope_amd.build`).  There is no CPU fallback: if the library is missing or no
+GPU is usable the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+from . import _abi
+from .host import Api, BatchResult, Contig, IhpError, Match, RegionBatch, unaligned  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libindelope_hip.so")
+SYNTH_PATH = os.path.join(HERE, "lib", "libihp_synth.so")
+
+_API = None
+
+
+def load_library():
+    """dlopen the HIP library (works without a GPU; compute calls then return IHP_E_NODEVICE)."""
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built: run `python -m indelope_amd.build` (hipcc, gfx950); "
+                          "there is no CPU fallback" % LIB_PATH)
+    return C.CDLL(LIB_PATH)
+
+
+class HipApi(Api):
+    def __init__(self):
+        self.cdll = load_library()
+        super().__init__(_abi.bind(self.cdll, "ihp_", product=True))
+        self.cdll.ksw_extz2_sse.restype = None
+        self.cdll.ksw_extz2_sse.argtypes = _abi.KSW_ARGTYPES
+
+    def init(self, device=0):
+        rc = self.b.init(device)
+        if rc != 0:
+            raise IhpError(rc, "ihp_init: %s / %s" % (self.b.strerror(rc).decode(), self.b.last_hip_error().decode()))
+
+    def _chk_hip(self, rc, what):
+        if rc != 0:
+            raise IhpError(rc, "%s: %s / %s" % (what, self.b.strerror(rc).decode(),
+                                                  self.b.last_hip_error().decode()))
+
+    # device-resident batches (bench.py, multi-GPU driver)
+    def batch_upload(self, batch, params=None):
+        p = params if params is not None else self.params()
+        cin = batch.as_c()
+        h = C.c_void_p()
+        self._chk_hip(self.b.batch_upload(C.byref(p), C.byref(cin), C.byref(h)), "batch_upload")
+        return h
+
+    def batch_run(self, h):
+        self._chk_hip(self.b.batch_run(h), "batch_run")
+
+    def batch_sync(self, h):
+        self._chk_hip(self.b.batch_sync(h), "batch_sync")
+
+    def batch_fetch(self, h):
+        out = _abi.BatchOut()
+        self._chk_hip(self.b.batch_fetch(h, C.byref(out)), "batch_fetch")
+        try:
+            return BatchResult(out)
+        finally:
+            self.b.free_out(C.byref(out))
+
+    def batch_stage_ms(self, h):
+        ms = (C.c_float * 4)()
+        self._chk_hip(self.b.batch_stage_ms(h, ms), "batch_stage_ms")
+        return [float(x) for x in ms]
+
+    def batch_summary_dev(self, h):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk_hip(self.b.batch_summary_dev(h, C.byref(p), C.byref(n)), "batch_summary_dev")
+        return p.value, n.value
+
+    def batch_free(self, h):
+        self.b.batch_free(h)
+
+
+def api():
+    global _API
+    if _API is None:
+        _API = HipApi()
+    return _API

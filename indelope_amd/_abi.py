@@ -1,0 +1,198 @@
+"""ctypes mirror of include/indelope_hip.h.
+
+Everything here is a plain description of the C ABI: structure layouts and
+function prototypes.  `bind(cdll, prefix)` attaches prototypes to a loaded
+library; the product library exports the `ihp_` names, the test oracle exports
+the same signatures under `orc_` (see oracle/oracle.h), so parity tests drive
+both through identical code.
+"""
+import ctypes as C
+
+import numpy as np
+
+IHP_OK = 0
+IHP_E_NODEVICE, IHP_E_HIP, IHP_E_ARG, IHP_E_NOMEM, IHP_E_CAPACITY, IHP_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+IHP_UNALIGNED = -(2 ** 63)            # contig.nim:27
+IHP_ALLOW_DEFAULT, IHP_ALLOW_SUPPORT = 0, 1
+KSW_NEG_INF = -0x40000000
+KSW_EZ_SCORE_ONLY, KSW_EZ_RIGHT, KSW_EZ_GENERIC_SC = 0x01, 0x02, 0x04
+KSW_EZ_APPROX_MAX, KSW_EZ_APPROX_DROP, KSW_EZ_EXTZ_ONLY, KSW_EZ_REV_CIGAR = 0x08, 0x10, 0x40, 0x80
+IHP_GT_HOM_REF, IHP_GT_HET, IHP_GT_HOM_ALT, IHP_GT_UNKNOWN = 0, 1, 2, 3
+IHP_EV_TALLIED, IHP_EV_SHORT, IHP_EV_SAME_KMER, IHP_EV_LOW_CPLX = 0, 1, 2, 3
+IHP_EV_BUG_SAME, IHP_EV_OOB, IHP_EV_NON_ACGT = 4, 5, 6
+IHP_ALN_DONE, IHP_ALN_REF_CLAMPED = 1, 2
+
+i8p, u8p = C.POINTER(C.c_int8), C.POINTER(C.c_uint8)
+i32p, u32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
+
+
+class KswExtz(C.Structure):           # ksw2.h:22-30
+    _fields_ = [("max_zd", C.c_uint32), ("max_q", C.c_int), ("max_t", C.c_int),
+                ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int), ("mte_q", C.c_int),
+                ("score", C.c_int), ("m_cigar", C.c_int), ("n_cigar", C.c_int),
+                ("cigar", u32p)]
+
+    @property
+    def max(self):
+        return self.max_zd & 0x7FFFFFFF
+
+    @property
+    def zdropped(self):
+        return self.max_zd >> 31
+
+
+class Ez(C.Structure):                # ihp_ez
+    _fields_ = [(n, C.c_int32) for n in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t",
+                                          "mte", "mte_q", "score", "n_cigar")]
+
+
+EZ_DTYPE = np.dtype([(n, "<i4") for n in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t",
+                                           "mte", "mte_q", "score", "n_cigar")])
+
+
+class Contig(C.Structure):            # ihp_contig
+    _fields_ = [("sequence", u8p), ("support", u32p), ("len", C.c_int64), ("cap", C.c_int64),
+                ("nreads", C.c_int64), ("start", C.c_int64)]
+
+
+class Correction(C.Structure):
+    _fields_ = [("qoff", C.c_int64), ("toff", C.c_int64), ("qbest", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Match(C.Structure):
+    _fields_ = [("matches", C.c_int64), ("offset", C.c_int64), ("mismatches", C.c_int64),
+                ("n_corrections", C.c_int64), ("contig_i", C.c_int64),
+                ("corrections", C.POINTER(Correction)), ("corr_cap", C.c_int64)]
+
+
+class Genotype(C.Structure):
+    _fields_ = [("gt", C.c_int32), ("_pad", C.c_int32), ("gl", C.c_double * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("min_overlap_pct", C.c_double),
+                ("min_mapq_assemble", C.c_int32), ("min_mapq_stop", C.c_int32),
+                ("min_mapq_tally", C.c_int32), ("trim_min_qual", C.c_int32),
+                ("combine_min_support", C.c_int32), ("combine_min_overlap", C.c_int32),
+                ("max_mismatch", C.c_int32), ("max_pre_contigs", C.c_int32),
+                ("min_ctg_len", C.c_int32), ("min_reads", C.c_int32), ("min_event_len", C.c_int32),
+                ("K", C.c_int32), ("max_events", C.c_int32), ("ref_pad", C.c_int32),
+                ("match", C.c_int8), ("mismatch", C.c_int8), ("gap_open", C.c_int8), ("gap_ext", C.c_int8),
+                ("bw", C.c_int32), ("zdrop", C.c_int32), ("ksw_flag", C.c_int32),
+                ("error", C.c_double)]
+
+
+class BatchIn(C.Structure):
+    _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int64),
+                ("region_read_off", i64p), ("read_off", i64p), ("bases", u8p), ("quals", u8p),
+                ("read_start", i64p), ("read_stop", i64p), ("mapq", u8p), ("read_skip", u8p),
+                ("ref_off", i64p), ("ref_bases", u8p), ("ref_origin", i64p)]
+
+
+class Event(C.Structure):
+    _fields_ = [("tstart", C.c_int64), ("tstop", C.c_int64), ("qstart", C.c_int64), ("qstop", C.c_int64),
+                ("len", C.c_uint32), ("type", C.c_uint8), ("status", C.c_uint8),
+                ("fallback_needed", C.c_uint8), ("_pad", C.c_uint8),
+                ("cf_offset", C.c_int32), ("ref_support", C.c_int32), ("alt_support", C.c_int32),
+                ("both_found", C.c_int32), ("ref_kmer", C.c_char * 32), ("alt_kmer", C.c_char * 32),
+                ("gt", C.c_int32), ("gl", C.c_double * 3), ("qual", C.c_double)]
+
+
+EVENT_DTYPE = np.dtype({
+    "names": ["tstart", "tstop", "qstart", "qstop", "len", "type", "status", "fallback_needed",
+              "cf_offset", "ref_support", "alt_support", "both_found", "ref_kmer", "alt_kmer",
+              "gt", "gl", "qual"],
+    "formats": ["<i8", "<i8", "<i8", "<i8", "<u4", "u1", "u1", "u1",
+                "<i4", "<i4", "<i4", "<i4", "S32", "S32", "<i4", ("<f8", 3), "<f8"],
+    "offsets": [Event.tstart.offset, Event.tstop.offset, Event.qstart.offset, Event.qstop.offset,
+                Event.len.offset, Event.type.offset, Event.status.offset, Event.fallback_needed.offset,
+                Event.cf_offset.offset, Event.ref_support.offset, Event.alt_support.offset,
+                Event.both_found.offset, Event.ref_kmer.offset, Event.alt_kmer.offset,
+                Event.gt.offset, Event.gl.offset, Event.qual.offset],
+    "itemsize": C.sizeof(Event)})
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("n_regions", C.c_int32), ("n_contigs", C.c_int64), ("n_events", C.c_int64),
+                ("n_cigar_words", C.c_int64), ("n_bases", C.c_int64),
+                ("status", i32p), ("n_contigs_pre", i32p), ("contig_off", i64p),
+                ("ctg_start", i64p), ("ctg_nreads", i64p), ("ctg_seq_off", i64p),
+                ("ctg_seq", u8p), ("ctg_support", u32p),
+                ("aln_flags", i32p), ("aln_ref_start", i64p), ("aln_ref_len", i32p),
+                ("aln_ez", C.POINTER(Ez)), ("cigar_off", i64p), ("cigar", u32p),
+                ("event_off", i64p), ("events", C.POINTER(Event))]
+
+
+class RegionSummary(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("status", "n_contigs_pre", "n_contigs", "n_aligned",
+                                          "n_events", "n_tallied", "ref_support", "alt_support")]
+
+
+SUMMARY_DTYPE = np.dtype([(n, "<i4") for n in ("status", "n_contigs_pre", "n_contigs", "n_aligned",
+                                                "n_events", "n_tallied", "ref_support", "alt_support")])
+
+# name -> (restype, argtypes); names without prefix.
+_COMMON = {
+    "ksw_extz2_batch": (C.c_int, [C.c_int32, u8p, i64p, u8p, i64p, C.c_int8, i8p, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int, C.c_int, C.POINTER(Ez), u32p, C.c_int64, i64p]),
+    "encode": (None, [u8p, C.c_int64, u8p]),
+    "matrix": (None, [C.c_int8, C.c_int8, i8p]),
+    "slide_align": (C.c_int, [C.POINTER(Contig), C.POINTER(Contig), C.c_int64, C.c_int64, C.c_int,
+                              C.POINTER(Match)]),
+    "contig_insert": (C.c_int, [C.POINTER(Contig), C.POINTER(Contig), C.POINTER(Match)]),
+    "contig_trim": (C.c_int, [C.POINTER(Contig), C.c_int64]),
+    "kmer_tally": (C.c_int, [C.c_int32, u8p, i64p, u8p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p,
+                             i32p]),
+    "genotype": (C.c_int, [C.c_int64, C.c_int64, C.c_double, C.POINTER(Genotype)]),
+    "genotype_qual": (C.c_double, [C.POINTER(Genotype)]),
+    "params_default": (None, [C.POINTER(Params)]),
+    "run_regions": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(BatchOut)]),
+    "free_out": (None, [C.POINTER(BatchOut)]),
+}
+
+_PRODUCT_ONLY = {
+    "strerror": (C.c_char_p, [C.c_int]),
+    "last_hip_error": (C.c_char_p, []),
+    "version": (C.c_char_p, []),
+    "init": (C.c_int, [C.c_int]),
+    "device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), i64p]),
+    "shutdown": (None, []),
+    "batch_upload": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(C.c_void_p)]),
+    "batch_run": (C.c_int, [C.c_void_p]),
+    "batch_sync": (C.c_int, [C.c_void_p]),
+    "batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(BatchOut)]),
+    "batch_free": (None, [C.c_void_p]),
+    "batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
+}
+
+KSW_ARGTYPES = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
+                C.c_int, C.c_int, C.c_int, C.POINTER(KswExtz)]
+
+PRODUCT_SYMBOLS = ["ihp_" + n for n in list(_COMMON) + list(_PRODUCT_ONLY)] + ["ksw_extz2_sse"]
+
+
+class Bound:
+    """Function table of one loaded library (attribute access without prefix)."""
+
+    def __init__(self, cdll, prefix, product):
+        self.cdll, self.prefix = cdll, prefix
+        table = dict(_COMMON)
+        if product:
+            table.update(_PRODUCT_ONLY)
+        for name, (res, args) in table.items():
+            fn = getattr(cdll, prefix + name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+
+def bind(cdll, prefix="ihp_", product=True):
+    return Bound(cdll, prefix, product)
+
+
+def ptr(a, typ):
+    """ctypes pointer to a C-contiguous numpy array (or NULL for None)."""
+    if a is None:
+        return C.cast(None, typ)
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(typ)

@@ -1,0 +1,353 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+Names, argument meaning and defaults follow the Nim procs they replace
+(src/contig.nim, src/ksw2/ksw2.nim, src/genotyper.nim, src/indelope.nim) so the
+parity tests read like the reference's own `when isMainModule` tests.  Every
+call goes through the C ABI of include/indelope_hip.h; there is no Python or CPU
+implementation of the arithmetic in this package.
+
+`Api(bound)` is generic over a bound library: the package default binds the HIP
+library (`indelope_amd.api()`); tests bind the CPU oracle to the same class to
+compare results call by call.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _abi as A
+
+unaligned = A.IHP_UNALIGNED                      # contig.nim:27
+
+
+class IhpError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__("indelope_hip error %d %s" % (code, what))
+
+
+class Contig:
+    """contig.nim:7-15.  `sequence`/`support` are views of capacity-backed buffers."""
+
+    def __init__(self, dna, start=0, support=1, cap=None):   # make_contig, contig.nim:143-150
+        if isinstance(dna, str):
+            dna = dna.encode()
+        n = len(dna)
+        self.cap = int(cap if cap is not None else max(64, 4 * n + 64))
+        self._seq = np.zeros(self.cap, np.uint8)
+        self._sup = np.zeros(self.cap, np.uint32)
+        self._seq[:n] = np.frombuffer(dna, np.uint8)
+        self._sup[:n] = support
+        self.len, self.nreads, self.start = n, int(support), int(start)
+
+    @property
+    def sequence(self):
+        return self._seq[:self.len].tobytes().decode("latin1")
+
+    @property
+    def support(self):
+        return self._sup[:self.len].tolist()
+
+    def __len__(self):
+        return self.len
+
+    def _c(self):
+        return A.Contig(A.ptr(self._seq, A.u8p), A.ptr(self._sup, A.u32p), self.len, self.cap,
+                        self.nreads, self.start)
+
+    def _back(self, c):
+        self.len, self.nreads, self.start = c.len, c.nreads, c.start
+
+
+@dataclass
+class Match:                                      # contig.nim:21
+    matches: int = 0
+    offset: int = unaligned
+    mismatches: int = 0
+    corrections: list = field(default_factory=list)   # (qoff, toff, qbest)
+    contig_i: int = -1
+
+    @property
+    def aligned(self):                            # contig.nim:29
+        return self.offset != unaligned
+
+
+@dataclass
+class RegionBatch:
+    """Flat arrays of include/indelope_hip.h `ihp_batch_in`."""
+    region_read_off: np.ndarray
+    read_off: np.ndarray
+    bases: np.ndarray
+    quals: np.ndarray
+    read_start: np.ndarray
+    read_stop: np.ndarray
+    mapq: np.ndarray
+    read_skip: np.ndarray
+    ref_off: np.ndarray
+    ref_bases: np.ndarray
+    ref_origin: np.ndarray
+
+    @property
+    def n_regions(self):
+        return len(self.region_read_off) - 1
+
+    @property
+    def n_reads(self):
+        return len(self.read_off) - 1
+
+    def as_c(self):
+        g = lambda a, t, dt: A.ptr(None if a is None else np.ascontiguousarray(a, dt), t)
+        keep = []
+
+        def p(a, t, dt):
+            if a is None:
+                return A.ptr(None, t)
+            b = np.ascontiguousarray(a, dt)
+            keep.append(b)
+            return A.ptr(b, t)
+        c = A.BatchIn(self.n_regions, self.n_reads,
+                      p(self.region_read_off, A.i64p, np.int64), p(self.read_off, A.i64p, np.int64),
+                      p(self.bases, A.u8p, np.uint8), p(self.quals, A.u8p, np.uint8),
+                      p(self.read_start, A.i64p, np.int64), p(self.read_stop, A.i64p, np.int64),
+                      p(self.mapq, A.u8p, np.uint8), p(self.read_skip, A.u8p, np.uint8),
+                      p(self.ref_off, A.i64p, np.int64), p(self.ref_bases, A.u8p, np.uint8),
+                      p(self.ref_origin, A.i64p, np.int64))
+        c._keep = keep
+        return c
+
+    def slice(self, lo, hi):
+        """Regions [lo, hi) as an independent batch (used to shard across ranks)."""
+        r0, r1 = int(self.region_read_off[lo]), int(self.region_read_off[hi])
+        b0, b1 = int(self.read_off[r0]), int(self.read_off[r1])
+        f0, f1 = int(self.ref_off[lo]), int(self.ref_off[hi])
+        return RegionBatch(self.region_read_off[lo:hi + 1] - r0, self.read_off[r0:r1 + 1] - b0,
+                           self.bases[b0:b1], None if self.quals is None else self.quals[b0:b1],
+                           self.read_start[r0:r1], self.read_stop[r0:r1], self.mapq[r0:r1],
+                           None if self.read_skip is None else self.read_skip[r0:r1],
+                           self.ref_off[lo:hi + 1] - f0, self.ref_bases[f0:f1], self.ref_origin[lo:hi])
+
+    def algorithmic_input_bytes(self):
+        """sum_reads(len + 4 start + 1 mapq + 4 trim) + len_refwindow."""
+        return int(len(self.bases) + 9 * self.n_reads + len(self.ref_bases))
+
+
+def _np(ptr_, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr_, C.POINTER(C.c_uint8)), (n * np.dtype(dtype).itemsize,)) \
+        .view(dtype).copy()
+
+
+class BatchResult:
+    """numpy copy of `ihp_batch_out` (the C buffers are freed right after)."""
+    FIELDS = ("status", "n_contigs_pre", "contig_off", "ctg_start", "ctg_nreads", "ctg_seq_off",
+              "ctg_seq", "ctg_support", "aln_flags", "aln_ref_start", "aln_ref_len", "aln_ez",
+              "cigar_off", "cigar", "event_off", "events")
+
+    def __init__(self, o):
+        R, Cn, E, W, B = o.n_regions, o.n_contigs, o.n_events, o.n_cigar_words, o.n_bases
+        self.n_regions, self.n_contigs, self.n_events = R, Cn, E
+        self.status = _np(o.status, R, np.int32)
+        self.n_contigs_pre = _np(o.n_contigs_pre, R, np.int32)
+        self.contig_off = _np(o.contig_off, R + 1, np.int64)
+        self.ctg_start = _np(o.ctg_start, Cn, np.int64)
+        self.ctg_nreads = _np(o.ctg_nreads, Cn, np.int64)
+        self.ctg_seq_off = _np(o.ctg_seq_off, Cn + 1, np.int64)
+        self.ctg_seq = _np(o.ctg_seq, B, np.uint8)
+        self.ctg_support = _np(o.ctg_support, B, np.uint32)
+        self.aln_flags = _np(o.aln_flags, Cn, np.int32)
+        self.aln_ref_start = _np(o.aln_ref_start, Cn, np.int64)
+        self.aln_ref_len = _np(o.aln_ref_len, Cn, np.int32)
+        self.aln_ez = _np(o.aln_ez, Cn, A.EZ_DTYPE)
+        self.cigar_off = _np(o.cigar_off, Cn + 1, np.int64)
+        self.cigar = _np(o.cigar, W, np.uint32)
+        self.event_off = _np(o.event_off, Cn + 1, np.int64)
+        self.events = _np(o.events, E, A.EVENT_DTYPE)
+
+    def contig_sequence(self, c):
+        return self.ctg_seq[self.ctg_seq_off[c]:self.ctg_seq_off[c + 1]].tobytes().decode("latin1")
+
+    def contig_support(self, c):
+        return self.ctg_support[self.ctg_seq_off[c]:self.ctg_seq_off[c + 1]]
+
+    def cigar_string(self, c):
+        w = self.cigar[self.cigar_off[c]:self.cigar_off[c + 1]]
+        return "".join("%d%s" % (x >> 4, "MID"[x & 0xf]) for x in w.tolist())
+
+    def algorithmic_output_bytes(self, K):
+        """sum_contigs(5 len + 16) + sum_aln(44 + 4 n_cigar) + sum_events(2K + 12)."""
+        naln = int((self.aln_flags & A.IHP_ALN_DONE != 0).sum())
+        return int(5 * len(self.ctg_seq) + 16 * self.n_contigs + 44 * naln + 4 * len(self.cigar)
+                   + (2 * K + 12) * self.n_events)
+
+    def first_difference(self, other):
+        """None if bit-identical to `other`, else a description (integer fields only;
+        GL/qual are floating point and compared with a tolerance by the caller)."""
+        for f in self.FIELDS:
+            a, b = getattr(self, f), getattr(other, f)
+            if f == "events":
+                names = [n for n in a.dtype.names if n not in ("gl", "qual")]
+                if a.shape != b.shape:
+                    return "events: count %d != %d" % (len(a), len(b))
+                for n in names:
+                    if not np.array_equal(a[n], b[n]):
+                        i = int(np.flatnonzero(a[n] != b[n])[0])
+                        return "events.%s differs at %d: %r != %r" % (n, i, a[n][i], b[n][i])
+                continue
+            if a.shape != b.shape:
+                return "%s: shape %s != %s" % (f, a.shape, b.shape)
+            if not np.array_equal(a, b):
+                i = int(np.flatnonzero((a != b) if a.dtype.names is None else
+                                       np.array([x != y for x, y in zip(a, b)]))[0])
+                return "%s differs at %d: %r != %r" % (f, i, a[i], b[i])
+        return None
+
+
+class Api:
+    def __init__(self, bound):
+        self.b = bound
+
+    # ---- params ------------------------------------------------------------
+    def params(self, **kw):
+        p = A.Params()
+        self.b.params_default(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+    @staticmethod
+    def _chk(rc, what=""):
+        if rc != 0:
+            raise IhpError(rc, what)
+
+    # ---- contig.nim --------------------------------------------------------
+    def slide_align(self, q, t, min_overlap=50, max_mismatch=0, allowed=A.IHP_ALLOW_DEFAULT,
+                    qstart=0, tstart=0):
+        """contig.nim:70 (and the string overload :152)."""
+        if isinstance(q, (str, bytes)):
+            q = Contig(q, qstart)
+        if isinstance(t, (str, bytes)):
+            t = Contig(t, tstart)
+        cap = 16
+        while True:
+            corr = (A.Correction * cap)()
+            m = A.Match(corrections=corr, corr_cap=cap)
+            qc, tc = q._c(), t._c()
+            rc = self.b.slide_align(C.byref(qc), C.byref(tc), min_overlap, max_mismatch, allowed, C.byref(m))
+            if rc == A.IHP_E_CAPACITY:
+                cap = int(m.n_corrections)
+                continue
+            self._chk(rc, "slide_align")
+            break
+        return Match(m.matches, m.offset, m.mismatches,
+                     [(corr[i].qoff, corr[i].toff, bool(corr[i].qbest)) for i in range(m.n_corrections)],
+                     m.contig_i)
+
+    def insert(self, t, q, m):
+        """insert(t, q, m), contig.nim:156."""
+        n = len(m.corrections)
+        corr = (A.Correction * max(1, n))()
+        for i, (qo, to, qb) in enumerate(m.corrections):
+            corr[i].qoff, corr[i].toff, corr[i].qbest = qo, to, int(qb)
+        cm = A.Match(m.matches, m.offset, m.mismatches, n, m.contig_i, corr, max(1, n))
+        need = abs(m.offset) + t.len + q.len if m.aligned else 0
+        if need > t.cap:
+            t._seq = np.concatenate([t._seq, np.zeros(need, np.uint8)])
+            t._sup = np.concatenate([t._sup, np.zeros(need, np.uint32)])
+            t.cap = len(t._seq)
+        tc, qc = t._c(), q._c()
+        self._chk(self.b.contig_insert(C.byref(tc), C.byref(qc), C.byref(cm)), "contig_insert")
+        t._back(tc)
+        q._back(qc)
+
+    def trim(self, c, min_support=2):
+        """trim(c, min_support), contig.nim:49."""
+        cc = c._c()
+        self._chk(self.b.contig_trim(C.byref(cc), min_support), "contig_trim")
+        c._back(cc)
+
+    # ---- ksw2.nim ----------------------------------------------------------
+    def encode(self, dna):
+        """encode, ksw2.nim:129."""
+        if isinstance(dna, str):
+            dna = dna.encode()
+        a = np.frombuffer(dna, np.uint8).copy()
+        out = np.empty(len(a), np.uint8)
+        self.b.encode(A.ptr(a, A.u8p), len(a), A.ptr(out, A.u8p))
+        return out
+
+    def matrix(self, match=1, mismatch=-2):
+        """matrix, ksw2.nim:135."""
+        out = np.zeros(25, np.int8)
+        self.b.matrix(match, mismatch, A.ptr(out, A.i8p))
+        return out
+
+    def align_batch(self, queries, targets, match=1, mismatch=-2, gap_open=4, gap_ext=1,
+                    bw=-1, z=-1, flag=0, encoded=False):
+        """n x align_to (ksw2.nim:151-164).  Returns (ez records, list of CIGAR word arrays)."""
+        enc = (lambda s: np.asarray(s, np.uint8)) if encoded else self.encode
+        qs, ts = [enc(s) for s in queries], [enc(s) for s in targets]
+        n = len(qs)
+        q_off = np.zeros(n + 1, np.int64)
+        t_off = np.zeros(n + 1, np.int64)
+        q_off[1:] = np.cumsum([len(x) for x in qs])
+        t_off[1:] = np.cumsum([len(x) for x in ts])
+        qcat = np.concatenate(qs) if n else np.zeros(0, np.uint8)
+        tcat = np.concatenate(ts) if n else np.zeros(0, np.uint8)
+        qcat = np.ascontiguousarray(qcat if len(qcat) else np.zeros(1, np.uint8))
+        tcat = np.ascontiguousarray(tcat if len(tcat) else np.zeros(1, np.uint8))
+        mat = self.matrix(match, mismatch)
+        ez = np.zeros(n, A.EZ_DTYPE)
+        cap = max(64, 16 * n)
+        while True:
+            cig = np.zeros(cap, np.uint32)
+            coff = np.zeros(n + 1, np.int64)
+            rc = self.b.ksw_extz2_batch(n, A.ptr(qcat, A.u8p), A.ptr(q_off, A.i64p), A.ptr(tcat, A.u8p),
+                                        A.ptr(t_off, A.i64p), 5, A.ptr(mat, A.i8p), abs(gap_open), abs(gap_ext),
+                                        bw, z, flag, ez.ctypes.data_as(C.POINTER(A.Ez)),
+                                        A.ptr(cig, A.u32p), cap, A.ptr(coff, A.i64p))
+            if rc == A.IHP_E_CAPACITY:
+                cap = int(coff[n]) + 16
+                continue
+            self._chk(rc, "ksw_extz2_batch")
+            break
+        return ez, [cig[coff[i]:coff[i + 1]].copy() for i in range(n)]
+
+    # ---- tally / genotype ---------------------------------------------------
+    def kmer_tally(self, reads, ref_kmer, alt_kmer, K=27, mapq=None, min_mapq=10):
+        """The tally loop of indelope.nim:285-311 for one event."""
+        rs = [np.frombuffer(r.encode() if isinstance(r, str) else r, np.uint8) for r in reads]
+        off = np.zeros(len(rs) + 1, np.int64)
+        off[1:] = np.cumsum([len(r) for r in rs])
+        cat = np.ascontiguousarray(np.concatenate(rs) if rs else np.zeros(1, np.uint8))
+        mq = np.full(len(rs), 60, np.uint8) if mapq is None else np.asarray(mapq, np.uint8)
+        counts = np.zeros(3, np.int32)
+        self._chk(self.b.kmer_tally(len(rs), A.ptr(cat, A.u8p), A.ptr(off, A.i64p), A.ptr(mq, A.u8p), min_mapq, K,
+                                    ref_kmer.encode(), alt_kmer.encode(), A.ptr(counts, A.i32p)), "kmer_tally")
+        return tuple(int(x) for x in counts)
+
+    def genotype(self, r, a, error):
+        """genotype(r, a, error), genotyper.nim:36."""
+        g = A.Genotype()
+        self._chk(self.b.genotype(r, a, error, C.byref(g)), "genotype")
+        return g
+
+    def qual(self, g):
+        """qual(g), genotyper.nim:22."""
+        return float(self.b.genotype_qual(C.byref(g)))
+
+    # ---- the batched per-region path ----------------------------------------
+    def run_regions(self, batch, params=None):
+        p = params if params is not None else self.params()
+        cin = batch.as_c()
+        out = A.BatchOut()
+        self._chk(self.b.run_regions(C.byref(p), C.byref(cin), C.byref(out)), "run_regions")
+        try:
+            return BatchResult(out)
+        finally:
+            self.b.free_out(C.byref(out))
+
+
+GT_STR = ["0/0", "0/1", "1/1", "./."]             # genotyper.nim:17

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as _o
+    return _o.get()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    import indelope_amd
+    a = indelope_amd.api()
+    a.init(0)
+    return a

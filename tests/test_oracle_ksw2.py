@@ -1,0 +1,91 @@
+"""The scalar ksw2 restatement vs the reference's own C file compiled into oracle/_ref."""
+import numpy as np
+import pytest
+
+import kats
+from indelope_amd import _abi as A
+
+FIELDS = ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "n_cigar")
+
+
+def mutate(rng, s, kind):
+    """Plant an indel / substitutions so that alignments have events, z-drops and band exits."""
+    s = list(s)
+    n = len(s)
+    if n < 25:
+        kind = 2
+    if kind % 4 == 0:
+        p, l = rng.integers(10, n - 10), rng.integers(1, 70)
+        del s[p:p + l]
+    elif kind % 4 == 1:
+        p, l = rng.integers(10, n - 10), rng.integers(1, 70)
+        s[p:p] = list(kats.rand_dna(rng, l))
+    elif kind % 4 == 2:
+        for p in rng.integers(0, n, rng.integers(1, 12)):
+            s[p] = "ACGT"[rng.integers(0, 4)]
+    if kind % 7 == 0:
+        s[rng.integers(0, len(s))] = "N"
+    return "".join(s)
+
+
+def cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        tl = int(rng.integers(20, 700))
+        t = kats.rand_dna(rng, tl)
+        lo = int(rng.integers(0, max(1, tl // 3)))
+        hi = int(rng.integers(min(tl, lo + 10), tl + 1))
+        q = mutate(rng, t[lo:hi] if rng.random() < 0.7 else t[:hi], i)
+        if i % 11 == 0:
+            q = kats.rand_dna(rng, int(rng.integers(1, 40)))
+        yield q, t
+
+
+PARAMS = [dict(gapo=4, gape=1, w=50, zdrop=400, flag=0),                       # indelope.nim:221
+          dict(gapo=5, gape=1, w=-1, zdrop=-1, flag=0),                        # indelope.nim:317,343
+          dict(gapo=3, gape=1, w=-1, zdrop=-1, flag=A.KSW_EZ_EXTZ_ONLY | A.KSW_EZ_RIGHT),   # ksw2.nim:180
+          dict(gapo=4, gape=1, w=10, zdrop=30, flag=0),
+          dict(gapo=4, gape=2, w=50, zdrop=100, flag=A.KSW_EZ_RIGHT),
+          dict(gapo=4, gape=1, w=50, zdrop=400, flag=A.KSW_EZ_SCORE_ONLY),
+          dict(gapo=4, gape=1, w=50, zdrop=400, flag=A.KSW_EZ_APPROX_MAX | A.KSW_EZ_APPROX_DROP),
+          dict(gapo=4, gape=1, w=50, zdrop=400, flag=A.KSW_EZ_REV_CIGAR | A.KSW_EZ_GENERIC_SC)]
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["sse2", "sse41"])
+@pytest.mark.parametrize("pi", range(len(PARAMS)))
+def test_restatement_equals_compiled_reference(oracle, variant, pi):
+    if oracle.ref_lib(bool(variant)) is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    oracle.set_variant(variant)
+    kw = PARAMS[pi]
+    try:
+        for q, t in cases(1000 + pi, 120):
+            qe, te = oracle.encode(q), oracle.encode(t)
+            got, gc = oracle.ksw(qe, te, **kw)
+            exp, ec = oracle.ksw_ref(qe, te, sse41=bool(variant), **kw)
+            assert got == exp, (q, t, kw)
+            assert gc.tolist() == ec.tolist(), (q, t, kw)
+    finally:
+        oracle.set_variant(0)
+
+
+def test_sse2_and_sse41_reference_builds_agree(oracle):
+    """both code paths of the reference give identical results (production settings)."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    for q, t in cases(77, 150):
+        qe, te = oracle.encode(q), oracle.encode(t)
+        a = oracle.ksw_ref(qe, te, gapo=4, gape=1, w=50, zdrop=400)
+        b = oracle.ksw_ref(qe, te, sse41=True, gapo=4, gape=1, w=50, zdrop=400)
+        assert a[0] == b[0] and a[1].tolist() == b[1].tolist()
+
+
+def test_degenerate_inputs(oracle):
+    """ksw2_extz2_sse.c:146-147,171: reset + early return."""
+    e = np.zeros(0, np.uint8)
+    one = np.zeros(1, np.uint8)
+    for q, t in ((e, one), (one, e)):
+        got, cig = oracle.ksw(q if len(q) else one[:0], t if len(t) else one[:0])
+        assert got["n_cigar"] == 0 and got["score"] == A.KSW_NEG_INF and got["max"] == 0
+    got, cig = oracle.ksw(one, one, mat=oracle.matrix(1, -20))      # -min_sc > 2(q+e)
+    assert got["n_cigar"] == 0 and got["score"] == A.KSW_NEG_INF
