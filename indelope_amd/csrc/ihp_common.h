@@ -1,0 +1,64 @@
+// ihp_common.h -- shared device/host declarations of the HIP implementation.
+//
+// Execution model used by every kernel in this library: ONE 64-lane wavefront per
+// workgroup, one unit of work (region / alignment / contig) per wavefront at a
+// time, persistent grid pulling work items from an atomic counter.  All control
+// flow around WSYNC() is wave-uniform.  gfx950 only: wave size is hard-coded 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "indelope_hip.h"
+
+namespace ihp {
+
+constexpr int WAVE = 64;
+constexpr int MAXC = 256;        // contig slots per region (live at any time)
+constexpr int MAXLEN = 8192;     // longest contig the assembly kernel will build
+constexpr int FILTER_CH = 8;     // bases examined by the per-offset prefilter
+
+// Single-wave workgroup: the barrier itself is free; what matters is the
+// s_waitcnt + compiler fence that orders LDS / global scratch traffic between lanes.
+#define WSYNC() __syncthreads()
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p ? 1 : 0); }
+__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+__device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ int clz64(unsigned long long m) { return __clzll((long long)m); }
+__device__ __forceinline__ int bcast(int v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int first_lane_val(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// contig.nim:44-47 (rule 0) and contig.nim:287-290 (rule 1, the reference's test rule)
+__device__ __forceinline__ bool allowed(int rule, uint32_t qsup, uint32_t tsup, long long qreads, long long treads)
+{
+	if (rule == IHP_ALLOW_SUPPORT)
+		return (qsup < 3u && tsup > 3u * qsup) || (tsup < 3u && qsup > 3u * tsup);
+	return (qsup < 3u && tsup > 3u * qsup && qreads > 3ll * (long long)qsup) ||
+	       (tsup < 3u && qsup > 3u * tsup && treads > 3ll * (long long)tsup);
+}
+
+// One alignment job for the ksw2 kernel.
+struct AlnJob {
+	long long q_off;     // into the query byte array
+	long long t_off;     // into the target byte array
+	int qlen, tlen;
+	int out;             // result slot
+	int region;          // -1 for the plain batch API
+};
+
+// Device-side event record (host converts to ihp_event and adds the genotype).
+struct DevEvent {
+	int tstart_rel, tstop_rel;   // relative to ctg.start's region origin (int64 added on host)
+	int qstart, qstop;
+	unsigned len;
+	unsigned char type, status, fallback, pad;
+	int cf_offset;
+	int ref_support, alt_support, both_found;
+	char ref_kmer[32], alt_kmer[32];
+};
+
+struct KswParams {
+	int m; int sc_mch, sc_mis; int min_sc; int q, e, w, zdrop, flag; int encode_ascii;
+};
+
+}  // namespace ihp

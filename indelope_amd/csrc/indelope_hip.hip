@@ -1,0 +1,819 @@
+// indelope_hip.hip -- C ABI of include/indelope_hip.h over the gfx950 kernels.
+//
+// Host code here only moves bytes and launches kernels: uploads the flat batch,
+// sizes the per-workgroup scratch, launches assemble -> ksw2 -> tally -> summary
+// on one stream, and repacks the slot-indexed device outputs into the flat
+// `ihp_batch_out`.  The only arithmetic done on the host is genotype()
+// (genotyper.nim:36-47: three fp64 logs per event).  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+#include "kernels.h"
+
+using namespace ihp;
+
+// ------------------------------------------------------------------ context
+namespace {
+
+struct Ctx {
+	bool ready = false;
+	int device = -1;
+	int cus = 0;
+	int64_t hbm = 0;
+	int max_lds = 65536;
+	hipStream_t stream = nullptr;
+	char err[512] = "";
+};
+Ctx g;
+
+int hip_fail(hipError_t e, const char *what, int line)
+{
+	snprintf(g.err, sizeof(g.err), "%s (line %d): %s", what, line, hipGetErrorString(e));
+	return IHP_E_HIP;
+}
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x, __LINE__); } while (0)
+
+int ensure_init()
+{
+	if (g.ready) return 0;
+	return ihp_init(0);
+}
+
+// device buffer; freed on scope exit / batch free
+struct DBuf {
+	void *p = nullptr; size_t n = 0;
+	int alloc(size_t bytes) {
+		n = bytes;
+		hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+		if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __LINE__) == IHP_E_HIP ? IHP_E_NOMEM : IHP_E_NOMEM; }
+		return 0;
+	}
+	int upload(const void *src, size_t bytes, hipStream_t s) {
+		int rc = alloc(bytes);
+		if (rc) return rc;
+		if (bytes) HIPC(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s));
+		return 0;
+	}
+	int zero(hipStream_t s) { if (n) HIPC(hipMemsetAsync(p, 0, n, s)); return 0; }
+	template <class T> T *as() const { return (T *)p; }
+	~DBuf() { if (p) (void)hipFree(p); }
+	DBuf() = default;
+	DBuf(const DBuf &) = delete;
+	DBuf &operator=(const DBuf &) = delete;
+};
+
+int grid_for(int items, int waves_per_cu)
+{
+	long long g_ = (long long)g.cus * waves_per_cu;
+	if (g_ > items) g_ = items;
+	if (g_ < 1) g_ = 1;
+	return (int)g_;
+}
+
+KswParams make_ksw_params(int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag, int ascii)
+{
+	KswParams P;
+	P.m = m; P.sc_mch = mat[0]; P.sc_mis = mat[1];
+	int mn = mat[1];
+	for (int t = 1; t < m * m; ++t) mn = mn < mat[t] ? mn : mat[t];      // ksw2_extz2_sse.c:167-170
+	P.min_sc = mn; P.q = q; P.e = e; P.w = w; P.zdrop = zdrop; P.flag = flag; P.encode_ascii = ascii;
+	return P;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ basics
+extern "C" const char *ihp_strerror(int code)
+{
+	switch (code) {
+	case IHP_OK: return "ok";
+	case IHP_E_NODEVICE: return "no usable gfx950 device";
+	case IHP_E_HIP: return "HIP runtime error";
+	case IHP_E_ARG: return "bad argument";
+	case IHP_E_NOMEM: return "out of memory";
+	case IHP_E_CAPACITY: return "capacity exceeded";
+	case IHP_E_UNSUPPORTED: return "not supported on the GPU path";
+	}
+	return "unknown error";
+}
+
+extern "C" const char *ihp_last_hip_error(void) { return g.err; }
+extern "C" const char *ihp_version(void) { return "indelope_hip 0.1 (gfx950)"; }
+
+extern "C" int ihp_init(int device)
+{
+	if (g.ready && g.device == device) return 0;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g.err, sizeof(g.err), "no HIP device"); return IHP_E_NODEVICE; }
+	if (device < 0 || device >= n) return IHP_E_ARG;
+	HIPC(hipSetDevice(device));
+	hipDeviceProp_t pr;
+	HIPC(hipGetDeviceProperties(&pr, device));
+	if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) {
+		snprintf(g.err, sizeof(g.err), "device %d is %s; this library is built for gfx950 only", device, pr.gcnArchName);
+		return IHP_E_NODEVICE;
+	}
+	if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
+	HIPC(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+	g.device = device; g.cus = pr.multiProcessorCount; g.hbm = (int64_t)pr.totalGlobalMem;
+	g.max_lds = (int)pr.sharedMemPerBlock;
+	if (g.max_lds > 65536) {
+		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
+		(void)hipFuncSetAttribute((const void *)k_ksw, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+	}
+	g.ready = true;
+	return 0;
+}
+
+extern "C" int ihp_device_info(int *cu_count, int *wave_size, int64_t *hbm_bytes)
+{
+	int rc = ensure_init();
+	if (rc) return rc;
+	if (cu_count) *cu_count = g.cus;
+	if (wave_size) *wave_size = 64;
+	if (hbm_bytes) *hbm_bytes = g.hbm;
+	return 0;
+}
+
+extern "C" void ihp_shutdown(void)
+{
+	if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
+	g.ready = false; g.device = -1;
+}
+
+extern "C" void ihp_encode(const uint8_t *dna, int64_t n, uint8_t *out)
+{                                                       // ksw2.nim:127-132 (byte LUT, host helper)
+	for (int64_t i = 0; i < n; ++i) {
+		switch (dna[i]) {
+		case 'A': case 'a': out[i] = 0; break;
+		case 'C': case 'c': out[i] = 1; break;
+		case 'G': case 'g': out[i] = 2; break;
+		case 'T': case 't': out[i] = 3; break;
+		default: out[i] = 4;
+		}
+	}
+}
+
+extern "C" void ihp_matrix(int8_t match, int8_t mismatch, int8_t out25[25])
+{                                                       // ksw2.nim:135-140
+	for (int i = 0; i < 5; ++i)
+		for (int j = 0; j < 5; ++j) out25[i * 5 + j] = (i == 4 || j == 4) ? 0 : (i == j ? match : mismatch);
+}
+
+extern "C" void ihp_params_default(ihp_params *p)
+{
+	memset(p, 0, sizeof(*p));
+	p->struct_size = (int32_t)sizeof(*p);
+	p->min_overlap_pct = 0.88; p->min_mapq_assemble = 20; p->min_mapq_stop = 5; p->min_mapq_tally = 10;
+	p->trim_min_qual = 15; p->combine_min_support = 3; p->combine_min_overlap = 65; p->max_mismatch = 0;
+	p->max_pre_contigs = 20; p->min_ctg_len = 74; p->min_reads = 4; p->min_event_len = 4;
+	p->K = 27; p->max_events = 4; p->ref_pad = 50;
+	p->match = 1; p->mismatch = -2; p->gap_open = 4; p->gap_ext = 1;
+	p->bw = 50; p->zdrop = 400; p->ksw_flag = 0;
+	p->error = 1e-3;
+}
+
+// ------------------------------------------------------------- genotyper.nim
+extern "C" int ihp_genotype(int64_t r, int64_t a, double error, ihp_genotype_t *out)
+{                                                       // genotyper.nim:36-47
+	if (!out) return IHP_E_ARG;
+	const double log2_ = log(2.0);
+	const double total = (double)(r + a);
+	out->gt = IHP_GT_HOM_REF; out->_pad = 0;
+	out->gl[0] = out->gl[1] = out->gl[2] = 0.0;
+	if (total == 0) { out->gt = IHP_GT_UNKNOWN; return 0; }
+	for (int G = 0; G <= 2; ++G) {
+		const double gd = (double)G, hd = (double)(2 - G);
+		out->gl[G] = -total * log2_ + (double)r * log(gd * error + hd * (1 - error))
+		             + (double)a * log(gd * (1 - error) + hd * error);
+		if (out->gl[G] > out->gl[out->gt]) out->gt = G;
+	}
+	return 0;
+}
+
+extern "C" double ihp_genotype_qual(const ihp_genotype_t *g_)
+{                                                       // genotyper.nim:22-29
+	if (g_->gt == IHP_GT_HOM_REF) return g_->gl[0] - fmax(g_->gl[1], g_->gl[2]);
+	if (g_->gt == IHP_GT_HET) return g_->gl[1] - fmax(g_->gl[0], g_->gl[2]);
+	if (g_->gt == IHP_GT_HOM_ALT) return g_->gl[2] - fmax(g_->gl[0], g_->gl[1]);
+	return 0;
+}
+
+// ----------------------------------------------------------------- ksw2 batch
+static int ksw_flags_supported(int flag)
+{
+	return !(flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP));
+}
+
+// Run `n` jobs; qbase/tbase already on the device.  Results in host vectors.
+static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, const uint8_t *d_t, const KswParams &P,
+                        std::vector<KswOut> &ez, std::vector<long long> &coff, std::vector<uint32_t> &pool)
+{
+	const int n = (int)jobs.size();
+	ez.assign(n, KswOut());
+	coff.assign(n, -1);
+	pool.clear();
+	if (n == 0) return 0;
+	size_t lds_need = 0, p_need = 0; long long cig_bound = 0; int cig_cap = 0;
+	for (const AlnJob &j : jobs) {
+		if (j.qlen <= 0 || j.tlen <= 0) continue;
+		size_t T = (size_t)((j.tlen + 15) / 16) * 16, Q = (size_t)((j.qlen + 15) / 16) * 16 + 16;
+		lds_need = std::max(lds_need, 10 * T + Q);
+		int w = P.w < 0 ? std::max(j.qlen, j.tlen) : P.w;
+		int nc = (std::min(std::min(j.qlen, j.tlen), w + 1) + 15) / 16 + 1;
+		p_need = std::max(p_need, ((size_t)(j.qlen + j.tlen - 1) * nc + 1) * 16);
+		cig_bound += j.qlen + j.tlen;
+		cig_cap = std::max(cig_cap, j.qlen + j.tlen);
+	}
+	if ((long long)lds_need > g.max_lds - 2048) { snprintf(g.err, sizeof(g.err), "alignment needs %zu B of LDS", lds_need); return IHP_E_CAPACITY; }
+	const int grid = grid_for(n, 8);
+	DBuf d_jobs, d_p, d_ct, d_ez, d_coff, d_pool, d_misc;
+	int rc;
+	if ((rc = d_jobs.upload(jobs.data(), sizeof(AlnJob) * n, g.stream))) return rc;
+	if ((rc = d_p.alloc((p_need + 64) * grid))) return rc;
+	if ((rc = d_ct.alloc(sizeof(uint32_t) * (size_t)(cig_cap + 4) * grid))) return rc;
+	if ((rc = d_ez.alloc(sizeof(KswOut) * n))) return rc;
+	if ((rc = d_coff.alloc(sizeof(long long) * n))) return rc;
+	if ((rc = d_pool.alloc(sizeof(uint32_t) * (size_t)(cig_bound + 4)))) return rc;
+	if ((rc = d_misc.alloc(64))) return rc;      // [0] cursor u64, [2..4] overflow, [8] work counter
+	if ((rc = d_misc.zero(g.stream))) return rc;
+	KswArgs a;
+	a.jobs = d_jobs.as<AlnJob>(); a.n_jobs = nullptr; a.n_jobs_host = n;
+	a.qbase = d_q; a.tbase = d_t; a.P = P; a.lds_budget = (int)lds_need;
+	a.p_scratch = d_p.as<uint8_t>(); a.p_cap = p_need + 64;
+	a.cig_tmp = d_ct.as<uint32_t>(); a.cig_cap = cig_cap + 4;
+	a.ez = d_ez.as<KswOut>(); a.cig_off = d_coff.as<long long>();
+	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>(); a.cig_pool_cap = cig_bound + 4;
+	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 8;
+	hipLaunchKernelGGL(k_ksw, dim3(grid), dim3(64), lds_need + 64, g.stream, a);
+	HIPC(hipGetLastError());
+	long long misc[8];
+	HIPC(hipMemcpyAsync(ez.data(), d_ez.p, sizeof(KswOut) * n, hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipMemcpyAsync(coff.data(), d_coff.p, sizeof(long long) * n, hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipStreamSynchronize(g.stream));
+	const long long used = misc[0];
+	const int *ov = (const int *)misc + 2;
+	if (ov[0] || ov[1]) { snprintf(g.err, sizeof(g.err), "ksw2 kernel capacity overflow (%d,%d)", ov[0], ov[1]); return IHP_E_CAPACITY; }
+	pool.resize((size_t)used);
+	if (used) HIPC(hipMemcpy(pool.data(), d_pool.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int64_t *q_off,
+                                   const uint8_t *targets, const int64_t *t_off,
+                                   int8_t m, const int8_t *mat, int8_t q, int8_t e,
+                                   int w, int zdrop, int flag,
+                                   ihp_ez *ez, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_off)
+{
+	if (n < 0 || !q_off || !t_off || !mat || !ez || !cigar_off || (n && (!queries || !targets))) return IHP_E_ARG;
+	if (!ksw_flags_supported(flag)) return IHP_E_UNSUPPORTED;
+	int rc = ensure_init();
+	if (rc) return rc;
+	cigar_off[0] = 0;
+	if (n == 0) return 0;
+	std::vector<AlnJob> jobs(n);
+	for (int i = 0; i < n; ++i) {
+		jobs[i].q_off = q_off[i]; jobs[i].t_off = t_off[i];
+		jobs[i].qlen = (int)(q_off[i + 1] - q_off[i]); jobs[i].tlen = (int)(t_off[i + 1] - t_off[i]);
+		jobs[i].out = i; jobs[i].region = -1;
+	}
+	DBuf d_q, d_t;
+	if ((rc = d_q.upload(queries, (size_t)q_off[n], g.stream))) return rc;
+	if ((rc = d_t.upload(targets, (size_t)t_off[n], g.stream))) return rc;
+	std::vector<KswOut> out; std::vector<long long> coff; std::vector<uint32_t> pool;
+	rc = run_ksw_jobs(jobs, d_q.as<uint8_t>(), d_t.as<uint8_t>(), make_ksw_params(m, mat, q, e, w, zdrop, flag, 0), out, coff, pool);
+	if (rc) return rc;
+	int64_t used = 0; int ret = 0;
+	for (int i = 0; i < n; ++i) {
+		const KswOut &o = out[i];
+		ez[i].max = o.max; ez[i].zdropped = o.zdropped; ez[i].max_q = o.max_q; ez[i].max_t = o.max_t;
+		ez[i].mqe = o.mqe; ez[i].mqe_t = o.mqe_t; ez[i].mte = o.mte; ez[i].mte_q = o.mte_q;
+		ez[i].score = o.score; ez[i].n_cigar = o.n_cigar;
+		if (o.n_cigar > 0) {
+			if (used + o.n_cigar <= cigar_cap) memcpy(cigar + used, pool.data() + coff[i], sizeof(uint32_t) * (size_t)o.n_cigar);
+			else ret = IHP_E_CAPACITY;
+			used += o.n_cigar;
+		}
+		cigar_off[i + 1] = used;
+	}
+	return ret;
+}
+
+// Drop-in for the reference's FFI seam (ksw2.h:54).
+extern "C" void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                              int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag,
+                              ksw_extz_t *ez)
+{
+	(void)km;
+	ez->max_q = ez->max_t = ez->mqe_t = ez->mte_q = -1;          // ksw_reset_extz, ksw2_extz2_sse.c:81-86
+	ez->max = 0; ez->score = ez->mqe = ez->mte = KSW_NEG_INF;
+	ez->n_cigar = 0; ez->zdropped = 0;
+	if (m <= 0 || qlen <= 0 || tlen <= 0) return;
+	int64_t qo[2] = {0, qlen}, to[2] = {0, tlen}, co[2];
+	ihp_ez r;
+	std::vector<uint32_t> cig((size_t)qlen + tlen + 4);
+	const int rc = ihp_ksw_extz2_batch(1, query, qo, target, to, m, mat, q, e, w, zdrop, flag, &r, cig.data(), (int64_t)cig.size(), co);
+	if (rc) { if (rc != IHP_E_HIP) snprintf(g.err, sizeof(g.err), "ksw_extz2_sse: %s", ihp_strerror(rc)); return; }
+	ez->max = (uint32_t)r.max; ez->zdropped = (uint32_t)r.zdropped; ez->max_q = r.max_q; ez->max_t = r.max_t;
+	ez->mqe = r.mqe; ez->mqe_t = r.mqe_t; ez->mte = r.mte; ez->mte_q = r.mte_q; ez->score = r.score;
+	if (r.n_cigar > ez->m_cigar) {                               // grow like ksw_push_cigar (:34-37): powers of two from 4
+		int mc = ez->m_cigar ? ez->m_cigar : 4;
+		while (mc < r.n_cigar) mc <<= 1;
+		ez->cigar = (uint32_t *)realloc(ez->cigar, (size_t)mc << 2);
+		ez->m_cigar = mc;
+	}
+	if (r.n_cigar > 0) memcpy(ez->cigar, cig.data(), sizeof(uint32_t) * (size_t)r.n_cigar);
+	ez->n_cigar = r.n_cigar;
+}
+
+// ------------------------------------------------------------ Contig API ops
+static int contig_op(int op, ihp_contig *t, ihp_contig *q, int64_t min_overlap, int64_t max_mismatch, int rule,
+                     const ihp_match *min_, ihp_match *mout, int64_t min_support)
+{
+	int rc = ensure_init();
+	if (rc) return rc;
+	const int64_t tl = t->len, ql = q ? q->len : 0;
+	if (tl < 0 || ql < 0 || tl > MAXLEN || ql > MAXLEN) return IHP_E_CAPACITY;
+	const int t_cap = (int)tl + 16, q_cap = (int)ql + 16;
+	const int arena_cap = t_cap + q_cap + 3 * (int)(tl + ql) + 1024;
+	const int corr_cap = (int)std::max<int64_t>(tl + ql, 16);
+	DBuf d_seq, d_sup, d_corr, d_res;
+	if ((rc = d_seq.alloc((size_t)arena_cap))) return rc;
+	if ((rc = d_sup.alloc(sizeof(uint32_t) * (size_t)arena_cap))) return rc;
+	if ((rc = d_corr.alloc(sizeof(Corr) * (size_t)corr_cap))) return rc;
+	if ((rc = d_res.alloc(sizeof(long long) * 16))) return rc;
+	if (tl) {
+		HIPC(hipMemcpyAsync(d_seq.as<uint8_t>(), t->sequence, (size_t)tl, hipMemcpyHostToDevice, g.stream));
+		HIPC(hipMemcpyAsync(d_sup.as<uint32_t>(), t->support, sizeof(uint32_t) * (size_t)tl, hipMemcpyHostToDevice, g.stream));
+	}
+	if (ql) {
+		HIPC(hipMemcpyAsync(d_seq.as<uint8_t>() + t_cap, q->sequence, (size_t)ql, hipMemcpyHostToDevice, g.stream));
+		HIPC(hipMemcpyAsync(d_sup.as<uint32_t>() + t_cap, q->support, sizeof(uint32_t) * (size_t)ql, hipMemcpyHostToDevice, g.stream));
+	}
+	OpArgs a;
+	memset(&a, 0, sizeof(a));
+	a.op = op; a.arena_seq = d_seq.as<uint8_t>(); a.arena_sup = d_sup.as<uint32_t>(); a.arena_cap = arena_cap;
+	a.corr = d_corr.as<Corr>(); a.corr_cap = corr_cap;
+	a.t_off = 0; a.t_len = (int)tl; a.t_cap = t_cap; a.t_nreads = t->nreads; a.t_start = t->start;
+	a.q_off = t_cap; a.q_len = (int)ql; a.q_cap = q_cap; a.q_nreads = q ? q->nreads : 0; a.q_start = q ? q->start : 0;
+	a.min_overlap = min_overlap; a.max_mismatch = max_mismatch; a.rule = rule; a.min_support = min_support;
+	a.result = d_res.as<long long>();
+	std::vector<Corr> hc;
+	if (op == 1) {
+		if (min_->offset == IHP_UNALIGNED) return 0;             // contig.nim:159
+		const int64_t off = min_->offset, aoff = off < 0 ? -off : off;
+		if (aoff > MAXLEN) return IHP_E_ARG;
+		int64_t newlen = off < 0 ? std::max(aoff + tl, ql) : std::max(tl, off + ql);
+		if (newlen > t->cap) return IHP_E_CAPACITY;
+		if (min_->n_corrections > corr_cap) return IHP_E_CAPACITY;
+		hc.resize((size_t)min_->n_corrections);
+		for (int64_t i = 0; i < min_->n_corrections; ++i) {
+			const ihp_correction &c = min_->corrections[i];
+			if (c.qoff < 0 || c.qoff >= ql || c.toff < 0 || c.toff >= tl) return IHP_E_ARG;
+			hc[i].qoff = (int)c.qoff; hc[i].toff = (int)c.toff; hc[i].qbest = c.qbest;
+		}
+		if (!hc.empty()) HIPC(hipMemcpyAsync(d_corr.p, hc.data(), sizeof(Corr) * hc.size(), hipMemcpyHostToDevice, g.stream));
+		a.off = (int)off; a.ncorr = (int)hc.size();
+	}
+	hipLaunchKernelGGL(k_contig_op, dim3(1), dim3(64), 0, g.stream, a);
+	HIPC(hipGetLastError());
+	long long R[16];
+	HIPC(hipMemcpyAsync(R, d_res.p, sizeof(R), hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipStreamSynchronize(g.stream));
+	if (R[0]) return (int)R[0];
+	if (op == 0) {
+		mout->matches = R[2]; mout->mismatches = R[3]; mout->contig_i = -1;
+		mout->offset = R[1] ? R[4] : IHP_UNALIGNED;
+		mout->n_corrections = R[5];
+		if (R[5] > mout->corr_cap) return IHP_E_CAPACITY;
+		if (R[5]) {
+			hc.resize((size_t)R[5]);
+			HIPC(hipMemcpy(hc.data(), d_corr.p, sizeof(Corr) * hc.size(), hipMemcpyDeviceToHost));
+			for (size_t i = 0; i < hc.size(); ++i) {
+				mout->corrections[i].qoff = hc[i].qoff; mout->corrections[i].toff = hc[i].toff;
+				mout->corrections[i].qbest = hc[i].qbest; mout->corrections[i]._pad = 0;
+			}
+		}
+		return 0;
+	}
+	// insert / trim: copy the (possibly relocated) contigs back
+	const int64_t ntl = R[7];
+	if (ntl > t->cap) return IHP_E_CAPACITY;
+	if (ntl) {
+		HIPC(hipMemcpy(t->sequence, d_seq.as<uint8_t>() + R[6], (size_t)ntl, hipMemcpyDeviceToHost));
+		HIPC(hipMemcpy(t->support, d_sup.as<uint32_t>() + R[6], sizeof(uint32_t) * (size_t)ntl, hipMemcpyDeviceToHost));
+	}
+	t->len = ntl; t->nreads = R[8]; t->start = R[9];
+	if (op == 1 && ql) {
+		HIPC(hipMemcpy(q->sequence, d_seq.as<uint8_t>() + R[10], (size_t)ql, hipMemcpyDeviceToHost));
+		HIPC(hipMemcpy(q->support, d_sup.as<uint32_t>() + R[10], sizeof(uint32_t) * (size_t)ql, hipMemcpyDeviceToHost));
+	}
+	return 0;
+}
+
+extern "C" int ihp_slide_align(const ihp_contig *q, const ihp_contig *t, int64_t min_overlap,
+                               int64_t max_mismatch, int allow_rule, ihp_match *out)
+{
+	if (!q || !t || !out) return IHP_E_ARG;
+	if (min_overlap < -MAXLEN || min_overlap > (1 << 30) || max_mismatch < 0 || max_mismatch > (1 << 30)) return IHP_E_ARG;
+	return contig_op(0, (ihp_contig *)t, (ihp_contig *)q, min_overlap, max_mismatch, allow_rule, nullptr, out, 0);
+}
+
+extern "C" int ihp_contig_insert(ihp_contig *t, ihp_contig *q, const ihp_match *m)
+{
+	if (!t || !q || !m) return IHP_E_ARG;
+	return contig_op(1, t, q, 0, 0, 0, m, nullptr, 0);
+}
+
+extern "C" int ihp_contig_trim(ihp_contig *c, int64_t min_support)
+{
+	if (!c) return IHP_E_ARG;
+	return contig_op(2, c, nullptr, 0, 0, 0, nullptr, nullptr, min_support);
+}
+
+// -------------------------------------------------------------- k-mer tally
+static bool host_mincode(const char *kmer, int K, unsigned long long &code)
+{
+	unsigned long long f = 0, rc = 0;
+	for (int i = 0; i < K; ++i) {
+		int b;
+		switch (kmer[i]) { case 'A': b = 0; break; case 'C': b = 1; break; case 'G': b = 2; break; case 'T': b = 3; break; default: return false; }
+		f = (f << 2) | (unsigned long long)b;
+		rc |= (unsigned long long)(3 - b) << (2 * i);
+	}
+	code = f < rc ? f : rc;
+	return true;
+}
+
+extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64_t *read_off,
+                              const uint8_t *mapq, int32_t min_mapq, int32_t K,
+                              const char *ref_kmer, const char *alt_kmer, int32_t counts[3])
+{
+	if (n_reads < 0 || !read_off || !ref_kmer || !alt_kmer || !counts || K < 1 || K > 31) return IHP_E_ARG;
+	if ((int)strnlen(ref_kmer, (size_t)K) < K || (int)strnlen(alt_kmer, (size_t)K) < K) return IHP_E_ARG;
+	int rc = ensure_init();
+	if (rc) return rc;
+	TallyOneArgs a;
+	if (!host_mincode(ref_kmer, K, a.refe) || !host_mincode(alt_kmer, K, a.alte)) return IHP_E_UNSUPPORTED;
+	DBuf d_b, d_o, d_m, d_c;
+	if ((rc = d_b.upload(bases, (size_t)read_off[n_reads], g.stream))) return rc;
+	if ((rc = d_o.upload(read_off, sizeof(int64_t) * (size_t)(n_reads + 1), g.stream))) return rc;
+	if (mapq && (rc = d_m.upload(mapq, (size_t)n_reads, g.stream))) return rc;
+	if ((rc = d_c.alloc(16))) return rc;
+	a.bases = d_b.as<uint8_t>(); a.read_off = d_o.as<long long>(); a.mapq = mapq ? d_m.as<uint8_t>() : nullptr;
+	a.n_reads = n_reads; a.min_mapq = min_mapq; a.K = K; a.counts = d_c.as<int>();
+	hipLaunchKernelGGL(k_tally_one, dim3(1), dim3(64), 0, g.stream, a);
+	HIPC(hipGetLastError());
+	HIPC(hipMemcpyAsync(counts, d_c.p, 12, hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+// ------------------------------------------------------- the batched region path
+struct ihp_batch {
+	ihp_params P;
+	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
+	int max_region_bases = 0, max_read_len = 0, max_ref_len = 0;
+	std::vector<int64_t> h_region_read_off, h_ref_origin;
+	// inputs
+	DBuf region_read_off, read_off, bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin;
+	bool has_quals = false, has_skip = false;
+	// scratch
+	DBuf arena_seq, arena_sup, corr, p_scratch, cig_tmp, misc;
+	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
+	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
+	size_t p_cap = 0;
+	long long cig_pool_cap = 0, ev_pool_cap = 0;
+	// outputs
+	DBuf status, n_pre, n_final, ctg_start, ctg_nreads, ctg_seq_off, ctg_len, aln_flags, aln_ref_len, aln_ref_start;
+	DBuf out_seq, out_sup, jobs, ez, cig_off, cig_pool, ev_off, n_ev, ev_pool, summary;
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	bool ran = false;
+	~ihp_batch() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+};
+
+// misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
+// [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_WORDS = 16 };
+
+extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
+{
+	if (!p || !in || !bout || p->struct_size != (int32_t)sizeof(ihp_params)) return IHP_E_ARG;
+	if (p->K < 1 || p->K > 31 || in->n_regions < 0 || in->n_reads < 0) return IHP_E_ARG;
+	if (!ksw_flags_supported(p->ksw_flag)) return IHP_E_UNSUPPORTED;
+	if (in->n_regions && (!in->region_read_off || !in->ref_off || !in->ref_origin)) return IHP_E_ARG;
+	if (in->n_reads && (!in->read_off || !in->bases || !in->read_start || !in->read_stop || !in->mapq)) return IHP_E_ARG;
+	int rc = ensure_init();
+	if (rc) return rc;
+	ihp_batch *b = new (std::nothrow) ihp_batch();
+	if (!b) return IHP_E_NOMEM;
+	b->P = *p; b->R = in->n_regions; b->n_reads = in->n_reads;
+	const int R = b->R; const long long NR = b->n_reads;
+	static const int64_t zero2[2] = {0, 0};
+	const int64_t *rro = R ? in->region_read_off : zero2, *ro = NR ? in->read_off : zero2, *fo = R ? in->ref_off : zero2;
+	if (rro[R] != NR) { delete b; return IHP_E_ARG; }
+	b->n_bases = ro[NR]; b->n_ref = fo[R];
+	for (int r = 0; r < R; ++r) {
+		if (rro[r + 1] < rro[r] || fo[r + 1] < fo[r]) { delete b; return IHP_E_ARG; }
+		const int64_t nb = ro[rro[r + 1]] - ro[rro[r]];
+		if (nb > (1 << 30) || fo[r + 1] - fo[r] > (1 << 30)) { delete b; return IHP_E_CAPACITY; }
+		b->max_region_bases = std::max(b->max_region_bases, (int)nb);
+		b->max_ref_len = std::max(b->max_ref_len, (int)(fo[r + 1] - fo[r]));
+	}
+	for (long long i = 0; i < NR; ++i) {
+		if (ro[i + 1] < ro[i]) { delete b; return IHP_E_ARG; }
+		b->max_read_len = std::max<int>(b->max_read_len, (int)std::min<int64_t>(ro[i + 1] - ro[i], 1 << 30));
+	}
+	b->h_region_read_off.assign(rro, rro + R + 1);
+	b->h_ref_origin.assign(in->ref_origin, in->ref_origin + R);
+	hipStream_t s = g.stream;
+#define UP(buf, ptr, bytes) do { if ((rc = b->buf.upload(ptr, (size_t)(bytes), s))) { delete b; return rc; } } while (0)
+	UP(region_read_off, rro, sizeof(int64_t) * (R + 1));
+	UP(read_off, ro, sizeof(int64_t) * (NR + 1));
+	UP(bases, in->bases, b->n_bases);
+	b->has_quals = in->quals != nullptr; b->has_skip = in->read_skip != nullptr;
+	if (b->has_quals) UP(quals, in->quals, b->n_bases);
+	UP(read_start, in->read_start, sizeof(int64_t) * NR);
+	UP(read_stop, in->read_stop, sizeof(int64_t) * NR);
+	UP(mapq, in->mapq, NR);
+	if (b->has_skip) UP(read_skip, in->read_skip, NR);
+	UP(ref_off, fo, sizeof(int64_t) * (R + 1));
+	UP(ref_bases, in->ref_bases, b->n_ref);
+	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
+#undef UP
+	// scratch sizing
+	b->grid_asm = grid_for(R, 16);
+	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
+	b->arena_cap = 3 * b->max_region_bases + 4 * b->stage_cap + 2048;
+	b->corr_cap = std::min(MAXLEN, b->max_region_bases) + 16;
+	const long long slots = NR;
+	// ksw2: contig length is bounded by the region's read bases (every contig base comes from a read)
+	const int qmax = std::min(MAXLEN, b->max_region_bases), tmax = b->max_ref_len;
+	{
+		const size_t T = (size_t)((tmax + 15) / 16) * 16, Q = (size_t)((qmax + 15) / 16) * 16 + 16;
+		size_t need = 10 * T + Q + 64;
+		// contigs are rarely longer than the reference window + band; cap the LDS request there and let the
+		// kernel flag anything larger (reported as IHP_E_CAPACITY for that batch)
+		const size_t typical = 10 * T + ((size_t)(tmax + 15) / 16 * 16 + 64) + 64;
+		need = std::min(need, std::max(typical, (size_t)8192));
+		need = std::min(need, (size_t)g.max_lds - 2048);
+		b->lds_ksw = (int)need;
+		const int w = p->bw < 0 ? std::max(qmax, tmax) : p->bw;
+		const int nc = (std::min(std::min(qmax, tmax), w + 1) + 15) / 16 + 1;
+		const int qeff = std::min(qmax, tmax + 2 * std::max(w, 64));
+		b->p_cap = ((size_t)(qeff + tmax) * nc + 1) * 16 + 64;
+		b->cig_cap = qeff + tmax + 8;
+	}
+	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), 8);
+	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), 8);
+	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
+	b->cig_pool_cap = 64 * njobs_cap + 1024;
+	b->ev_pool_cap = (long long)std::max(1, p->max_events) * njobs_cap + 16;
+#define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
+	AL(arena_seq, (size_t)b->arena_cap * b->grid_asm);
+	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_asm);
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * b->grid_asm);
+	AL(p_scratch, b->p_cap * b->grid_ksw);
+	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
+	AL(misc, sizeof(int) * M_WORDS);
+	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
+	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
+	AL(ctg_len, 4 * slots); AL(aln_flags, 4 * slots); AL(aln_ref_len, 4 * slots); AL(aln_ref_start, 8 * slots);
+	AL(out_seq, b->n_bases); AL(out_sup, 4 * (size_t)b->n_bases);
+	AL(jobs, sizeof(AlnJob) * slots); AL(ez, sizeof(KswOut) * slots); AL(cig_off, 8 * slots);
+	AL(cig_pool, 4 * (size_t)b->cig_pool_cap);
+	AL(ev_off, 8 * slots); AL(n_ev, 4 * slots); AL(ev_pool, sizeof(DevEvent) * (size_t)b->ev_pool_cap);
+	AL(summary, sizeof(ihp_region_summary) * R);
+#undef AL
+	for (auto &e : b->ev) HIPC(hipEventCreate(&e));
+	HIPC(hipStreamSynchronize(s));
+	*bout = b;
+	return 0;
+}
+
+extern "C" int ihp_batch_run(ihp_batch *b)
+{
+	if (!b) return IHP_E_ARG;
+	hipStream_t s = g.stream;
+	const ihp_params &p = b->P;
+	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
+	int *misc = b->misc.as<int>();
+	HIPC(hipEventRecord(b->ev[0], s));
+	if (b->R > 0) {
+		AsmArgs a;
+		a.n_regions = b->R;
+		a.region_read_off = b->region_read_off.as<long long>(); a.read_off = b->read_off.as<long long>();
+		a.bases = b->bases.as<uint8_t>(); a.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr;
+		a.read_start = b->read_start.as<long long>(); a.read_stop = b->read_stop.as<long long>();
+		a.mapq = b->mapq.as<uint8_t>(); a.read_skip = b->has_skip ? b->read_skip.as<uint8_t>() : nullptr;
+		a.ref_off = b->ref_off.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
+		a.min_overlap_pct = p.min_overlap_pct; a.min_mapq_assemble = p.min_mapq_assemble; a.min_mapq_stop = p.min_mapq_stop;
+		a.trim_min_qual = p.trim_min_qual; a.combine_min_support = p.combine_min_support;
+		a.combine_min_overlap = p.combine_min_overlap; a.max_mismatch = p.max_mismatch;
+		a.max_pre_contigs = p.max_pre_contigs; a.min_ctg_len = p.min_ctg_len; a.min_reads = p.min_reads;
+		a.K = p.K; a.ref_pad = p.ref_pad;
+		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>();
+		a.arena_cap = b->arena_cap; a.stage_cap = b->stage_cap; a.corr = b->corr.as<Corr>(); a.corr_cap = b->corr_cap;
+		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
+		a.ctg_start = b->ctg_start.as<long long>(); a.ctg_nreads = b->ctg_nreads.as<long long>();
+		a.ctg_seq_off = b->ctg_seq_off.as<long long>(); a.ctg_len = b->ctg_len.as<int>();
+		a.aln_flags = b->aln_flags.as<int>(); a.aln_ref_len = b->aln_ref_len.as<int>();
+		a.aln_ref_start = b->aln_ref_start.as<long long>();
+		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
+		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = misc + M_CNT_ASM;
+		hipLaunchKernelGGL(k_assemble, dim3(b->grid_asm), dim3(64), 0, s, a);
+		HIPC(hipGetLastError());
+	}
+	HIPC(hipEventRecord(b->ev[1], s));
+	if (b->R > 0 && b->n_reads > 0) {
+		int8_t mat[25];
+		ihp_matrix(p.match, p.mismatch, mat);
+		KswArgs a;
+		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.n_jobs_host = 0;
+		a.qbase = b->out_seq.as<uint8_t>(); a.tbase = b->ref_bases.as<uint8_t>();
+		a.P = make_ksw_params(5, mat, p.gap_open, p.gap_ext, p.bw, p.zdrop, p.ksw_flag, 1);   // ksw2.nim:154-157
+		a.lds_budget = b->lds_ksw - 64;
+		a.p_scratch = b->p_scratch.as<uint8_t>(); a.p_cap = b->p_cap;
+		a.cig_tmp = b->cig_tmp.as<uint32_t>(); a.cig_cap = b->cig_cap;
+		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>();
+		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
+		a.cig_pool_cap = b->cig_pool_cap; a.overflow = misc + M_OVF; a.work_counter = misc + M_CNT_KSW;
+		hipLaunchKernelGGL(k_ksw, dim3(b->grid_ksw), dim3(64), b->lds_ksw, s, a);
+		HIPC(hipGetLastError());
+	}
+	HIPC(hipEventRecord(b->ev[2], s));
+	if (b->R > 0 && b->n_reads > 0) {
+		TallyArgs a;
+		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS;
+		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>();
+		a.bases = b->bases.as<uint8_t>(); a.mapq = b->mapq.as<uint8_t>();
+		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();
+		a.ref_origin = b->ref_origin.as<long long>(); a.ctg_start = b->ctg_start.as<long long>();
+		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>(); a.cig_pool = b->cig_pool.as<uint32_t>();
+		a.P.K = p.K; a.P.min_event_len = p.min_event_len; a.P.max_events = p.max_events; a.P.min_mapq_tally = p.min_mapq_tally;
+		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
+		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
+		a.overflow = misc + M_OVF; a.work_counter = misc + M_CNT_TALLY;
+		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), 0, s, a);
+		HIPC(hipGetLastError());
+	}
+	HIPC(hipEventRecord(b->ev[3], s));
+	if (b->R > 0) {
+		SummaryArgs a;
+		a.n_regions = b->R; a.region_read_off = b->region_read_off.as<long long>();
+		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
+		a.aln_flags = b->aln_flags.as<int>(); a.n_ev = b->n_ev.as<int>(); a.ev_off = b->ev_off.as<long long>();
+		a.ev_pool = b->ev_pool.as<DevEvent>(); a.out = b->summary.as<ihp_region_summary>();
+		hipLaunchKernelGGL(k_summary, dim3((b->R + 255) / 256), dim3(256), 0, s, a);
+		HIPC(hipGetLastError());
+	}
+	HIPC(hipEventRecord(b->ev[4], s));
+	b->ran = true;
+	return 0;
+}
+
+extern "C" int ihp_batch_sync(ihp_batch *b)
+{
+	if (!b) return IHP_E_ARG;
+	HIPC(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
+{
+	if (!b || !b->ran) return IHP_E_ARG;
+	HIPC(hipEventSynchronize(b->ev[4]));
+	for (int i = 0; i < 3; ++i) HIPC(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+	HIPC(hipEventElapsedTime(&ms[3], b->ev[0], b->ev[4]));
+	return 0;
+}
+
+extern "C" int ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n)
+{
+	if (!b || !dev_ptr || !n) return IHP_E_ARG;
+	*dev_ptr = b->summary.p; *n = b->R;
+	return 0;
+}
+
+extern "C" void ihp_batch_free(ihp_batch *b) { delete b; }
+
+extern "C" void ihp_free_out(ihp_batch_out *o)
+{
+	if (!o) return;
+	free(o->status); free(o->n_contigs_pre); free(o->contig_off);
+	free(o->ctg_start); free(o->ctg_nreads); free(o->ctg_seq_off); free(o->ctg_seq); free(o->ctg_support);
+	free(o->aln_flags); free(o->aln_ref_start); free(o->aln_ref_len); free(o->aln_ez);
+	free(o->cigar_off); free(o->cigar); free(o->event_off); free(o->events);
+	memset(o, 0, sizeof(*o));
+}
+
+template <class T> static int fetch(std::vector<T> &h, const DBuf &d, size_t n)
+{
+	h.resize(n);
+	if (n) HIPC(hipMemcpyAsync(h.data(), d.p, sizeof(T) * n, hipMemcpyDeviceToHost, g.stream));
+	return 0;
+}
+
+extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
+{
+	if (!b || !out || !b->ran) return IHP_E_ARG;
+	memset(out, 0, sizeof(*out));
+	const int R = b->R; const size_t S = (size_t)b->n_reads;
+	int misc[M_WORDS];
+	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipStreamSynchronize(g.stream));
+	if (misc[M_OVF] || misc[M_OVF + 1] || misc[M_OVF + 2]) {
+		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d", misc[M_OVF], misc[M_OVF + 1], misc[M_OVF + 2]);
+		return IHP_E_CAPACITY;
+	}
+	unsigned long long ncig, nev;
+	memcpy(&ncig, misc + M_CIG, 8); memcpy(&nev, misc + M_EV, 8);
+	std::vector<int> status, n_pre, n_final, ctg_len, aln_flags, aln_ref_len, n_ev;
+	std::vector<long long> ctg_start, ctg_nreads, ctg_seq_off, aln_ref_start, cig_off, ev_off;
+	std::vector<uint8_t> seq; std::vector<uint32_t> sup, pool; std::vector<KswOut> ez; std::vector<DevEvent> evp;
+	int rc;
+	if ((rc = fetch(status, b->status, R)) || (rc = fetch(n_pre, b->n_pre, R)) || (rc = fetch(n_final, b->n_final, R)) ||
+	    (rc = fetch(ctg_len, b->ctg_len, S)) || (rc = fetch(aln_flags, b->aln_flags, S)) ||
+	    (rc = fetch(aln_ref_len, b->aln_ref_len, S)) || (rc = fetch(n_ev, b->n_ev, S)) ||
+	    (rc = fetch(ctg_start, b->ctg_start, S)) || (rc = fetch(ctg_nreads, b->ctg_nreads, S)) ||
+	    (rc = fetch(ctg_seq_off, b->ctg_seq_off, S)) || (rc = fetch(aln_ref_start, b->aln_ref_start, S)) ||
+	    (rc = fetch(cig_off, b->cig_off, S)) || (rc = fetch(ev_off, b->ev_off, S)) ||
+	    (rc = fetch(seq, b->out_seq, (size_t)b->n_bases)) || (rc = fetch(sup, b->out_sup, (size_t)b->n_bases)) ||
+	    (rc = fetch(pool, b->cig_pool, (size_t)ncig)) || (rc = fetch(ez, b->ez, S)) || (rc = fetch(evp, b->ev_pool, (size_t)nev)))
+		return rc;
+	HIPC(hipStreamSynchronize(g.stream));
+	// repack slot-indexed device results into the flat output
+	long long C = 0, B = 0, W = 0, E = 0;
+	for (int r = 0; r < R; ++r) {
+		const long long base = b->h_region_read_off[r];
+		for (int k = 0; k < n_final[r]; ++k) {
+			const long long sl = base + k;
+			C++; B += ctg_len[sl];
+			if (aln_flags[sl] & IHP_ALN_DONE) { W += ez[sl].n_cigar > 0 ? ez[sl].n_cigar : 0; E += n_ev[sl]; }
+		}
+	}
+	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B;
+#define ALLOC(T, n) ((T *)calloc((size_t)((n) ? (n) : 1), sizeof(T)))
+	out->status = ALLOC(int32_t, R); out->n_contigs_pre = ALLOC(int32_t, R); out->contig_off = ALLOC(int64_t, R + 1);
+	out->ctg_start = ALLOC(int64_t, C); out->ctg_nreads = ALLOC(int64_t, C); out->ctg_seq_off = ALLOC(int64_t, C + 1);
+	out->ctg_seq = ALLOC(uint8_t, B); out->ctg_support = ALLOC(uint32_t, B);
+	out->aln_flags = ALLOC(int32_t, C); out->aln_ref_start = ALLOC(int64_t, C); out->aln_ref_len = ALLOC(int32_t, C);
+	out->aln_ez = ALLOC(ihp_ez, C); out->cigar_off = ALLOC(int64_t, C + 1); out->cigar = ALLOC(uint32_t, W);
+	out->event_off = ALLOC(int64_t, C + 1); out->events = ALLOC(ihp_event, E);
+#undef ALLOC
+	long long c = 0, bb = 0, wd = 0, ev = 0;
+	for (int r = 0; r < R; ++r) {
+		out->status[r] = status[r]; out->n_contigs_pre[r] = n_pre[r]; out->contig_off[r] = c;
+		const long long base = b->h_region_read_off[r], origin = b->h_ref_origin[r];
+		for (int k = 0; k < n_final[r]; ++k, ++c) {
+			const long long sl = base + k;
+			out->ctg_start[c] = ctg_start[sl]; out->ctg_nreads[c] = ctg_nreads[sl]; out->ctg_seq_off[c] = bb;
+			memcpy(out->ctg_seq + bb, seq.data() + ctg_seq_off[sl], (size_t)ctg_len[sl]);
+			memcpy(out->ctg_support + bb, sup.data() + ctg_seq_off[sl], sizeof(uint32_t) * (size_t)ctg_len[sl]);
+			bb += ctg_len[sl];
+			out->aln_flags[c] = aln_flags[sl]; out->aln_ref_start[c] = aln_ref_start[sl]; out->aln_ref_len[c] = aln_ref_len[sl];
+			out->cigar_off[c] = wd; out->event_off[c] = ev;
+			if (!(aln_flags[sl] & IHP_ALN_DONE)) continue;
+			const KswOut &z = ez[sl];
+			ihp_ez &o = out->aln_ez[c];
+			o.max = z.max; o.zdropped = z.zdropped; o.max_q = z.max_q; o.max_t = z.max_t; o.mqe = z.mqe; o.mqe_t = z.mqe_t;
+			o.mte = z.mte; o.mte_q = z.mte_q; o.score = z.score; o.n_cigar = z.n_cigar;
+			if (z.n_cigar > 0) { memcpy(out->cigar + wd, pool.data() + cig_off[sl], sizeof(uint32_t) * (size_t)z.n_cigar); wd += z.n_cigar; }
+			for (int e = 0; e < n_ev[sl]; ++e, ++ev) {
+				const DevEvent &d = evp[(size_t)ev_off[sl] + e];
+				ihp_event &x = out->events[ev];
+				x.tstart = origin + d.tstart_rel; x.tstop = origin + d.tstop_rel; x.qstart = d.qstart; x.qstop = d.qstop;
+				x.len = d.len; x.type = d.type; x.status = d.status; x.fallback_needed = d.fallback; x._pad = 0;
+				x.cf_offset = d.cf_offset; x.ref_support = d.ref_support; x.alt_support = d.alt_support; x.both_found = d.both_found;
+				memcpy(x.ref_kmer, d.ref_kmer, 32); memcpy(x.alt_kmer, d.alt_kmer, 32);
+				x.gt = IHP_GT_UNKNOWN; x.gl[0] = x.gl[1] = x.gl[2] = 0; x.qual = 0;
+				if (d.status == IHP_EV_TALLIED) {                  // indelope.nim:379
+					ihp_genotype_t gt;
+					ihp_genotype(d.ref_support, d.alt_support, b->P.error, &gt);
+					x.gt = gt.gt; x.gl[0] = gt.gl[0]; x.gl[1] = gt.gl[1]; x.gl[2] = gt.gl[2];
+					x.qual = ihp_genotype_qual(&gt);
+				}
+			}
+		}
+	}
+	out->contig_off[R] = c; out->ctg_seq_off[C] = bb; out->cigar_off[C] = wd; out->event_off[C] = ev;
+	return 0;
+}
+
+extern "C" int ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out)
+{
+	if (!out) return IHP_E_ARG;
+	ihp_batch *b = nullptr;
+	int rc = ihp_batch_upload(p, in, &b);
+	if (rc) return rc;
+	rc = ihp_batch_run(b);
+	if (!rc) rc = ihp_batch_fetch(b, out);
+	ihp_batch_free(b);
+	return rc;
+}

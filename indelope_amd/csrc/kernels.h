@@ -1,0 +1,398 @@
+// kernels.h -- the __global__ entry points (gfx950).  Every kernel is a persistent
+// grid of single-wavefront workgroups pulling work items off an atomic counter.
+#pragma once
+#include "contig_dev.h"
+#include "ksw_dev.h"
+#include "tally_dev.h"
+
+namespace ihp {
+
+// ------------------------------------------------------------------ assemble
+struct AsmArgs {
+	int n_regions;
+	const long long *region_read_off, *read_off;
+	const uint8_t *bases, *quals;
+	const long long *read_start, *read_stop;
+	const uint8_t *mapq, *read_skip;
+	const long long *ref_off, *ref_origin;
+	double min_overlap_pct;
+	int min_mapq_assemble, min_mapq_stop, trim_min_qual, combine_min_support, combine_min_overlap;
+	int max_mismatch, max_pre_contigs, min_ctg_len, min_reads, K, ref_pad;
+	// per-workgroup scratch (strides in elements)
+	uint8_t *arena_seq; uint32_t *arena_sup; int arena_cap, stage_cap;
+	Corr *corr; int corr_cap;
+	// outputs
+	int *status, *n_pre, *n_final;                     // [R]
+	long long *ctg_start, *ctg_nreads, *ctg_seq_off;   // [slots]
+	int *ctg_len, *aln_flags, *aln_ref_len;
+	long long *aln_ref_start;
+	uint8_t *out_seq; uint32_t *out_sup;
+	AlnJob *jobs; int *n_jobs;
+	int *work_counter;
+};
+
+// indelope.nim:23-38 on one read, lanes over bases.  Returns a; kept range [lo,hi).
+__device__ inline int read_trim_dev(const uint8_t *q, int n, int min_quality, int &lo, int &hi)
+{
+	const int lane = lane_id();
+	const int high = n - 1;
+	const uint8_t mq = (uint8_t)min_quality;
+	int a = high > 0 ? high : 0;
+	for (int b = 0; b < high; b += 64) {                       // :25
+		const int i = b + lane;
+		const unsigned long long m = ballot(i < high && q[i] >= mq);
+		if (m) { a = b + ctz64(m); break; }
+	}
+	if (a == high) { lo = 0; hi = 0; return a; }               // :28-30
+	int bb = a;
+	for (int top = high; top > a; top -= 64) {                 // :33
+		const int i = top - lane;
+		const unsigned long long m = ballot(i > a && q[i] >= mq);
+		if (m) { bb = top - ctz64(m); break; }
+	}
+	lo = a; hi = bb + 1;
+	if (n <= 0) { lo = 0; hi = 0; }
+	return a;
+}
+
+__device__ inline int assemble_region(const AsmArgs &a, RegionState &S, Arena &A, int r, int &n_pre, int &n_final)
+{
+	const int lane = lane_id();
+	const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
+	for (int i = lane; i <= MAXC; i += 64) S.alive[i] = 0;
+	if (lane == 0) { S.bump = 0; S.err = 0; }
+	WSYNC();
+	int n = 0;
+	n_pre = 0; n_final = 0;
+	for (long long ri = r0; ri < r1; ++ri) {                   // indelope.nim:163-169
+		if (a.mapq[ri] < a.min_mapq_assemble) continue;        // :164
+		if (a.read_skip && a.read_skip[ri]) continue;          // :165
+		const long long b0 = a.read_off[ri];
+		const int len = (int)(a.read_off[ri + 1] - b0);
+		int lo = 0, hi = len, o = 0;
+		if (a.quals) o = read_trim_dev(a.quals + b0, len, a.trim_min_qual, lo, hi);   // :168
+		const int tl = hi - lo;
+		if (tl > a.stage_cap || tl > MAXLEN) return IHP_E_CAPACITY;
+		for (int i = lane; i < tl; i += 64) { A.seq[A.stage_off + i] = a.bases[b0 + lo + i]; A.sup[A.stage_off + i] = 1u; }
+		if (lane == 0) {                                       // make_contig, contig.nim:143-150
+			S.off[QSLOT] = A.stage_off; S.len[QSLOT] = tl; S.cap[QSLOT] = tl;
+			S.nreads[QSLOT] = 1; S.start[QSLOT] = a.read_start[ri] + o;
+		}
+		WSYNC();
+		const int min_overlap = (int)(a.min_overlap_pct * (double)tl);   // :169
+		Best b = best_match_dev(S, A, QSLOT, S.listA, n, min_overlap, a.max_mismatch);   // contig.nim:243-244
+		if (b.found) {
+			const int nc = emit_corrections(S, A, QSLOT, b.slot, b.off, IHP_ALLOW_DEFAULT);
+			if (nc < 0) return IHP_E_CAPACITY;
+			const int rc = insert_dev(S, A, b.slot, QSLOT, b.off, nc);   // contig.nim:246
+			if (rc) return rc;
+		} else {                                               // contig.nim:248
+			const int slot = alloc_slot(S);
+			if (slot < 0 || n >= MAXC) return IHP_E_CAPACITY;
+			int need = tl + headroom(tl);
+			if (!ensure_space(S, A, need)) { need = tl; if (!ensure_space(S, A, need)) return IHP_E_CAPACITY; }
+			const int noff = S.bump;
+			for (int i = lane; i < tl; i += 64) { A.seq[noff + i] = A.seq[A.stage_off + i]; A.sup[noff + i] = 1u; }
+			if (lane == 0) {
+				S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = need; S.nreads[slot] = 1;
+				S.start[slot] = S.start[QSLOT]; S.alive[slot] = 1; S.bump = noff + need;
+				S.listA[n] = (short)slot;
+			}
+			n++;
+		}
+		WSYNC();
+	}
+	n_pre = n;                                                 // :171
+	// combine(min_support) = pass with min_support 0, then the trimmed pass (contig.nim:259-260)
+	const int n2 = combine_pass(S, A, S.listA, n, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
+	if (n2 < 0) return n2;
+	WSYNC();
+	const int n3 = combine_pass(S, A, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap, a.max_mismatch);
+	if (n3 < 0) return n3;
+	WSYNC();
+	n_final = n3;
+	return 0;
+}
+
+__global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
+{
+	__shared__ RegionState S;
+	__shared__ int s_item;
+	const int lane = lane_id();
+	Arena A;
+	A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap;
+	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
+	A.cap = a.arena_cap; A.stage_off = a.arena_cap - a.stage_cap;
+	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap;
+	for (;;) {
+		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
+		WSYNC();
+		const int r = s_item;
+		WSYNC();
+		if (r >= a.n_regions) break;
+		int n_pre = 0, n_final = 0;
+		const int err = assemble_region(a, S, A, r, n_pre, n_final);
+		WSYNC();
+		if (err) n_final = 0;
+		const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
+		// max_stop over reads with mapq > 5 (indelope.nim:213-216)
+		long long mstop = -0x7fffffffffffffffll - 1;
+		for (long long ri = r0 + lane; ri < r1; ri += 64)
+			if (a.mapq[ri] > a.min_mapq_stop && a.read_stop[ri] > mstop) mstop = a.read_stop[ri];
+		mstop = -wave_min_ll(-mstop - 1) - 1;                  // wave max without negating LLONG_MIN
+		const long long seq_base = r0 < r1 ? a.read_off[r0] : 0;
+		const long long origin = a.ref_origin[r];
+		const long long L = a.ref_off[r + 1] - a.ref_off[r];
+		const int width = (int)((double)(a.K + 1) / 2.0 - 1.0);   // :218
+		long long cursor = 0;
+		for (int k = 0; k < n_final; ++k) {
+			const int c = S.listA[k];
+			const long long slot = r0 + k;
+			const int len = S.len[c];
+			const uint8_t *cs = A.seq + S.off[c]; const uint32_t *cp = A.sup + S.off[c];
+			for (int i = lane; i < len; i += 64) { a.out_seq[seq_base + cursor + i] = cs[i]; a.out_sup[seq_base + cursor + i] = cp[i]; }
+			if (lane == 0) {
+				const long long cstart = S.start[c], cn = S.nreads[c];
+				a.ctg_start[slot] = cstart; a.ctg_nreads[slot] = cn; a.ctg_len[slot] = len;
+				a.ctg_seq_off[slot] = seq_base + cursor;
+				int flags = 0; long long rs = 0; int rl = 0;
+				if (n_pre <= a.max_pre_contigs && cn >= a.min_reads && len >= a.min_ctg_len) {   // :209-211
+					const long long max_stop = cstart > mstop ? cstart : mstop;
+					// fai.get(chrom, ctg.start, max_stop+width+50) :220 -- faidx_fetch_seq clamping
+					long long beg = cstart - origin, end = max_stop + width + a.ref_pad - origin;
+					int clamped = 0;
+					if (end < beg) { beg = end; clamped = 1; }
+					if (beg < 0) { beg = 0; clamped = 1; } else if (L <= beg) { beg = L - 1; clamped = 1; }
+					if (end < 0) { end = 0; clamped = 1; } else if (L <= end) { end = L - 1; clamped = 1; }
+					long long reflen = L > 0 ? end - beg + 1 : 0;
+					if (L <= 0) { beg = 0; clamped = 1; }
+					flags = IHP_ALN_DONE | (clamped ? IHP_ALN_REF_CLAMPED : 0);
+					rs = origin + beg; rl = (int)reflen;
+					const int j = atomicAdd(a.n_jobs, 1);
+					AlnJob jb;
+					jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
+					jb.out = (int)slot; jb.region = r;
+					a.jobs[j] = jb;
+				}
+				a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
+			}
+			cursor += len;
+		}
+		if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
+		WSYNC();
+	}
+}
+
+// ---------------------------------------------------------------------- ksw2
+struct KswArgs {
+	const AlnJob *jobs; const int *n_jobs; int n_jobs_host;   // n_jobs may be null (use n_jobs_host)
+	const uint8_t *qbase, *tbase;
+	KswParams P;
+	int lds_budget;
+	uint8_t *p_scratch; size_t p_cap;          // per workgroup
+	uint32_t *cig_tmp; int cig_cap;            // per workgroup
+	KswOut *ez;                                // [slots]
+	long long *cig_off;                        // [slots] offset into the pool (or -1)
+	uint32_t *cig_pool; unsigned long long *cig_cursor; long long cig_pool_cap;
+	int *overflow;                             // [0] cigar pool, [1] LDS/p budget
+	int *work_counter;
+};
+
+__global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	__shared__ int s_item;
+	__shared__ long long s_off;
+	const int lane = lane_id();
+	const int njobs = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
+	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
+	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
+	for (;;) {
+		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
+		WSYNC();
+		const int j = s_item;
+		WSYNC();
+		if (j >= njobs) break;
+		const AlnJob jb = a.jobs[j];
+		KswOut out;
+		int w = a.P.w;
+		if (w < 0) w = jb.tlen > jb.qlen ? jb.tlen : jb.qlen;
+		int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
+		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
+		const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
+		if (jb.qlen > 0 && jb.tlen > 0 &&
+		    (ksw_lds_bytes(jb.qlen, jb.tlen) > (size_t)a.lds_budget || pneed > a.p_cap)) {
+			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
+			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
+			if (lane == 0) atomicExch(&a.overflow[1], 1);
+		} else {
+			ksw_wave(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out);
+		}
+		long long off = -1;
+		if (out.n_cigar > 0) {
+			if (lane == 0) s_off = (long long)atomicAdd(a.cig_cursor, (unsigned long long)out.n_cigar);
+			WSYNC();
+			off = s_off;
+			if (off + out.n_cigar <= a.cig_pool_cap) {
+				for (int i = lane; i < out.n_cigar; i += 64) a.cig_pool[off + i] = ct[i];
+			} else {
+				if (lane == 0) atomicExch(&a.overflow[0], 1);
+				off = -1;
+			}
+		} else if (out.n_cigar < 0) {
+			if (lane == 0) atomicExch(&a.overflow[1], 1);
+		}
+		if (lane == 0) { a.ez[jb.out] = out; a.cig_off[jb.out] = off; }
+		WSYNC();
+	}
+}
+
+// --------------------------------------------------------------------- tally
+struct TallyArgs {
+	const AlnJob *jobs; const int *n_jobs;
+	const uint8_t *out_seq, *ref_bases, *bases, *mapq;
+	const long long *read_off, *region_read_off, *ref_origin, *ctg_start;
+	const KswOut *ez; const long long *cig_off; const uint32_t *cig_pool;
+	TallyParams P;
+	DevEvent *ev_pool; unsigned long long *ev_cursor; long long ev_pool_cap;
+	long long *ev_off; int *n_ev;              // [slots]
+	int *overflow;                             // [2] event pool
+	int *work_counter;
+};
+
+__global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
+{
+	__shared__ int s_item;
+	__shared__ long long s_off;
+	const int lane = lane_id();
+	const int njobs = *a.n_jobs;
+	for (;;) {
+		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
+		WSYNC();
+		const int j = s_item;
+		WSYNC();
+		if (j >= njobs) break;
+		const AlnJob jb = a.jobs[j];
+		const KswOut ez = a.ez[jb.out];
+		const long long coff = a.cig_off[jb.out];
+		int nev = 0, ntrunc = 0;
+		if (ez.n_cigar > 0 && coff >= 0) nev = count_events(a.cig_pool + coff, ez.n_cigar, ez.max_q, &ntrunc);
+		long long eoff = -1;
+		if (nev > 0 && nev <= a.P.max_events) {                 // indelope.nim:229
+			if (lane == 0) s_off = (long long)atomicAdd(a.ev_cursor, (unsigned long long)nev);
+			WSYNC();
+			eoff = s_off;
+			if (eoff + nev <= a.ev_pool_cap) {
+				const int r = jb.region;
+				fill_events(a.cig_pool + coff, ntrunc, a.out_seq + jb.q_off, jb.qlen,
+				            (int)(a.ctg_start[jb.out] - a.ref_origin[r]), a.ref_bases + jb.t_off, jb.tlen,
+				            a.bases, a.read_off, a.mapq, a.region_read_off[r], a.region_read_off[r + 1],
+				            a.P, a.ev_pool + eoff);
+			} else {
+				if (lane == 0) atomicExch(&a.overflow[2], 1);
+				eoff = -1; nev = 0;
+			}
+		} else nev = 0;
+		if (lane == 0) { a.ev_off[jb.out] = eoff; a.n_ev[jb.out] = nev; }
+		WSYNC();
+	}
+}
+
+// ------------------------------------------------------------------- summary
+struct SummaryArgs {
+	int n_regions;
+	const long long *region_read_off;
+	const int *status, *n_pre, *n_final, *aln_flags, *n_ev;
+	const long long *ev_off;
+	const DevEvent *ev_pool;
+	ihp_region_summary *out;
+};
+
+__global__ void k_summary(const SummaryArgs a)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.n_regions) return;
+	ihp_region_summary s;
+	s.status = a.status[r]; s.n_contigs_pre = a.n_pre[r]; s.n_contigs = a.n_final[r];
+	s.n_aligned = 0; s.n_events = 0; s.n_tallied = 0; s.ref_support = -1; s.alt_support = -1;
+	const long long base = a.region_read_off[r];
+	for (int k = 0; k < s.n_contigs; ++k) {
+		const long long slot = base + k;
+		if (!(a.aln_flags[slot] & IHP_ALN_DONE)) continue;
+		s.n_aligned++;
+		const int ne = a.n_ev[slot];
+		s.n_events += ne;
+		for (int e = 0; e < ne; ++e) {
+			const DevEvent &E = a.ev_pool[a.ev_off[slot] + e];
+			if (E.status == IHP_EV_TALLIED) {
+				if (s.n_tallied == 0) { s.ref_support = E.ref_support; s.alt_support = E.alt_support; }
+				s.n_tallied++;
+			}
+		}
+	}
+	a.out[r] = s;
+}
+
+// ------------------------------------------------ single-op kernels (Contig API)
+struct OpArgs {
+	int op;                      // 0 slide_align, 1 insert, 2 trim
+	uint8_t *arena_seq; uint32_t *arena_sup; int arena_cap;
+	Corr *corr; int corr_cap;
+	int t_off, t_len, t_cap; long long t_nreads, t_start;
+	int q_off, q_len, q_cap; long long q_nreads, q_start;
+	long long min_overlap, max_mismatch; int rule;
+	int off, ncorr; long long min_support;
+	long long *result;           // [16]
+};
+
+__global__ __launch_bounds__(64) void k_contig_op(const OpArgs a)
+{
+	__shared__ RegionState S;
+	const int lane = lane_id();
+	Arena A; A.seq = a.arena_seq; A.sup = a.arena_sup; A.cap = a.arena_cap; A.stage_off = a.arena_cap;
+	A.corr = a.corr; A.corr_cap = a.corr_cap;
+	for (int i = lane; i <= MAXC; i += 64) S.alive[i] = 0;
+	if (lane == 0) {
+		S.off[0] = a.t_off; S.len[0] = a.t_len; S.cap[0] = a.t_cap; S.nreads[0] = a.t_nreads; S.start[0] = a.t_start; S.alive[0] = 1;
+		S.off[1] = a.q_off; S.len[1] = a.q_len; S.cap[1] = a.q_cap; S.nreads[1] = a.q_nreads; S.start[1] = a.q_start; S.alive[1] = 1;
+		S.bump = a.q_off + a.q_cap; S.err = 0;
+	}
+	WSYNC();
+	long long rc = 0, found = 0, ma = 0, mm = 0, off = 0, nc = 0;
+	if (a.op == 0) {
+		Best b = {0, 0, 0, -1, -1, 0};
+		slide_scan(S, A, 1, 0, 0, (int)a.min_overlap, (int)a.max_mismatch, a.rule, b);
+		found = b.found; ma = b.found ? b.ma : a.min_overlap - 1; mm = b.found ? b.mm : a.max_mismatch + 1; off = b.off;
+		if (b.found) {
+			const int n = emit_corrections(S, A, 1, 0, b.off, a.rule);
+			if (n < 0) { rc = IHP_E_CAPACITY; nc = 0; } else nc = n;
+		}
+	} else if (a.op == 1) {
+		rc = insert_dev(S, A, 0, 1, a.off, a.ncorr);
+	} else {
+		trim_dev(S, A, 0, a.min_support);
+	}
+	WSYNC();
+	if (lane == 0) {
+		long long *R = a.result;
+		R[0] = rc; R[1] = found; R[2] = ma; R[3] = mm; R[4] = off; R[5] = nc;
+		R[6] = S.off[0]; R[7] = S.len[0]; R[8] = S.nreads[0]; R[9] = S.start[0];
+		R[10] = S.off[1]; R[11] = S.len[1]; R[12] = S.nreads[1]; R[13] = S.start[1];
+	}
+}
+
+struct TallyOneArgs {
+	const uint8_t *bases; const long long *read_off; const uint8_t *mapq;
+	int n_reads, min_mapq, K;
+	unsigned long long refe, alte;
+	int *counts;
+};
+
+__global__ __launch_bounds__(64) void k_tally_one(const TallyOneArgs a)
+{
+	int counts[3];
+	tally_reads(a.bases, a.read_off, a.mapq, 0, a.n_reads, a.min_mapq, a.K, a.refe, a.alte, counts);
+	if (lane_id() == 0) { a.counts[0] = counts[0]; a.counts[1] = counts[1]; a.counts[2] = counts[2]; }
+}
+
+}  // namespace ihp

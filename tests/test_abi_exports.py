@@ -1,0 +1,53 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/indelope_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import indelope_amd
+from indelope_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "indelope_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(ihp_[a-z0-9_]+)\s*\(", src))
+    names.add("ksw_extz2_sse")
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = indelope_amd.load_library()
+    decl = declared_symbols()
+    assert len(decl) >= 25
+    for name in sorted(decl):
+        assert hasattr(lib, name), "missing export: " + name
+    assert set(A.PRODUCT_SYMBOLS) <= decl, set(A.PRODUCT_SYMBOLS) - decl
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(A.KswExtz) == 48            # ksw2.h:22-30 on LP64
+    assert C.sizeof(A.Ez) == 40
+    assert C.sizeof(A.Event) == 160 and A.EVENT_DTYPE.itemsize == 160
+    assert C.sizeof(A.Params) == 96
+    lib = indelope_amd.load_library()
+    p = A.Params()
+    lib.ihp_params_default.argtypes = [C.POINTER(A.Params)]
+    lib.ihp_params_default(C.byref(p))
+    assert p.struct_size == C.sizeof(A.Params)
+    assert (p.K, p.bw, p.zdrop, p.min_reads, p.min_ctg_len, p.combine_min_overlap) == (27, 50, 400, 4, 74, 65)
+    assert (p.match, p.mismatch, p.gap_open, p.gap_ext) == (1, -2, 4, 1)
+    assert abs(p.min_overlap_pct - 0.88) < 1e-15 and abs(p.error - 1e-3) < 1e-18
+
+
+def test_host_helpers_need_no_gpu(oracle):
+    """encode/matrix/genotype are host code in the product library too."""
+    api = indelope_amd.api()
+    assert api.encode("ACGTNacgtn").tolist() == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4]
+    assert api.matrix().tolist() == oracle.matrix().tolist()
+    import kats
+    kats.kat_genotype(api)
+    for r, a, e in [(3, 9, 1e-3), (0, 5, 1e-3), (40, 2, 1e-2)]:
+        g, o = api.genotype(r, a, e), oracle.genotype(r, a, e)
+        assert g.gt == o.gt and list(g.gl) == list(o.gl) and api.qual(g) == oracle.qual(o)

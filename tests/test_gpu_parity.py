@@ -1,0 +1,217 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+Bit-exact for every integer output; GL/qual (fp64 host maths) to 1e-12 relative."""
+import numpy as np
+import pytest
+
+import golden_util
+import kats
+from indelope_amd import Contig, synth
+from indelope_amd import _abi as A
+from indelope_amd.host import BatchResult
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kat", kats.CONTIG_KATS, ids=lambda f: f.__name__)
+def test_contig_kats(hip, kat):
+    kat(hip)
+
+
+def test_ksw2_kat(hip):
+    kats.kat_ksw2(hip)
+
+
+def test_genotype_kat(hip):
+    kats.kat_genotype(hip)
+
+
+def test_golden_ksw2(hip):
+    """Every ksw_extz_t field + full CIGAR vs outputs of the compiled reference C (tests/golden)."""
+    assert golden_util.check_ksw2(hip) >= 200
+
+
+@pytest.mark.parametrize("name", ["c1", "small", "long"])
+def test_golden_regions(hip, name):
+    golden_util.check_regions(hip, name)
+
+
+def assert_same(got, exp):
+    d = BatchResult.first_difference(got, exp)
+    assert d is None, d
+    np.testing.assert_allclose(got.events["gl"], exp.events["gl"], rtol=1e-12)
+    np.testing.assert_allclose(got.events["qual"], exp.events["qual"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_regions=200, n_reads=(64, 64), err_rate=1e-3, config_id=2),            # C2-shaped
+    dict(n_regions=120, n_reads=(16, 256), err_rate=1e-3, config_id=3),           # C3-shaped
+    dict(n_regions=150, n_reads=(4, 48), err_rate=0.0, config_id=21),
+    dict(n_regions=100, n_reads=(8, 64), err_rate=1e-2, config_id=22),            # many singleton contigs (>20 pre)
+    dict(n_regions=40, read_len=300, n_reads=(64, 64), err_rate=1e-3, n_events=2, window_len=1400, event_pos=500,
+         config_id=5, K=31),                                                       # C5-shaped
+    dict(n_regions=60, read_len=100, n_reads=(20, 60), err_rate=2e-3, config_id=23, K=21),
+])
+def test_regions_match_oracle(hip, oracle, cfg):
+    b, _ = synth.generate(**cfg)
+    K = cfg.get("K", 27)
+    got = hip.run_regions(b, hip.params(K=K))
+    exp = oracle.run_regions(b, oracle.params(K=K))
+    assert_same(got, exp)
+    assert (got.status == 0).all()
+
+
+def test_cli_defaults_and_filters(hip, oracle):
+    """CLI defaults (indelope.nim:568-570) and mapq / skip / quality-trim inputs."""
+    b, _ = synth.generate(120, n_reads=(12, 64), err_rate=2e-3, config_id=24)
+    rng = np.random.default_rng(5)
+    b.mapq = rng.choice(np.array([0, 4, 5, 6, 9, 10, 19, 20, 60], np.uint8), b.n_reads)
+    b.read_skip = (rng.random(b.n_reads) < 0.05).astype(np.uint8)
+    q = b.quals.copy()
+    for i in range(b.n_reads):
+        lo, hi = b.read_off[i], b.read_off[i + 1]
+        k = rng.integers(0, 4)
+        if k == 1:
+            q[lo:lo + rng.integers(1, 30)] = 2
+        elif k == 2:
+            q[hi - rng.integers(1, 30):hi] = 2
+        elif k == 3 and rng.random() < 0.2:
+            q[lo:hi] = 2
+    b.quals = q
+    kw = dict(min_reads=3, min_ctg_len=73, min_event_len=4)
+    assert_same(hip.run_regions(b, hip.params(**kw)), oracle.run_regions(b, oracle.params(**kw)))
+
+
+def test_edge_batches(hip, oracle):
+    b, _ = synth.generate(3, n_reads=(12, 12), config_id=10)
+    b.mapq = b.mapq.copy()
+    b.quals = b.quals.copy()
+    r0, r1 = b.region_read_off[1], b.region_read_off[2]
+    b.mapq[r0:r1] = 3
+    r2 = b.region_read_off[2]
+    b.quals[b.read_off[r2]:b.read_off[r2 + 1]] = 2
+    assert_same(hip.run_regions(b), oracle.run_regions(b))
+    e = b.slice(0, 0)
+    assert hip.run_regions(e).n_contigs == 0
+    one = b.slice(0, 1)                                 # a region with a reference window but no reads
+    z8, z64 = np.zeros(0, np.uint8), np.zeros(0, np.int64)
+    one.region_read_off, one.read_off = np.array([0, 0], np.int64), np.array([0], np.int64)
+    one.bases, one.quals, one.mapq, one.read_skip, one.read_start, one.read_stop = z8, z8, z8, z8, z64, z64
+    assert_same(hip.run_regions(one), oracle.run_regions(one))
+    nq = b.slice(0, 3)
+    nq.quals = None
+    nq.read_skip = None
+    assert_same(hip.run_regions(nq), oracle.run_regions(nq))
+
+
+def test_votes_fire_in_combine(hip, oracle):
+    """Low-support tails vs well-supported contigs: the only place allowable_mismatch (contig.nim:44-47) is true."""
+    b, _ = synth.generate(150, n_reads=(40, 120), err_rate=4e-3, config_id=25)
+    assert_same(hip.run_regions(b), oracle.run_regions(b))
+
+
+def test_slide_align_random_pairs(hip, oracle):
+    rng = np.random.default_rng(11)
+    for i in range(60):
+        n = int(rng.integers(30, 400))
+        base = kats.rand_dna(rng, n + 200)
+        o = int(rng.integers(0, 150))
+        t = Contig(base[50:50 + n], 100, int(rng.integers(1, 9)))
+        ql = int(rng.integers(20, 200))
+        qs = list(base[50 + o - 30:50 + o - 30 + ql]) if rng.random() < 0.5 else list(base[50 + o:50 + o + ql])
+        for p in rng.integers(0, len(qs), rng.integers(0, 4)):
+            qs[p] = "ACGT"[rng.integers(0, 4)]
+        q = Contig("".join(qs), 7, int(rng.integers(1, 9)))
+        for c in (q, t):
+            c._sup[:c.len] = rng.integers(1, 12, c.len)
+            c.nreads = int(rng.integers(1, 40))
+        mo, mm, rule = int(rng.integers(5, 60)), int(rng.integers(0, 3)), int(rng.integers(0, 2))
+        a = hip.slide_align(q, t, min_overlap=mo, max_mismatch=mm, allowed=rule)
+        e = oracle.slide_align(q, t, min_overlap=mo, max_mismatch=mm, allowed=rule)
+        assert (a.offset, a.corrections) == (e.offset, e.corrections), (i, a, e)
+        if e.aligned:
+            assert (a.matches, a.mismatches) == (e.matches, e.mismatches)
+            import copy
+            t1, q1, t2, q2 = copy.deepcopy(t), copy.deepcopy(q), copy.deepcopy(t), copy.deepcopy(q)
+            hip.insert(t1, q1, a)
+            oracle.insert(t2, q2, e)
+            assert (t1.sequence, t1.support, t1.start, t1.nreads) == (t2.sequence, t2.support, t2.start, t2.nreads)
+            assert (q1.sequence, q1.support) == (q2.sequence, q2.support)
+
+
+def test_ksw2_random_vs_oracle(hip, oracle):
+    import test_oracle_ksw2 as tk
+    for pi in (0, 1, 2, 3, 4, 7):
+        kw = tk.PARAMS[pi]
+        if kw["flag"] & A.KSW_EZ_GENERIC_SC:
+            kw = dict(kw, flag=kw["flag"] & ~A.KSW_EZ_GENERIC_SC)
+        pairs = list(tk.cases(300 + pi, 80))
+        args = dict(gap_open=kw["gapo"], gap_ext=kw["gape"], bw=kw["w"], z=kw["zdrop"], flag=kw["flag"])
+        ez, cg = hip.align_batch([q for q, t in pairs], [t for q, t in pairs], **args)
+        ez2, cg2 = oracle.align_batch([q for q, t in pairs], [t for q, t in pairs], **args)
+        assert ez.tolist() == ez2.tolist(), pi
+        assert [c.tolist() for c in cg] == [c.tolist() for c in cg2], pi
+
+
+def test_ksw_extz2_sse_symbol_is_a_drop_in(hip, oracle):
+    """The reference's FFI seam (ksw2_c.nim:53-55) served by the HIP library, incl. cigar buffer reuse."""
+    import ctypes as C
+    qe, te = hip.encode(kats.KSW_QRY), hip.encode(kats.KSW_TGT)
+    mat = hip.matrix()
+    ez = A.KswExtz()
+    for flag, gapo, w, z, exp in ((A.KSW_EZ_EXTZ_ONLY | A.KSW_EZ_RIGHT, 3, -1, -1, "72M19D26M28D"), (0, 4, 50, 400, "52M19D46M28D")):
+        ez.n_cigar = 0                                   # ksw2.nim:153
+        hip.cdll.ksw_extz2_sse(None, len(qe), A.ptr(qe, A.u8p), len(te), A.ptr(te, A.u8p), 5, A.ptr(mat, A.i8p),
+                               gapo, 1, w, z, flag, C.byref(ez))
+        ref, cig = oracle.ksw(qe, te, gapo=gapo, gape=1, w=w, zdrop=z, flag=flag)
+        got = [ez.cigar[i] for i in range(ez.n_cigar)]
+        assert got == cig.tolist()
+        assert (ez.max, ez.zdropped, ez.max_q, ez.max_t, ez.mqe, ez.mqe_t, ez.mte, ez.mte_q, ez.score) == \
+            tuple(ref[k] for k in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score"))
+        assert ez.m_cigar >= ez.n_cigar
+
+
+def test_kmer_tally_matches_oracle(hip, oracle):
+    rng = np.random.default_rng(3)
+    for K in (11, 27, 31):
+        core = kats.rand_dna(rng, 400)
+        reads = [core[s:s + 150] for s in rng.integers(0, 250, 90)]
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        reads = [r if rng.random() < 0.5 else "".join(comp[c] for c in reversed(r)) for r in reads]
+        reads[3] = reads[3][:70] + "N" + reads[3][71:]
+        mapq = rng.choice(np.array([0, 9, 10, 60], np.uint8), len(reads))
+        ref_k, alt_k = core[200:200 + K], core[230:230 + K]
+        assert hip.kmer_tally(reads, ref_k, alt_k, K=K, mapq=mapq) == oracle.kmer_tally(reads, ref_k, alt_k, K=K, mapq=mapq)
+
+
+def test_full_size_c2_properties(hip, oracle):
+    """BASELINE config C2 at full size (10k regions x 64 reads): size-independent checks + sampled oracle parity."""
+    b, truth = synth.config("C2")
+    got = hip.run_regions(b)
+    assert (got.status == 0).all()
+    # determinism: a second run is bit-identical
+    again = hip.run_regions(b)
+    assert BatchResult.first_difference(got, again) is None
+    # conservation: every tallied event accounts for <= n_reads, supports are consistent
+    ev = got.events[got.events["status"] == A.IHP_EV_TALLIED]
+    assert len(ev) > 0.9 * b.n_regions
+    assert (ev["ref_support"] + ev["alt_support"] - ev["both_found"] <= 64).all()
+    # every contig base has support >= 1 and nreads sums to <= reads per region
+    assert got.ctg_support.min() >= 1
+    per_region = np.add.reduceat(got.ctg_nreads, got.contig_off[:-1][np.diff(got.contig_off) > 0])
+    assert per_region.max() <= 64
+    # planted events are recovered for the large majority of regions
+    first = {}
+    for c in range(got.n_contigs):
+        for e in got.events[got.event_off[c]:got.event_off[c + 1]]:
+            if e["status"] == 0:
+                first.setdefault(int(np.searchsorted(got.contig_off, c, side="right") - 1), []).append(e)
+    hit = sum(any(e["type"] == truth[r, 0] and e["len"] == truth[r, 1] for e in evs) for r, evs in first.items())
+    assert hit > 0.9 * b.n_regions
+    # sharded parity against the oracle on 3 disjoint slices (sharding must not change results)
+    for lo in (0, 4321, 9000):
+        sub = b.slice(lo, lo + 250)
+        exp = oracle.run_regions(sub)
+        assert_same(hip.run_regions(sub), exp)
+        c0, c1 = got.contig_off[lo], got.contig_off[lo + 250]
+        assert np.array_equal(got.ctg_start[c0:c1], exp.ctg_start)
+        assert np.array_equal(got.ctg_seq[got.ctg_seq_off[c0]:got.ctg_seq_off[c1]], exp.ctg_seq)

@@ -75,6 +75,8 @@ def test_edge_regions(oracle):
     # an empty batch and a batch with an empty region
     e = b.slice(0, 0)
     assert oracle.run_regions(e).n_contigs == 0
-    one = b.slice(0, 1)
-    one.region_read_off = np.array([0, 0], np.int64)
+    one = b.slice(0, 1)                                 # a region with a reference window but no reads
+    z8, z64 = np.zeros(0, np.uint8), np.zeros(0, np.int64)
+    one.region_read_off, one.read_off = np.array([0, 0], np.int64), np.array([0], np.int64)
+    one.bases, one.quals, one.mapq, one.read_skip, one.read_start, one.read_stop = z8, z8, z8, z8, z64, z64
     assert oracle.run_regions(one).n_contigs == 0
