@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate regions/sec through assemble + ksw2 + k-mer tally on MI355X.
+
+One "step" = one pass of the whole hot path (three HIP kernels + the per-region summary kernel) over one
+batch of synthetic candidate regions that is already resident in HBM.  Default workload = BASELINE.json
+configs[1] ("C2": 10k regions x 64 x 150 bp reads, SURVEY.md §8d generator).  With --gpus N each rank
+holds its own shard of regions (weak scaling: N x the same per-GPU batch) and every step ends with one
+RCCL gather of the fixed-size per-region result records to rank 0.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP events on the library's
+stream); `cpu_baseline` times the CPU oracle on this host's cores (checker used as a reported baseline
+only -- the Nim reference cannot be built in this image).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+KERNELS = ["k_assemble", "k_ksw", "k_tally"]
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, n_int32):
+        self.__cuda_array_interface__ = {"shape": (n_int32,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(batch, K, want_seconds=12.0):
+    """Oracle on the host cores over a bounded sample of the same workload."""
+    import oracle
+    o = oracle.get()
+    used_ref = o.use_reference_ksw(True)
+    cores = os.cpu_count() or 1
+    p = o.params(K=K)
+    probe = batch.slice(0, min(batch.n_regions, 256))
+    t0 = time.perf_counter()
+    o.run_regions(probe, p)
+    rate1 = probe.n_regions / (time.perf_counter() - t0)
+    n = int(min(batch.n_regions, max(256, rate1 * cores * want_seconds / 2)))
+    sample = batch.slice(0, n)
+    t0 = time.perf_counter()
+    o.run_regions_mt(sample, p, nthreads=cores)
+    dt = time.perf_counter() - t0
+    o.use_reference_ksw(False)
+    return {"value": round(n / dt, 1), "unit": "regions/s", "cores": cores, "kind": "port",
+            "value_1thread": round(rate1, 1),
+            "sample": "first %d regions of the workload, %d threads over independent regions; C restatement of "
+                      "contig.nim/indelope.nim (oracle/), ksw2 = %s; Nim reference not buildable here"
+                      % (n, cores, "reference ksw2_extz2_sse.c compiled (oracle/_ref)" if used_ref
+                         else "scalar restatement (oracle/_ref absent)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", help="BASELINE config id (C2, C3, C5) for the per-GPU batch")
+    ap.add_argument("--regions", type=int, default=0, help="override regions per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import indelope_amd
+    from indelope_amd import synth
+    api = indelope_amd.api()
+    api.init(local_rank)
+
+    cfg = dict(synth.CONFIGS[args.config])
+    R = args.regions or min(cfg["n_regions"], 200_000)
+    cfg["n_regions"] = R
+    K = cfg["K"]
+    batch, _ = synth.generate(first_region=rank * R, **cfg)
+    params = api.params(K=K)
+    h = api.batch_upload(batch, params)
+    sptr, sn = api.batch_summary_dev(h)
+    nint = sn * 8
+    summary = torch.as_tensor(_DevArray(sptr, nint), device="cuda") if nint else torch.zeros(0, dtype=torch.int32, device="cuda")
+    gather_list = [torch.empty_like(summary) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        api.batch_run(h)
+        api.batch_sync(h)
+        if world > 1:
+            dist.gather(summary, gather_list, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    stage = np.zeros(4)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        stage += api.batch_stage_ms(h)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stage /= max(args.steps, 1)
+
+    if rank == 0:
+        res = api.batch_fetch(h)
+        assert (res.status == 0).all(), "regions failed on the device"
+        # B = sum_reads(len+9) + len_refwindow + sum_contigs(5 len+16) + sum_aln(44+4 n_cigar) + sum_events(2K+12)
+        alg_bytes = batch.algorithmic_input_bytes() + res.algorithmic_output_bytes(K)
+        dom = int(np.argmax(stage[:3]))
+        achieved = alg_bytes / (stage[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "candidate regions/sec (assemble+ksw2+kmer-genotype), 150bp x 64-read batches",
+            "value": round(world * R * args.steps / dt, 1), "unit": "regions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s: %d regions/GPU x %s reads x %d bp, K=%d, err %g (SURVEY 8d generator, seed 0x1DE10BE^%d)"
+                                   % (args.config, R, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
+                                      else str(cfg["n_reads"][0]), cfg["read_len"], K, cfg["err_rate"], cfg["config_id"]),
+                       "regions_per_gpu": R, "sharding": "contiguous region ranges per rank, one RCCL gather of "
+                       "per-region result records per step" if world > 1 else "single GPU"},
+            "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)},
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "algorithmic_bytes_per_region": round(alg_bytes / R, 1)},
+            "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),
+                        "tallied": int((res.events["status"] == 0).sum())},
+        }
+        if os.environ.get("IHP_PROFILE"):
+            out["profile_cycles"] = [int(x) for x in api.batch_profile(h)]
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(batch, K)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    api.batch_free(h)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

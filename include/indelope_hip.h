@@ -278,6 +278,10 @@ void ihp_batch_free(ihp_batch *b);
 /* Per-stage device time of the most recent ihp_batch_run+sync, from HIP events
  * on the batch stream: ms[0] assemble, ms[1] ksw2, ms[2] tally, ms[3] total.  */
 int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);
+/* Diagnostics: with IHP_PROFILE=1 in the environment the kernels sum shader-clock cycles
+ * per phase over all waves: [0] assemble, [1] combine, [2] assemble+output, [3] regions;
+ * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments.                       */
+int  ihp_batch_profile(ihp_batch *b, int64_t out[16]);
 /* Fixed-size per-region summary record left on the device for the multi-GPU
  * gather (one RCCL gather of these at the end).     */
 typedef struct {

@@ -75,6 +75,12 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_summary_dev(h, C.byref(p), C.byref(n)), "batch_summary_dev")
         return p.value, n.value
 
+    def batch_profile(self, h):
+        import numpy as np
+        out = np.zeros(16, np.int64)
+        self._chk_hip(self.b.batch_profile(h, _abi.ptr(out, _abi.i64p)), "batch_profile")
+        return out
+
     def batch_free(self, h):
         self.b.batch_free(h)
 

@@ -19,6 +19,9 @@ constexpr int FILTER_CH = 8;     // bases examined by the per-offset prefilter
 // Single-wave workgroup: the barrier itself is free; what matters is the
 // s_waitcnt + compiler fence that orders LDS / global scratch traffic between lanes.
 #define WSYNC() __syncthreads()
+// LDS traffic of one wave is serviced in program order, so between lanes of the SAME wave a compiler
+// barrier is all that LDS read-after-write needs; unlike WSYNC it does not wait for global stores.
+#define LDS_ORDER() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p ? 1 : 0); }

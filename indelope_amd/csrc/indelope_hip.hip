@@ -222,8 +222,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	size_t lds_need = 0, p_need = 0; long long cig_bound = 0; int cig_cap = 0;
 	for (const AlnJob &j : jobs) {
 		if (j.qlen <= 0 || j.tlen <= 0) continue;
-		size_t T = (size_t)((j.tlen + 15) / 16) * 16, Q = (size_t)((j.qlen + 15) / 16) * 16 + 16;
-		lds_need = std::max(lds_need, 10 * T + Q);
+		lds_need = std::max(lds_need, (P.w >= 0 && P.w <= 62) ? ksw_fast_lds_bytes(j.qlen, j.tlen) : ksw_lds_bytes(j.qlen, j.tlen));
 		int w = P.w < 0 ? std::max(j.qlen, j.tlen) : P.w;
 		int nc = (std::min(std::min(j.qlen, j.tlen), w + 1) + 15) / 16 + 1;
 		p_need = std::max(p_need, ((size_t)(j.qlen + j.tlen - 1) * nc + 1) * 16);
@@ -231,7 +230,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 		cig_cap = std::max(cig_cap, j.qlen + j.tlen);
 	}
 	if ((long long)lds_need > g.max_lds - 2048) { snprintf(g.err, sizeof(g.err), "alignment needs %zu B of LDS", lds_need); return IHP_E_CAPACITY; }
-	const int grid = grid_for(n, 8);
+	const int grid = grid_for(n, 32);
 	DBuf d_jobs, d_p, d_ct, d_ez, d_coff, d_pool, d_misc;
 	int rc;
 	if ((rc = d_jobs.upload(jobs.data(), sizeof(AlnJob) * n, g.stream))) return rc;
@@ -249,7 +248,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.cig_tmp = d_ct.as<uint32_t>(); a.cig_cap = cig_cap + 4;
 	a.ez = d_ez.as<KswOut>(); a.cig_off = d_coff.as<long long>();
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>(); a.cig_pool_cap = cig_bound + 4;
-	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 8;
+	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 8; a.prof = nullptr;
 	hipLaunchKernelGGL(k_ksw, dim3(grid), dim3(64), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
@@ -485,7 +484,7 @@ struct ihp_batch {
 	DBuf region_read_off, read_off, bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin;
 	bool has_quals = false, has_skip = false;
 	// scratch
-	DBuf arena_seq, arena_sup, corr, p_scratch, cig_tmp, misc;
+	DBuf arena_seq, arena_sup, corr, p_scratch, cig_tmp, misc, prof;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
@@ -556,12 +555,12 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	// ksw2: contig length is bounded by the region's read bases (every contig base comes from a read)
 	const int qmax = std::min(MAXLEN, b->max_region_bases), tmax = b->max_ref_len;
 	{
-		const size_t T = (size_t)((tmax + 15) / 16) * 16, Q = (size_t)((qmax + 15) / 16) * 16 + 16;
-		size_t need = 10 * T + Q + 64;
+		const bool fastp = p->bw >= 0 && p->bw <= 62;
+		size_t need = (fastp ? ksw_fast_lds_bytes(qmax, tmax) : ksw_lds_bytes(qmax, tmax)) + 64;
 		// contigs are rarely longer than the reference window + band; cap the LDS request there and let the
 		// kernel flag anything larger (reported as IHP_E_CAPACITY for that batch)
-		const size_t typical = 10 * T + ((size_t)(tmax + 15) / 16 * 16 + 64) + 64;
-		need = std::min(need, std::max(typical, (size_t)8192));
+		const size_t typical = (fastp ? ksw_fast_lds_bytes(tmax + 64, tmax) : ksw_lds_bytes(tmax + 64, tmax)) + 64;
+		need = std::min(need, std::max(typical, (size_t)(fastp ? 2048 : 8192)));
 		need = std::min(need, (size_t)g.max_lds - 2048);
 		b->lds_ksw = (int)need;
 		const int w = p->bw < 0 ? std::max(qmax, tmax) : p->bw;
@@ -570,7 +569,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		b->p_cap = ((size_t)(qeff + tmax) * nc + 1) * 16 + 64;
 		b->cig_cap = qeff + tmax + 8;
 	}
-	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), 8);
+	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), 32);
 	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), 8);
 	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
 	b->cig_pool_cap = 64 * njobs_cap + 1024;
@@ -582,6 +581,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(misc, sizeof(int) * M_WORDS);
+	AL(prof, sizeof(long long) * 16);
 	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
 	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
 	AL(ctg_len, 4 * slots); AL(aln_flags, 4 * slots); AL(aln_ref_len, 4 * slots); AL(aln_ref_start, 8 * slots);
@@ -603,6 +603,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	hipStream_t s = g.stream;
 	const ihp_params &p = b->P;
 	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
+	const bool profiling = getenv("IHP_PROFILE") != nullptr;
+	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 16, s));
 	int *misc = b->misc.as<int>();
 	HIPC(hipEventRecord(b->ev[0], s));
 	if (b->R > 0) {
@@ -627,6 +629,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.aln_ref_start = b->aln_ref_start.as<long long>();
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = misc + M_CNT_ASM;
+		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		hipLaunchKernelGGL(k_assemble, dim3(b->grid_asm), dim3(64), 0, s, a);
 		HIPC(hipGetLastError());
 	}
@@ -644,6 +647,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>();
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
 		a.cig_pool_cap = b->cig_pool_cap; a.overflow = misc + M_OVF; a.work_counter = misc + M_CNT_KSW;
+		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		hipLaunchKernelGGL(k_ksw, dim3(b->grid_ksw), dim3(64), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 	}
@@ -691,6 +695,15 @@ extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
 	HIPC(hipEventSynchronize(b->ev[4]));
 	for (int i = 0; i < 3; ++i) HIPC(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
 	HIPC(hipEventElapsedTime(&ms[3], b->ev[0], b->ev[4]));
+	return 0;
+}
+
+// Diagnostics (IHP_PROFILE=1): shader-clock cycles summed over waves.
+// [0] assemble total, [1] combine, [2] assemble+output, [3] regions; [8] ksw init, [9] ksw DP, [10] ksw traceback, [11] jobs
+extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[16])
+{
+	if (!b || !out) return IHP_E_ARG;
+	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 16, hipMemcpyDeviceToHost));
 	return 0;
 }
 

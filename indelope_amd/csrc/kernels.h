@@ -3,6 +3,7 @@
 #pragma once
 #include "contig_dev.h"
 #include "ksw_dev.h"
+#include "ksw_fast.h"
 #include "tally_dev.h"
 
 namespace ihp {
@@ -29,6 +30,7 @@ struct AsmArgs {
 	uint8_t *out_seq; uint32_t *out_sup;
 	AlnJob *jobs; int *n_jobs;
 	int *work_counter;
+	long long *prof;                                   // optional cycle counters (diagnostics)
 };
 
 // indelope.nim:23-38 on one read, lanes over bases.  Returns a; kept range [lo,hi).
@@ -103,6 +105,7 @@ __device__ inline int assemble_region(const AsmArgs &a, RegionState &S, Arena &A
 		WSYNC();
 	}
 	n_pre = n;                                                 // :171
+	const long long tcA = a.prof ? (long long)clock64() : 0;
 	// combine(min_support) = pass with min_support 0, then the trimmed pass (contig.nim:259-260)
 	const int n2 = combine_pass(S, A, S.listA, n, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
 	if (n2 < 0) return n2;
@@ -111,6 +114,7 @@ __device__ inline int assemble_region(const AsmArgs &a, RegionState &S, Arena &A
 	if (n3 < 0) return n3;
 	WSYNC();
 	n_final = n3;
+	if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[1], (unsigned long long)((long long)clock64() - tcA));
 	return 0;
 }
 
@@ -131,8 +135,10 @@ __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 		WSYNC();
 		if (r >= a.n_regions) break;
 		int n_pre = 0, n_final = 0;
+		const long long tcR = a.prof ? (long long)clock64() : 0;
 		const int err = assemble_region(a, S, A, r, n_pre, n_final);
 		WSYNC();
+		if (a.prof && lane == 0) { atomicAdd((unsigned long long *)&a.prof[0], (unsigned long long)((long long)clock64() - tcR)); atomicAdd((unsigned long long *)&a.prof[3], 1ull); }
 		if (err) n_final = 0;
 		const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
 		// max_stop over reads with mapq > 5 (indelope.nim:213-216)
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 			cursor += len;
 		}
 		if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
+		if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[2], (unsigned long long)((long long)clock64() - tcR));
 		WSYNC();
 	}
 }
@@ -196,6 +203,7 @@ struct KswArgs {
 	uint32_t *cig_pool; unsigned long long *cig_cursor; long long cig_pool_cap;
 	int *overflow;                             // [0] cigar pool, [1] LDS/p budget
 	int *work_counter;
+	long long *prof;                           // optional cycle counters (diagnostics)
 };
 
 __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 	const int njobs = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
 	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
 	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
+	long long pacc[4] = {0, 0, 0, 0};
 	for (;;) {
 		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
 		WSYNC();
@@ -220,13 +229,19 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 		int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
 		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
 		const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
-		if (jb.qlen > 0 && jb.tlen > 0 &&
-		    (ksw_lds_bytes(jb.qlen, jb.tlen) > (size_t)a.lds_budget || pneed > a.p_cap)) {
+		const bool fast = ksw_fast_ok(a.P.w) && !(a.P.flag & KSW_EZ_SCORE_ONLY);
+		const size_t lneed = fast ? ksw_fast_lds_bytes(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen);
+		if (jb.qlen > 0 && jb.tlen > 0 && (lneed > (size_t)a.lds_budget || pneed > a.p_cap)) {
 			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
 			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
 			if (lane == 0) atomicExch(&a.overflow[1], 1);
+		} else if (fast) {
+			if (a.P.flag & KSW_EZ_RIGHT)
+				ksw_wave_fast<true>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
+			else
+				ksw_wave_fast<false>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
 		} else {
-			ksw_wave(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out);
+			ksw_wave(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
 		}
 		long long off = -1;
 		if (out.n_cigar > 0) {
@@ -245,6 +260,8 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 		if (lane == 0) { a.ez[jb.out] = out; a.cig_off[jb.out] = off; }
 		WSYNC();
 	}
+	if (a.prof && lane == 0)
+		for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long *)&a.prof[8 + k], (unsigned long long)pacc[k]);
 }
 
 // --------------------------------------------------------------------- tally

@@ -2,15 +2,23 @@
 // (reference: src/ksw2/csrc/ksw2_extz2_sse.c:113-388, the only native code on the path).
 //
 // The reference sweeps anti-diagonals r and, on each, 16-byte SSE blocks of the
-// band; here the band cells of one anti-diagonal are the lanes of the wave.  To
-// be bit-exact the kernel keeps the reference's observable layout: one zeroed
-// byte block u|v|x|y|s|sf|qr in LDS (:173-175) indexed by absolute target
-// position, the 16-rounded computed band [st,en] (:205), the 16-wide score
-// stores that run past the band and leave stale bytes (:215-228), wrapping int8
-// arithmetic with the SSE2 path's unsigned max/min (:131-132,:271-272), the
-// H[en0] special case (:318) and the 4-strided tie order of the exact max
-// (:323-348).  The traceback matrix p (80 B per diagonal at w=50) streams to a
-// per-wave HBM scratch row by row, coalesced; the walk back is done by lane 0.
+// band; here the band cells of one anti-diagonal are the lanes of the wave.  To be
+// bit-exact the kernel reproduces everything observable of the reference's work
+// arrays: values indexed by absolute target position t, the 16-rounded computed
+// band [st,en] (:205) whose padding cells feed real cells at the band edge and can
+// be walked by the traceback, score bytes s[] refreshed only in 16-byte groups from
+// st0 (:215-228) and stale elsewhere, wrapping int8 arithmetic with the SSE2 path's
+// unsigned max/min (:131-132,:271-272), the H[en0] special case (:318) and the
+// 4-strided tie order of the exact max (:323-348).
+//
+// LDS layout per wave: one 8-byte record per target position
+//   {x, v, u, y | s, target base, 0, 0}            (the u,v,x,y,s,sf arrays of :173-175)
+// + the reversed query (:187) + the 32-bit H[] (:177-178).  A cell reads its own
+// record (ds_read_b64), x/v of t-1 (ds_read_b32), one query byte and H[t]; it writes
+// its record and H[t].  The per-diagonal max is a DPP wave reduction + ballot.  The
+// traceback matrix p (n_col*16 B per diagonal, 80 B at w=50) streams to per-wave HBM
+// scratch, coalesced; the walk back is wave-parallel: 64 lanes speculate along the
+// current move direction and a ballot finds the run length.
 #pragma once
 #include "ihp_common.h"
 
@@ -31,10 +39,10 @@ __device__ __forceinline__ uint8_t enc_base(uint8_t c)
 	return 4;
 }
 
-__device__ __forceinline__ size_t ksw_lds_bytes(int qlen, int tlen)
+__host__ __device__ __forceinline__ size_t ksw_lds_bytes(int qlen, int tlen)
 {
 	const size_t T = (size_t)((tlen + 15) / 16) * 16, Q = (size_t)((qlen + 15) / 16) * 16 + 16;
-	return 6 * T + Q + 4 * T;                            // bytes block + H
+	return 8 * T + Q + 4 * T;
 }
 
 // Band of anti-diagonal r (:196-205).  Returns false when st > en (band exit).
@@ -51,13 +59,93 @@ __device__ __forceinline__ bool ksw_band(int r, int qlen, int tlen, int w, int &
 	return true;
 }
 
-// cig_tmp: per-wave scratch for the reversed CIGAR (capacity cig_cap words).
-// Returns n_cigar in out.n_cigar with the CIGAR (final order) in cig_tmp[0..n),
-// or out.n_cigar = -1 if cig_cap was too small.
+#define IHP_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
+
+// max over the 64 lanes (all lanes active); result is wave-uniform
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+	int o;
+	o = IHP_DPP(v, 0xB1); v = o > v ? o : v;            // quad_perm [1,0,3,2]
+	o = IHP_DPP(v, 0x4E); v = o > v ? o : v;            // quad_perm [2,3,0,1]
+	o = IHP_DPP(v, 0x141); v = o > v ? o : v;           // row_half_mirror
+	o = IHP_DPP(v, 0x140); v = o > v ? o : v;           // row_mirror
+	const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+	const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+	const int ab = a > b ? a : b, cd = c > d ? c : d;
+	return ab > cd ? ab : cd;
+}
+
+__device__ __forceinline__ int sext8(unsigned v) { return (int)(signed char)(v & 0xff); }
+
+// Wave-parallel walk back through p (:47-79, :380-385).  off[r]/off_end[r] are recomputed from r.
+// Lane k speculates on the cell reached after k moves in the direction of the current state; a
+// ballot gives the length of the run, so a CIGAR of n ops costs O(n + len/64) round trips to HBM.
+__device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, int tlen, int w, int flag,
+                                          int zdropped, int ez_max_t, int ez_max_q,
+                                          uint32_t *cig_tmp, int cig_cap, KswOut &out)
+{
+	const int lane = lane_id();
+	int i, j;
+	if (!zdropped && !(flag & KSW_EZ_EXTZ_ONLY)) { i = tlen - 1; j = qlen - 1; }
+	else if (ez_max_t >= 0 && ez_max_q >= 0) { i = ez_max_t; j = ez_max_q; }
+	else return;
+	int n_cigar = 0, ok = 1, state = 0;
+	uint32_t cur = 0;                                    // run being built (len<<4|op); 0 = none
+	auto push = [&](uint32_t op, int len) {              // ksw_push_cigar :31-41 (wave-uniform)
+		if (cur && (cur & 0xf) == op) { cur += (uint32_t)len << 4; return; }
+		if (cur) { if (n_cigar < cig_cap) { if (lane == 0) cig_tmp[n_cigar] = cur; } else ok = 0; n_cigar++; }
+		cur = (uint32_t)len << 4 | op;
+	};
+	while (i >= 0 && j >= 0) {
+		// lane k looks at the cell reached after k moves in the direction of the current state
+		const int di = state == 2 ? 0 : 1, dj = state == 1 ? 0 : 1;
+		const int ik = i - lane * di, jk = j - lane * dj;
+		int outst = -1;
+		if (ik >= 0 && jk >= 0) {
+			const int rr = ik + jk;
+			int st0, en0, st, en, force_state = -1;
+			ksw_band(rr, qlen, tlen, w, st0, en0, st, en);
+			if (ik < st) force_state = 2;                // :56
+			if (ik > en) force_state = 1;                // :57
+			const unsigned tmp = force_state < 0 ? p[(size_t)rr * ncol + ik - st] : 0;
+			int s = state;
+			if (s == 0) s = tmp & 7;                     // :64
+			else if (!((tmp >> (s + 2)) & 1)) s = 0;     // :65
+			if (s == 0) s = tmp & 7;                     // :66
+			if (force_state >= 0) s = force_state;       // :67
+			outst = s;
+		}
+		const unsigned long long cont = ballot(outst == state);
+		int n = cont == ~0ull ? 64 : ctz64(~cont);
+		if (n == 0) { state = __builtin_amdgcn_readlane(outst, 0); n = 1; }
+		const int mi = state == 2 ? 0 : 1, mj = (state == 1 || state == 3) ? 0 : 1;
+		push(state == 0 ? 0u : ((state == 1 || state == 3) ? 2u : 1u), n);           // :68-71
+		i -= n * mi; j -= n * mj;
+	}
+	if (i >= 0) push(2, i + 1);                          // :73
+	if (j >= 0) push(1, j + 1);                          // :74
+	if (cur) { if (n_cigar < cig_cap) { if (lane == 0) cig_tmp[n_cigar] = cur; } else ok = 0; n_cigar++; }
+	WSYNC();
+	if (!ok) { out.n_cigar = -1; return; }
+	if (!(flag & KSW_EZ_REV_CIGAR)) {                    // :75-77
+		for (int k0 = 0; k0 < n_cigar >> 1; k0 += 64) {
+			const int k = k0 + lane;
+			if (k < n_cigar >> 1) {
+				const uint32_t a = cig_tmp[k], b = cig_tmp[n_cigar - 1 - k];
+				cig_tmp[k] = b; cig_tmp[n_cigar - 1 - k] = a;
+			}
+		}
+		WSYNC();
+	}
+	out.n_cigar = n_cigar;
+}
+
+// cig_tmp: per-wave scratch for the CIGAR (capacity cig_cap words).  out.n_cigar = -1 if too small.
 __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *target, int tlen,
                                 const KswParams P, uint8_t *lds, uint8_t *p, uint32_t *cig_tmp, int cig_cap,
-                                KswOut &out)
+                                KswOut &out, long long *pacc = nullptr)
 {
+	const long long tc0 = pacc ? (long long)clock64() : 0;
 	const int lane = lane_id();
 	int w = P.w;
 	const int q = P.q, e = P.e, qe = q + e, flag = P.flag;
@@ -70,16 +158,19 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 	int n_col_ = qlen < tlen ? qlen : tlen;
 	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
 	const int ncol = n_col_ * 16;
-	const int T = tlen_ * 16;
-	uint8_t *u = lds, *v = u + T, *x = v + T, *y = x + T, *s = y + T, *sf = s + T, *qr = sf + T;
-	const int QR = qlen_ * 16 + 16;
-	int32_t *H = (int32_t *)(lds + 6 * T + QR);
-	const uint8_t qe2 = (uint8_t)(qe * 2), sc_mch = (uint8_t)P.sc_mch, sc_mis = (uint8_t)P.sc_mis;
-	const uint8_t m1 = (uint8_t)(P.m - 1), max_sc8 = (uint8_t)(P.sc_mch + qe * 2);
+	const int T = tlen_ * 16, QR = qlen_ * 16 + 16;
+	uint2 *rec = (uint2 *)lds;                           // [T]
+	uint8_t *qr = lds + 8 * (size_t)T;                   // [QR]
+	int *H = (int *)(lds + 8 * (size_t)T + QR);          // [T]
+	const unsigned qe2 = (unsigned)(qe * 2) & 0xff, sc_mch = (unsigned)P.sc_mch & 0xff, sc_mis = (unsigned)P.sc_mis & 0xff;
+	const unsigned m1 = (unsigned)(P.m - 1) & 0xff, max_sc8 = (unsigned)(P.sc_mch + qe * 2) & 0xff, q8 = (unsigned)q & 0xff;
 	const bool with_cigar = !(flag & KSW_EZ_SCORE_ONLY), right = (flag & KSW_EZ_RIGHT) != 0;
 
-	for (int i = lane; i < 5 * T; i += 64) lds[i] = 0;   // kcalloc :173
-	for (int i = lane; i < T; i += 64) { sf[i] = i < tlen ? (P.encode_ascii ? enc_base(target[i]) : target[i]) : 0; H[i] = KSW_NEG_INF; }
+	for (int i = lane; i < T; i += 64) {                 // kcalloc :173, memcpy :188, H init :177-178
+		const unsigned tb = i < tlen ? (P.encode_ascii ? enc_base(target[i]) : target[i]) : 0;
+		rec[i] = make_uint2(0u, tb << 8);
+		H[i] = KSW_NEG_INF;
+	}
 	for (int i = lane; i < QR; i += 64) {                // :187
 		uint8_t b = 0;
 		if (i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base(b); }
@@ -87,117 +178,120 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 	}
 	WSYNC();
 
+	const long long tc1 = pacc ? (long long)clock64() : 0;
 	int last_st = -1, last_en = -1;
 	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, mqe = KSW_NEG_INF, mqe_t = -1, mte = KSW_NEG_INF, mte_q = -1;
 	int score = KSW_NEG_INF, zdropped = 0;
 	for (int r = 0; r < qlen + tlen - 1; ++r) {
 		int st0, en0, st, en;
 		if (!ksw_band(r, qlen, tlen, w, st0, en0, st, en)) { zdropped = 1; break; }   // :200-203
-		uint8_t x1, v1;                                  // :207-211
-		if (st > 0) {
-			if (st - 1 >= last_st && st - 1 <= last_en) { x1 = x[st - 1]; v1 = v[st - 1]; }
-			else x1 = v1 = 0;
-		} else { x1 = 0; v1 = r ? (uint8_t)q : 0; }
-		WSYNC();
-		if (en >= r && lane == 0) { y[r] = 0; u[r] = r ? (uint8_t)q : 0; }   // :212
-		// scores (:214-228): 16-byte groups starting at st0, past en0 up to 15 bytes
-		{
-			const uint8_t *qrr = qr + (qlen - 1 - r);
-			const int nsc = ((en0 - st0) / 16 + 1) * 16;
-			for (int j0 = 0; j0 < nsc; j0 += 64) {
-				const int j = st0 + j0 + lane;
-				if (j0 + lane < nsc) {
-					const uint8_t sq = sf[j], sq2 = qrr[j];
-					uint8_t val = sq == sq2 ? sc_mch : sc_mis;
-					if (sq == m1 || sq2 == m1) val = 0;
-					s[j] = val;
-				}
-			}
-		}
-		WSYNC();
-		// core recurrence over [st,en], top chunk first so lane t still sees x[t-1], v[t-1] of r-1
-		const int nch = (en - st + 64) / 64;
+		// left boundary of the computed band (:207-211)
+		const bool nb_valid = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
+		const unsigned xv_edge = st > 0 ? 0u : (r ? q8 << 8 : 0u);                    // x1 | v1<<8 when not read from LDS
+		const int sc_hi = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;                      // last refreshed score byte (:215)
+		const int qoff = qlen - 1 - r;                                                // qrr = qr + qoff (:193)
+		const int Hen0m1 = (r > 0 && en0 > 0) ? H[en0 - 1] : 0;                       // old value, for :318
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
 		uint8_t *pr = p + (size_t)r * ncol - st;
-		for (int c = nch - 1; c >= 0; --c) {
-			const int t = st + c * 64 + lane;
+		int bh = -0x7fffffff - 1, brk = 0x7fffffff, bt = 0, Hen0 = 0, Hst0 = 0;
+		// the 16-byte score stores run up to 15 bytes past en (:215-228); those bytes stay behind as the
+		// stale s[] of later diagonals, so lanes in (en, sc_hi] refresh their score byte and nothing else
+		const int hi = sc_hi < T ? (sc_hi > en ? sc_hi : en) : (T - 1 > en ? T - 1 : en);
+		const int nch = (hi - st + 64) / 64;
+		for (int c = nch - 1; c >= 0; --c) {             // top chunk first: t-1 of r-1 is still intact below
+			const int tb = st + c * 64, t = tb + lane;
 			const bool act = t <= en;
-			uint8_t z = 0, a = 0, b = 0, ut = 0, vt1 = 0, d = 0;
-			if (act) {
-				z = (uint8_t)(s[t] + qe2);
-				const uint8_t xt1 = t == st ? x1 : x[t - 1];
-				vt1 = t == st ? v1 : v[t - 1];
-				a = (uint8_t)(xt1 + vt1);
-				ut = u[t];
-				b = (uint8_t)(y[t] + ut);
+			int h = -0x7fffffff - 1;
+			if (!act && t <= hi) {
+				const unsigned ry = rec[t].y, sfb = (ry >> 8) & 0xff, qb = qr[qoff + t];
+				unsigned sv = sfb == qb ? sc_mch : sc_mis;
+				if (sfb == m1 || qb == m1) sv = 0;
+				rec[t].y = sv | sfb << 8;
 			}
-			WSYNC();
 			if (act) {
-				if (!right) d = (int8_t)a > (int8_t)z ? 1 : 0;              // :265
-				else        d = (int8_t)z > (int8_t)a ? 0 : 1;              // :291
-				z = (int8_t)z > 0 ? z : 0;                                  // :271 (SSE2 path)
-				z = z > a ? z : a;                                          // :272 unsigned max
-				if (!right) { if ((int8_t)b > (int8_t)z) d = 2; }           // :273-274
-				else        { if (!((int8_t)z > (int8_t)b)) d = 2; }        // :299-300
-				z = z > b ? z : b;                                          // :131
-				z = z < max_sc8 ? z : max_sc8;                              // :132
-				u[t] = (uint8_t)(z - vt1);                                  // :133
-				v[t] = (uint8_t)(z - ut);                                   // :134
-				z = (uint8_t)(z - (uint8_t)q);
-				a = (uint8_t)(a - z);
-				b = (uint8_t)(b - z);
-				if (!right) {
-					const bool ta = (int8_t)a > 0, tb = (int8_t)b > 0;      // :277-282
-					x[t] = ta ? a : 0; y[t] = tb ? b : 0;
-					d |= (ta ? 0x08 : 0) | (tb ? 0x10 : 0);
-				} else {
-					const bool ta = 0 > (int8_t)a, tb = 0 > (int8_t)b;      // :303-308
-					x[t] = ta ? 0 : a; y[t] = tb ? 0 : b;
-					d |= (ta ? 0 : 0x08) | (tb ? 0 : 0x10);
+				const uint2 R = rec[t];
+				unsigned xv;
+				if (t == st) xv = nb_valid ? (rec[t - 1].x & 0xffffu) : xv_edge;
+				else xv = rec[t - 1].x & 0xffffu;
+				unsigned sv = R.y & 0xff;
+				const unsigned sfb = (R.y >> 8) & 0xff;
+				if (t >= st0 && t <= sc_hi) {            // :214-228
+					const unsigned qb = qr[qoff + t];
+					sv = sfb == qb ? sc_mch : sc_mis;
+					if (sfb == m1 || qb == m1) sv = 0;
 				}
-				if (with_cigar) pr[t] = d;                                  // :283
+				unsigned ut = (R.x >> 16) & 0xff, yt = R.x >> 24;
+				if (t == r) { yt = 0; ut = r ? q8 : 0; } // :212 (en >= r whenever t == r is computed)
+				const unsigned xt1 = xv & 0xff, vt1 = xv >> 8;
+				unsigned z = (sv + qe2) & 0xff;
+				unsigned a = (xt1 + vt1) & 0xff, b = (yt + ut) & 0xff;
+				unsigned d;
+				if (!right) d = sext8(a) > sext8(z) ? 1 : 0;                          // :265
+				else        d = sext8(z) > sext8(a) ? 0 : 1;                          // :291
+				z = sext8(z) > 0 ? z : 0;                                             // :271 (SSE2 path)
+				z = z > a ? z : a;                                                    // :272 unsigned max
+				if (!right) { if (sext8(b) > sext8(z)) d = 2; }                       // :273-274
+				else        { if (!(sext8(z) > sext8(b))) d = 2; }                    // :299-300
+				z = z > b ? z : b;                                                    // :131
+				z = z < max_sc8 ? z : max_sc8;                                        // :132
+				const unsigned un = (z - vt1) & 0xff, vn = (z - ut) & 0xff;           // :133-134
+				z = (z - q8) & 0xff;
+				a = (a - z) & 0xff; b = (b - z) & 0xff;
+				unsigned xn, yn;
+				if (!right) {
+					const bool ta = sext8(a) > 0, tb2 = sext8(b) > 0;                 // :277-282
+					xn = ta ? a : 0; yn = tb2 ? b : 0;
+					d |= (ta ? 0x08u : 0u) | (tb2 ? 0x10u : 0u);
+				} else {
+					const bool ta = 0 > sext8(a), tb2 = 0 > sext8(b);                 // :303-308
+					xn = ta ? 0 : a; yn = tb2 ? 0 : b;
+					d |= (ta ? 0u : 0x08u) | (tb2 ? 0u : 0x10u);
+				}
+				rec[t] = make_uint2(xn | vn << 8 | un << 16 | yn << 24, sv | sfb << 8);
+				if (with_cigar) pr[t] = (uint8_t)d;                                   // :283
+				// exact max, 32-bit (:312-349)
+				if (r > 0) {
+					if (t == en0) h = (en0 > 0 ? Hen0m1 + (int)un : H[t] + (int)vn) - qe;   // :318
+					else if (t >= st0 && t < en0) h = H[t] + (int)vn - qe;            // :323-329, :345
+				} else if (t == 0) h = (int)vn - qe - qe;                             // :349
+				if (t >= st0 && t <= en0) H[t] = h;
 			}
-		}
-		WSYNC();
-		// exact max with the 32-bit score array (:312-357)
-		int max_H, max_t;
-		if (r > 0) {
-			const int en1 = st0 + (en0 - st0) / 4 * 4;
-			const int ncell = en0 - st0 + 1, nhc = (ncell + 63) / 64;
-			int bh = -0x7fffffff - 1, br = 0x7fffffff, bt = 0;
-			for (int c = nhc - 1; c >= 0; --c) {
-				const int t = st0 + c * 64 + lane;
-				const bool act = t <= en0;
-				int h = -0x7fffffff - 1, rk = 0x7fffffff;
-				if (act) {
-					if (t == en0) {                                         // :318
-						h = (en0 > 0 ? H[en0 - 1] + (int)u[en0] : H[en0] + (int)v[en0]) - qe;
-						rk = 0;
+			const bool intrue = act && t >= st0 && t <= en0;
+			const int hm = wave_max_i32(intrue ? h : -0x7fffffff - 1);
+			const unsigned long long m = ballot(intrue && h == hm);
+			if (m) {
+				// tie order of :320-348: en0 first, then the vector part by stride class, then the tail
+				int rk, tt;
+				const int ben0 = en0 - tb;
+				if (ben0 >= 0 && ben0 < 64 && ((m >> ben0) & 1)) { rk = 0; tt = en0; }
+				else {
+					const int nv = en1 - tb;                                          // lanes below nv are in the vector part
+					const unsigned long long mv = nv <= 0 ? 0ull : (nv >= 64 ? m : (m & ((1ull << nv) - 1)));
+					rk = 0x7fffffff; tt = 0;
+					if (mv) {
+						for (int j = 0; j < 4; ++j) {
+							const int sh = (j - (tb - st0)) & 3;
+							const unsigned long long cm = mv & (0x1111111111111111ull << sh);
+							if (cm) { tt = tb + ctz64(cm); rk = 1 + (j << 24) + ((tt - st0) >> 2); break; }
+						}
 					} else {
-						h = H[t] + (int)v[t] - qe;                          // :323-329, :345
-						rk = t < en1 ? 1 + (((t - st0) & 3) << 24) + ((t - st0) >> 2)
-						             : 1 + (4 << 24) + (t - en1);
+						const unsigned long long mt = m & ~mv;
+						tt = tb + ctz64(mt); rk = 1 + (4 << 24) + (tt - en1);
 					}
 				}
-				WSYNC();
-				if (act) H[t] = h;
-				int ht = h, rt = rk, tt = t;
-				for (int dd = 32; dd >= 1; dd >>= 1) {
-					const int oh = __shfl_xor(ht, dd, 64), orr = __shfl_xor(rt, dd, 64), ot = __shfl_xor(tt, dd, 64);
-					if (oh > ht || (oh == ht && orr < rt)) { ht = oh; rt = orr; tt = ot; }
-				}
-				if (ht > bh || (ht == bh && rt < br)) { bh = ht; br = rt; bt = tt; }
+				if (hm > bh || (hm == bh && rk < brk)) { bh = hm; brk = rk; bt = tt; }
 			}
-			max_H = bh; max_t = bt;
-		} else {
-			WSYNC();
-			const int h0 = (int)v[0] - qe - qe;                             // :349
-			if (lane == 0) H[0] = h0;
-			max_H = h0; max_t = 0;
+			{
+				const int l1 = en0 - tb, l2 = st0 - tb;
+				if (l1 >= 0 && l1 < 64) Hen0 = __builtin_amdgcn_readlane(h, l1);
+				if (l2 >= 0 && l2 < 64) Hst0 = __builtin_amdgcn_readlane(h, l2);
+			}
 		}
-		WSYNC();
-		if (en0 == tlen - 1) { const int h = H[en0]; if (h > mte) { mte = h; mte_q = r - en; } }       // :351-352
-		if (r - st0 == qlen - 1) { const int h = H[st0]; if (h > mqe) { mqe = h; mqe_t = st0; } }      // :353-354
-		{                                                                   // ksw_apply_zdrop :88-104
+		LDS_ORDER();                                     // p stores keep streaming; LDS is in order per wave
+		const int max_H = bh, max_t = bt;
+		if (en0 == tlen - 1 && Hen0 > mte) { mte = Hen0; mte_q = r - en; }            // :351-352 (rounded en)
+		if (r - st0 == qlen - 1 && Hst0 > mqe) { mqe = Hst0; mqe_t = st0; }           // :353-354
+		{                                                                             // ksw_apply_zdrop :88-104
 			const int t = max_t;
 			if (max_H > ez_max) { ez_max = max_H; ez_max_t = t; ez_max_q = r - t; }
 			else if (t >= ez_max_t && r - t >= ez_max_q) {
@@ -206,56 +300,17 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 				if (P.zdrop >= 0 && ez_max - max_H > P.zdrop + l * e) { zdropped = 1; break; }
 			}
 		}
-		if (r == qlen + tlen - 2 && en0 == tlen - 1) score = H[tlen - 1];   // :356-357
+		if (r == qlen + tlen - 2 && en0 == tlen - 1) score = Hen0;                    // :356-357 (en0 == tlen-1)
 		last_st = st; last_en = en;
 	}
 	out.max = ez_max; out.zdropped = zdropped; out.max_q = ez_max_q; out.max_t = ez_max_t;
 	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = score;
 	WSYNC();
+	const long long tc2 = pacc ? (long long)clock64() : 0;
+	if (pacc) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
 	if (!with_cigar) return;
-	// backtrack (:47-79, :380-385); off[r]/off_end[r] are recomputed from r
-	int i0, j0;
-	if (!zdropped && !(flag & KSW_EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
-	else if (ez_max_t >= 0 && ez_max_q >= 0) { i0 = ez_max_t; j0 = ez_max_q; }
-	else return;
-	__threadfence_block();
-	int n_cigar = 0;
-	if (lane == 0) {
-		int i = i0, j = j0, state = 0, ok = 1;
-		uint32_t cur = 0;                                    // run being built (len<<4|op), 0 = none
-		auto push = [&](uint32_t op, int len) {              // ksw_push_cigar :31-41
-			if (cur && (cur & 0xf) == op) { cur += (uint32_t)len << 4; return; }
-			if (cur) { if (n_cigar < cig_cap) cig_tmp[n_cigar] = cur; else ok = 0; n_cigar++; }
-			cur = (uint32_t)len << 4 | op;
-		};
-		while (i >= 0 && j >= 0) {
-			const int r = i + j;
-			int st0, en0, st, en, force_state = -1;
-			ksw_band(r, qlen, tlen, w, st0, en0, st, en);
-			if (i < st) force_state = 2;
-			if (i > en) force_state = 1;
-			const uint32_t tmp = force_state < 0 ? p[(size_t)r * ncol + i - st] : 0;
-			if (state == 0) state = tmp & 7;
-			else if (!(tmp >> (state + 2) & 1)) state = 0;
-			if (state == 0) state = tmp & 7;
-			if (force_state >= 0) state = force_state;
-			if (state == 0) { push(0, 1); --i; --j; }
-			else if (state == 1 || state == 3) { push(2, 1); --i; }
-			else { push(1, 1); --j; }
-		}
-		if (i >= 0) push(2, i + 1);
-		if (j >= 0) push(1, j + 1);
-		if (cur) { if (n_cigar < cig_cap) cig_tmp[n_cigar] = cur; else ok = 0; n_cigar++; }
-		if (!ok) n_cigar = -1;
-		else if (!(flag & KSW_EZ_REV_CIGAR))
-			for (int k = 0; k < n_cigar >> 1; ++k) {
-				const uint32_t t = cig_tmp[k];
-				cig_tmp[k] = cig_tmp[n_cigar - 1 - k]; cig_tmp[n_cigar - 1 - k] = t;
-			}
-	}
-	n_cigar = bcast(n_cigar, 0);
-	out.n_cigar = n_cigar;
-	WSYNC();
+	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, zdropped, ez_max_t, ez_max_q, cig_tmp, cig_cap, out);
+	if (pacc) pacc[2] += (long long)clock64() - tc2;
 }
 
 }  // namespace ihp

@@ -1,0 +1,253 @@
+// ksw_fast.h -- register-resident ksw2 anti-diagonal sweep for narrow bands (0 <= w <= 62),
+// the production case (indelope.nim:221: bw=50).  Same contract and bit-exact results as
+// ksw_wave() in ksw_dev.h (reference: src/ksw2/csrc/ksw2_extz2_sse.c:113-388).
+//
+// The reference's computed band on a diagonal is at most five 16-byte SSE blocks
+// [st, en] = [st0/16*16, (en0+16)/16*16-1].  Lanes are band-relative:
+//     slot A: lane l  <->  t = st + l          (blocks 0..3, all 64 lanes)
+//     slot B: lane l  <->  t = st + 64 + l     (block 4, l < 16)
+// u, v, x, y, s, H and the target base of each cell live in VGPRs; the t-1 neighbour
+// comes from a DPP wave_shr:1 (the SSE code's _mm_slli_si128 carry, :119-125) with the
+// block edge x1/v1 (:207-211) injected as the DPP `old` value.  When st advances by 16
+// (every ~32 diagonals) the registers are rotated 16 lanes with two ds_bpermute each and
+// slot B is re-seeded from the zeroed state of :173.  The per-diagonal exact max (:312-349)
+// is a DPP max + ballot; ties (rare) are resolved with the reference's stride-4 order on
+// the scalar unit.  Only the reversed query and the target bytes are kept in LDS.
+#pragma once
+#include "ksw_dev.h"
+
+namespace ihp {
+
+__host__ __device__ __forceinline__ size_t ksw_fast_lds_bytes(int qlen, int tlen)
+{
+	return (size_t)((tlen + 15) / 16) * 16 + 96 + (size_t)((qlen + 15) / 16) * 16 + 96;
+}
+
+__device__ __forceinline__ bool ksw_fast_ok(int w) { return w >= 0 && w <= 62; }
+
+__device__ __forceinline__ unsigned dpp_shr1(unsigned v, unsigned edge)
+{   // lane l gets v[l-1]; lane 0 gets `edge`
+	return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ unsigned rot16(unsigned a, unsigned b, int lane)
+{   // new A lane l = old A lane l+16 (l < 48), old B lane l-48 (l >= 48)
+	const unsigned ra = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)a);
+	const unsigned rb = (unsigned)__builtin_amdgcn_ds_bpermute(((lane - 48) & 63) << 2, (int)b);
+	return lane < 48 ? ra : rb;
+}
+
+struct FastConst { unsigned qe2, sc_mch, sc_mis, m1, max_sc8, q8; };
+
+__device__ __forceinline__ unsigned score_byte(unsigned sfb, unsigned qb, const FastConst &C)
+{   // :219-226
+	unsigned sv = sfb == qb ? C.sc_mch : C.sc_mis;
+	if (sfb == C.m1 || qb == C.m1) sv = 0;
+	return sv;
+}
+
+// One cell of the recurrence (:116-137 + :262-310).  In: sv, xt1, vt1, ut, yt.  Out: new x,v,u,y and d.
+template <bool RIGHT>
+__device__ __forceinline__ void ksw_cell(unsigned sv, unsigned xt1, unsigned vt1, unsigned ut, unsigned yt,
+                                         const FastConst &C, unsigned &xn, unsigned &vn, unsigned &un, unsigned &yn, unsigned &d)
+{
+	unsigned z = (sv + C.qe2) & 0xff;
+	unsigned a = (xt1 + vt1) & 0xff, b = (yt + ut) & 0xff;
+	if (!RIGHT) d = sext8(a) > sext8(z) ? 1 : 0;                          // :265
+	else          d = sext8(z) > sext8(a) ? 0 : 1;                          // :291
+	z = sext8(z) > 0 ? z : 0;                                               // :271 (SSE2 path)
+	z = z > a ? z : a;                                                      // :272 unsigned max
+	if (!RIGHT) { if (sext8(b) > sext8(z)) d = 2; }                       // :273-274
+	else          { if (!(sext8(z) > sext8(b))) d = 2; }                    // :299-300
+	z = z > b ? z : b;                                                      // :131
+	z = z < C.max_sc8 ? z : C.max_sc8;                                      // :132
+	un = (z - vt1) & 0xff; vn = (z - ut) & 0xff;                            // :133-134
+	z = (z - C.q8) & 0xff;
+	a = (a - z) & 0xff; b = (b - z) & 0xff;
+	if (!RIGHT) {
+		const bool ta = sext8(a) > 0, tb = sext8(b) > 0;                    // :277-282
+		xn = ta ? a : 0; yn = tb ? b : 0;
+		d |= (ta ? 0x08u : 0u) | (tb ? 0x10u : 0u);
+	} else {
+		const bool ta = 0 > sext8(a), tb = 0 > sext8(b);                    // :303-308
+		xn = ta ? 0 : a; yn = tb ? 0 : b;
+		d |= (ta ? 0u : 0x08u) | (tb ? 0u : 0x10u);
+	}
+}
+
+template <bool RIGHT>
+__device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8_t *target, int tlen,
+                                     const KswParams P, uint8_t *lds, uint8_t *p, uint32_t *cig_tmp, int cig_cap,
+                                     KswOut &out, long long *pacc = nullptr)
+{
+	const long long tc0 = pacc ? (long long)clock64() : 0;
+	const int lane = lane_id();
+	const int w = P.w;
+	const int q = P.q, e = P.e, qe = q + e, flag = P.flag;
+	out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;   // :81-86
+	out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = 0;
+	if (P.m <= 0 || qlen <= 0 || tlen <= 0) return;      // :147
+	if (-P.min_sc > 2 * (q + e)) return;                 // :171
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int ncol = n_col_ * 16;
+	const int TP = (tlen + 15) / 16 * 16 + 96, QR = (qlen + 15) / 16 * 16 + 96;
+	uint8_t *tg = lds;                                   // target codes, zero padded (sf of :175,:188)
+	uint8_t *qr = lds + TP;                              // reversed query, zero padded (:187)
+	FastConst C;
+	C.qe2 = (unsigned)(qe * 2) & 0xff; C.sc_mch = (unsigned)P.sc_mch & 0xff; C.sc_mis = (unsigned)P.sc_mis & 0xff;
+	C.m1 = (unsigned)(P.m - 1) & 0xff; C.max_sc8 = (unsigned)(P.sc_mch + qe * 2) & 0xff; C.q8 = (unsigned)q & 0xff;
+	const bool with_cigar = !(flag & KSW_EZ_SCORE_ONLY);
+	for (int i = lane; i < TP; i += 64) tg[i] = i < tlen ? (P.encode_ascii ? enc_base(target[i]) : target[i]) : 0;
+	for (int i = lane; i < QR; i += 64) {
+		uint8_t b = 0;
+		if (i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base(b); }
+		qr[i] = b;
+	}
+	WSYNC();
+	const long long tc1 = pacc ? (long long)clock64() : 0;
+
+	// cell state
+	unsigned xA = 0, vA = 0, uA = 0, yA = 0, sA = 0, sfA = tg[lane];
+	unsigned xB = 0, vB = 0, uB = 0, yB = 0, sB = 0, sfB = tg[64 + (lane & 15)];
+	int HA = KSW_NEG_INF, HB = KSW_NEG_INF;
+	int st = 0;                                          // current computed-band origin (multiple of 16)
+	unsigned edge_x = 0, edge_v = 0;                     // x[st-1], v[st-1] when valid (:207-210)
+	int edge_h = KSW_NEG_INF;                            // H[st-1]: frozen once t = st-1 left the band
+	int last_st = -1, last_en = -1;
+	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, mqe = KSW_NEG_INF, mqe_t = -1, mte = KSW_NEG_INF, mte_q = -1;
+	int score = KSW_NEG_INF, zdropped = 0;
+	const int INTMIN = -0x7fffffff - 1;
+	for (int r = 0; r < qlen + tlen - 1; ++r) {
+		int st0, en0, nst, en;
+		if (!ksw_band(r, qlen, tlen, w, st0, en0, nst, en)) { zdropped = 1; break; }   // :200-203
+		if (nst != st) {
+			// the band origin moved one block right: rotate the registers 16 lanes, re-seed slot B
+			edge_x = (st + 15 >= last_st && st + 15 <= last_en) ? (unsigned)__builtin_amdgcn_readlane((int)xA, 15) : 0u;
+			edge_v = (st + 15 >= last_st && st + 15 <= last_en) ? (unsigned)__builtin_amdgcn_readlane((int)vA, 15) : 0u;
+			edge_h = __builtin_amdgcn_readlane(HA, 15);
+			xA = rot16(xA, xB, lane); vA = rot16(vA, vB, lane); uA = rot16(uA, uB, lane); yA = rot16(yA, yB, lane);
+			sA = rot16(sA, sB, lane); sfA = rot16(sfA, sfB, lane); HA = (int)rot16((unsigned)HA, (unsigned)HB, lane);
+			st = nst;
+			xB = vB = uB = yB = sB = 0; HB = KSW_NEG_INF;
+			sfB = tg[st + 64 + (lane & 15)];
+		} else if (st > 0) {
+			// x[st-1], v[st-1] are only "calculated in the last round" right after the origin moved (:208)
+			if (!(st - 1 >= last_st && st - 1 <= last_en)) { edge_x = 0; edge_v = 0; }
+		}
+		unsigned ex, ev;
+		if (st > 0) { ex = edge_x; ev = edge_v; } else { ex = 0; ev = r ? C.q8 : 0; }   // :207-211
+		const int loA = st0 - st;                        // first true-band lane
+		const int hiT = en0 - st;                        // last true-band lane (may be >= 64: slot B)
+		const int nTop = en - st;                        // last computed lane (<= 79)
+		const int sc = st0 + ((en0 - st0) / 16 + 1) * 16 - 1 - st;   // last refreshed score lane (:215)
+		const int qbase = qlen - 1 - r + st;             // qrr[t] = qr[qbase + lane]
+		uint8_t *pr = p + (size_t)r * ncol;
+		// neighbours of r-1 (taken before anything is overwritten)
+		const unsigned xpA = dpp_shr1(xA, ex), vpA = dpp_shr1(vA, ev);
+		const int HpA = (int)dpp_shr1((unsigned)HA, (unsigned)edge_h);
+		int hB = INTMIN, hA = INTMIN;
+		const int spec = (r > 0 && en0 > 0) ? hiT : -1000;          // lane of the H[en0] special case (:318)
+		// ---- slot B (block 4) ------------------------------------------------------------
+		if (sc >= 64) {
+			int qi = qbase + 64 + lane;
+			const unsigned qbB = (lane < 16 && qi >= 0 && qi < QR) ? qr[qi] : 0u;
+			if (lane <= sc - 64) sB = score_byte(sfB, qbB, C);      // :214-228 (runs past en)
+		}
+		if (nTop >= 64) {
+			const unsigned exB = (unsigned)__builtin_amdgcn_readlane((int)xA, 63), evB = (unsigned)__builtin_amdgcn_readlane((int)vA, 63);
+			const int HeB = __builtin_amdgcn_readlane(HA, 63);
+			const unsigned xpB = dpp_shr1(xB, exB), vpB = dpp_shr1(vB, evB);
+			const int HpB = (int)dpp_shr1((unsigned)HB, (unsigned)HeB);
+			if (lane <= nTop - 64) {
+				unsigned ut = uB, yt = yB;
+				if (st + 64 + lane == r) { yt = 0; ut = r ? C.q8 : 0; }   // :212
+				unsigned xn, vn, un, yn, d;
+				ksw_cell<RIGHT>(sB, xpB, vpB, ut, yt, C, xn, vn, un, yn, d);
+				xB = xn; vB = vn; uB = un; yB = yn;
+				if (with_cigar) pr[64 + lane] = (uint8_t)d;          // :283
+				const int l = 64 + lane;
+				if (l >= loA && l <= hiT) {
+					hB = (l == spec ? HpB + (int)un : HB + (int)vn) - qe;   // :318, :323-329
+					HB = hB;
+				}
+			}
+		}
+		// ---- slot A (blocks 0..3) --------------------------------------------------------
+		{
+			int qi = qbase + lane;
+			const unsigned qbA = (qi >= 0 && qi < QR) ? qr[qi] : 0u;
+			if (lane >= loA && lane <= sc) sA = score_byte(sfA, qbA, C);   // :214-228
+			if (lane <= nTop) {
+				unsigned ut = uA, yt = yA;
+				if (st + lane == r) { yt = 0; ut = r ? C.q8 : 0; }  // :212
+				unsigned xn, vn, un, yn, d;
+				ksw_cell<RIGHT>(sA, xpA, vpA, ut, yt, C, xn, vn, un, yn, d);
+				xA = xn; vA = vn; uA = un; yA = yn;
+				if (with_cigar) pr[lane] = (uint8_t)d;
+				if (lane >= loA && lane <= hiT) {
+					if (r > 0) hA = (lane == spec ? HpA + (int)un : HA + (int)vn) - qe;
+					else hA = (int)vn - qe - qe;                     // :349
+					HA = hA;
+				}
+			}
+		}
+		// ---- exact max (:320-348) ----------------------------------------------------------
+		int max_H = wave_max_i32(hA), max_t;
+		if (nTop >= 64) { const int mb = wave_max_i32(hB); max_H = mb > max_H ? mb : max_H; }
+		{
+			const unsigned long long mA = ballot(hA == max_H && lane >= loA && lane <= hiT);
+			const unsigned long long mB = nTop >= 64 ? ballot(hB == max_H && lane < 16 && 64 + lane >= loA && 64 + lane <= hiT) : 0ull;
+			if (popc64(mA) + popc64(mB) == 1) {
+				max_t = mA ? st + ctz64(mA) : st + 64 + ctz64(mB);
+			} else {
+				// ties: en0 first, then stride classes of the vector part, then the scalar tail
+				const unsigned long long m = loA ? ((mA >> loA) | (mB << (64 - loA))) : mA;   // bit i <-> t = st0 + i
+				const int ie = en0 - st0, nv = (en0 - st0) / 4 * 4;
+				if ((m >> ie) & 1) max_t = en0;
+				else {
+					const unsigned long long mv = nv ? (m & ((1ull << nv) - 1)) : 0ull;
+					max_t = en0;
+					if (mv) {
+						for (int j = 0; j < 4; ++j) {
+							const unsigned long long cm = mv & (0x1111111111111111ull << j);
+							if (cm) { max_t = st0 + ctz64(cm); break; }
+						}
+					} else {
+						const unsigned long long mt = m & ~mv;
+						if (mt) max_t = st0 + ctz64(mt);
+					}
+				}
+			}
+		}
+		// ---- ez updates (:351-357) -----------------------------------------------------------
+		int Hen0 = 0;
+		if (en0 == tlen - 1 || r - st0 == qlen - 1) {
+			Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
+			const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
+			if (en0 == tlen - 1 && Hen0 > mte) { mte = Hen0; mte_q = r - en; }        // rounded en (:352)
+			if (r - st0 == qlen - 1 && Hst0 > mqe) { mqe = Hst0; mqe_t = st0; }
+		}
+		{                                                                             // ksw_apply_zdrop :88-104
+			const int t = max_t;
+			if (max_H > ez_max) { ez_max = max_H; ez_max_t = t; ez_max_q = r - t; }
+			else if (t >= ez_max_t && r - t >= ez_max_q) {
+				const int tl = t - ez_max_t, ql = (r - t) - ez_max_q;
+				const int l = tl > ql ? tl - ql : ql - tl;
+				if (P.zdrop >= 0 && ez_max - max_H > P.zdrop + l * e) { zdropped = 1; break; }
+			}
+		}
+		if (r == qlen + tlen - 2 && en0 == tlen - 1) score = Hen0;                    // :356-357
+		last_st = st; last_en = en;
+	}
+	out.max = ez_max; out.zdropped = zdropped; out.max_q = ez_max_q; out.max_t = ez_max_t;
+	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = score;
+	WSYNC();
+	const long long tc2 = pacc ? (long long)clock64() : 0;
+	if (pacc) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
+	if (!with_cigar) return;
+	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, zdropped, ez_max_t, ez_max_q, cig_tmp, cig_cap, out);
+	if (pacc) pacc[2] += (long long)clock64() - tc2;
+}
+
+}  // namespace ihp
