@@ -13,23 +13,27 @@
 
 namespace ihp {
 
-constexpr int QSLOT = MAXC;      // metadata slot of the read currently being inserted
-
 struct Corr { int qoff; int toff; int qbest; };   // contig.nim:17
 
-struct RegionState {             // LDS, one per wave
-	int off[MAXC + 1], len[MAXC + 1], cap[MAXC + 1];
-	long long nreads[MAXC + 1], start[MAXC + 1];
-	unsigned char alive[MAXC + 1];
-	short listA[MAXC], listB[MAXC];
+// Contig metadata of one region, in LDS, one per wave.  MC = contig slots; slot MC (QSLOT)
+// describes the read currently being inserted.
+template <int MC>
+struct RegionStateT {
+	static constexpr int MAXC = MC;
+	static constexpr int QSLOT = MC;
+	int off[MC + 1], len[MC + 1], cap[MC + 1];
+	long long nreads[MC + 1], start[MC + 1];
+	unsigned smin[MC + 1], smax[MC + 1];          // min / max support of the contig (combine phase)
+	unsigned char alive[MC + 1];
+	short listA[MC], listB[MC];
 	unsigned bitmap[MAXLEN / 32];
 	int bump;
 	int err;
 };
 
 struct Arena {
-	uint8_t *seq;                // [cap]
-	uint32_t *sup;               // [cap]
+	uint8_t *seq;                // [cap] bases; LDS in the batched kernel, HBM otherwise; 4-byte aligned
+	uint32_t *sup;               // [cap] supports (HBM); during the read phase: support DIFFERENCES
 	int cap;                     // total elements
 	int stage_off;               // [stage_off, cap) is the staging area of the read being inserted
 	Corr *corr;                  // [corr_cap] corrections of the winning offset
@@ -71,57 +75,29 @@ __device__ __forceinline__ void wcopy(uint8_t *dseq, uint32_t *dsup, const uint8
 	WSYNC();
 }
 
-__device__ __forceinline__ int alloc_slot(RegionState &S)
+template <class ST>
+__device__ __forceinline__ int alloc_slot(ST &S)
 {
 	const int lane = lane_id();
-	for (int b = 0; b < MAXC; b += 64) {
+	for (int b = 0; b < ST::MAXC; b += 64) {
 		unsigned long long m = ballot(!S.alive[b + lane]);
 		if (m) return b + ctz64(m);
 	}
 	return -1;
 }
 
-// Slide every live contig down to close the holes left by relocations.
-__device__ inline void compact(RegionState &S, Arena &A)
-{
-	const int lane = lane_id();
-	int newbump = 0;
-	long long last = -1;
-	for (;;) {
-		long long key = 0x7fffffffffffffffll;
-		for (int b = 0; b < MAXC; b += 64) {
-			int s = b + lane;
-			if (S.alive[s] && (long long)S.off[s] > last) {
-				long long k = ((long long)S.off[s] << 16) | s;
-				key = k < key ? k : key;
-			}
-		}
-		key = wave_min_ll(key);
-		if (key == 0x7fffffffffffffffll) break;
-		int s = (int)(key & 0xffff), o = (int)(key >> 16), n = S.len[s];
-		WSYNC();
-		if (o != newbump) wcopy(A.seq + newbump, A.sup + newbump, A.seq + o, A.sup + o, n);
-		if (lane == 0) { S.off[s] = newbump; S.cap[s] = n; }
-		WSYNC();
-		newbump += n;
-		last = o;
-	}
-	if (lane == 0) S.bump = newbump;
-	WSYNC();
-}
-
-__device__ inline bool ensure_space(RegionState &S, Arena &A, int need)
-{
-	if (S.bump + need <= A.stage_off) return true;
-	compact(S, A);
-	return S.bump + need <= A.stage_off;
-}
-
+__device__ __forceinline__ int align4(int n);
+template <class ST> __device__ inline bool ensure_space2(ST &S, Arena &A, int need, bool dmode);
+template <class ST> __device__ inline void recompute_minmax(ST &S, const Arena &A, int s);
+template <class ST> __device__ inline Best best_match_combine(const ST &S, const Arena &A, int qs, const short *list, int n,
+                                                              int min_overlap, int max_mm);
+constexpr int SLOT_PAD = 8;      // bytes after a slot's cap: difference entry [cap] + dword over-reads
 __device__ __forceinline__ int headroom(int n) { int h = n >> 1; return h < 128 ? 128 : h; }
 
 // ---- slide_align + best_match (contig.nim:70-141, :224-240) -----------------
 // Scan one target contig; update `best` under the reference's total order.
-__device__ inline void slide_scan(const RegionState &S, const Arena &A, int qs, int ts, int pos,
+template <class ST>
+__device__ inline void slide_scan(const ST &S, const Arena &A, int qs, int ts, int pos,
                                   int min_overlap, int max_mm, int rule, Best &best)
 {
 	const int lane = lane_id();
@@ -187,7 +163,8 @@ __device__ inline void slide_scan(const RegionState &S, const Arena &A, int qs, 
 
 // Corrections of one (q, t, offset), in scan order, into A.corr (contig.nim:99,:128).
 // Returns the count, or -1 if it does not fit.
-__device__ inline int emit_corrections(const RegionState &S, Arena &A, int qs, int ts, int off, int rule)
+template <class ST>
+__device__ inline int emit_corrections(const ST &S, Arena &A, int qs, int ts, int off, int rule)
 {
 	const int lane = lane_id();
 	const uint8_t *qseq = A.seq + S.off[qs], *tseq = A.seq + S.off[ts];
@@ -217,7 +194,8 @@ __device__ inline int emit_corrections(const RegionState &S, Arena &A, int qs, i
 
 // insert(t, q, m) of contig.nim:156-222 with the corrections in A.corr[0..ncorr).
 // Mutates q as the reference does.  Returns 0, or IHP_E_CAPACITY.
-__device__ inline int insert_dev(RegionState &S, Arena &A, int ts, int qs, int off, int ncorr)
+template <class ST>
+__device__ inline int insert_dev(ST &S, Arena &A, int ts, int qs, int off, int ncorr)
 {
 	const int lane = lane_id();
 	const int qlen = S.len[qs], tlen = S.len[ts];
@@ -228,11 +206,11 @@ __device__ inline int insert_dev(RegionState &S, Arena &A, int ts, int qs, int o
 	if (newlen > MAXLEN) return IHP_E_CAPACITY;
 	// room first: compaction moves contigs, so pointers are taken afterwards
 	const bool reloc = off < 0 || newlen > S.cap[ts];
-	int ncap = newlen + headroom(newlen);
+	int ncap = align4(newlen + headroom(newlen));
 	if (reloc) {
-		if (!ensure_space(S, A, ncap)) {
-			ncap = newlen;
-			if (!ensure_space(S, A, ncap)) return IHP_E_CAPACITY;
+		if (!ensure_space2(S, A, ncap, false)) {
+			ncap = align4(newlen);
+			if (!ensure_space2(S, A, ncap, false)) return IHP_E_CAPACITY;
 		}
 	}
 	uint8_t *qseq = A.seq + S.off[qs], *tseq = A.seq + S.off[ts];
@@ -260,7 +238,7 @@ __device__ inline int insert_dev(RegionState &S, Arena &A, int ts, int qs, int o
 		}
 		WSYNC();
 		if (lane == 0) {
-			S.off[ts] = noff; S.len[ts] = newlen; S.cap[ts] = ncap; S.bump = noff + ncap;
+			S.off[ts] = noff; S.len[ts] = newlen; S.cap[ts] = ncap; S.bump = noff + ncap + SLOT_PAD;
 			S.nreads[ts] += S.nreads[qs];                          // :203
 			S.start[ts] = S.start[qs];                             // :204
 		}
@@ -270,7 +248,7 @@ __device__ inline int insert_dev(RegionState &S, Arena &A, int ts, int qs, int o
 	if (reloc) {
 		const int noff = S.bump;
 		wcopy(A.seq + noff, A.sup + noff, tseq, tsup, tlen);
-		if (lane == 0) { S.off[ts] = noff; S.cap[ts] = ncap; S.bump = noff + ncap; }
+		if (lane == 0) { S.off[ts] = noff; S.cap[ts] = ncap; S.bump = noff + ncap + SLOT_PAD; }
 		WSYNC();
 		tseq = A.seq + noff; tsup = A.sup + noff;
 	}
@@ -291,7 +269,8 @@ __device__ inline int insert_dev(RegionState &S, Arena &A, int ts, int qs, int o
 }
 
 // trim(c, min_support) of contig.nim:49-68: only the slot's (off,len,start) move.
-__device__ inline void trim_dev(RegionState &S, const Arena &A, int s, long long min_support)
+template <class ST>
+__device__ inline void trim_dev(ST &S, const Arena &A, int s, long long min_support)
 {
 	const int lane = lane_id();
 	const uint32_t ms = (uint32_t)min_support;
@@ -321,7 +300,8 @@ __device__ inline void trim_dev(RegionState &S, const Arena &A, int s, long long
 }
 
 // best_match (contig.nim:224-240) over `list[0..n)`.
-__device__ inline Best best_match_dev(const RegionState &S, const Arena &A, int qs, const short *list, int n,
+template <class ST>
+__device__ inline Best best_match_dev(const ST &S, const Arena &A, int qs, const short *list, int n,
                                       int min_overlap, int max_mm)
 {
 	Best best = {0, 0, 0, -1, -1, 0};
@@ -334,7 +314,8 @@ __device__ inline Best best_match_dev(const RegionState &S, const Arena &A, int 
 }
 
 // One pass of combine (contig.nim:263-281): `in` -> `out`, returns the new count or <0.
-__device__ inline int combine_pass(RegionState &S, Arena &A, short *in, int n, short *out, long long min_support,
+template <class ST>
+__device__ inline int combine_pass(ST &S, Arena &A, short *in, int n, short *out, long long min_support,
                                    int combine_min_overlap, int max_mm)
 {
 	const int lane = lane_id();
@@ -344,6 +325,7 @@ __device__ inline int combine_pass(RegionState &S, Arena &A, short *in, int n, s
 		if (min_support > 0) {
 			const long long ms = S.nreads[c] < min_support ? S.nreads[c] : min_support;
 			trim_dev(S, A, c, ms);
+			recompute_minmax(S, A, c);
 		}
 		if (S.nreads[c] > 0 && nout == 0) {
 			if (lane == 0) out[0] = (short)c;
@@ -359,13 +341,14 @@ __device__ inline int combine_pass(RegionState &S, Arena &A, short *in, int n, s
 	for (int i = 0; i < n; ++i) {                                  // :274-281
 		if (i == usedi) continue;
 		const int c = in[i];
-		Best b = best_match_dev(S, A, c, out, nout, combine_min_overlap, max_mm);
+		Best b = best_match_combine(S, A, c, out, nout, combine_min_overlap, max_mm);
 		if (b.found) {
 			const int nc = emit_corrections(S, A, c, b.slot, b.off, IHP_ALLOW_DEFAULT);
 			if (nc < 0) return IHP_E_CAPACITY;
 			const int rc = insert_dev(S, A, b.slot, c, b.off, nc);
 			if (rc) return rc;
 			if (lane == 0) S.alive[c] = 0;
+			recompute_minmax(S, A, b.slot);
 		} else if (S.nreads[c] > 0) {
 			if (lane == 0) out[nout] = (short)c;
 			nout++;
@@ -375,6 +358,328 @@ __device__ inline int combine_pass(RegionState &S, Arena &A, short *in, int n, s
 		WSYNC();
 	}
 	return nout;
+}
+
+
+// ============================================================================================
+// Fast paths.  (1) Exact-match scan: with max_mismatch == 0 and no position where the vote rule
+// (contig.nim:44-47) can fire, slide_align reduces to "longest exactly matching overlap, first in
+// scan order", done here on 8 / 4 bases per lane with dword loads from the 4-byte aligned arena.
+// (2) Read phase of assemble (indelope.nim:163-169): every query is a fresh read (support 1
+// everywhere, nreads 1), for which the vote rule can never fire because every contig base has
+// support >= 1; `t.support[i] += q.support[j]` over the overlap is then a +1 on a range, kept as a
+// DIFFERENCE array in A.sup (two scalar updates per insert) and turned into supports by one prefix
+// sum per contig before combine (materialize_supports).
+// ============================================================================================
+__device__ __forceinline__ int align4(int n) { return (n + 3) & ~3; }
+
+__device__ __forceinline__ unsigned ld32u(const uint32_t *b32, int byteoff)
+{   // unaligned 32-bit load
+	const int w = byteoff >> 2;
+	return __builtin_amdgcn_alignbit(b32[w + 1], b32[w], (unsigned)(byteoff & 3) * 8u);
+}
+
+__device__ __forceinline__ void ld64u(const uint32_t *b32, int byteoff, unsigned &lo, unsigned &hi)
+{
+	const int w = byteoff >> 2;
+	const unsigned sh = (unsigned)(byteoff & 3) * 8u;
+	const unsigned w0 = b32[w], w1 = b32[w + 1], w2 = b32[w + 2];
+	lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+	hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+}
+
+// Can allowable_mismatch (default rule) be true for any pair of positions of q and t?  Necessary
+// condition from the per-contig support extrema; false => the exact scan is equivalent.
+template <class ST>
+__device__ __forceinline__ bool may_allow(const ST &S, int qs, int ts)
+{
+	const unsigned qmin = S.smin[qs], qmax = S.smax[qs], tmin = S.smin[ts], tmax = S.smax[ts];
+	const long long qreads = S.nreads[qs], treads = S.nreads[ts];
+	const bool p1 = qmin < 3u && tmax > 3u * qmin && qreads > 3ll * (long long)qmin;
+	const bool p2 = tmin < 3u && qmax > 3u * tmin && treads > 3ll * (long long)tmin;
+	return p1 || p2;
+}
+
+// slide_align for max_mismatch == 0 without votes (contig.nim:70-141), same total order as slide_scan.
+template <class ST>
+__device__ inline void slide_scan_exact(const ST &S, const Arena &A, int qs, int ts, int pos, int min_overlap, Best &best)
+{
+	const int lane = lane_id();
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	const int qb = S.off[qs], tb = S.off[ts];
+	const int qlen = S.len[qs], tlen = S.len[ts];
+	const int omax = tlen - min_overlap;
+	int omin_abs = qlen - min_overlap;
+	if (omin_abs < 0) omin_abs = -omin_abs;
+	const int n1 = omax >= 0 ? omax + 1 : 0;
+	const int total = n1 + omin_abs;
+	if (total <= 0) return;
+	unsigned q0, q1, t0, t1;                         // first 8 bases of q and of t (wave-uniform)
+	ld64u(a32, qb, q0, q1);
+	ld64u(a32, tb, t0, t1);
+	for (int base = 0; base < total; base += 64) {
+		const int idx = base + lane;
+		const bool ph1 = idx < n1;
+		const int o = ph1 ? idx : idx - n1 + 1;
+		int n = ph1 ? (qlen < tlen - o ? qlen : tlen - o) : (qlen - o < tlen ? qlen - o : tlen);
+		if (n < 0) n = 0;
+		// accepted offsets have mm == 0, so a later one only wins with strictly more matches (:107)
+		const int need = best.found ? best.ma + 1 : min_overlap - 1;
+		bool surv = idx < total && n >= need;
+		if (surv) {
+			unsigned lo, hi;
+			ld64u(a32, ph1 ? tb + o : qb + o, lo, hi);
+			unsigned x0 = lo ^ (ph1 ? q0 : t0), x1 = hi ^ (ph1 ? q1 : t1);
+			if (n < 8) {
+				if (n <= 4) { x1 = 0; x0 = n == 4 ? x0 : (n == 0 ? 0u : x0 & ((1u << (8 * n)) - 1u)); }
+				else x1 &= (1u << (8 * (n - 4))) - 1u;
+			}
+			surv = (x0 | x1) == 0;
+		}
+		unsigned long long mask = ballot(surv);
+		while (mask) {
+			const int sl = ctz64(mask);
+			mask &= mask - 1;
+			const int co = bcast(o, sl), cn = bcast(n, sl), cph = bcast((int)ph1, sl);
+			if (best.found && cn <= best.ma) continue;          // uniform
+			const int cq = cph ? 0 : co, ct = cph ? co : 0;
+			bool ok = true;
+			for (int k0 = 0; k0 < cn; k0 += 256) {
+				const int k = k0 + 4 * lane;
+				bool bad = false;
+				if (k < cn) {
+					unsigned x = ld32u(a32, qb + cq + k) ^ ld32u(a32, tb + ct + k);
+					const int rem = cn - k;
+					if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+					bad = x != 0;
+				}
+				if (ballot(bad)) { ok = false; break; }
+			}
+			if (ok && cn >= min_overlap - 1 && (!best.found || cn > best.ma)) {
+				best.found = 1; best.ma = cn; best.mm = 0; best.pos = pos; best.slot = ts;
+				best.off = cq ? -cq : ct;
+			}
+		}
+	}
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ unsigned wave_scan_add(unsigned v)
+{
+	const int lane = lane_id();
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned o = (unsigned)__shfl_up((int)v, d, 64);
+		if (lane >= d) v += o;
+	}
+	return v;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+	for (int d = 32; d >= 1; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+	return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+	for (int d = 32; d >= 1; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
+	return v;
+}
+
+template <class ST>
+__device__ inline void recompute_minmax(ST &S, const Arena &A, int s)
+{
+	const int lane = lane_id();
+	const uint32_t *sup = A.sup + S.off[s];
+	const int n = S.len[s];
+	unsigned mn = 0xffffffffu, mx = 0;
+	for (int i = lane; i < n; i += 64) { const unsigned v = sup[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+	mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+	if (lane == 0) { S.smin[s] = mn; S.smax[s] = mx; }
+	WSYNC();
+}
+
+// Difference arrays -> supports, in place, plus the support extrema (end of the read phase).
+template <class ST>
+__device__ inline void materialize_supports(ST &S, Arena &A, const short *list, int n)
+{
+	const int lane = lane_id();
+	for (int c = 0; c < n; ++c) {
+		const int s = list[c];
+		uint32_t *d = A.sup + S.off[s];
+		const int len = S.len[s];
+		unsigned carry = 0, mn = 0xffffffffu, mx = 0;
+		for (int i0 = 0; i0 < len; i0 += 64) {
+			const int i = i0 + lane;
+			unsigned v = i < len ? d[i] : 0u;
+			v = wave_scan_add(v) + carry;
+			if (i < len) { d[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+			carry = (unsigned)__shfl((int)v, 63, 64);
+		}
+		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+		if (lane == 0) { S.smin[s] = mn; S.smax[s] = mx; }
+	}
+	WSYNC();
+}
+
+// Close the holes of the arena (read-phase flavour keeps the difference arrays valid: len+1 entries
+// move, the rest of the new capacity is zeroed).
+template <class ST>
+__device__ inline void compact2(ST &S, Arena &A, bool dmode)
+{
+	const int lane = lane_id();
+	int newbump = 0;
+	long long last = -1;
+	for (;;) {
+		long long key = 0x7fffffffffffffffll;
+		for (int b = 0; b < ST::MAXC; b += 64) {
+			const int s = b + lane;
+			if (S.alive[s] && (long long)S.off[s] > last) {
+				const long long k = ((long long)S.off[s] << 16) | s;
+				key = k < key ? k : key;
+			}
+		}
+		key = wave_min_ll(key);
+		if (key == 0x7fffffffffffffffll) break;
+		const int s = (int)(key & 0xffff), o = (int)(key >> 16), n = S.len[s];
+		const int ncap = align4(n);
+		WSYNC();
+		if (o != newbump) {
+			// ascending 64-element chunks; dst < src so a chunk is fully read before it is overwritten
+			const int nd = dmode ? n + 1 : n;
+			for (int i0 = 0; i0 < nd; i0 += 64) {
+				const int i = i0 + lane;
+				uint8_t b = 0; uint32_t v = 0;
+				if (i < n) b = A.seq[o + i];
+				if (i < nd) v = A.sup[o + i];
+				WSYNC();
+				if (i < n) A.seq[newbump + i] = b;
+				if (i < nd) A.sup[newbump + i] = v;
+			}
+			WSYNC();
+		}
+		if (dmode) for (int i = n + 1 + lane; i <= ncap; i += 64) A.sup[newbump + i] = 0;
+		if (lane == 0) { S.off[s] = newbump; S.cap[s] = ncap; }
+		WSYNC();
+		newbump += ncap + SLOT_PAD;
+		last = o;
+	}
+	if (lane == 0) S.bump = newbump;
+	WSYNC();
+}
+
+template <class ST>
+__device__ inline bool ensure_space2(ST &S, Arena &A, int need, bool dmode)
+{
+	if (S.bump + need + SLOT_PAD <= A.stage_off) return true;
+	compact2(S, A, dmode);
+	return S.bump + need + SLOT_PAD <= A.stage_off;
+}
+
+// New contig from the staged read (contig.nim:143-150, :248), read-phase representation.
+template <class ST>
+__device__ inline int new_contig_from_read(ST &S, Arena &A, int &slot_out)
+{
+	const int lane = lane_id();
+	const int tl = S.len[ST::QSLOT];
+	const int slot = alloc_slot(S);
+	if (slot < 0) return IHP_E_CAPACITY;
+	int cap = align4(tl + headroom(tl));
+	if (!ensure_space2(S, A, cap, true)) { cap = align4(tl); if (!ensure_space2(S, A, cap, true)) return IHP_E_CAPACITY; }
+	const int noff = S.bump;
+	for (int i = lane; i < tl; i += 64) A.seq[noff + i] = A.seq[A.stage_off + i];
+	for (int i = lane; i <= cap; i += 64) A.sup[noff + i] = i == 0 ? 1u : (i == tl ? 0xffffffffu : 0u);   // +1 on [0, tl)
+	if (tl == 0 && lane == 0) A.sup[noff] = 0;
+	if (lane == 0) {
+		S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = cap; S.nreads[slot] = 1;
+		S.start[slot] = S.start[ST::QSLOT]; S.alive[slot] = 1; S.bump = noff + cap + SLOT_PAD;
+	}
+	WSYNC();
+	slot_out = slot;
+	return 0;
+}
+
+// insert(t, q, m) of contig.nim:156-222 for a fresh read q (no corrections possible), with the
+// supports kept as differences.
+template <class ST>
+__device__ inline int insert_read(ST &S, Arena &A, int ts, int off)
+{
+	const int lane = lane_id();
+	const int qs = ST::QSLOT;
+	const int qlen = S.len[qs], tlen = S.len[ts];
+	const int aoff = off < 0 ? -off : off;
+	int newlen;
+	if (off < 0) { newlen = aoff + tlen; if (qlen > newlen) newlen = qlen; }
+	else { newlen = tlen; if (off + qlen > newlen) newlen = off + qlen; }
+	if (newlen > MAXLEN) return IHP_E_CAPACITY;
+	const bool reloc = off < 0 || newlen > S.cap[ts];
+	int ncap = align4(newlen + headroom(newlen));
+	if (reloc) {
+		if (!ensure_space2(S, A, ncap, true)) { ncap = align4(newlen); if (!ensure_space2(S, A, ncap, true)) return IHP_E_CAPACITY; }
+	}
+	const uint8_t *qseq = A.seq + S.off[qs];
+	uint8_t *tseq = A.seq + S.off[ts];
+	uint32_t *td = A.sup + S.off[ts];
+	if (off < 0) {                                                 // :180-205
+		const int noff = S.bump;
+		uint8_t *nseq = A.seq + noff; uint32_t *nd = A.sup + noff;
+		for (int i = lane; i < newlen; i += 64)
+			nseq[i] = i < aoff ? qseq[i] : (i < aoff + tlen ? tseq[i - aoff] : qseq[i]);
+		for (int i = lane; i <= ncap; i += 64) {
+			uint32_t v = (i >= aoff && i - aoff <= tlen) ? td[i - aoff] : 0u;
+			if (i == 0) v += 1u;                                   // q covers [0, qlen) of the new contig
+			if (i == qlen) v -= 1u;
+			nd[i] = v;
+		}
+		WSYNC();
+		if (lane == 0) {
+			S.off[ts] = noff; S.len[ts] = newlen; S.cap[ts] = ncap; S.bump = noff + ncap + SLOT_PAD;
+			S.nreads[ts] += 1;                                     // :203
+			S.start[ts] = S.start[qs];                             // :204
+		}
+		WSYNC();
+		return 0;
+	}
+	if (reloc) {
+		const int noff = S.bump;
+		uint8_t *nseq = A.seq + noff; uint32_t *nd = A.sup + noff;
+		for (int i = lane; i < tlen; i += 64) nseq[i] = tseq[i];
+		for (int i = lane; i <= ncap; i += 64) nd[i] = i <= tlen ? td[i] : 0u;
+		WSYNC();
+		if (lane == 0) { S.off[ts] = noff; S.cap[ts] = ncap; S.bump = noff + ncap + SLOT_PAD; }
+		WSYNC();
+		tseq = nseq; td = nd;
+	}
+	for (int i = tlen + lane; i < newlen; i += 64) tseq[i] = qseq[i - off];   // :220-221
+	if (lane == 0) {
+		td[off] += 1u; td[off + qlen] -= 1u;                       // :216-219 as a range update
+		S.len[ts] = newlen; S.nreads[ts] += 1;                     // :222
+	}
+	WSYNC();
+	return 0;
+}
+
+// best_match (contig.nim:224-240) for a fresh read against list[0..n): always the exact scan.
+template <class ST>
+__device__ inline Best best_match_read(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
+{
+	Best best = {0, 0, 0, -1, -1, 0};
+	for (int i = 0; i < n; ++i) slide_scan_exact(S, A, ST::QSLOT, list[i], i, min_overlap, best);
+	return best;
+}
+
+// best_match for the combine phase: exact scan when the vote rule cannot fire for the pair.
+template <class ST>
+__device__ inline Best best_match_combine(const ST &S, const Arena &A, int qs, const short *list, int n,
+                                          int min_overlap, int max_mm)
+{
+	Best best = {0, 0, 0, -1, -1, 0};
+	for (int i = 0; i < n; ++i) {
+		const int ts = list[i];
+		if (ts == qs) continue;                                    // :227
+		if (max_mm == 0 && !may_allow(S, qs, ts)) slide_scan_exact(S, A, qs, ts, i, min_overlap, best);
+		else slide_scan(S, A, qs, ts, i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, best);
+	}
+	return best;
 }
 
 }  // namespace ihp

@@ -12,7 +12,6 @@
 namespace ihp {
 
 constexpr int WAVE = 64;
-constexpr int MAXC = 256;        // contig slots per region (live at any time)
 constexpr int MAXLEN = 8192;     // longest contig the assembly kernel will build
 constexpr int FILTER_CH = 8;     // bases examined by the per-offset prefilter
 

@@ -339,12 +339,12 @@ static int contig_op(int op, ihp_contig *t, ihp_contig *q, int64_t min_overlap, 
 	if (rc) return rc;
 	const int64_t tl = t->len, ql = q ? q->len : 0;
 	if (tl < 0 || ql < 0 || tl > MAXLEN || ql > MAXLEN) return IHP_E_CAPACITY;
-	const int t_cap = (int)tl + 16, q_cap = (int)ql + 16;
+	const int t_cap = ((int)tl + 3) / 4 * 4 + 16, q_cap = ((int)ql + 3) / 4 * 4 + 16;
 	const int arena_cap = t_cap + q_cap + 3 * (int)(tl + ql) + 1024;
 	const int corr_cap = (int)std::max<int64_t>(tl + ql, 16);
 	DBuf d_seq, d_sup, d_corr, d_res;
-	if ((rc = d_seq.alloc((size_t)arena_cap))) return rc;
-	if ((rc = d_sup.alloc(sizeof(uint32_t) * (size_t)arena_cap))) return rc;
+	if ((rc = d_seq.alloc((size_t)arena_cap + 64))) return rc;
+	if ((rc = d_sup.alloc(sizeof(uint32_t) * ((size_t)arena_cap + 64)))) return rc;
 	if ((rc = d_corr.alloc(sizeof(Corr) * (size_t)corr_cap))) return rc;
 	if ((rc = d_res.alloc(sizeof(long long) * 16))) return rc;
 	if (tl) {
@@ -484,7 +484,8 @@ struct ihp_batch {
 	DBuf region_read_off, read_off, bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin;
 	bool has_quals = false, has_skip = false;
 	// scratch
-	DBuf arena_seq, arena_sup, corr, p_scratch, cig_tmp, misc, prof;
+	DBuf arena_seq, arena_sup, lds_sup, corr, p_scratch, cig_tmp, misc, prof, retry_list;
+	int grid_retry = 0;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
@@ -499,7 +500,7 @@ struct ihp_batch {
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_WORDS = 16 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_WORDS = 16 };
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
@@ -547,9 +548,10 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
 #undef UP
 	// scratch sizing
-	b->grid_asm = grid_for(R, 16);
+	b->grid_asm = grid_for(R, 12);
+	b->grid_retry = grid_for(R, 2);
 	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
-	b->arena_cap = 3 * b->max_region_bases + 4 * b->stage_cap + 2048;
+	b->arena_cap = (3 * b->max_region_bases + 4 * b->stage_cap + 2048 + 15) / 16 * 16;
 	b->corr_cap = std::min(MAXLEN, b->max_region_bases) + 16;
 	const long long slots = NR;
 	// ksw2: contig length is bounded by the region's read bases (every contig base comes from a read)
@@ -575,9 +577,11 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	b->cig_pool_cap = 64 * njobs_cap + 1024;
 	b->ev_pool_cap = (long long)std::max(1, p->max_events) * njobs_cap + 16;
 #define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
-	AL(arena_seq, (size_t)b->arena_cap * b->grid_asm);
-	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_asm);
-	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * b->grid_asm);
+	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);
+	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_retry);
+	AL(lds_sup, sizeof(uint32_t) * (size_t)LDS_ARENA * b->grid_asm);
+	AL(retry_list, sizeof(int) * (size_t)R);
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(b->grid_asm, b->grid_retry));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(misc, sizeof(int) * M_WORDS);
@@ -620,8 +624,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.combine_min_overlap = p.combine_min_overlap; a.max_mismatch = p.max_mismatch;
 		a.max_pre_contigs = p.max_pre_contigs; a.min_ctg_len = p.min_ctg_len; a.min_reads = p.min_reads;
 		a.K = p.K; a.ref_pad = p.ref_pad;
-		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>();
-		a.arena_cap = b->arena_cap; a.stage_cap = b->stage_cap; a.corr = b->corr.as<Corr>(); a.corr_cap = b->corr_cap;
+		a.stage_cap = b->stage_cap; a.corr = b->corr.as<Corr>(); a.corr_cap = b->corr_cap;
+		a.retry_list = b->retry_list.as<int>(); a.n_retry = misc + M_NRETRY;
 		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
 		a.ctg_start = b->ctg_start.as<long long>(); a.ctg_nreads = b->ctg_nreads.as<long long>();
 		a.ctg_seq_off = b->ctg_seq_off.as<long long>(); a.ctg_len = b->ctg_len.as<int>();
@@ -630,7 +634,13 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = misc + M_CNT_ASM;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
-		hipLaunchKernelGGL(k_assemble, dim3(b->grid_asm), dim3(64), 0, s, a);
+		// pass 1: contig bases in LDS; pass 2: the regions that did not fit, with an HBM arena
+		a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = LDS_ARENA;
+		hipLaunchKernelGGL((k_assemble<128, true>), dim3(b->grid_asm), dim3(64), 0, s, a);
+		HIPC(hipGetLastError());
+		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>(); a.arena_cap = b->arena_cap;
+		a.work_counter = misc + M_CNT_RETRY;
+		hipLaunchKernelGGL((k_assemble<1024, false>), dim3(b->grid_retry), dim3(64), 0, s, a);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[1], s));

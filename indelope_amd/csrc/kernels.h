@@ -30,6 +30,7 @@ struct AsmArgs {
 	uint8_t *out_seq; uint32_t *out_sup;
 	AlnJob *jobs; int *n_jobs;
 	int *work_counter;
+	int *retry_list, *n_retry;                         // regions that did not fit the LDS arena
 	long long *prof;                                   // optional cycle counters (diagnostics)
 };
 
@@ -57,11 +58,16 @@ __device__ inline int read_trim_dev(const uint8_t *q, int n, int min_quality, in
 	return a;
 }
 
-__device__ inline int assemble_region(const AsmArgs &a, RegionState &S, Arena &A, int r, int &n_pre, int &n_final)
+// assemble (indelope.nim:157-183) for one region.  FAST = max_mismatch == 0: read phase with the
+// exact scan and difference-array supports (contig_dev.h "Fast paths"); otherwise the generic scan.
+template <class ST>
+__device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, int &n_pre, int &n_final)
 {
+	constexpr int QSLOT = ST::QSLOT;
 	const int lane = lane_id();
 	const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
-	for (int i = lane; i <= MAXC; i += 64) S.alive[i] = 0;
+	const bool fast = a.max_mismatch == 0;
+	for (int i = lane; i <= ST::MAXC; i += 64) S.alive[i] = 0;
 	if (lane == 0) { S.bump = 0; S.err = 0; }
 	WSYNC();
 	int n = 0;
@@ -75,37 +81,56 @@ __device__ inline int assemble_region(const AsmArgs &a, RegionState &S, Arena &A
 		if (a.quals) o = read_trim_dev(a.quals + b0, len, a.trim_min_qual, lo, hi);   // :168
 		const int tl = hi - lo;
 		if (tl > a.stage_cap || tl > MAXLEN) return IHP_E_CAPACITY;
-		for (int i = lane; i < tl; i += 64) { A.seq[A.stage_off + i] = a.bases[b0 + lo + i]; A.sup[A.stage_off + i] = 1u; }
+		for (int i = lane; i < tl; i += 64) A.seq[A.stage_off + i] = a.bases[b0 + lo + i];
+		if (!fast) for (int i = lane; i < tl; i += 64) A.sup[A.stage_off + i] = 1u;
 		if (lane == 0) {                                       // make_contig, contig.nim:143-150
 			S.off[QSLOT] = A.stage_off; S.len[QSLOT] = tl; S.cap[QSLOT] = tl;
 			S.nreads[QSLOT] = 1; S.start[QSLOT] = a.read_start[ri] + o;
+			S.smin[QSLOT] = 1; S.smax[QSLOT] = 1;
 		}
 		WSYNC();
 		const int min_overlap = (int)(a.min_overlap_pct * (double)tl);   // :169
-		Best b = best_match_dev(S, A, QSLOT, S.listA, n, min_overlap, a.max_mismatch);   // contig.nim:243-244
-		if (b.found) {
-			const int nc = emit_corrections(S, A, QSLOT, b.slot, b.off, IHP_ALLOW_DEFAULT);
-			if (nc < 0) return IHP_E_CAPACITY;
-			const int rc = insert_dev(S, A, b.slot, QSLOT, b.off, nc);   // contig.nim:246
-			if (rc) return rc;
-		} else {                                               // contig.nim:248
-			const int slot = alloc_slot(S);
-			if (slot < 0 || n >= MAXC) return IHP_E_CAPACITY;
-			int need = tl + headroom(tl);
-			if (!ensure_space(S, A, need)) { need = tl; if (!ensure_space(S, A, need)) return IHP_E_CAPACITY; }
-			const int noff = S.bump;
-			for (int i = lane; i < tl; i += 64) { A.seq[noff + i] = A.seq[A.stage_off + i]; A.sup[noff + i] = 1u; }
-			if (lane == 0) {
-				S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = need; S.nreads[slot] = 1;
-				S.start[slot] = S.start[QSLOT]; S.alive[slot] = 1; S.bump = noff + need;
-				S.listA[n] = (short)slot;
+		if (fast) {
+			Best b = best_match_read(S, A, S.listA, n, min_overlap);     // contig.nim:243-244
+			if (b.found) {
+				const int rc = insert_read(S, A, b.slot, b.off);         // contig.nim:246
+				if (rc) return rc;
+			} else {                                           // contig.nim:248
+				if (n >= ST::MAXC) return IHP_E_CAPACITY;
+				int slot;
+				const int rc = new_contig_from_read(S, A, slot);
+				if (rc) return rc;
+				if (lane == 0) S.listA[n] = (short)slot;
+				n++;
 			}
-			n++;
+		} else {
+			Best b = best_match_dev(S, A, QSLOT, S.listA, n, min_overlap, a.max_mismatch);
+			if (b.found) {
+				const int nc = emit_corrections(S, A, QSLOT, b.slot, b.off, IHP_ALLOW_DEFAULT);
+				if (nc < 0) return IHP_E_CAPACITY;
+				const int rc = insert_dev(S, A, b.slot, QSLOT, b.off, nc);
+				if (rc) return rc;
+			} else {
+				const int slot = alloc_slot(S);
+				if (slot < 0 || n >= ST::MAXC) return IHP_E_CAPACITY;
+				int need = align4(tl + headroom(tl));
+				if (!ensure_space2(S, A, need, false)) { need = align4(tl); if (!ensure_space2(S, A, need, false)) return IHP_E_CAPACITY; }
+				const int noff = S.bump;
+				for (int i = lane; i < tl; i += 64) { A.seq[noff + i] = A.seq[A.stage_off + i]; A.sup[noff + i] = 1u; }
+				if (lane == 0) {
+					S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = need; S.nreads[slot] = 1;
+					S.start[slot] = S.start[QSLOT]; S.alive[slot] = 1; S.bump = noff + need + SLOT_PAD;
+					S.listA[n] = (short)slot;
+				}
+				n++;
+			}
 		}
 		WSYNC();
 	}
 	n_pre = n;                                                 // :171
 	const long long tcA = a.prof ? (long long)clock64() : 0;
+	if (fast) materialize_supports(S, A, S.listA, n);
+	else for (int i = 0; i < n; ++i) recompute_minmax(S, A, S.listA[i]);
 	// combine(min_support) = pass with min_support 0, then the trimmed pass (contig.nim:259-260)
 	const int n2 = combine_pass(S, A, S.listA, n, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
 	if (n2 < 0) return n2;
@@ -118,27 +143,40 @@ __device__ inline int assemble_region(const AsmArgs &a, RegionState &S, Arena &A
 	return 0;
 }
 
+// MC contig slots; LDSA: contig bases in an LDS arena of LDS_ARENA bytes (regions that do not fit are
+// queued for the HBM-arena instantiation through retry_list).
+constexpr int LDS_ARENA = 8192;
+
+template <int MC, bool LDSA>
 __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 {
-	__shared__ RegionState S;
+	typedef RegionStateT<MC> ST;
+	__shared__ ST S;
 	__shared__ int s_item;
+	__shared__ __attribute__((aligned(16))) uint8_t lds_arena[LDSA ? LDS_ARENA : 16];
 	const int lane = lane_id();
 	Arena A;
-	A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap;
 	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
-	A.cap = a.arena_cap; A.stage_off = a.arena_cap - a.stage_cap;
+	if (LDSA) { A.seq = lds_arena; A.cap = LDS_ARENA - 16; A.stage_off = LDS_ARENA - 16 - a.stage_cap; }
+	else { A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap; A.cap = a.arena_cap - 16; A.stage_off = a.arena_cap - 16 - a.stage_cap; }
 	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap;
 	for (;;) {
 		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
 		WSYNC();
-		const int r = s_item;
+		int r = s_item;
 		WSYNC();
-		if (r >= a.n_regions) break;
+		if (LDSA) { if (r >= a.n_regions) break; }
+		else { if (r >= *a.n_retry) break; r = a.retry_list[r]; }
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
-		const int err = assemble_region(a, S, A, r, n_pre, n_final);
+		int err = assemble_region(a, S, A, r, n_pre, n_final);
 		WSYNC();
 		if (a.prof && lane == 0) { atomicAdd((unsigned long long *)&a.prof[0], (unsigned long long)((long long)clock64() - tcR)); atomicAdd((unsigned long long *)&a.prof[3], 1ull); }
+		if (LDSA && err == IHP_E_CAPACITY) {                   // does not fit the LDS arena / slot count: HBM pass
+			if (lane == 0) a.retry_list[atomicAdd(a.n_retry, 1)] = r;
+			WSYNC();
+			continue;
+		}
 		if (err) n_final = 0;
 		const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
 		// max_stop over reads with mapq > 5 (indelope.nim:213-216)
@@ -364,15 +402,16 @@ struct OpArgs {
 
 __global__ __launch_bounds__(64) void k_contig_op(const OpArgs a)
 {
-	__shared__ RegionState S;
+	typedef RegionStateT<64> ST;
+	__shared__ ST S;
 	const int lane = lane_id();
 	Arena A; A.seq = a.arena_seq; A.sup = a.arena_sup; A.cap = a.arena_cap; A.stage_off = a.arena_cap;
 	A.corr = a.corr; A.corr_cap = a.corr_cap;
-	for (int i = lane; i <= MAXC; i += 64) S.alive[i] = 0;
+	for (int i = lane; i <= ST::MAXC; i += 64) S.alive[i] = 0;
 	if (lane == 0) {
 		S.off[0] = a.t_off; S.len[0] = a.t_len; S.cap[0] = a.t_cap; S.nreads[0] = a.t_nreads; S.start[0] = a.t_start; S.alive[0] = 1;
 		S.off[1] = a.q_off; S.len[1] = a.q_len; S.cap[1] = a.q_cap; S.nreads[1] = a.q_nreads; S.start[1] = a.q_start; S.alive[1] = 1;
-		S.bump = a.q_off + a.q_cap; S.err = 0;
+		S.bump = align4(a.q_off + a.q_cap); S.err = 0;
 	}
 	WSYNC();
 	long long rc = 0, found = 0, ma = 0, mm = 0, off = 0, nc = 0;
