@@ -24,6 +24,7 @@ struct RegionStateT {
 	int off[MC + 1], len[MC + 1], cap[MC + 1];
 	long long nreads[MC + 1], start[MC + 1];
 	unsigned smin[MC + 1], smax[MC + 1];          // min / max support of the contig (combine phase)
+	int lo3[MC + 1], hi3[MC + 1];                 // every base in [lo3, hi3) has support >= 3 (empty if lo3 >= hi3)
 	unsigned char alive[MC + 1];
 	short listA[MC], listB[MC];
 	unsigned bitmap[MAXLEN / 32];
@@ -38,7 +39,11 @@ struct Arena {
 	int stage_off;               // [stage_off, cap) is the staging area of the read being inserted
 	Corr *corr;                  // [corr_cap] corrections of the winning offset
 	int corr_cap;
+	long long *prof;             // optional cycle counters (diagnostics)
 };
+
+#define IHP_T0(A) const long long t0_ = (A).prof ? (long long)clock64() : 0
+#define IHP_T1(A, k) do { if ((A).prof && lane_id() == 0) atomicAdd((unsigned long long *)&(A).prof[k], (unsigned long long)((long long)clock64() - t0_)); } while (0)
 
 struct Best {
 	int found, ma, mm, pos, slot, off;
@@ -86,7 +91,23 @@ __device__ __forceinline__ int alloc_slot(ST &S)
 	return -1;
 }
 
-__device__ __forceinline__ int align4(int n);
+__device__ __forceinline__ int align4(int n) { return (n + 3) & ~3; }
+
+__device__ __forceinline__ unsigned ld32u(const uint32_t *b32, int byteoff)
+{   // unaligned 32-bit load
+	const int w = byteoff >> 2;
+	return __builtin_amdgcn_alignbit(b32[w + 1], b32[w], (unsigned)(byteoff & 3) * 8u);
+}
+
+__device__ __forceinline__ void ld64u(const uint32_t *b32, int byteoff, unsigned &lo, unsigned &hi)
+{
+	const int w = byteoff >> 2;
+	const unsigned sh = (unsigned)(byteoff & 3) * 8u;
+	const unsigned w0 = b32[w], w1 = b32[w + 1], w2 = b32[w + 2];
+	lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+	hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+}
+
 template <class ST> __device__ inline bool ensure_space2(ST &S, Arena &A, int need, bool dmode);
 template <class ST> __device__ inline void recompute_minmax(ST &S, const Arena &A, int s);
 template <class ST> __device__ inline Best best_match_combine(const ST &S, const Arena &A, int qs, const short *list, int n,
@@ -105,6 +126,9 @@ __device__ inline void slide_scan(const ST &S, const Arena &A, int qs, int ts, i
 	const uint32_t *qsup = A.sup + S.off[qs], *tsup = A.sup + S.off[ts];
 	const int qlen = S.len[qs], tlen = S.len[ts];
 	const long long qreads = S.nreads[qs], treads = S.nreads[ts];
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	const int qb = S.off[qs], tb = S.off[ts];
+	const int qlo3 = S.lo3[qs], qhi3 = S.hi3[qs], tlo3 = S.lo3[ts], thi3 = S.hi3[ts];
 	const int omax = tlen - min_overlap;                       // :79
 	int omin_abs = qlen - min_overlap;                         // :78, :114 abs(omin)
 	if (omin_abs < 0) omin_abs = -omin_abs;
@@ -122,15 +146,32 @@ __device__ inline void slide_scan(const ST &S, const Arena &A, int qs, int ts, i
 		const int need = best.found && best.ma > min_overlap - 1 ? best.ma : min_overlap - 1;
 		bool surv = active && n >= need;
 		if (surv) {
-			int mmf = 0;
-			const int nf = n < FILTER_CH ? n : FILTER_CH;
-			for (int k = 0; k < nf; ++k) {
-				if (qseq[qo0 + k] != tseq[to0 + k] &&
-				    !allowed(rule, qsup[qo0 + k], tsup[to0 + k], qreads, treads)) {
-					if (++mmf > max_mm) break;
+			// A window of 8 bases where both contigs have support >= 3 everywhere: a mismatch there can
+			// never be voted away (contig.nim:44-47 needs qsup < 3 or tsup < 3), so counting differing
+			// bytes is exact.  Otherwise examine the first bases one by one with the supports.
+			int klo = qlo3 - qo0 > tlo3 - to0 ? qlo3 - qo0 : tlo3 - to0;
+			if (klo < 0) klo = 0;
+			int khi = qhi3 - qo0 < thi3 - to0 ? qhi3 - qo0 : thi3 - to0;
+			if (khi > n) khi = n;
+			if (khi - klo >= 8) {
+				unsigned a0, a1, b0, b1;
+				ld64u(a32, qb + qo0 + klo, a0, a1);
+				ld64u(a32, tb + to0 + klo, b0, b1);
+				const unsigned x0 = a0 ^ b0, x1 = a1 ^ b1;
+				const unsigned z0 = (((x0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x0) & 0x80808080u;
+				const unsigned z1 = (((x1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x1) & 0x80808080u;
+				surv = __popc(z0) + __popc(z1) <= max_mm;
+			} else {
+				int mmf = 0;
+				const int nf = n < FILTER_CH ? n : FILTER_CH;
+				for (int k = 0; k < nf; ++k) {
+					if (qseq[qo0 + k] != tseq[to0 + k] &&
+					    !allowed(rule, qsup[qo0 + k], tsup[to0 + k], qreads, treads)) {
+						if (++mmf > max_mm) break;
+					}
 				}
+				surv = mmf <= max_mm;
 			}
-			surv = mmf <= max_mm;
 		}
 		unsigned long long mask = ballot(surv);
 		while (mask) {
@@ -324,8 +365,10 @@ __device__ inline int combine_pass(ST &S, Arena &A, short *in, int n, short *out
 		const int c = in[i];
 		if (min_support > 0) {
 			const long long ms = S.nreads[c] < min_support ? S.nreads[c] : min_support;
+			IHP_T0(A);
 			trim_dev(S, A, c, ms);
 			recompute_minmax(S, A, c);
+			IHP_T1(A, 7);
 		}
 		if (S.nreads[c] > 0 && nout == 0) {
 			if (lane == 0) out[0] = (short)c;
@@ -343,12 +386,14 @@ __device__ inline int combine_pass(ST &S, Arena &A, short *in, int n, short *out
 		const int c = in[i];
 		Best b = best_match_combine(S, A, c, out, nout, combine_min_overlap, max_mm);
 		if (b.found) {
+			IHP_T0(A);
 			const int nc = emit_corrections(S, A, c, b.slot, b.off, IHP_ALLOW_DEFAULT);
 			if (nc < 0) return IHP_E_CAPACITY;
 			const int rc = insert_dev(S, A, b.slot, c, b.off, nc);
 			if (rc) return rc;
 			if (lane == 0) S.alive[c] = 0;
 			recompute_minmax(S, A, b.slot);
+			IHP_T1(A, 6);
 		} else if (S.nreads[c] > 0) {
 			if (lane == 0) out[nout] = (short)c;
 			nout++;
@@ -371,22 +416,6 @@ __device__ inline int combine_pass(ST &S, Arena &A, short *in, int n, short *out
 // DIFFERENCE array in A.sup (two scalar updates per insert) and turned into supports by one prefix
 // sum per contig before combine (materialize_supports).
 // ============================================================================================
-__device__ __forceinline__ int align4(int n) { return (n + 3) & ~3; }
-
-__device__ __forceinline__ unsigned ld32u(const uint32_t *b32, int byteoff)
-{   // unaligned 32-bit load
-	const int w = byteoff >> 2;
-	return __builtin_amdgcn_alignbit(b32[w + 1], b32[w], (unsigned)(byteoff & 3) * 8u);
-}
-
-__device__ __forceinline__ void ld64u(const uint32_t *b32, int byteoff, unsigned &lo, unsigned &hi)
-{
-	const int w = byteoff >> 2;
-	const unsigned sh = (unsigned)(byteoff & 3) * 8u;
-	const unsigned w0 = b32[w], w1 = b32[w + 1], w2 = b32[w + 2];
-	lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-	hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-}
 
 // Can allowable_mismatch (default rule) be true for any pair of positions of q and t?  Necessary
 // condition from the per-contig support extrema; false => the exact scan is equivalent.
@@ -485,6 +514,18 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 	return v;
 }
 
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+	for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+	return v;
+}
+__device__ __forceinline__ int wave_max_i32s(int v)
+{
+	for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+	return v;
+}
+
+// Support extrema and the clean zone [lo3, hi3) (every support >= 3) of one contig.
 template <class ST>
 __device__ inline void recompute_minmax(ST &S, const Arena &A, int s)
 {
@@ -492,9 +533,20 @@ __device__ inline void recompute_minmax(ST &S, const Arena &A, int s)
 	const uint32_t *sup = A.sup + S.off[s];
 	const int n = S.len[s];
 	unsigned mn = 0xffffffffu, mx = 0;
-	for (int i = lane; i < n; i += 64) { const unsigned v = sup[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+	int first = 0x7fffffff, last = -1, cnt = 0;
+	for (int i = lane; i < n; i += 64) {
+		const unsigned v = sup[i];
+		mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+		if (v >= 3u) { first = i < first ? i : first; last = i > last ? i : last; cnt++; }
+	}
 	mn = wave_min_u32(mn); mx = wave_max_u32(mx);
-	if (lane == 0) { S.smin[s] = mn; S.smax[s] = mx; }
+	first = wave_min_i32(first); last = wave_max_i32s(last); cnt = wave_sum_i(cnt);
+	if (lane == 0) {
+		S.smin[s] = mn; S.smax[s] = mx;
+		const bool clean = last >= first && cnt == last - first + 1;    // no dip below 3 inside
+		// sentinel small enough that lo3 - offset never overflows
+		S.lo3[s] = clean ? first : 0x3fffffff; S.hi3[s] = clean ? last + 1 : 0;
+	}
 	WSYNC();
 }
 
@@ -515,8 +567,9 @@ __device__ inline void materialize_supports(ST &S, Arena &A, const short *list, 
 			if (i < len) { d[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
 			carry = (unsigned)__shfl((int)v, 63, 64);
 		}
-		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
-		if (lane == 0) { S.smin[s] = mn; S.smax[s] = mx; }
+		(void)mn; (void)mx;
+		WSYNC();
+		recompute_minmax(S, A, s);
 	}
 	WSYNC();
 }
@@ -651,10 +704,13 @@ __device__ inline int insert_read(ST &S, Arena &A, int ts, int off)
 	}
 	for (int i = tlen + lane; i < newlen; i += 64) tseq[i] = qseq[i - off];   // :220-221
 	if (lane == 0) {
-		td[off] += 1u; td[off + qlen] -= 1u;                       // :216-219 as a range update
+		// :216-219 as a range update; result-less atomics so nothing waits on HBM (the arrays are only
+		// read after a WSYNC: relocation, compaction, materialize_supports)
+		__hip_atomic_fetch_add(&td[off], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_fetch_add(&td[off + qlen], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		S.len[ts] = newlen; S.nreads[ts] += 1;                     // :222
 	}
-	WSYNC();
+	LDS_ORDER();
 	return 0;
 }
 
@@ -676,8 +732,8 @@ __device__ inline Best best_match_combine(const ST &S, const Arena &A, int qs, c
 	for (int i = 0; i < n; ++i) {
 		const int ts = list[i];
 		if (ts == qs) continue;                                    // :227
-		if (max_mm == 0 && !may_allow(S, qs, ts)) slide_scan_exact(S, A, qs, ts, i, min_overlap, best);
-		else slide_scan(S, A, qs, ts, i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, best);
+		if (max_mm == 0 && !may_allow(S, qs, ts)) { IHP_T0(A); slide_scan_exact(S, A, qs, ts, i, min_overlap, best); IHP_T1(A, 5); }
+		else { IHP_T0(A); slide_scan(S, A, qs, ts, i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, best); IHP_T1(A, 4); }
 	}
 	return best;
 }

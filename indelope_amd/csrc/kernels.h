@@ -86,12 +86,14 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 		if (lane == 0) {                                       // make_contig, contig.nim:143-150
 			S.off[QSLOT] = A.stage_off; S.len[QSLOT] = tl; S.cap[QSLOT] = tl;
 			S.nreads[QSLOT] = 1; S.start[QSLOT] = a.read_start[ri] + o;
-			S.smin[QSLOT] = 1; S.smax[QSLOT] = 1;
+			S.smin[QSLOT] = 1; S.smax[QSLOT] = 1; S.lo3[QSLOT] = 0x3fffffff; S.hi3[QSLOT] = 0;
 		}
 		WSYNC();
 		const int min_overlap = (int)(a.min_overlap_pct * (double)tl);   // :169
 		if (fast) {
-			Best b = best_match_read(S, A, S.listA, n, min_overlap);     // contig.nim:243-244
+			Best b;
+			{ IHP_T0(A); b = best_match_read(S, A, S.listA, n, min_overlap); IHP_T1(A, 12); }   // contig.nim:243-244
+			IHP_T0(A);
 			if (b.found) {
 				const int rc = insert_read(S, A, b.slot, b.off);         // contig.nim:246
 				if (rc) return rc;
@@ -103,6 +105,7 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 				if (lane == 0) S.listA[n] = (short)slot;
 				n++;
 			}
+			IHP_T1(A, 13);
 		} else {
 			Best b = best_match_dev(S, A, QSLOT, S.listA, n, min_overlap, a.max_mismatch);
 			if (b.found) {
@@ -129,7 +132,8 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 	}
 	n_pre = n;                                                 // :171
 	const long long tcA = a.prof ? (long long)clock64() : 0;
-	if (fast) materialize_supports(S, A, S.listA, n);
+	{ IHP_T0(A); if (fast) materialize_supports(S, A, S.listA, n); IHP_T1(A, 14); }
+	if (fast) {}
 	else for (int i = 0; i < n; ++i) recompute_minmax(S, A, S.listA[i]);
 	// combine(min_support) = pass with min_support 0, then the trimmed pass (contig.nim:259-260)
 	const int n2 = combine_pass(S, A, S.listA, n, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
 	if (LDSA) { A.seq = lds_arena; A.cap = LDS_ARENA - 16; A.stage_off = LDS_ARENA - 16 - a.stage_cap; }
 	else { A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap; A.cap = a.arena_cap - 16; A.stage_off = a.arena_cap - 16 - a.stage_cap; }
-	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap;
+	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof;
 	for (;;) {
 		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
 		WSYNC();
@@ -406,12 +410,13 @@ __global__ __launch_bounds__(64) void k_contig_op(const OpArgs a)
 	__shared__ ST S;
 	const int lane = lane_id();
 	Arena A; A.seq = a.arena_seq; A.sup = a.arena_sup; A.cap = a.arena_cap; A.stage_off = a.arena_cap;
-	A.corr = a.corr; A.corr_cap = a.corr_cap;
+	A.corr = a.corr; A.corr_cap = a.corr_cap; A.prof = nullptr;
 	for (int i = lane; i <= ST::MAXC; i += 64) S.alive[i] = 0;
 	if (lane == 0) {
 		S.off[0] = a.t_off; S.len[0] = a.t_len; S.cap[0] = a.t_cap; S.nreads[0] = a.t_nreads; S.start[0] = a.t_start; S.alive[0] = 1;
 		S.off[1] = a.q_off; S.len[1] = a.q_len; S.cap[1] = a.q_cap; S.nreads[1] = a.q_nreads; S.start[1] = a.q_start; S.alive[1] = 1;
 		S.bump = align4(a.q_off + a.q_cap); S.err = 0;
+		S.lo3[0] = S.lo3[1] = 0x3fffffff; S.hi3[0] = S.hi3[1] = 0;
 	}
 	WSYNC();
 	long long rc = 0, found = 0, ma = 0, mm = 0, off = 0, nc = 0;
