@@ -40,19 +40,22 @@ def cpu_baseline(batch, K, want_seconds=12.0):
     used_ref = o.use_reference_ksw(True)
     cores = os.cpu_count() or 1
     p = o.params(K=K)
-    probe = batch.slice(0, min(batch.n_regions, 256))
+    probe = batch.slice(0, min(batch.n_regions, 512))
     t0 = time.perf_counter()
-    o.run_regions(probe, p)
+    o.bench_regions(probe, p, nthreads=1, reps=1)
     rate1 = probe.n_regions / (time.perf_counter() - t0)
-    n = int(min(batch.n_regions, max(256, rate1 * cores * want_seconds / 2)))
-    sample = batch.slice(0, n)
+    # all cores: every thread owns a contiguous share of the regions and repeats it `reps` times
+    sample = batch.slice(0, min(batch.n_regions, max(cores * 8, 2048)))
+    n = sample.n_regions
+    reps = max(1, int(rate1 * cores * want_seconds / n / 2))
     t0 = time.perf_counter()
-    o.run_regions_mt(sample, p, nthreads=cores)
+    o.bench_regions(sample, p, nthreads=cores, reps=reps)
     dt = time.perf_counter() - t0
+    n = n * reps
     o.use_reference_ksw(False)
     return {"value": round(n / dt, 1), "unit": "regions/s", "cores": cores, "kind": "port",
             "value_1thread": round(rate1, 1),
-            "sample": "first %d regions of the workload, %d threads over independent regions; C restatement of "
+            "sample": "%d region passes (first regions of the workload, repeated), %d threads over independent regions; C restatement of "
                       "contig.nim/indelope.nim (oracle/), ksw2 = %s; Nim reference not buildable here"
                       % (n, cores, "reference ksw2_extz2_sse.c compiled (oracle/_ref)" if used_ref
                          else "scalar restatement (oracle/_ref absent)")}

@@ -43,6 +43,8 @@ class Oracle(Api):
         d.orc_read_trim.restype = C.c_int64
         d.orc_read_trim.argtypes = [A.u8p, C.c_int64, C.c_int, A.i64p, A.i64p]
         d.orc_counters.argtypes = [A.i64p]
+        d.orc_bench_regions.restype = C.c_int
+        d.orc_bench_regions.argtypes = [C.POINTER(A.Params), C.POINTER(A.BatchIn), C.c_int, C.c_int]
         self._ref = {}
 
     def set_variant(self, v):
@@ -109,6 +111,11 @@ class Oracle(Api):
             return BatchResult(out)
         finally:
             self.b.free_out(C.byref(out))
+
+    def bench_regions(self, batch, params=None, nthreads=1, reps=1):
+        p = params if params is not None else self.params()
+        cin = batch.as_c()
+        self._chk(self.cdll.orc_bench_regions(C.byref(p), C.byref(cin), nthreads, reps), "bench_regions")
 
     def counters(self):
         c = np.zeros(3, np.int64)

@@ -70,6 +70,8 @@ void orc_params_default(ihp_params *p);
 int  orc_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out);
 int  orc_run_regions_mt(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out, int nthreads);
 void orc_free_out(ihp_batch_out *out);
+/* cpu_baseline probe: each thread runs its share of the regions `reps` times, results discarded. */
+int  orc_bench_regions(const ihp_params *p, const ihp_batch_in *in, int nthreads, int reps);
 
 /* Deterministic work counters of the last orc_run_regions call (single thread):
  * [0] char compares in slide_align, [1] ksw2 DP cells, [2] k-mer steps.       */

@@ -386,6 +386,47 @@ int orc_run_regions_mt(const ihp_params *p, const ihp_batch_in *in, ihp_batch_ou
 	return 0;
 }
 
+/* Throughput probe for bench.py's cpu_baseline: every thread runs its contiguous share of the regions
+ * `reps` times and throws the results away (no flattening), so the timed work is the path itself. */
+typedef struct { const ihp_params *p; const ihp_batch_in *in; int32_t lo, hi; int reps; } bjob_t;
+
+static void free_region(region_res *rr)
+{
+	for (int64_t k = 0; k < rr->contigs.n; ++k) {
+		free(rr->res[k].cigar); free(rr->res[k].events);
+		orc_contig_free(rr->contigs.v[k]);
+	}
+	free(rr->contigs.v); free(rr->res);
+}
+
+static void *bworker(void *arg)
+{
+	bjob_t *j = (bjob_t *)arg;
+	region_res rr;
+	for (int rep = 0; rep < j->reps; ++rep)
+		for (int32_t r = j->lo; r < j->hi; ++r) { run_region(j->p, j->in, r, &rr); free_region(&rr); }
+	return 0;
+}
+
+int orc_bench_regions(const ihp_params *p, const ihp_batch_in *in, int nthreads, int reps)
+{
+	if (!p || !in || p->struct_size != (int32_t)sizeof(ihp_params)) return IHP_E_ARG;
+	const int32_t R = in->n_regions;
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > R) nthreads = R ? R : 1;
+	bjob_t *jobs = (bjob_t *)calloc((size_t)nthreads, sizeof(bjob_t));
+	pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+	for (int t = 0; t < nthreads; ++t) {
+		jobs[t].p = p; jobs[t].in = in; jobs[t].reps = reps;
+		jobs[t].lo = (int32_t)((int64_t)R * t / nthreads);
+		jobs[t].hi = (int32_t)((int64_t)R * (t + 1) / nthreads);
+	}
+	for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], 0, bworker, &jobs[t]);
+	for (int t = 0; t < nthreads; ++t) pthread_join(th[t], 0);
+	free(jobs); free(th);
+	return 0;
+}
+
 int orc_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out)
 {
 	return orc_run_regions_mt(p, in, out, 1);
