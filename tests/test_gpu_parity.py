@@ -215,3 +215,25 @@ def test_full_size_c2_properties(hip, oracle):
         c0, c1 = got.contig_off[lo], got.contig_off[lo + 250]
         assert np.array_equal(got.ctg_start[c0:c1], exp.ctg_start)
         assert np.array_equal(got.ctg_seq[got.ctg_seq_off[c0]:got.ctg_seq_off[c1]], exp.ctg_seq)
+
+
+def test_device_summary_records(hip):
+    """The per-region records gathered across GPUs (k_summary) equal the same records built from the fetched results."""
+    import torch
+    from indelope_amd import dist as idist
+    b, _ = synth.generate(300, n_reads=(8, 64), err_rate=2e-3, config_id=33)
+    h = hip.batch_upload(b)
+    try:
+        hip.batch_run(h)
+        hip.batch_sync(h)
+        ptr, n = hip.batch_summary_dev(h)
+        assert n == b.n_regions
+
+        class Dev:
+            __cuda_array_interface__ = {"shape": (n * idist.SUMMARY_WORDS,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        got = torch.as_tensor(Dev(), device="cuda").cpu().numpy().reshape(-1, idist.SUMMARY_WORDS)
+        res = hip.batch_fetch(h)
+    finally:
+        hip.batch_free(h)
+    exp = idist.summaries_from_result(res).view(np.int32).reshape(-1, idist.SUMMARY_WORDS)
+    assert np.array_equal(got, exp)
