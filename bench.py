@@ -130,6 +130,12 @@ def main():
         alg_bytes = batch.algorithmic_input_bytes() + res.algorithmic_output_bytes(K)
         dom = int(np.argmax(stage[:3]))
         achieved = alg_bytes / (stage[dom] * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
+        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
+        if args.config == "C2" and R == 10_000 and os.path.exists(pmc):
+            k = json.load(open(pmc))["kernels"]
+            key = {"k_assemble": "k_assemble<128, true>", "k_ksw": "k_ksw", "k_tally": "k_tally"}[KERNELS[dom]]
+            traffic = k.get(key, {}).get("traffic")
         out = {
             "metric": "candidate regions/sec (assemble+ksw2+kmer-genotype), 150bp x 64-read batches",
             "value": round(world * R * args.steps / dt, 1), "unit": "regions/s",
@@ -143,7 +149,7 @@ def main():
                        "per-region result records per step" if world > 1 else "single GPU"},
             "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "algorithmic_bytes_per_region": round(alg_bytes / R, 1)},
             "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),

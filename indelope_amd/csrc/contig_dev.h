@@ -30,6 +30,7 @@ struct RegionStateT {
 	unsigned bitmap[MAXLEN / 32];
 	int bump;
 	int err;
+	long long prof[16];
 };
 
 struct Arena {
@@ -39,11 +40,11 @@ struct Arena {
 	int stage_off;               // [stage_off, cap) is the staging area of the read being inserted
 	Corr *corr;                  // [corr_cap] corrections of the winning offset
 	int corr_cap;
-	long long *prof;             // optional cycle counters (diagnostics)
+	long long *prof;             // optional per-wave cycle counters in LDS (diagnostics)
 };
 
 #define IHP_T0(A) const long long t0_ = (A).prof ? (long long)clock64() : 0
-#define IHP_T1(A, k) do { if ((A).prof && lane_id() == 0) atomicAdd((unsigned long long *)&(A).prof[k], (unsigned long long)((long long)clock64() - t0_)); } while (0)
+#define IHP_T1(A, k) do { if ((A).prof && lane_id() == 0) (A).prof[k] += (long long)clock64() - t0_; } while (0)
 
 struct Best {
 	int found, ma, mm, pos, slot, off;

@@ -143,7 +143,7 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 	if (n3 < 0) return n3;
 	WSYNC();
 	n_final = n3;
-	if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[1], (unsigned long long)((long long)clock64() - tcA));
+	if (a.prof && lane == 0) S.prof[1] += (long long)clock64() - tcA;
 	return 0;
 }
 
@@ -163,7 +163,9 @@ __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
 	if (LDSA) { A.seq = lds_arena; A.cap = LDS_ARENA - 16; A.stage_off = LDS_ARENA - 16 - a.stage_cap; }
 	else { A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap; A.cap = a.arena_cap - 16; A.stage_off = a.arena_cap - 16 - a.stage_cap; }
-	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof;
+	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof ? S.prof : nullptr;
+	if (lane < 16) S.prof[lane] = 0;
+	WSYNC();
 	for (;;) {
 		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
 		WSYNC();
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 		const long long tcR = a.prof ? (long long)clock64() : 0;
 		int err = assemble_region(a, S, A, r, n_pre, n_final);
 		WSYNC();
-		if (a.prof && lane == 0) { atomicAdd((unsigned long long *)&a.prof[0], (unsigned long long)((long long)clock64() - tcR)); atomicAdd((unsigned long long *)&a.prof[3], 1ull); }
+		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[3] += 1; }
 		if (LDSA && err == IHP_E_CAPACITY) {                   // does not fit the LDS arena / slot count: HBM pass
 			if (lane == 0) a.retry_list[atomicAdd(a.n_retry, 1)] = r;
 			WSYNC();
@@ -227,9 +229,12 @@ __global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
 			cursor += len;
 		}
 		if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
-		if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[2], (unsigned long long)((long long)clock64() - tcR));
+		if (a.prof && lane == 0) S.prof[2] += (long long)clock64() - tcR;
 		WSYNC();
 	}
+	WSYNC();
+	if (a.prof && lane < 16 && lane != 8 && lane != 9 && lane != 10 && lane != 11 && S.prof[lane])
+		atomicAdd((unsigned long long *)&a.prof[lane], (unsigned long long)S.prof[lane]);
 }
 
 // ---------------------------------------------------------------------- ksw2
