@@ -61,14 +61,20 @@ __device__ __forceinline__ bool ksw_band(int r, int qlen, int tlen, int w, int &
 
 #define IHP_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
 
-// max over the 64 lanes (all lanes active); result is wave-uniform
+// max over the 64 lanes (all lanes active); result is wave-uniform.  Four v_max_i32 with a DPP
+// operand (xor 1, xor 2, 8-lane mirror, 16-lane mirror) leave each row's max in all its lanes.
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-	int o;
-	o = IHP_DPP(v, 0xB1); v = o > v ? o : v;            // quad_perm [1,0,3,2]
-	o = IHP_DPP(v, 0x4E); v = o > v ? o : v;            // quad_perm [2,3,0,1]
-	o = IHP_DPP(v, 0x141); v = o > v ? o : v;           // row_half_mirror
-	o = IHP_DPP(v, 0x140); v = o > v ? o : v;           // row_mirror
+	asm("s_nop 1\n\t"
+	    "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1"
+	    : "+v"(v));
 	const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
 	const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
 	const int ab = a > b ? a : b, cd = c > d ? c : d;

@@ -20,7 +20,7 @@ namespace ihp {
 
 __host__ __device__ __forceinline__ size_t ksw_fast_lds_bytes(int qlen, int tlen)
 {
-	return (size_t)((tlen + 15) / 16) * 16 + 96 + (size_t)((qlen + 15) / 16) * 16 + 96;
+	return (size_t)((tlen + 15) / 16) * 16 + 96 + 16 + (size_t)((qlen + 15) / 16) * 16 + 96;
 }
 
 __device__ __forceinline__ bool ksw_fast_ok(int w) { return w >= 0 && w <= 62; }
@@ -93,15 +93,16 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 	const int ncol = n_col_ * 16;
 	const int TP = (tlen + 15) / 16 * 16 + 96, QR = (qlen + 15) / 16 * 16 + 96;
 	uint8_t *tg = lds;                                   // target codes, zero padded (sf of :175,:188)
-	uint8_t *qr = lds + TP;                              // reversed query, zero padded (:187)
+	uint8_t *qr = lds + TP + 16;                         // reversed query, zero padded on both sides (:187):
+	                                                     // every index qlen-1-r+t a lane can form lies in [-16, QR)
 	FastConst C;
 	C.qe2 = (unsigned)(qe * 2) & 0xff; C.sc_mch = (unsigned)P.sc_mch & 0xff; C.sc_mis = (unsigned)P.sc_mis & 0xff;
 	C.m1 = (unsigned)(P.m - 1) & 0xff; C.max_sc8 = (unsigned)(P.sc_mch + qe * 2) & 0xff; C.q8 = (unsigned)q & 0xff;
 	const bool with_cigar = !(flag & KSW_EZ_SCORE_ONLY);
 	for (int i = lane; i < TP; i += 64) tg[i] = i < tlen ? (P.encode_ascii ? enc_base(target[i]) : target[i]) : 0;
-	for (int i = lane; i < QR; i += 64) {
+	for (int i = lane - 16; i < QR; i += 64) {
 		uint8_t b = 0;
-		if (i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base(b); }
+		if (i >= 0 && i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base(b); }
 		qr[i] = b;
 	}
 	WSYNC();
@@ -109,7 +110,8 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 
 	// cell state
 	unsigned xA = 0, vA = 0, uA = 0, yA = 0, sA = 0, sfA = tg[lane];
-	unsigned xB = 0, vB = 0, uB = 0, yB = 0, sB = 0, sfB = tg[64 + (lane & 15)];
+	unsigned xB = 0, vB = 0, uB = 0, yB = 0, sfB = tg[64 + (lane & 15)];
+	int rlB = -1;                                        // slot B: diagonal of the last score refresh (lazy s[])
 	int HA = KSW_NEG_INF, HB = KSW_NEG_INF;
 	int st = 0;                                          // current computed-band origin (multiple of 16)
 	unsigned edge_x = 0, edge_v = 0;                     // x[st-1], v[st-1] when valid (:207-210)
@@ -127,9 +129,10 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 			edge_v = (st + 15 >= last_st && st + 15 <= last_en) ? (unsigned)__builtin_amdgcn_readlane((int)vA, 15) : 0u;
 			edge_h = __builtin_amdgcn_readlane(HA, 15);
 			xA = rot16(xA, xB, lane); vA = rot16(vA, vB, lane); uA = rot16(uA, uB, lane); yA = rot16(yA, yB, lane);
-			sA = rot16(sA, sB, lane); sfA = rot16(sfA, sfB, lane); HA = (int)rot16((unsigned)HA, (unsigned)HB, lane);
+			const unsigned sBm = rlB < 0 ? 0u : score_byte(sfB, qr[qlen - 1 - rlB + st + 64 + (lane & 15)], C);
+			sA = rot16(sA, sBm, lane); sfA = rot16(sfA, sfB, lane); HA = (int)rot16((unsigned)HA, (unsigned)HB, lane);
 			st = nst;
-			xB = vB = uB = yB = sB = 0; HB = KSW_NEG_INF;
+			xB = vB = uB = yB = 0; rlB = -1; HB = KSW_NEG_INF;
 			sfB = tg[st + 64 + (lane & 15)];
 		} else if (st > 0) {
 			// x[st-1], v[st-1] are only "calculated in the last round" right after the origin moved (:208)
@@ -149,16 +152,13 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 		int hB = INTMIN, hA = INTMIN;
 		const int spec = (r > 0 && en0 > 0) ? hiT : -1000;          // lane of the H[en0] special case (:318)
 		// ---- slot B (block 4) ------------------------------------------------------------
-		if (sc >= 64) {
-			int qi = qbase + 64 + lane;
-			const unsigned qbB = (lane < 16 && qi >= 0 && qi < QR) ? qr[qi] : 0u;
-			if (lane <= sc - 64) sB = score_byte(sfB, qbB, C);      // :214-228 (runs past en)
-		}
+		if (sc >= 64) rlB = lane <= sc - 64 ? r : rlB;                // :214-228 runs past en; value formed on use
 		if (nTop >= 64) {
 			const unsigned exB = (unsigned)__builtin_amdgcn_readlane((int)xA, 63), evB = (unsigned)__builtin_amdgcn_readlane((int)vA, 63);
 			const int HeB = __builtin_amdgcn_readlane(HA, 63);
 			const unsigned xpB = dpp_shr1(xB, exB), vpB = dpp_shr1(vB, evB);
 			const int HpB = (int)dpp_shr1((unsigned)HB, (unsigned)HeB);
+			const unsigned sB = rlB < 0 ? 0u : score_byte(sfB, qr[qlen - 1 - rlB + st + 64 + (lane & 15)], C);
 			if (lane <= nTop - 64) {
 				unsigned ut = uB, yt = yB;
 				if (st + 64 + lane == r) { yt = 0; ut = r ? C.q8 : 0; }   // :212
@@ -175,12 +175,13 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 		}
 		// ---- slot A (blocks 0..3) --------------------------------------------------------
 		{
-			int qi = qbase + lane;
-			const unsigned qbA = (qi >= 0 && qi < QR) ? qr[qi] : 0u;
+			const unsigned qbA = qr[qbase + lane];
 			if (lane >= loA && lane <= sc) sA = score_byte(sfA, qbA, C);   // :214-228
+			if (r <= en && r - st < 64) {                       // :212 (only while the band still touches t == r)
+				if (st + lane == r) { yA = 0; uA = r ? C.q8 : 0; }
+			}
 			if (lane <= nTop) {
 				unsigned ut = uA, yt = yA;
-				if (st + lane == r) { yt = 0; ut = r ? C.q8 : 0; }  // :212
 				unsigned xn, vn, un, yn, d;
 				ksw_cell<RIGHT>(sA, xpA, vpA, ut, yt, C, xn, vn, un, yn, d);
 				xA = xn; vA = vn; uA = un; yA = yn;
