@@ -75,6 +75,19 @@ int grid_for(int items, int waves_per_cu)
 	return (int)g_;
 }
 
+int ksw_mode(const KswParams &P)
+{
+	if (P.w < 0 || P.w > 62) return 2;
+	return (P.flag & KSW_EZ_RIGHT) ? 1 : 0;
+}
+
+template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStream_t s, const KswArgs &a)
+{
+	if (mode == 0) hipLaunchKernelGGL(k_ksw<0>, grid, dim3(64), lds, s, a);
+	else if (mode == 1) hipLaunchKernelGGL(k_ksw<1>, grid, dim3(64), lds, s, a);
+	else hipLaunchKernelGGL(k_ksw<2>, grid, dim3(64), lds, s, a);
+}
+
 KswParams make_ksw_params(int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag, int ascii)
 {
 	KswParams P;
@@ -124,7 +137,9 @@ extern "C" int ihp_init(int device)
 	g.max_lds = (int)pr.sharedMemPerBlock;
 	if (g.max_lds > 65536) {
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
-		(void)hipFuncSetAttribute((const void *)k_ksw, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 	}
 	g.ready = true;
 	return 0;
@@ -249,7 +264,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.ez = d_ez.as<KswOut>(); a.cig_off = d_coff.as<long long>();
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>(); a.cig_pool_cap = cig_bound + 4;
 	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 8; a.prof = nullptr;
-	hipLaunchKernelGGL(k_ksw, dim3(grid), dim3(64), lds_need + 64, g.stream, a);
+	launch_ksw(ksw_mode(P), dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
 	HIPC(hipMemcpyAsync(ez.data(), d_ez.p, sizeof(KswOut) * n, hipMemcpyDeviceToHost, g.stream));
@@ -658,7 +673,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
 		a.cig_pool_cap = b->cig_pool_cap; a.overflow = misc + M_OVF; a.work_counter = misc + M_CNT_KSW;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
-		hipLaunchKernelGGL(k_ksw, dim3(b->grid_ksw), dim3(64), b->lds_ksw, s, a);
+		launch_ksw(ksw_mode(a.P), dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[2], s));

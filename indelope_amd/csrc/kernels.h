@@ -253,6 +253,9 @@ struct KswArgs {
 	long long *prof;                           // optional cycle counters (diagnostics)
 };
 
+// MODE 0: register-resident sweep, left-aligned gaps; 1: same, KSW_EZ_RIGHT; 2: generic LDS sweep (any band).
+// Separate instantiations keep each kernel's register footprint to what its sweep needs.
+template <int MODE>
 __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -262,7 +265,9 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 	const int njobs = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
 	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
 	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
-	long long pacc[4] = {0, 0, 0, 0};
+	long long *pacc = (long long *)(lds + a.lds_budget + 16);   // per-wave cycle counters live past the sweep's LDS
+	if (a.prof && lane < 4) pacc[lane] = 0;
+	WSYNC();
 	for (;;) {
 		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
 		WSYNC();
@@ -276,17 +281,16 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 		int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
 		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
 		const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
-		const bool fast = ksw_fast_ok(a.P.w) && !(a.P.flag & KSW_EZ_SCORE_ONLY);
+		constexpr bool fast = MODE != 2;
 		const size_t lneed = fast ? ksw_fast_lds_bytes(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen);
 		if (jb.qlen > 0 && jb.tlen > 0 && (lneed > (size_t)a.lds_budget || pneed > a.p_cap)) {
 			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
 			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
 			if (lane == 0) atomicExch(&a.overflow[1], 1);
-		} else if (fast) {
-			if (a.P.flag & KSW_EZ_RIGHT)
-				ksw_wave_fast<true>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
-			else
-				ksw_wave_fast<false>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
+		} else if (MODE == 0) {
+			ksw_wave_fast<false>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
+		} else if (MODE == 1) {
+			ksw_wave_fast<true>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
 		} else {
 			ksw_wave(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
 		}
@@ -307,8 +311,8 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 		if (lane == 0) { a.ez[jb.out] = out; a.cig_off[jb.out] = off; }
 		WSYNC();
 	}
-	if (a.prof && lane == 0)
-		for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long *)&a.prof[8 + k], (unsigned long long)pacc[k]);
+	WSYNC();
+	if (a.prof && lane < 4) atomicAdd((unsigned long long *)&a.prof[8 + lane], (unsigned long long)pacc[lane]);
 }
 
 // --------------------------------------------------------------------- tally

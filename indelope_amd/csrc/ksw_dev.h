@@ -65,7 +65,7 @@ __device__ __forceinline__ bool ksw_band(int r, int qlen, int tlen, int w, int &
 // operand (xor 1, xor 2, 8-lane mirror, 16-lane mirror) leave each row's max in all its lanes.
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-	asm("s_nop 1\n\t"
+	asm("s_nop 4\n\t"          // covers VALU-writes-EXEC -> DPP (5 wait states) as well as VGPR -> DPP (2)
 	    "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 	    "s_nop 1\n\t"
 	    "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
@@ -313,10 +313,10 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = score;
 	WSYNC();
 	const long long tc2 = pacc ? (long long)clock64() : 0;
-	if (pacc) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
+	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
 	if (!with_cigar) return;
 	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, zdropped, ez_max_t, ez_max_q, cig_tmp, cig_cap, out);
-	if (pacc) pacc[2] += (long long)clock64() - tc2;
+	if (pacc && lane == 0) pacc[2] += (long long)clock64() - tc2;
 }
 
 }  // namespace ihp

@@ -100,9 +100,10 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 	C.m1 = (unsigned)(P.m - 1) & 0xff; C.max_sc8 = (unsigned)(P.sc_mch + qe * 2) & 0xff; C.q8 = (unsigned)q & 0xff;
 	const bool with_cigar = !(flag & KSW_EZ_SCORE_ONLY);
 	for (int i = lane; i < TP; i += 64) tg[i] = i < tlen ? (P.encode_ascii ? enc_base(target[i]) : target[i]) : 0;
-	for (int i = lane - 16; i < QR; i += 64) {
+	if (lane < 16) qr[lane - 16] = 0;
+	for (int i = lane; i < QR; i += 64) {
 		uint8_t b = 0;
-		if (i >= 0 && i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base(b); }
+		if (i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base(b); }
 		qr[i] = b;
 	}
 	WSYNC();
@@ -245,10 +246,10 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = score;
 	WSYNC();
 	const long long tc2 = pacc ? (long long)clock64() : 0;
-	if (pacc) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
+	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
 	if (!with_cigar) return;
 	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, zdropped, ez_max_t, ez_max_q, cig_tmp, cig_cap, out);
-	if (pacc) pacc[2] += (long long)clock64() - tc2;
+	if (pacc && lane == 0) pacc[2] += (long long)clock64() - tc2;
 }
 
 }  // namespace ihp

@@ -17,3 +17,11 @@ def hip_cig(c): return "".join("%d%s" % (x >> 4, "MID"[x & 15]) for x in c.tolis
 cmp([kats.KSW_QRY], [kats.KSW_TGT], gap_open=4, gap_ext=1, bw=50, z=400, flag=0)
 pairs = list(tk.cases(300, 200))
 cmp([q for q, t in pairs], [t for q, t in pairs], gap_open=4, gap_ext=1, bw=50, z=400, flag=0)
+# one pair per call (no persistent-loop reuse) vs the batch
+bad = 0
+for i, (q, t) in enumerate(pairs[:60]):
+    a, ca = hip.align_batch([q], [t], gap_open=4, gap_ext=1, bw=50, z=400, flag=0)
+    b, cb = o.align_batch([q], [t], gap_open=4, gap_ext=1, bw=50, z=400, flag=0)
+    if a[0].tolist() != b[0].tolist() or ca[0].tolist() != cb[0].tolist():
+        bad += 1
+print("single-call bad", bad, "of 60")
