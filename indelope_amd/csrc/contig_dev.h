@@ -94,6 +94,13 @@ __device__ __forceinline__ int alloc_slot(ST &S)
 
 __device__ __forceinline__ int align4(int n) { return (n + 3) & ~3; }
 
+// Read of a difference-array entry: the entries are updated by L2 atomics, so read them at L2 too
+// (a plain load could be served from a stale line of this CU's vector L1).
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ unsigned ld32u(const uint32_t *b32, int byteoff)
 {   // unaligned 32-bit load
 	const int w = byteoff >> 2;
@@ -563,7 +570,7 @@ __device__ inline void materialize_supports(ST &S, Arena &A, const short *list, 
 		unsigned carry = 0, mn = 0xffffffffu, mx = 0;
 		for (int i0 = 0; i0 < len; i0 += 64) {
 			const int i = i0 + lane;
-			unsigned v = i < len ? d[i] : 0u;
+			unsigned v = i < len ? ld_l2(&d[i]) : 0u;
 			v = wave_scan_add(v) + carry;
 			if (i < len) { d[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
 			carry = (unsigned)__shfl((int)v, 63, 64);
@@ -604,7 +611,7 @@ __device__ inline void compact2(ST &S, Arena &A, bool dmode)
 				const int i = i0 + lane;
 				uint8_t b = 0; uint32_t v = 0;
 				if (i < n) b = A.seq[o + i];
-				if (i < nd) v = A.sup[o + i];
+				if (i < nd) v = dmode ? ld_l2(&A.sup[o + i]) : A.sup[o + i];
 				WSYNC();
 				if (i < n) A.seq[newbump + i] = b;
 				if (i < nd) A.sup[newbump + i] = v;
@@ -673,13 +680,14 @@ __device__ inline int insert_read(ST &S, Arena &A, int ts, int off)
 	const uint8_t *qseq = A.seq + S.off[qs];
 	uint8_t *tseq = A.seq + S.off[ts];
 	uint32_t *td = A.sup + S.off[ts];
+	if (reloc) WSYNC();                                            // earlier range updates must have landed
 	if (off < 0) {                                                 // :180-205
 		const int noff = S.bump;
 		uint8_t *nseq = A.seq + noff; uint32_t *nd = A.sup + noff;
 		for (int i = lane; i < newlen; i += 64)
 			nseq[i] = i < aoff ? qseq[i] : (i < aoff + tlen ? tseq[i - aoff] : qseq[i]);
 		for (int i = lane; i <= ncap; i += 64) {
-			uint32_t v = (i >= aoff && i - aoff <= tlen) ? td[i - aoff] : 0u;
+			uint32_t v = (i >= aoff && i - aoff <= tlen) ? ld_l2(&td[i - aoff]) : 0u;
 			if (i == 0) v += 1u;                                   // q covers [0, qlen) of the new contig
 			if (i == qlen) v -= 1u;
 			nd[i] = v;
@@ -697,7 +705,7 @@ __device__ inline int insert_read(ST &S, Arena &A, int ts, int off)
 		const int noff = S.bump;
 		uint8_t *nseq = A.seq + noff; uint32_t *nd = A.sup + noff;
 		for (int i = lane; i < tlen; i += 64) nseq[i] = tseq[i];
-		for (int i = lane; i <= ncap; i += 64) nd[i] = i <= tlen ? td[i] : 0u;
+		for (int i = lane; i <= ncap; i += 64) nd[i] = i <= tlen ? ld_l2(&td[i]) : 0u;
 		WSYNC();
 		if (lane == 0) { S.off[ts] = noff; S.cap[ts] = ncap; S.bump = noff + ncap + SLOT_PAD; }
 		WSYNC();

@@ -58,8 +58,86 @@ __device__ inline int read_trim_dev(const uint8_t *q, int n, int min_quality, in
 	return a;
 }
 
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
+// One read held in registers: lane l holds bases/quals [4l, 4l+4) and [256+4l, 256+4l+4).
+struct ReadRegs { unsigned b[2], q[2]; int len; long long start; };
+
+__device__ __forceinline__ void read_prefetch(const AsmArgs &a, long long off, int len, long long start, ReadRegs &R)
+{
+	const int lane = lane_id();
+	R.len = len; R.start = start;
+#pragma unroll
+	for (int w = 0; w < 2; ++w) {
+		const int i = w * 256 + 4 * lane;
+		R.b[w] = 0; R.q[w] = 0xffffffffu;
+		if (i < len) {
+			R.b[w] = *(const u32_unaligned *)(a.bases + off + i);
+			if (a.quals) R.q[w] = *(const u32_unaligned *)(a.quals + off + i);
+		}
+	}
+}
+
+// indelope.nim:23-38 on a read held in registers (len <= 512).  Returns a; kept range [lo, hi).
+__device__ __forceinline__ int read_trim_regs(const ReadRegs &R, int min_quality, int &lo, int &hi)
+{
+	const int lane = lane_id();
+	const int n = R.len, high = n - 1;
+	const unsigned mq = (unsigned)min_quality & 0xff;
+	if (n <= 0) { lo = 0; hi = 0; return 0; }
+	unsigned good[2];                                         // bit j: quality of base w*256+4l+j >= mq
+#pragma unroll
+	for (int w = 0; w < 2; ++w) {
+		good[w] = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) if (((R.q[w] >> (8 * j)) & 0xff) >= mq) good[w] |= 1u << j;
+	}
+	int a = high;                                             // :25 first i < high with q[i] >= mq, else high
+#pragma unroll
+	for (int w = 1; w >= 0; --w) {
+		const int base = w * 256 + 4 * lane;
+		unsigned m4 = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) if (base + j < high && (good[w] >> j & 1)) m4 |= 1u << j;
+		const unsigned long long bm = ballot(m4 != 0);
+		if (bm) { const int L = ctz64(bm); a = w * 256 + 4 * L + (__ffs((int)bcast((int)m4, L)) - 1); }
+	}
+	if (a == high) { lo = 0; hi = 0; return a; }              // :28-30
+	int bb = a;                                               // :33 last i > a with q[i] >= mq, else a
+#pragma unroll
+	for (int w = 0; w < 2; ++w) {
+		const int base = w * 256 + 4 * lane;
+		unsigned m4 = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) if (base + j > a && base + j <= high && (good[w] >> j & 1)) m4 |= 1u << j;
+		const unsigned long long bm = ballot(m4 != 0);
+		if (bm) { const int L = 63 - clz64(bm); bb = w * 256 + 4 * L + (31 - __clz((int)bcast((int)m4, L))); }
+	}
+	lo = a; hi = bb + 1;
+	return a;
+}
+
+// Trimmed read [lo,hi) from registers into the LDS staging area.
+__device__ __forceinline__ void read_stage_regs(const ReadRegs &R, Arena &A, int lo, int hi)
+{
+	const int lane = lane_id();
+#pragma unroll
+	for (int w = 0; w < 2; ++w) {
+		const int base = w * 256 + 4 * lane;
+		if (base >= hi || base + 4 <= lo) continue;
+		if (lo == 0) *(uint32_t *)(A.seq + A.stage_off + base) = R.b[w];      // staging is 4-byte aligned
+		else {
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+				if (base + j >= lo && base + j < hi) A.seq[A.stage_off + base + j - lo] = (uint8_t)(R.b[w] >> (8 * j));
+		}
+	}
+}
+
 // assemble (indelope.nim:157-183) for one region.  FAST = max_mismatch == 0: read phase with the
 // exact scan and difference-array supports (contig_dev.h "Fast paths"); otherwise the generic scan.
+// The next read's bases and qualities are fetched from HBM into registers while the current one is
+// scanned, so the read loop never waits on global memory.
 template <class ST>
 __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, int &n_pre, int &n_final)
 {
@@ -72,69 +150,100 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 	WSYNC();
 	int n = 0;
 	n_pre = 0; n_final = 0;
-	for (long long ri = r0; ri < r1; ++ri) {                   // indelope.nim:163-169
-		if (a.mapq[ri] < a.min_mapq_assemble) continue;        // :164
-		if (a.read_skip && a.read_skip[ri]) continue;          // :165
-		const long long b0 = a.read_off[ri];
-		const int len = (int)(a.read_off[ri + 1] - b0);
-		int lo = 0, hi = len, o = 0;
-		if (a.quals) o = read_trim_dev(a.quals + b0, len, a.trim_min_qual, lo, hi);   // :168
-		const int tl = hi - lo;
-		if (tl > a.stage_cap || tl > MAXLEN) return IHP_E_CAPACITY;
-		for (int i = lane; i < tl; i += 64) A.seq[A.stage_off + i] = a.bases[b0 + lo + i];
-		if (!fast) for (int i = lane; i < tl; i += 64) A.sup[A.stage_off + i] = 1u;
-		if (lane == 0) {                                       // make_contig, contig.nim:143-150
-			S.off[QSLOT] = A.stage_off; S.len[QSLOT] = tl; S.cap[QSLOT] = tl;
-			S.nreads[QSLOT] = 1; S.start[QSLOT] = a.read_start[ri] + o;
-			S.smin[QSLOT] = 1; S.smax[QSLOT] = 1; S.lo3[QSLOT] = 0x3fffffff; S.hi3[QSLOT] = 0;
+	for (long long g0 = r0; g0 < r1; g0 += 64) {               // indelope.nim:163-169, 64 reads of metadata at a time
+		const long long my = g0 + lane;
+		const bool in = my < r1;
+		long long moff = 0, mstart = 0; int mlen = 0; bool ok = false;
+		if (in) {
+			moff = a.read_off[my]; mlen = (int)(a.read_off[my + 1] - moff); mstart = a.read_start[my];
+			ok = a.mapq[my] >= a.min_mapq_assemble && !(a.read_skip && a.read_skip[my]);   // :164-165
 		}
-		WSYNC();
-		const int min_overlap = (int)(a.min_overlap_pct * (double)tl);   // :169
-		if (fast) {
-			Best b;
-			{ IHP_T0(A); b = best_match_read(S, A, S.listA, n, min_overlap); IHP_T1(A, 12); }   // contig.nim:243-244
-			IHP_T0(A);
-			if (b.found) {
-				const int rc = insert_read(S, A, b.slot, b.off);         // contig.nim:246
-				if (rc) return rc;
-			} else {                                           // contig.nim:248
-				if (n >= ST::MAXC) return IHP_E_CAPACITY;
-				int slot;
-				const int rc = new_contig_from_read(S, A, slot);
-				if (rc) return rc;
-				if (lane == 0) S.listA[n] = (short)slot;
-				n++;
+		unsigned long long elig = ballot(ok);
+		ReadRegs cur, nxt;
+		cur.len = 0; nxt.len = 0;
+		if (elig) {
+			const int k = ctz64(elig);
+			const long long off = ((long long)bcast((int)(moff >> 32), k) << 32) | (unsigned)bcast((int)moff, k);
+			const long long st = ((long long)bcast((int)(mstart >> 32), k) << 32) | (unsigned)bcast((int)mstart, k);
+			read_prefetch(a, off, bcast(mlen, k) <= 512 ? bcast(mlen, k) : 0, st, cur);
+		}
+		while (elig) {
+			const int k = ctz64(elig);
+			elig &= elig - 1;
+			const long long b0 = ((long long)bcast((int)(moff >> 32), k) << 32) | (unsigned)bcast((int)moff, k);
+			const int len = bcast(mlen, k);
+			const long long rstart = ((long long)bcast((int)(mstart >> 32), k) << 32) | (unsigned)bcast((int)mstart, k);
+			if (elig) {                                        // start fetching the next eligible read now
+				const int k2 = ctz64(elig);
+				const long long off2 = ((long long)bcast((int)(moff >> 32), k2) << 32) | (unsigned)bcast((int)moff, k2);
+				const long long st2 = ((long long)bcast((int)(mstart >> 32), k2) << 32) | (unsigned)bcast((int)mstart, k2);
+				const int len2 = bcast(mlen, k2);
+				read_prefetch(a, off2, len2 <= 512 ? len2 : 0, st2, nxt);
 			}
-			IHP_T1(A, 13);
-		} else {
-			Best b = best_match_dev(S, A, QSLOT, S.listA, n, min_overlap, a.max_mismatch);
-			if (b.found) {
-				const int nc = emit_corrections(S, A, QSLOT, b.slot, b.off, IHP_ALLOW_DEFAULT);
-				if (nc < 0) return IHP_E_CAPACITY;
-				const int rc = insert_dev(S, A, b.slot, QSLOT, b.off, nc);
-				if (rc) return rc;
-			} else {
-				const int slot = alloc_slot(S);
-				if (slot < 0 || n >= ST::MAXC) return IHP_E_CAPACITY;
-				int need = align4(tl + headroom(tl));
-				if (!ensure_space2(S, A, need, false)) { need = align4(tl); if (!ensure_space2(S, A, need, false)) return IHP_E_CAPACITY; }
-				const int noff = S.bump;
-				for (int i = lane; i < tl; i += 64) { A.seq[noff + i] = A.seq[A.stage_off + i]; A.sup[noff + i] = 1u; }
-				if (lane == 0) {
-					S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = need; S.nreads[slot] = 1;
-					S.start[slot] = S.start[QSLOT]; S.alive[slot] = 1; S.bump = noff + need + SLOT_PAD;
-					S.listA[n] = (short)slot;
+			int lo = 0, hi = len, o = 0;
+			if (len <= 512) {
+				if (a.quals) o = read_trim_regs(cur, a.trim_min_qual, lo, hi);    // :168
+			} else if (a.quals) o = read_trim_dev(a.quals + b0, len, a.trim_min_qual, lo, hi);
+			const int tl = hi - lo;
+			if (tl > a.stage_cap || tl > MAXLEN) return IHP_E_CAPACITY;
+			if (len <= 512) read_stage_regs(cur, A, lo, hi);
+			else for (int i = lane; i < tl; i += 64) A.seq[A.stage_off + i] = a.bases[b0 + lo + i];
+			if (!fast) for (int i = lane; i < tl; i += 64) A.sup[A.stage_off + i] = 1u;
+			if (lane == 0) {                                   // make_contig, contig.nim:143-150
+				S.off[QSLOT] = A.stage_off; S.len[QSLOT] = tl; S.cap[QSLOT] = tl;
+				S.nreads[QSLOT] = 1; S.start[QSLOT] = rstart + o;
+				S.smin[QSLOT] = 1; S.smax[QSLOT] = 1; S.lo3[QSLOT] = 0x3fffffff; S.hi3[QSLOT] = 0;
+			}
+			if (fast) LDS_ORDER(); else WSYNC();
+			const int min_overlap = (int)(a.min_overlap_pct * (double)tl);   // :169
+			if (fast) {
+				Best b;
+				{ IHP_T0(A); b = best_match_read(S, A, S.listA, n, min_overlap); IHP_T1(A, 12); }   // contig.nim:243-244
+				IHP_T0(A);
+				if (b.found) {
+					const int rc = insert_read(S, A, b.slot, b.off);     // contig.nim:246
+					if (rc) return rc;
+				} else {                                       // contig.nim:248
+					if (n >= ST::MAXC) return IHP_E_CAPACITY;
+					int slot;
+					const int rc = new_contig_from_read(S, A, slot);
+					if (rc) return rc;
+					if (lane == 0) S.listA[n] = (short)slot;
+					n++;
 				}
-				n++;
+				IHP_T1(A, 13);
+				LDS_ORDER();
+			} else {
+				Best b = best_match_dev(S, A, QSLOT, S.listA, n, min_overlap, a.max_mismatch);
+				if (b.found) {
+					const int nc = emit_corrections(S, A, QSLOT, b.slot, b.off, IHP_ALLOW_DEFAULT);
+					if (nc < 0) return IHP_E_CAPACITY;
+					const int rc = insert_dev(S, A, b.slot, QSLOT, b.off, nc);
+					if (rc) return rc;
+				} else {
+					const int slot = alloc_slot(S);
+					if (slot < 0 || n >= ST::MAXC) return IHP_E_CAPACITY;
+					int need = align4(tl + headroom(tl));
+					if (!ensure_space2(S, A, need, false)) { need = align4(tl); if (!ensure_space2(S, A, need, false)) return IHP_E_CAPACITY; }
+					const int noff = S.bump;
+					for (int i = lane; i < tl; i += 64) { A.seq[noff + i] = A.seq[A.stage_off + i]; A.sup[noff + i] = 1u; }
+					if (lane == 0) {
+						S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = need; S.nreads[slot] = 1;
+						S.start[slot] = S.start[QSLOT]; S.alive[slot] = 1; S.bump = noff + need + SLOT_PAD;
+						S.listA[n] = (short)slot;
+					}
+					n++;
+				}
+				WSYNC();
 			}
+			cur = nxt;
 		}
-		WSYNC();
 	}
+	WSYNC();
 	n_pre = n;                                                 // :171
 	const long long tcA = a.prof ? (long long)clock64() : 0;
 	{ IHP_T0(A); if (fast) materialize_supports(S, A, S.listA, n); IHP_T1(A, 14); }
-	if (fast) {}
-	else for (int i = 0; i < n; ++i) recompute_minmax(S, A, S.listA[i]);
+	if (!fast) for (int i = 0; i < n; ++i) recompute_minmax(S, A, S.listA[i]);
 	// combine(min_support) = pass with min_support 0, then the trimmed pass (contig.nim:259-260)
 	const int n2 = combine_pass(S, A, S.listA, n, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
 	if (n2 < 0) return n2;
