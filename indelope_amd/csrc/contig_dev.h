@@ -121,7 +121,9 @@ template <class ST> __device__ inline void recompute_minmax(ST &S, const Arena &
 template <class ST> __device__ inline Best best_match_combine(const ST &S, const Arena &A, int qs, const short *list, int n,
                                                               int min_overlap, int max_mm);
 constexpr int SLOT_PAD = 8;      // bytes after a slot's cap: difference entry [cap] + dword over-reads
-__device__ __forceinline__ int headroom(int n) { int h = n >> 1; return h < 128 ? 128 : h; }
+// spare capacity of a (re)allocated contig: most contigs are single error reads that never grow, the few
+// that do are relocated O(log) times
+__device__ __forceinline__ int headroom(int n) { int h = n >> 1; return h < 32 ? 32 : h; }
 
 // ---- slide_align + best_match (contig.nim:70-141, :224-240) -----------------
 // Scan one target contig; update `best` under the reference's total order.

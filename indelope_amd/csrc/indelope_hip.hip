@@ -137,6 +137,7 @@ extern "C" int ihp_init(int device)
 	g.max_lds = (int)pr.sharedMemPerBlock;
 	if (g.max_lds > 65536) {
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
+		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -499,8 +500,9 @@ struct ihp_batch {
 	DBuf region_read_off, read_off, bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin;
 	bool has_quals = false, has_skip = false;
 	// scratch
-	DBuf arena_seq, arena_sup, lds_sup, corr, p_scratch, cig_tmp, misc, prof, retry_list;
-	int grid_retry = 0;
+	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
+	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
+	DBuf lds_sup3;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
@@ -515,7 +517,7 @@ struct ihp_batch {
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_WORDS = 16 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_WORDS = 20 };
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
@@ -563,8 +565,17 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
 #undef UP
 	// scratch sizing
-	b->grid_asm = grid_for(R, 12);
+	b->grid_asm = grid_for(R, 16);
 	b->grid_retry = grid_for(R, 2);
+	b->lds_arena1 = 6144;                                           // + 4.4 KB of state: 15 workgroups per CU
+	b->lds_arena2 = 12288;                                          // + 7.5 KB (RegionStateT<128>): 8 per CU
+	{
+		long long want = ((long long)b->max_region_bases * 4 / 5 + 4 * ((b->max_read_len + 15) / 16 * 16 + 16) + 1024 + 15) / 16 * 16;
+		const long long cap = (long long)g.max_lds - 16384;          // RegionStateT<256> is ~13.7 KB of static LDS
+		b->lds_arena3 = (int)std::max<long long>(16384, std::min(want, cap));
+	}
+	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
+	b->grid_asm3 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena3 + 14336)));
 	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
 	b->arena_cap = (3 * b->max_region_bases + 4 * b->stage_cap + 2048 + 15) / 16 * 16;
 	b->corr_cap = std::min(MAXLEN, b->max_region_bases) + 16;
@@ -594,9 +605,12 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 #define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
 	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);
 	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_retry);
-	AL(lds_sup, sizeof(uint32_t) * (size_t)LDS_ARENA * b->grid_asm);
+	AL(lds_sup, sizeof(uint32_t) * (size_t)b->lds_arena1 * b->grid_asm);
+	AL(lds_sup2, sizeof(uint32_t) * (size_t)b->lds_arena2 * b->grid_asm2);
+	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
-	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(b->grid_asm, b->grid_retry));
+	AL(retry_list2, sizeof(int) * (size_t)R);
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm, b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(misc, sizeof(int) * M_WORDS);
@@ -640,7 +654,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.max_pre_contigs = p.max_pre_contigs; a.min_ctg_len = p.min_ctg_len; a.min_reads = p.min_reads;
 		a.K = p.K; a.ref_pad = p.ref_pad;
 		a.stage_cap = b->stage_cap; a.corr = b->corr.as<Corr>(); a.corr_cap = b->corr_cap;
-		a.retry_list = b->retry_list.as<int>(); a.n_retry = misc + M_NRETRY;
 		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
 		a.ctg_start = b->ctg_start.as<long long>(); a.ctg_nreads = b->ctg_nreads.as<long long>();
 		a.ctg_seq_off = b->ctg_seq_off.as<long long>(); a.ctg_len = b->ctg_len.as<int>();
@@ -649,13 +662,24 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = misc + M_CNT_ASM;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
-		// pass 1: contig bases in LDS; pass 2: the regions that did not fit, with an HBM arena
-		a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = LDS_ARENA;
-		hipLaunchKernelGGL((k_assemble<128, true>), dim3(b->grid_asm), dim3(64), 0, s, a);
+		// passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  A region
+		// moves on when it is predicted not to fit, or when it runs out of arena / contig slots.
+		int *l1 = b->retry_list.as<int>(), *l2 = b->retry_list2.as<int>();
+		a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
+		a.in_list = nullptr; a.n_in = nullptr; a.out_list = l1; a.n_out = misc + M_NRETRY;
+		hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
 		HIPC(hipGetLastError());
-		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>(); a.arena_cap = b->arena_cap;
-		a.work_counter = misc + M_CNT_RETRY;
-		hipLaunchKernelGGL((k_assemble<1024, false>), dim3(b->grid_retry), dim3(64), 0, s, a);
+		a.arena_sup = b->lds_sup2.as<uint32_t>(); a.arena_cap = b->lds_arena2; a.lds_arena = b->lds_arena2;
+		a.in_list = l1; a.n_in = misc + M_NRETRY; a.out_list = l2; a.n_out = misc + M_NRETRY2; a.work_counter = misc + M_CNT_ASM2;
+		hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(b->grid_asm2), dim3(64), b->lds_arena2, s, a);
+		HIPC(hipGetLastError());
+		a.arena_sup = b->lds_sup3.as<uint32_t>(); a.arena_cap = b->lds_arena3; a.lds_arena = b->lds_arena3;
+		a.in_list = l2; a.n_in = misc + M_NRETRY2; a.out_list = l1; a.n_out = misc + M_NRETRY3; a.work_counter = misc + M_CNT_ASM3;
+		hipLaunchKernelGGL((k_assemble<256, true, 1>), dim3(b->grid_asm3), dim3(64), b->lds_arena3, s, a);
+		HIPC(hipGetLastError());
+		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>(); a.arena_cap = b->arena_cap; a.lds_arena = 0;
+		a.in_list = l1; a.n_in = misc + M_NRETRY3; a.out_list = nullptr; a.n_out = nullptr; a.work_counter = misc + M_CNT_RETRY;
+		hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(b->grid_retry), dim3(64), 0, s, a);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[1], s));
@@ -729,6 +753,13 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[16])
 {
 	if (!b || !out) return IHP_E_ARG;
 	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+	int nretry = 0;
+	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY, sizeof(int), hipMemcpyDeviceToHost));
+	out[15] = nretry;                                 // regions forwarded to the large-arena pass
+	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY2, sizeof(int), hipMemcpyDeviceToHost));
+	out[7] = nretry;                                  // ... on to the third LDS pass
+	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY3, sizeof(int), hipMemcpyDeviceToHost));
+	out[11] = nretry;                                 // ... and to the HBM-arena pass
 	return 0;
 }
 

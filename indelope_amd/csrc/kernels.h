@@ -30,7 +30,9 @@ struct AsmArgs {
 	uint8_t *out_seq; uint32_t *out_sup;
 	AlnJob *jobs; int *n_jobs;
 	int *work_counter;
-	int *retry_list, *n_retry;                         // regions that did not fit the LDS arena
+	const int *in_list, *n_in;                         // regions to process (null: all n_regions)
+	int *out_list, *n_out;                             // regions handed to the next, roomier pass (null: none)
+	int lds_arena;                                     // bytes of the dynamic LDS arena (LDS passes)
 	long long *prof;                                   // optional cycle counters (diagnostics)
 };
 
@@ -256,39 +258,51 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 	return 0;
 }
 
-// MC contig slots; LDSA: contig bases in an LDS arena of LDS_ARENA bytes (regions that do not fit are
-// queued for the HBM-arena instantiation through retry_list).
-constexpr int LDS_ARENA = 8192;
-
-template <int MC, bool LDSA>
-__global__ __launch_bounds__(64) void k_assemble(const AsmArgs a)
+// MC contig slots; LDSA: contig bases in an LDS arena of a.lds_arena bytes (dynamic LDS).  Three passes
+// share this kernel: <64,true> with a small arena for typical regions at 16 waves/CU, <128,true> with a
+// large arena for regions whose reads cannot fit the small one, <1024,false> with an HBM arena as the
+// catch-all.  A region is forwarded (out_list) either up front, from its read bases, or when it runs out
+// of arena / contig slots; results never depend on which pass produced them.
+template <int MC, bool LDSA, int MINW>
+__global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 {
 	typedef RegionStateT<MC> ST;
 	__shared__ ST S;
 	__shared__ int s_item;
-	__shared__ __attribute__((aligned(16))) uint8_t lds_arena[LDSA ? LDS_ARENA : 16];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
 	const int lane = lane_id();
 	Arena A;
 	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
-	if (LDSA) { A.seq = lds_arena; A.cap = LDS_ARENA - 16; A.stage_off = LDS_ARENA - 16 - a.stage_cap; }
+	if (LDSA) { A.seq = lds_arena; A.cap = a.lds_arena - 16; A.stage_off = a.lds_arena - 16 - a.stage_cap; }
 	else { A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap; A.cap = a.arena_cap - 16; A.stage_off = a.arena_cap - 16 - a.stage_cap; }
 	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof ? S.prof : nullptr;
 	if (lane < 16) S.prof[lane] = 0;
 	WSYNC();
+	const int n_items = a.in_list ? *a.n_in : a.n_regions;
 	for (;;) {
 		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
 		WSYNC();
 		int r = s_item;
 		WSYNC();
-		if (LDSA) { if (r >= a.n_regions) break; }
-		else { if (r >= *a.n_retry) break; r = a.retry_list[r]; }
+		if (r >= n_items) break;
+		if (a.in_list) r = a.in_list[r];
+		if (LDSA && a.out_list) {
+			// live contig bytes (with headroom) stay below ~30% of the read bases on indel-region pile-ups;
+			// do not start what is unlikely to fit (a wrong guess only costs the forward on overflow)
+			const long long nb = a.read_off[a.region_read_off[r + 1]] - a.read_off[a.region_read_off[r]];
+			if (nb * 3 / 10 + 2 * a.stage_cap > a.lds_arena) {
+				if (lane == 0) a.out_list[atomicAdd(a.n_out, 1)] = r;
+				WSYNC();
+				continue;
+			}
+		}
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
 		int err = assemble_region(a, S, A, r, n_pre, n_final);
 		WSYNC();
 		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[3] += 1; }
-		if (LDSA && err == IHP_E_CAPACITY) {                   // does not fit the LDS arena / slot count: HBM pass
-			if (lane == 0) a.retry_list[atomicAdd(a.n_retry, 1)] = r;
+		if (err == IHP_E_CAPACITY && a.out_list) {             // out of arena / contig slots: next pass
+			if (lane == 0) a.out_list[atomicAdd(a.n_out, 1)] = r;
 			WSYNC();
 			continue;
 		}
