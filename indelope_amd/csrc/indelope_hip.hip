@@ -597,7 +597,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		b->p_cap = ((size_t)(qeff + tmax) * nc + 1) * 16 + 64;
 		b->cig_cap = qeff + tmax + 8;
 	}
-	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), 32);
+	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_KSW_WAVES") ? atoi(getenv("IHP_KSW_WAVES")) : 32);
 	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), 8);
 	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
 	b->cig_pool_cap = 64 * njobs_cap + 1024;

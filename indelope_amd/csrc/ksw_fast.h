@@ -75,6 +75,159 @@ __device__ __forceinline__ void ksw_cell(unsigned sv, unsigned xt1, unsigned vt1
 	}
 }
 
+// Everything a diagonal reads and writes; lives in registers (the struct is scalar-replaced after inlining).
+struct FastState {
+	unsigned xA, vA, uA, yA, sA, sfA;                    // slot A cells
+	unsigned xB, vB, uB, yB, sfB;                        // slot B cells
+	int rlB;                                             // slot B: diagonal of the last score refresh (lazy s[])
+	int HA, HB;
+	int st;                                              // current computed-band origin (multiple of 16)
+	unsigned edge_x, edge_v;                             // x[st-1], v[st-1] when valid (:207-210)
+	int edge_h;                                          // H[st-1]: frozen once t = st-1 left the band
+	int last_st, last_en;
+	int ez_max, ez_max_t, ez_max_q, mqe, mqe_t, mte, mte_q, score, zdropped;
+};
+
+struct FastEnv {
+	const uint8_t *tg, *qr;
+	uint8_t *p;
+	int qlen, tlen, w, ncol, qe, e, zdrop;
+	bool with_cigar;
+};
+
+// One anti-diagonal.  STEADY = the band is limited by w on both sides, ends before the last target base, does
+// not reach the last query base and lies above t == r (true for w+32 <= r < min(2 tlen, 2 qlen) - w - 2): the
+// start/end special cases of the reference (:212, :349, :351-357) cannot apply and are compiled out.
+// Returns true when the sweep must stop (band exit :200-203 or z-drop :98-101).
+template <bool RIGHT, bool STEADY>
+__device__ __forceinline__ bool fast_diag(FastState &F, const FastEnv &E, const FastConst &C, int r)
+{
+	const int lane = lane_id();
+	const int INTMIN = -0x7fffffff - 1;
+	int st0, en0, nst, en;
+	if (STEADY) {
+		st0 = (r - E.w + 1) >> 1; en0 = (r + E.w) >> 1;
+		nst = st0 & ~15; en = ((en0 + 16) & ~15) - 1;
+	} else if (!ksw_band(r, E.qlen, E.tlen, E.w, st0, en0, nst, en)) { F.zdropped = 1; return true; }   // :200-203
+	unsigned ex = 0, ev = 0;
+	if (nst != F.st) {
+		// the band origin moved one block right: rotate the registers 16 lanes, re-seed slot B
+		const bool valid = STEADY || (F.st + 15 >= F.last_st && F.st + 15 <= F.last_en);
+		ex = valid ? (unsigned)__builtin_amdgcn_readlane((int)F.xA, 15) : 0u;
+		ev = valid ? (unsigned)__builtin_amdgcn_readlane((int)F.vA, 15) : 0u;
+		F.edge_h = __builtin_amdgcn_readlane(F.HA, 15);
+		F.xA = rot16(F.xA, F.xB, lane); F.vA = rot16(F.vA, F.vB, lane);
+		F.uA = rot16(F.uA, F.uB, lane); F.yA = rot16(F.yA, F.yB, lane);
+		const unsigned sBm = F.rlB < 0 ? 0u : score_byte(F.sfB, E.qr[E.qlen - 1 - F.rlB + F.st + 64 + (lane & 15)], C);
+		F.sA = rot16(F.sA, sBm, lane); F.sfA = rot16(F.sfA, F.sfB, lane);
+		F.HA = (int)rot16((unsigned)F.HA, (unsigned)F.HB, lane);
+		F.st = nst;
+		F.xB = F.vB = F.uB = F.yB = 0; F.rlB = -1; F.HB = KSW_NEG_INF;
+		F.sfB = E.tg[F.st + 64 + (lane & 15)];
+	} else if (!STEADY && F.st == 0) { ev = r ? C.q8 : 0; }       // :211; for st > 0 without a move x1 = v1 = 0 (:210)
+	const int st = F.st;
+	const int loA = st0 - st;                            // first true-band lane
+	const int hiT = en0 - st;                            // last true-band lane (may be >= 64: slot B)
+	const int nTop = en - st;                            // last computed lane (<= 79)
+	const int sc = st0 + ((en0 - st0) / 16 + 1) * 16 - 1 - st;   // last refreshed score lane (:215)
+	const int qbase = E.qlen - 1 - r + st;               // qrr[t] = qr[qbase + lane]
+	uint8_t *pr = E.p + (size_t)r * E.ncol;
+	// neighbours of r-1 (taken before anything is overwritten)
+	const unsigned xpA = dpp_shr1(F.xA, ex), vpA = dpp_shr1(F.vA, ev);
+	const int HpA = (int)dpp_shr1((unsigned)F.HA, (unsigned)F.edge_h);
+	int hB = INTMIN, hA = INTMIN;
+	const int spec = (STEADY || (r > 0 && en0 > 0)) ? hiT : -1000;      // lane of the H[en0] special case (:318)
+	// ---- slot B (block 4) ------------------------------------------------------------
+	if (sc >= 64) F.rlB = lane <= sc - 64 ? r : F.rlB;                  // :214-228 runs past en; value formed on use
+	if (nTop >= 64) {
+		const unsigned exB = (unsigned)__builtin_amdgcn_readlane((int)F.xA, 63), evB = (unsigned)__builtin_amdgcn_readlane((int)F.vA, 63);
+		const int HeB = __builtin_amdgcn_readlane(F.HA, 63);
+		const unsigned xpB = dpp_shr1(F.xB, exB), vpB = dpp_shr1(F.vB, evB);
+		const int HpB = (int)dpp_shr1((unsigned)F.HB, (unsigned)HeB);
+		const unsigned sB = F.rlB < 0 ? 0u : score_byte(F.sfB, E.qr[E.qlen - 1 - F.rlB + st + 64 + (lane & 15)], C);
+		if (lane <= nTop - 64) {
+			unsigned ut = F.uB, yt = F.yB;
+			if (!STEADY && st + 64 + lane == r) { yt = 0; ut = r ? C.q8 : 0; }   // :212
+			unsigned xn, vn, un, yn, d;
+			ksw_cell<RIGHT>(sB, xpB, vpB, ut, yt, C, xn, vn, un, yn, d);
+			F.xB = xn; F.vB = vn; F.uB = un; F.yB = yn;
+			if (E.with_cigar) pr[64 + lane] = (uint8_t)d;        // :283
+			const int l = 64 + lane;
+			if (l >= loA && l <= hiT) {
+				hB = (l == spec ? HpB + (int)un : F.HB + (int)vn) - E.qe;   // :318, :323-329
+				F.HB = hB;
+			}
+		}
+	}
+	// ---- slot A (blocks 0..3) --------------------------------------------------------
+	{
+		const unsigned qbA = E.qr[qbase + lane];
+		if (lane >= loA && lane <= sc) F.sA = score_byte(F.sfA, qbA, C);   // :214-228
+		if (!STEADY && r <= en && r - st < 64) {             // :212 (only while the band still touches t == r)
+			if (st + lane == r) { F.yA = 0; F.uA = r ? C.q8 : 0; }
+		}
+		if (STEADY || lane <= nTop) {                        // a steady band always covers blocks 0..3
+			unsigned xn, vn, un, yn, d;
+			ksw_cell<RIGHT>(F.sA, xpA, vpA, F.uA, F.yA, C, xn, vn, un, yn, d);
+			F.xA = xn; F.vA = vn; F.uA = un; F.yA = yn;
+			if (E.with_cigar) pr[lane] = (uint8_t)d;
+			if (lane >= loA && lane <= hiT) {
+				if (STEADY || r > 0) hA = (lane == spec ? HpA + (int)un : F.HA + (int)vn) - E.qe;
+				else hA = (int)vn - E.qe - E.qe;                 // :349
+				F.HA = hA;
+			}
+		}
+	}
+	// ---- exact max (:320-348) ----------------------------------------------------------
+	int max_H = wave_max_i32(hA), max_t;
+	if (nTop >= 64) { const int mb = wave_max_i32(hB); max_H = mb > max_H ? mb : max_H; }
+	{
+		const unsigned long long mA = ballot(hA == max_H && lane >= loA && lane <= hiT);
+		const unsigned long long mB = nTop >= 64 ? ballot(hB == max_H && lane < 16 && 64 + lane >= loA && 64 + lane <= hiT) : 0ull;
+		if (popc64(mA) + popc64(mB) == 1) {
+			max_t = mA ? st + ctz64(mA) : st + 64 + ctz64(mB);
+		} else {
+			// ties: en0 first, then stride classes of the vector part, then the scalar tail
+			const unsigned long long m = loA ? ((mA >> loA) | (mB << (64 - loA))) : mA;   // bit i <-> t = st0 + i
+			const int ie = en0 - st0, nv = (en0 - st0) / 4 * 4;
+			if ((m >> ie) & 1) max_t = en0;
+			else {
+				const unsigned long long mv = nv ? (m & ((1ull << nv) - 1)) : 0ull;
+				max_t = en0;
+				if (mv) {
+					for (int j = 0; j < 4; ++j) {
+						const unsigned long long cm = mv & (0x1111111111111111ull << j);
+						if (cm) { max_t = st0 + ctz64(cm); break; }
+					}
+				} else {
+					const unsigned long long mt = m & ~mv;
+					if (mt) max_t = st0 + ctz64(mt);
+				}
+			}
+		}
+	}
+	// ---- ez updates (:351-357) -----------------------------------------------------------
+	int Hen0 = 0;
+	if (!STEADY && (en0 == E.tlen - 1 || r - st0 == E.qlen - 1)) {
+		Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
+		const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
+		if (en0 == E.tlen - 1 && Hen0 > F.mte) { F.mte = Hen0; F.mte_q = r - en; }        // rounded en (:352)
+		if (r - st0 == E.qlen - 1 && Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st0; }
+	}
+	{                                                                             // ksw_apply_zdrop :88-104
+		const int t = max_t;
+		if (max_H > F.ez_max) { F.ez_max = max_H; F.ez_max_t = t; F.ez_max_q = r - t; }
+		else if (t >= F.ez_max_t && r - t >= F.ez_max_q) {
+			const int tl = t - F.ez_max_t, ql = (r - t) - F.ez_max_q;
+			const int l = tl > ql ? tl - ql : ql - tl;
+			if (E.zdrop >= 0 && F.ez_max - max_H > E.zdrop + l * E.e) { F.zdropped = 1; return true; }
+		}
+	}
+	if (!STEADY && r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;           // :356-357
+	F.last_st = st; F.last_en = en;
+	return false;
+}
+
 template <bool RIGHT>
 __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8_t *target, int tlen,
                                      const KswParams P, uint8_t *lds, uint8_t *p, uint32_t *cig_tmp, int cig_cap,
@@ -109,146 +262,32 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 	WSYNC();
 	const long long tc1 = pacc ? (long long)clock64() : 0;
 
-	// cell state
-	unsigned xA = 0, vA = 0, uA = 0, yA = 0, sA = 0, sfA = tg[lane];
-	unsigned xB = 0, vB = 0, uB = 0, yB = 0, sfB = tg[64 + (lane & 15)];
-	int rlB = -1;                                        // slot B: diagonal of the last score refresh (lazy s[])
-	int HA = KSW_NEG_INF, HB = KSW_NEG_INF;
-	int st = 0;                                          // current computed-band origin (multiple of 16)
-	unsigned edge_x = 0, edge_v = 0;                     // x[st-1], v[st-1] when valid (:207-210)
-	int edge_h = KSW_NEG_INF;                            // H[st-1]: frozen once t = st-1 left the band
-	int last_st = -1, last_en = -1;
-	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, mqe = KSW_NEG_INF, mqe_t = -1, mte = KSW_NEG_INF, mte_q = -1;
-	int score = KSW_NEG_INF, zdropped = 0;
-	const int INTMIN = -0x7fffffff - 1;
-	for (int r = 0; r < qlen + tlen - 1; ++r) {
-		int st0, en0, nst, en;
-		if (!ksw_band(r, qlen, tlen, w, st0, en0, nst, en)) { zdropped = 1; break; }   // :200-203
-		if (nst != st) {
-			// the band origin moved one block right: rotate the registers 16 lanes, re-seed slot B
-			edge_x = (st + 15 >= last_st && st + 15 <= last_en) ? (unsigned)__builtin_amdgcn_readlane((int)xA, 15) : 0u;
-			edge_v = (st + 15 >= last_st && st + 15 <= last_en) ? (unsigned)__builtin_amdgcn_readlane((int)vA, 15) : 0u;
-			edge_h = __builtin_amdgcn_readlane(HA, 15);
-			xA = rot16(xA, xB, lane); vA = rot16(vA, vB, lane); uA = rot16(uA, uB, lane); yA = rot16(yA, yB, lane);
-			const unsigned sBm = rlB < 0 ? 0u : score_byte(sfB, qr[qlen - 1 - rlB + st + 64 + (lane & 15)], C);
-			sA = rot16(sA, sBm, lane); sfA = rot16(sfA, sfB, lane); HA = (int)rot16((unsigned)HA, (unsigned)HB, lane);
-			st = nst;
-			xB = vB = uB = yB = 0; rlB = -1; HB = KSW_NEG_INF;
-			sfB = tg[st + 64 + (lane & 15)];
-		} else if (st > 0) {
-			// x[st-1], v[st-1] are only "calculated in the last round" right after the origin moved (:208)
-			if (!(st - 1 >= last_st && st - 1 <= last_en)) { edge_x = 0; edge_v = 0; }
-		}
-		unsigned ex, ev;
-		if (st > 0) { ex = edge_x; ev = edge_v; } else { ex = 0; ev = r ? C.q8 : 0; }   // :207-211
-		const int loA = st0 - st;                        // first true-band lane
-		const int hiT = en0 - st;                        // last true-band lane (may be >= 64: slot B)
-		const int nTop = en - st;                        // last computed lane (<= 79)
-		const int sc = st0 + ((en0 - st0) / 16 + 1) * 16 - 1 - st;   // last refreshed score lane (:215)
-		const int qbase = qlen - 1 - r + st;             // qrr[t] = qr[qbase + lane]
-		uint8_t *pr = p + (size_t)r * ncol;
-		// neighbours of r-1 (taken before anything is overwritten)
-		const unsigned xpA = dpp_shr1(xA, ex), vpA = dpp_shr1(vA, ev);
-		const int HpA = (int)dpp_shr1((unsigned)HA, (unsigned)edge_h);
-		int hB = INTMIN, hA = INTMIN;
-		const int spec = (r > 0 && en0 > 0) ? hiT : -1000;          // lane of the H[en0] special case (:318)
-		// ---- slot B (block 4) ------------------------------------------------------------
-		if (sc >= 64) rlB = lane <= sc - 64 ? r : rlB;                // :214-228 runs past en; value formed on use
-		if (nTop >= 64) {
-			const unsigned exB = (unsigned)__builtin_amdgcn_readlane((int)xA, 63), evB = (unsigned)__builtin_amdgcn_readlane((int)vA, 63);
-			const int HeB = __builtin_amdgcn_readlane(HA, 63);
-			const unsigned xpB = dpp_shr1(xB, exB), vpB = dpp_shr1(vB, evB);
-			const int HpB = (int)dpp_shr1((unsigned)HB, (unsigned)HeB);
-			const unsigned sB = rlB < 0 ? 0u : score_byte(sfB, qr[qlen - 1 - rlB + st + 64 + (lane & 15)], C);
-			if (lane <= nTop - 64) {
-				unsigned ut = uB, yt = yB;
-				if (st + 64 + lane == r) { yt = 0; ut = r ? C.q8 : 0; }   // :212
-				unsigned xn, vn, un, yn, d;
-				ksw_cell<RIGHT>(sB, xpB, vpB, ut, yt, C, xn, vn, un, yn, d);
-				xB = xn; vB = vn; uB = un; yB = yn;
-				if (with_cigar) pr[64 + lane] = (uint8_t)d;          // :283
-				const int l = 64 + lane;
-				if (l >= loA && l <= hiT) {
-					hB = (l == spec ? HpB + (int)un : HB + (int)vn) - qe;   // :318, :323-329
-					HB = hB;
-				}
-			}
-		}
-		// ---- slot A (blocks 0..3) --------------------------------------------------------
-		{
-			const unsigned qbA = qr[qbase + lane];
-			if (lane >= loA && lane <= sc) sA = score_byte(sfA, qbA, C);   // :214-228
-			if (r <= en && r - st < 64) {                       // :212 (only while the band still touches t == r)
-				if (st + lane == r) { yA = 0; uA = r ? C.q8 : 0; }
-			}
-			if (lane <= nTop) {
-				unsigned ut = uA, yt = yA;
-				unsigned xn, vn, un, yn, d;
-				ksw_cell<RIGHT>(sA, xpA, vpA, ut, yt, C, xn, vn, un, yn, d);
-				xA = xn; vA = vn; uA = un; yA = yn;
-				if (with_cigar) pr[lane] = (uint8_t)d;
-				if (lane >= loA && lane <= hiT) {
-					if (r > 0) hA = (lane == spec ? HpA + (int)un : HA + (int)vn) - qe;
-					else hA = (int)vn - qe - qe;                     // :349
-					HA = hA;
-				}
-			}
-		}
-		// ---- exact max (:320-348) ----------------------------------------------------------
-		int max_H = wave_max_i32(hA), max_t;
-		if (nTop >= 64) { const int mb = wave_max_i32(hB); max_H = mb > max_H ? mb : max_H; }
-		{
-			const unsigned long long mA = ballot(hA == max_H && lane >= loA && lane <= hiT);
-			const unsigned long long mB = nTop >= 64 ? ballot(hB == max_H && lane < 16 && 64 + lane >= loA && 64 + lane <= hiT) : 0ull;
-			if (popc64(mA) + popc64(mB) == 1) {
-				max_t = mA ? st + ctz64(mA) : st + 64 + ctz64(mB);
-			} else {
-				// ties: en0 first, then stride classes of the vector part, then the scalar tail
-				const unsigned long long m = loA ? ((mA >> loA) | (mB << (64 - loA))) : mA;   // bit i <-> t = st0 + i
-				const int ie = en0 - st0, nv = (en0 - st0) / 4 * 4;
-				if ((m >> ie) & 1) max_t = en0;
-				else {
-					const unsigned long long mv = nv ? (m & ((1ull << nv) - 1)) : 0ull;
-					max_t = en0;
-					if (mv) {
-						for (int j = 0; j < 4; ++j) {
-							const unsigned long long cm = mv & (0x1111111111111111ull << j);
-							if (cm) { max_t = st0 + ctz64(cm); break; }
-						}
-					} else {
-						const unsigned long long mt = m & ~mv;
-						if (mt) max_t = st0 + ctz64(mt);
-					}
-				}
-			}
-		}
-		// ---- ez updates (:351-357) -----------------------------------------------------------
-		int Hen0 = 0;
-		if (en0 == tlen - 1 || r - st0 == qlen - 1) {
-			Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
-			const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
-			if (en0 == tlen - 1 && Hen0 > mte) { mte = Hen0; mte_q = r - en; }        // rounded en (:352)
-			if (r - st0 == qlen - 1 && Hst0 > mqe) { mqe = Hst0; mqe_t = st0; }
-		}
-		{                                                                             // ksw_apply_zdrop :88-104
-			const int t = max_t;
-			if (max_H > ez_max) { ez_max = max_H; ez_max_t = t; ez_max_q = r - t; }
-			else if (t >= ez_max_t && r - t >= ez_max_q) {
-				const int tl = t - ez_max_t, ql = (r - t) - ez_max_q;
-				const int l = tl > ql ? tl - ql : ql - tl;
-				if (P.zdrop >= 0 && ez_max - max_H > P.zdrop + l * e) { zdropped = 1; break; }
-			}
-		}
-		if (r == qlen + tlen - 2 && en0 == tlen - 1) score = Hen0;                    // :356-357
-		last_st = st; last_en = en;
-	}
-	out.max = ez_max; out.zdropped = zdropped; out.max_q = ez_max_q; out.max_t = ez_max_t;
-	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = score;
+	FastState F;
+	F.xA = F.vA = F.uA = F.yA = F.sA = 0; F.sfA = tg[lane];
+	F.xB = F.vB = F.uB = F.yB = 0; F.sfB = tg[64 + (lane & 15)];
+	F.rlB = -1; F.HA = F.HB = KSW_NEG_INF; F.st = 0;
+	F.edge_x = F.edge_v = 0; F.edge_h = KSW_NEG_INF; F.last_st = F.last_en = -1;
+	F.ez_max = 0; F.ez_max_t = F.ez_max_q = -1; F.mqe = F.mte = F.score = KSW_NEG_INF; F.mqe_t = F.mte_q = -1; F.zdropped = 0;
+	FastEnv E;
+	E.tg = tg; E.qr = qr; E.p = p; E.qlen = qlen; E.tlen = tlen; E.w = w; E.ncol = ncol; E.qe = qe; E.e = e;
+	E.zdrop = P.zdrop; E.with_cigar = with_cigar;
+	const int total = qlen + tlen - 1;
+	// steady diagonals: st0 = (r-w+1)>>1 > r-qlen+1, en0 = (r+w)>>1 < tlen-1, en < r
+	const int r_lo = w + 32;
+	int r_hi = 2 * tlen - 3 - w < 2 * qlen - w - 3 ? 2 * tlen - 3 - w : 2 * qlen - w - 3;
+	r_hi = r_hi + 1 < total ? r_hi + 1 : total;
+	int r = 0;
+	bool stop = false;
+	for (; r < total && r < r_lo && !stop; ++r) stop = fast_diag<RIGHT, false>(F, E, C, r);
+	if (w >= 49) for (; r < r_hi && !stop; ++r) stop = fast_diag<RIGHT, true>(F, E, C, r);   // w >= 49: a steady band spans blocks 0..3
+	for (; r < total && !stop; ++r) stop = fast_diag<RIGHT, false>(F, E, C, r);
+	out.max = F.ez_max; out.zdropped = F.zdropped; out.max_q = F.ez_max_q; out.max_t = F.ez_max_t;
+	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.score;
 	WSYNC();
 	const long long tc2 = pacc ? (long long)clock64() : 0;
 	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
 	if (!with_cigar) return;
-	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, zdropped, ez_max_t, ez_max_q, cig_tmp, cig_cap, out);
+	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, F.zdropped, F.ez_max_t, F.ez_max_q, cig_tmp, cig_cap, out);
 	if (pacc && lane == 0) pacc[2] += (long long)clock64() - tc2;
 }
 
