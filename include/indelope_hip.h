@@ -281,7 +281,7 @@ int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);
 /* Diagnostics: with IHP_PROFILE=1 in the environment the kernels sum shader-clock cycles
  * per phase over all waves: [0] assemble, [1] combine, [2] assemble+output, [3] regions;
  * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments.                       */
-int  ihp_batch_profile(ihp_batch *b, int64_t out[16]);
+int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
 /* Fixed-size per-region summary record left on the device for the multi-GPU
  * gather (one RCCL gather of these at the end).     */
 typedef struct {

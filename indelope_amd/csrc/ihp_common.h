@@ -39,6 +39,25 @@ __device__ __forceinline__ bool allowed(int rule, uint32_t qsup, uint32_t tsup, 
 	       (tsup < 3u && qsup > 3u * tsup && treads > 3ll * (long long)tsup);
 }
 
+// Work queue of a persistent grid: eight counters on separate cache lines (item j belongs to shard j & 7).
+// A single dequeue word saturates near 90 dequeues/us on this chip, which at ~20k short items per launch
+// costs more than the items themselves; a workgroup pulls from its home shard first and steals from the
+// others when it runs dry.  Call from lane 0 only.
+constexpr int WQ_WORDS = 8 * 16;
+__device__ __forceinline__ int wq_next(int *q, int n, int home, unsigned &dead)
+{
+	for (int t = 0; t < 8; ++t) {
+		const int s = (home + t) & 7;
+		if ((dead >> s) & 1) continue;
+		if (__hip_atomic_load(&q[s * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8 + s < n) {
+			const int j = atomicAdd(&q[s * 16], 1) * 8 + s;
+			if (j < n) return j;
+		}
+		dead |= 1u << s;
+	}
+	return -1;
+}
+
 // One alignment job for the ksw2 kernel.
 struct AlnJob {
 	long long q_off;     // into the query byte array

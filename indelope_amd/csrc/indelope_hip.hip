@@ -49,7 +49,7 @@ struct DBuf {
 	void *p = nullptr; size_t n = 0;
 	int alloc(size_t bytes) {
 		n = bytes;
-		hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+		hipError_t e = hipMalloc(&p, bytes + 64);          // +64: kernels read whole dwords at the tail of byte arrays
 		if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __LINE__) == IHP_E_HIP ? IHP_E_NOMEM : IHP_E_NOMEM; }
 		return 0;
 	}
@@ -138,6 +138,7 @@ extern "C" int ihp_init(int device)
 	if (g.max_lds > 65536) {
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
+		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -254,8 +255,9 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	if ((rc = d_ct.alloc(sizeof(uint32_t) * (size_t)(cig_cap + 4) * grid))) return rc;
 	if ((rc = d_ez.alloc(sizeof(KswOut) * n))) return rc;
 	if ((rc = d_coff.alloc(sizeof(long long) * n))) return rc;
-	if ((rc = d_pool.alloc(sizeof(uint32_t) * (size_t)(cig_bound + 4)))) return rc;
-	if ((rc = d_misc.alloc(64))) return rc;      // [0] cursor u64, [2..4] overflow, [8] work counter
+	const long long fixed_words = (long long)n * CIG_SLOT;
+	if ((rc = d_pool.alloc(sizeof(uint32_t) * (size_t)(cig_bound + 4 + fixed_words)))) return rc;
+	if ((rc = d_misc.alloc(64 + sizeof(int) * WQ_WORDS))) return rc;      // [0] cursor u64, [2..4] overflow, [16..] work queue
 	if ((rc = d_misc.zero(g.stream))) return rc;
 	KswArgs a;
 	a.jobs = d_jobs.as<AlnJob>(); a.n_jobs = nullptr; a.n_jobs_host = n;
@@ -263,8 +265,9 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.p_scratch = d_p.as<uint8_t>(); a.p_cap = p_need + 64;
 	a.cig_tmp = d_ct.as<uint32_t>(); a.cig_cap = cig_cap + 4;
 	a.ez = d_ez.as<KswOut>(); a.cig_off = d_coff.as<long long>();
-	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>(); a.cig_pool_cap = cig_bound + 4;
-	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 8; a.prof = nullptr;
+	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
+	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
+	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr;
 	launch_ksw(ksw_mode(P), dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
@@ -275,8 +278,9 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	const long long used = misc[0];
 	const int *ov = (const int *)misc + 2;
 	if (ov[0] || ov[1]) { snprintf(g.err, sizeof(g.err), "ksw2 kernel capacity overflow (%d,%d)", ov[0], ov[1]); return IHP_E_CAPACITY; }
-	pool.resize((size_t)used);
-	if (used) HIPC(hipMemcpy(pool.data(), d_pool.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost));
+	(void)used;
+	pool.resize((size_t)a.cig_pool_cap);
+	HIPC(hipMemcpy(pool.data(), d_pool.p, sizeof(uint32_t) * pool.size(), hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -506,7 +510,8 @@ struct ihp_batch {
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
-	long long cig_pool_cap = 0, ev_pool_cap = 0;
+	long long cig_pool_cap = 0, cig_bump_cap = 0, ev_pool_cap = 0, njobs_cap = 0;
+	DBuf queues;
 	// outputs
 	DBuf status, n_pre, n_final, ctg_start, ctg_nreads, ctg_seq_off, ctg_len, aln_flags, aln_ref_len, aln_ref_start;
 	DBuf out_seq, out_sup, jobs, ez, cig_off, cig_pool, ev_off, n_ev, ev_pool, summary;
@@ -598,9 +603,11 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		b->cig_cap = qeff + tmax + 8;
 	}
 	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_KSW_WAVES") ? atoi(getenv("IHP_KSW_WAVES")) : 32);
-	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), 8);
+	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), 32);
 	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
-	b->cig_pool_cap = 64 * njobs_cap + 1024;
+	b->njobs_cap = njobs_cap;
+	b->cig_bump_cap = 8 * njobs_cap + 4096;                      // CIGARs longer than CIG_SLOT words
+	b->cig_pool_cap = b->cig_bump_cap + (long long)CIG_SLOT * njobs_cap;
 	b->ev_pool_cap = (long long)std::max(1, p->max_events) * njobs_cap + 16;
 #define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
 	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);
@@ -614,7 +621,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(misc, sizeof(int) * M_WORDS);
-	AL(prof, sizeof(long long) * 16);
+	AL(queues, sizeof(int) * WQ_WORDS * 6);
+	AL(prof, sizeof(long long) * 32);
 	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
 	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
 	AL(ctg_len, 4 * slots); AL(aln_flags, 4 * slots); AL(aln_ref_len, 4 * slots); AL(aln_ref_start, 8 * slots);
@@ -636,8 +644,10 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	hipStream_t s = g.stream;
 	const ihp_params &p = b->P;
 	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
+	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * 6, s));
+	int *wq = b->queues.as<int>();
 	const bool profiling = getenv("IHP_PROFILE") != nullptr;
-	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 16, s));
+	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
 	int *misc = b->misc.as<int>();
 	HIPC(hipEventRecord(b->ev[0], s));
 	if (b->R > 0) {
@@ -660,7 +670,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.aln_flags = b->aln_flags.as<int>(); a.aln_ref_len = b->aln_ref_len.as<int>();
 		a.aln_ref_start = b->aln_ref_start.as<long long>();
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
-		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = misc + M_CNT_ASM;
+		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		// passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  A region
 		// moves on when it is predicted not to fit, or when it runs out of arena / contig slots.
@@ -670,15 +680,15 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
 		HIPC(hipGetLastError());
 		a.arena_sup = b->lds_sup2.as<uint32_t>(); a.arena_cap = b->lds_arena2; a.lds_arena = b->lds_arena2;
-		a.in_list = l1; a.n_in = misc + M_NRETRY; a.out_list = l2; a.n_out = misc + M_NRETRY2; a.work_counter = misc + M_CNT_ASM2;
+		a.in_list = l1; a.n_in = misc + M_NRETRY; a.out_list = l2; a.n_out = misc + M_NRETRY2; a.work_counter = wq + WQ_WORDS;
 		hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(b->grid_asm2), dim3(64), b->lds_arena2, s, a);
 		HIPC(hipGetLastError());
 		a.arena_sup = b->lds_sup3.as<uint32_t>(); a.arena_cap = b->lds_arena3; a.lds_arena = b->lds_arena3;
-		a.in_list = l2; a.n_in = misc + M_NRETRY2; a.out_list = l1; a.n_out = misc + M_NRETRY3; a.work_counter = misc + M_CNT_ASM3;
+		a.in_list = l2; a.n_in = misc + M_NRETRY2; a.out_list = l1; a.n_out = misc + M_NRETRY3; a.work_counter = wq + 2 * WQ_WORDS;
 		hipLaunchKernelGGL((k_assemble<256, true, 1>), dim3(b->grid_asm3), dim3(64), b->lds_arena3, s, a);
 		HIPC(hipGetLastError());
 		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>(); a.arena_cap = b->arena_cap; a.lds_arena = 0;
-		a.in_list = l1; a.n_in = misc + M_NRETRY3; a.out_list = nullptr; a.n_out = nullptr; a.work_counter = misc + M_CNT_RETRY;
+		a.in_list = l1; a.n_in = misc + M_NRETRY3; a.out_list = nullptr; a.n_out = nullptr; a.work_counter = wq + 3 * WQ_WORDS;
 		hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(b->grid_retry), dim3(64), 0, s, a);
 		HIPC(hipGetLastError());
 	}
@@ -695,7 +705,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_tmp = b->cig_tmp.as<uint32_t>(); a.cig_cap = b->cig_cap;
 		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>();
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
-		a.cig_pool_cap = b->cig_pool_cap; a.overflow = misc + M_OVF; a.work_counter = misc + M_CNT_KSW;
+		a.cig_pool_cap = b->cig_pool_cap; a.cig_bump_cap = b->cig_bump_cap; a.overflow = misc + M_OVF; a.work_counter = wq + 4 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		launch_ksw(ksw_mode(a.P), dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
@@ -712,8 +722,10 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.P.K = p.K; a.P.min_event_len = p.min_event_len; a.P.max_events = p.max_events; a.P.min_mapq_tally = p.min_mapq_tally;
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
-		a.overflow = misc + M_OVF; a.work_counter = misc + M_CNT_TALLY;
-		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), 0, s, a);
+		a.overflow = misc + M_OVF; a.work_counter = wq + 5 * WQ_WORDS;
+		a.prof = profiling ? b->prof.as<long long>() : nullptr;
+		a.lds_bytes = std::min(g.max_lds - 4096, 64 * ((b->max_read_len + 3) / 4 * 4) + 64);
+		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[3], s));
@@ -749,10 +761,10 @@ extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
 
 // Diagnostics (IHP_PROFILE=1): shader-clock cycles summed over waves.
 // [0] assemble total, [1] combine, [2] assemble+output, [3] regions; [8] ksw init, [9] ksw DP, [10] ksw traceback, [11] jobs
-extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[16])
+extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 {
 	if (!b || !out) return IHP_E_ARG;
-	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
 	int nretry = 0;
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY, sizeof(int), hipMemcpyDeviceToHost));
 	out[15] = nretry;                                 // regions forwarded to the large-arena pass
@@ -801,8 +813,9 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d", misc[M_OVF], misc[M_OVF + 1], misc[M_OVF + 2]);
 		return IHP_E_CAPACITY;
 	}
-	unsigned long long ncig, nev;
-	memcpy(&ncig, misc + M_CIG, 8); memcpy(&nev, misc + M_EV, 8);
+	const long long njobs = misc[M_NJOBS];
+	const unsigned long long ncig = (unsigned long long)(b->cig_bump_cap + njobs * CIG_SLOT);
+	const unsigned long long nev = (unsigned long long)(njobs * std::max(1, b->P.max_events));
 	std::vector<int> status, n_pre, n_final, ctg_len, aln_flags, aln_ref_len, n_ev;
 	std::vector<long long> ctg_start, ctg_nreads, ctg_seq_off, aln_ref_start, cig_off, ev_off;
 	std::vector<uint8_t> seq; std::vector<uint32_t> sup, pool; std::vector<KswOut> ez; std::vector<DevEvent> evp;

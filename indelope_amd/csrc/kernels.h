@@ -279,12 +279,13 @@ __global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 	if (lane < 16) S.prof[lane] = 0;
 	WSYNC();
 	const int n_items = a.in_list ? *a.n_in : a.n_regions;
+	unsigned wq_dead = 0;
 	for (;;) {
-		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
+		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
 		WSYNC();
 		int r = s_item;
 		WSYNC();
-		if (r >= n_items) break;
+		if (r < 0) break;
 		if (a.in_list) r = a.in_list[r];
 		if (LDSA && a.out_list) {
 			// live contig bytes (with headroom) stay below ~30% of the read bases on indel-region pile-ups;
@@ -361,6 +362,8 @@ __global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 }
 
 // ---------------------------------------------------------------------- ksw2
+constexpr int CIG_SLOT = 32;      // CIGAR words reserved per alignment job (longer ones go to the bump pool)
+
 struct KswArgs {
 	const AlnJob *jobs; const int *n_jobs; int n_jobs_host;   // n_jobs may be null (use n_jobs_host)
 	const uint8_t *qbase, *tbase;
@@ -370,7 +373,8 @@ struct KswArgs {
 	uint32_t *cig_tmp; int cig_cap;            // per workgroup
 	KswOut *ez;                                // [slots]
 	long long *cig_off;                        // [slots] offset into the pool (or -1)
-	uint32_t *cig_pool; unsigned long long *cig_cursor; long long cig_pool_cap;
+	uint32_t *cig_pool; unsigned long long *cig_cursor; long long cig_pool_cap;   // [0, cig_bump_cap): bump region,
+	long long cig_bump_cap;                    // then one CIG_SLOT-word slot per job
 	int *overflow;                             // [0] cigar pool, [1] LDS/p budget
 	int *work_counter;
 	long long *prof;                           // optional cycle counters (diagnostics)
@@ -391,12 +395,13 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 	long long *pacc = (long long *)(lds + a.lds_budget + 16);   // per-wave cycle counters live past the sweep's LDS
 	if (a.prof && lane < 4) pacc[lane] = 0;
 	WSYNC();
+	unsigned wq_dead = 0;
 	for (;;) {
-		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
+		if (lane == 0) s_item = wq_next(a.work_counter, njobs, (int)blockIdx.x, wq_dead);
 		WSYNC();
 		const int j = s_item;
 		WSYNC();
-		if (j >= njobs) break;
+		if (j < 0) break;
 		const AlnJob jb = a.jobs[j];
 		KswOut out;
 		int w = a.P.w;
@@ -419,9 +424,13 @@ __global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
 		}
 		long long off = -1;
 		if (out.n_cigar > 0) {
-			if (lane == 0) s_off = (long long)atomicAdd(a.cig_cursor, (unsigned long long)out.n_cigar);
-			WSYNC();
-			off = s_off;
+			if (out.n_cigar <= CIG_SLOT) off = a.cig_bump_cap + (long long)j * CIG_SLOT;   // the job's own slot: no atomic
+			else {
+				if (lane == 0) s_off = (long long)atomicAdd(a.cig_cursor, (unsigned long long)out.n_cigar);
+				WSYNC();
+				off = s_off;
+				if (off + out.n_cigar > a.cig_bump_cap) off = a.cig_pool_cap;     // bump region exhausted
+			}
 			if (off + out.n_cigar <= a.cig_pool_cap) {
 				for (int i = lane; i < out.n_cigar; i += 64) a.cig_pool[off + i] = ct[i];
 			} else {
@@ -449,36 +458,43 @@ struct TallyArgs {
 	long long *ev_off; int *n_ev;              // [slots]
 	int *overflow;                             // [2] event pool
 	int *work_counter;
+	long long *prof;                           // optional cycle counters (diagnostics)
+	int lds_bytes;                             // dynamic LDS for staging 64 reads
 };
 
 __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 {
+	extern __shared__ __attribute__((aligned(16))) uint32_t tally_lds[];
 	__shared__ int s_item;
 	__shared__ long long s_off;
 	const int lane = lane_id();
 	const int njobs = *a.n_jobs;
+	unsigned wq_dead = 0;
 	for (;;) {
-		if (lane == 0) s_item = atomicAdd(a.work_counter, 1);
+		if (lane == 0) s_item = wq_next(a.work_counter, njobs, (int)blockIdx.x, wq_dead);
 		WSYNC();
 		const int j = s_item;
 		WSYNC();
-		if (j >= njobs) break;
+		if (j < 0) break;
+		const long long tj0 = a.prof ? (long long)clock64() : 0;
 		const AlnJob jb = a.jobs[j];
 		const KswOut ez = a.ez[jb.out];
 		const long long coff = a.cig_off[jb.out];
 		int nev = 0, ntrunc = 0;
 		if (ez.n_cigar > 0 && coff >= 0) nev = count_events(a.cig_pool + coff, ez.n_cigar, ez.max_q, &ntrunc);
 		long long eoff = -1;
+		const long long tj1 = a.prof ? (long long)clock64() : 0;
+		if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[20], (unsigned long long)(tj1 - tj0));
 		if (nev > 0 && nev <= a.P.max_events) {                 // indelope.nim:229
-			if (lane == 0) s_off = (long long)atomicAdd(a.ev_cursor, (unsigned long long)nev);
-			WSYNC();
-			eoff = s_off;
+			eoff = (long long)j * a.P.max_events;               // the job's own slots: no atomic
+			if (lane == 0) atomicAdd(a.ev_cursor, (unsigned long long)nev);   // count only (result unused)
+			if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[21], (unsigned long long)((long long)clock64() - tj1));
 			if (eoff + nev <= a.ev_pool_cap) {
 				const int r = jb.region;
 				fill_events(a.cig_pool + coff, ntrunc, a.out_seq + jb.q_off, jb.qlen,
 				            (int)(a.ctg_start[jb.out] - a.ref_origin[r]), a.ref_bases + jb.t_off, jb.tlen,
 				            a.bases, a.read_off, a.mapq, a.region_read_off[r], a.region_read_off[r + 1],
-				            a.P, a.ev_pool + eoff);
+				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes);
 			} else {
 				if (lane == 0) atomicExch(&a.overflow[2], 1);
 				eoff = -1; nev = 0;
@@ -486,6 +502,10 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 		} else nev = 0;
 		if (lane == 0) { a.ev_off[jb.out] = eoff; a.n_ev[jb.out] = nev; }
 		WSYNC();
+		if (a.prof && lane == 0) {
+			atomicAdd((unsigned long long *)&a.prof[nev ? 16 : 17], (unsigned long long)((long long)clock64() - tj0));
+			atomicAdd((unsigned long long *)&a.prof[nev ? 18 : 19], 1ull);
+		}
 	}
 }
 

@@ -31,13 +31,18 @@ __device__ inline bool mincode_dev(const char *kmer, int K, unsigned long long &
 	return true;
 }
 
-// indelope.nim:293-311: lanes = reads.  counts[0..3) = ref_support, alt_support, both_found
+typedef uint32_t tally_u32u __attribute__((aligned(1)));
+
+// indelope.nim:293-311: lanes = reads.  counts[0..3) = ref_support, alt_support, both_found.
+// Each lane walks its read four bases per (unaligned) dword load; the byte arrays are padded so the last
+// partial dword of the last read is readable.
 __device__ inline void tally_reads(const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                    long long r0, long long r1, int min_mapq, int K,
                                    unsigned long long refe, unsigned long long alte, int counts[3])
 {
 	const int lane = lane_id();
 	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
+	const int hs = 2 * (K - 1);
 	int nref = 0, nalt = 0, nboth = 0;
 	for (long long b = r0; b < r1; b += 64) {
 		const long long ri = b + lane;
@@ -47,15 +52,86 @@ __device__ inline void tally_reads(const uint8_t *bases, const long long *read_o
 			const int n = (int)(read_off[ri + 1] - read_off[ri]);
 			unsigned long long f = 0, rc = 0;
 			int valid = 0;
-			for (int i = 0; i < n; ++i) {
-				const int c = base2(seq[i]);
-				if (c < 0) { valid = 0; f = rc = 0; continue; }
-				f = ((f << 2) | (unsigned long long)c) & mask;
-				rc = (rc >> 2) | ((unsigned long long)(3 - c) << (2 * (K - 1)));
-				if (++valid < K) continue;
-				const unsigned long long e = f < rc ? f : rc;
-				rf |= e == refe;                                 // :301-309
-				af |= e == alte;
+			for (int i0 = 0; i0 < n; i0 += 4) {
+				const unsigned wv = *(const tally_u32u *)(seq + i0);
+				const int m = n - i0 < 4 ? n - i0 : 4;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					if (j < m) {
+						const int c = base2((uint8_t)(wv >> (8 * j)));
+						if (c < 0) { valid = 0; f = rc = 0; }
+						else {
+							f = ((f << 2) | (unsigned long long)c) & mask;
+							rc = (rc >> 2) | ((unsigned long long)(3 - c) << hs);
+							if (++valid >= K) {
+								const unsigned long long e = f < rc ? f : rc;
+								rf |= e == refe;                         // :301-309
+								af |= e == alte;
+							}
+						}
+					}
+				}
+			}
+		}
+		nref += popc64(ballot(rf));
+		nalt += popc64(ballot(af));
+		nboth += popc64(ballot(rf && af));                       // :310-311
+	}
+	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
+}
+
+// The same tally with the reads staged through LDS: 64 reads at a time are copied with coalesced dword
+// loads (they are contiguous in `bases`), then each lane walks its own read out of LDS.  A lane-per-read
+// walk straight from HBM touches 64 different cache lines per load instruction.
+__device__ inline void tally_reads_lds(const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
+                                       long long r0, long long r1, int min_mapq, int K,
+                                       unsigned long long refe, unsigned long long alte, int counts[3],
+                                       uint32_t *lds32, int lds_bytes)
+{
+	const int lane = lane_id();
+	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
+	const int hs = 2 * (K - 1);
+	int nref = 0, nalt = 0, nboth = 0;
+	for (long long b = r0; b < r1; b += 64) {
+		const long long e = b + 64 < r1 ? b + 64 : r1;
+		const long long base0 = read_off[b];
+		const int nbytes = (int)(read_off[e] - base0);
+		if (nbytes + 8 > lds_bytes) {                            // does not fit: walk HBM directly (rare)
+			int c[3];
+			tally_reads(bases, read_off, mapq, b, e, min_mapq, K, refe, alte, c);
+			nref += c[0]; nalt += c[1]; nboth += c[2];
+			continue;
+		}
+		WSYNC();
+		for (int i = 4 * lane; i < nbytes; i += 256) lds32[i >> 2] = *(const tally_u32u *)(bases + base0 + i);
+		WSYNC();
+		const long long ri = b + lane;
+		bool rf = false, af = false;
+		if (ri < e && !(mapq && mapq[ri] < min_mapq)) {          // :294
+			const int off = (int)(read_off[ri] - base0);
+			const int n = (int)(read_off[ri + 1] - read_off[ri]);
+			unsigned long long f = 0, rc = 0;
+			int valid = 0;
+			for (int i0 = 0; i0 < n; i0 += 4) {
+				const int bo = off + i0, w = bo >> 2;
+				const unsigned wv = __builtin_amdgcn_alignbit(lds32[w + 1], lds32[w], (unsigned)(bo & 3) * 8u);
+				const int m = n - i0 < 4 ? n - i0 : 4;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					if (j < m) {
+						const int c = base2((uint8_t)(wv >> (8 * j)));
+						if (c < 0) { valid = 0; f = rc = 0; }
+						else {
+							f = ((f << 2) | (unsigned long long)c) & mask;
+							rc = (rc >> 2) | ((unsigned long long)(3 - c) << hs);
+							if (++valid >= K) {
+								const unsigned long long ee = f < rc ? f : rc;
+								rf |= ee == refe;                        // :301-309
+								af |= ee == alte;
+							}
+						}
+					}
+				}
 			}
 		}
 		nref += popc64(ballot(rf));
@@ -102,14 +178,48 @@ __device__ __forceinline__ int count_events(const uint32_t *cigar, int n_cigar, 
 	return nev;
 }
 
+// OR-reduce a 64-bit value over the wave
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
+{
+	unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+	for (int d = 32; d >= 1; d >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, d, 64); hi |= (unsigned)__shfl_xor((int)hi, d, 64); }
+	return ((unsigned long long)hi << 32) | lo;
+}
+
+// number of distinct byte values among lanes [0, K), saturated at 3 (only "== 1" and "< 3" are ever asked)
+__device__ __forceinline__ int distinct3(unsigned byte, int K)
+{
+	const int lane = lane_id();
+	const bool in = lane < K;
+	const unsigned v0 = (unsigned)bcast((int)byte, 0);
+	const unsigned long long m1 = ballot(in && byte != v0);
+	if (!m1) return 1;
+	const unsigned v1 = (unsigned)bcast((int)byte, ctz64(m1));
+	return ballot(in && byte != v0 && byte != v1) ? 3 : 2;
+}
+
+// canonical 2-bit code of the k-mer held one byte per lane; false if a byte is not upper-case ACGT
+__device__ __forceinline__ bool mincode_lanes(unsigned byte, int K, unsigned long long &code)
+{
+	const int lane = lane_id();
+	const int b = lane < K ? base2((uint8_t)byte) : 0;
+	if (ballot(lane < K && b < 0)) return false;
+	unsigned long long f = 0, rc = 0;
+	if (lane < K) { f = (unsigned long long)b << (2 * (K - 1 - lane)); rc = (unsigned long long)(3 - b) << (2 * lane); }
+	f = wave_or_u64(f); rc = wave_or_u64(rc);
+	code = f < rc ? f : rc;
+	return true;
+}
+
 // Events of one alignment (the caller has checked 0 < nev <= max_events, indelope.nim:229).
 // ctg_rel = ctg.start - region origin; reference points at the window the contig was
-// aligned to (length reflen).  Lane 0 stores the nev events to ev[].
+// aligned to (length reflen).  The ref/alt k-mers are held one byte per lane (K <= 31).
 __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
                                    const uint8_t *ctg, int ctg_len, int ctg_rel,
                                    const uint8_t *reference, int reflen,
                                    const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
-                                   long long r0, long long r1, const TallyParams P, DevEvent *ev)
+                                   long long r0, long long r1, const TallyParams P, DevEvent *ev,
+                                   uint32_t *lds32, int lds_bytes)
 {
 	const int lane = lane_id();
 	const int K = P.K;
@@ -119,60 +229,61 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
 		const uint32_t op = cigar[i] & 0xf, len = cigar[i] >> 4;
 		if (op == 0) { toff += (int)len; qoff += (int)len; continue; }
 		++ii;
-		DevEvent E;
-		E.len = len; E.pad = 0; E.fallback = 0; E.cf_offset = 0;
-		E.ref_support = E.alt_support = E.both_found = 0;
-		for (int k = 0; k < 32; ++k) E.ref_kmer[k] = E.alt_kmer[k] = 0;
+		int e_type, e_ts, e_te, e_qs, e_qe;
 		if (op == 1) {                                                   // ksw2.nim:75-76, :88-89
-			E.type = 0; E.tstart_rel = toff; E.tstop_rel = toff + 1; E.qstart = qoff; E.qstop = qoff + (int)len;
+			e_type = 0; e_ts = toff; e_te = toff + 1; e_qs = qoff; e_qe = qoff + (int)len;
 			qoff += (int)len;
 		} else {                                                         // ksw2.nim:77-78, :86-87
-			E.type = 1; E.tstart_rel = toff; E.tstop_rel = toff + (int)len; E.qstart = qoff; E.qstop = qoff + 1;
+			e_type = 1; e_ts = toff; e_te = toff + (int)len; e_qs = qoff; e_qe = qoff + 1;
 			toff += (int)len;
 		}
-		int status = -1;
+		int status = -1, cf = 0;
+		unsigned rk = 0, ak = 0;                                         // this lane's byte of ref_kmer / alt_kmer
 		unsigned long long refe = 0, alte = 0;
+		int counts[3] = {0, 0, 0};
 		if ((int)len < P.min_event_len) status = IHP_EV_SHORT;           // :234
 		else if (reflen < K || ctg_len < K) status = IHP_EV_OOB;
 		else {
-			int tstart = E.tstart_rel - ctg_rel - width;                 // :236-238
+			int tstart = e_ts - ctg_rel - width;                         // :236-238
 			if (tstart < 0) tstart = 0;
 			if (tstart + K > reflen) tstart = reflen - K;
-			for (int k = 0; k < K; ++k) E.ref_kmer[k] = (char)reference[tstart + k];   // :240
-			const int o1 = E.qstart, o2 = ctg_len - E.qstop - 1;
-			E.cf_offset = o1 < o2 ? o1 : o2;                             // :243
-			int qstart = E.qstart - width;                               // :244-246
+			if (lane < K) rk = reference[tstart + lane];                 // :240
+			const int o1 = e_qs, o2 = ctg_len - e_qe - 1;
+			cf = o1 < o2 ? o1 : o2;                                      // :243
+			int qstart = e_qs - width;                                   // :244-246
 			if (qstart < 0) qstart = 0;
 			if (qstart + K > ctg_len) qstart = ctg_len - K;
-			for (int k = 0; k < K; ++k) E.alt_kmer[k] = (char)ctg[qstart + k];          // :248
-			if (same_bytes(E.alt_kmer, E.ref_kmer, K)) {                 // :255-262
-				qstart = E.qstart - 3;
+			if (lane < K) ak = ctg[qstart + lane];                       // :248
+			if (!ballot(lane < K && rk != ak)) {                         // :255-262
+				qstart = e_qs - 3;
 				if (qstart < 0) qstart = 0;
 				if (qstart + K > ctg_len) {
-					const int qend = E.qstop + 4 < ctg_len ? E.qstop + 4 : ctg_len;
+					const int qend = e_qe + 4 < ctg_len ? e_qe + 4 : ctg_len;
 					if (qend - K < 0) status = IHP_EV_OOB;
-					else for (int k = 0; k < K; ++k) E.alt_kmer[k] = (char)ctg[qend - K + k];
-				} else {
-					for (int k = 0; k < K; ++k) E.alt_kmer[k] = (char)ctg[qstart + k];
-				}
+					else if (lane < K) ak = ctg[qend - K + lane];
+				} else if (lane < K) ak = ctg[qstart + lane];
 			}
 			if (status < 0) {
-				const bool same = same_bytes(E.alt_kmer, E.ref_kmer, K);
-				if (same && (E.qstart == 0 || distinct_bytes(E.alt_kmer, K) == 1)) status = IHP_EV_SAME_KMER;   // :264
-				else if (distinct_bytes(E.ref_kmer, K) < 3) status = IHP_EV_LOW_CPLX;                           // :266
-				else if (same) status = IHP_EV_BUG_SAME;                                                       // :268-275
-				else if (!mincode_dev(E.ref_kmer, K, refe) || !mincode_dev(E.alt_kmer, K, alte)) status = IHP_EV_NON_ACGT;
+				const bool same = !ballot(lane < K && rk != ak);
+				if (same && (e_qs == 0 || distinct3(ak, K) == 1)) status = IHP_EV_SAME_KMER;   // :264
+				else if (distinct3(rk, K) < 3) status = IHP_EV_LOW_CPLX;                       // :266
+				else if (same) status = IHP_EV_BUG_SAME;                                       // :268-275
+				else if (!mincode_lanes(rk, K, refe) || !mincode_lanes(ak, K, alte)) status = IHP_EV_NON_ACGT;
 			}
 		}
 		if (status < 0) {
-			int counts[3];
-			tally_reads(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts);
-			E.ref_support = counts[0]; E.alt_support = counts[1]; E.both_found = counts[2];
-			E.fallback = counts[2] > 0;                                  // :313
+			tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes);
 			status = IHP_EV_TALLIED;
 		}
-		E.status = (unsigned char)status;
-		if (lane == 0) ev[ii] = E;
+		DevEvent *o = ev + ii;
+		if (lane == 0) {
+			o->tstart_rel = e_ts; o->tstop_rel = e_te; o->qstart = e_qs; o->qstop = e_qe;
+			o->len = len; o->type = (unsigned char)e_type; o->status = (unsigned char)status;
+			o->fallback = status == IHP_EV_TALLIED && counts[2] > 0;     // :313
+			o->pad = 0; o->cf_offset = cf;
+			o->ref_support = counts[0]; o->alt_support = counts[1]; o->both_found = counts[2];
+		}
+		if (lane < 32) { o->ref_kmer[lane] = (char)(lane < K ? rk : 0); o->alt_kmer[lane] = (char)(lane < K ? ak : 0); }
 	}
 }
 
