@@ -466,7 +466,6 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t tally_lds[];
 	__shared__ int s_item;
-	__shared__ long long s_off;
 	const int lane = lane_id();
 	const int njobs = *a.n_jobs;
 	unsigned wq_dead = 0;
