@@ -29,6 +29,13 @@ __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((lon
 __device__ __forceinline__ int clz64(unsigned long long m) { return __clzll((long long)m); }
 __device__ __forceinline__ int bcast(int v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int first_lane_val(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A wave-uniform value that was loaded through the vector memory path sits in a VGPR, and the compiler then
+// does all the scalar arithmetic and branching that depends on it on the vector ALU.  uni() moves it to an SGPR.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni(long long v)
+{
+	return ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 
 // contig.nim:44-47 (rule 0) and contig.nim:287-290 (rule 1, the reference's test rule)
 __device__ __forceinline__ bool allowed(int rule, uint32_t qsup, uint32_t tsup, long long qreads, long long treads)

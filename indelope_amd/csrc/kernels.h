@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 	for (;;) {
 		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
 		WSYNC();
-		int r = s_item;
+		int r = __builtin_amdgcn_readfirstlane(s_item);
 		WSYNC();
 		if (r < 0) break;
 		if (a.in_list) r = a.in_list[r];

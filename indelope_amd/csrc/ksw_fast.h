@@ -41,9 +41,9 @@ struct FastConst { unsigned qe2, sc_mch, sc_mis, m1, max_sc8, q8; };
 
 __device__ __forceinline__ unsigned score_byte(unsigned sfb, unsigned qb, const FastConst &C)
 {   // :219-226
-	unsigned sv = sfb == qb ? C.sc_mch : C.sc_mis;
-	if (sfb == C.m1 || qb == C.m1) sv = 0;
-	return sv;
+	const unsigned sv = sfb == qb ? C.sc_mch : C.sc_mis;      // written as selects: no exec-mask branches
+	const bool wild = (sfb == C.m1) | (qb == C.m1);
+	return wild ? 0u : sv;
 }
 
 // One cell of the recurrence (:116-137 + :262-310).  In: sv, xt1, vt1, ut, yt.  Out: new x,v,u,y and d.
@@ -138,7 +138,7 @@ __device__ __forceinline__ bool fast_diag(FastState &F, const FastEnv &E, const 
 	int hB = INTMIN, hA = INTMIN;
 	const int spec = (STEADY || (r > 0 && en0 > 0)) ? hiT : -1000;      // lane of the H[en0] special case (:318)
 	// ---- slot B (block 4) ------------------------------------------------------------
-	if (sc >= 64) F.rlB = lane <= sc - 64 ? r : F.rlB;                  // :214-228 runs past en; value formed on use
+	F.rlB = lane <= sc - 64 ? r : F.rlB;                                // :214-228 runs past en; value formed on use
 	if (nTop >= 64) {
 		const unsigned exB = (unsigned)__builtin_amdgcn_readlane((int)F.xA, 63), evB = (unsigned)__builtin_amdgcn_readlane((int)F.vA, 63);
 		const int HeB = __builtin_amdgcn_readlane(F.HA, 63);
@@ -162,21 +162,28 @@ __device__ __forceinline__ bool fast_diag(FastState &F, const FastEnv &E, const 
 	// ---- slot A (blocks 0..3) --------------------------------------------------------
 	{
 		const unsigned qbA = E.qr[qbase + lane];
-		if (lane >= loA && lane <= sc) F.sA = score_byte(F.sfA, qbA, C);   // :214-228
+		const unsigned snew = score_byte(F.sfA, qbA, C);
+		F.sA = ((lane >= loA) & (lane <= sc)) ? snew : F.sA;       // :214-228
 		if (!STEADY && r <= en && r - st < 64) {             // :212 (only while the band still touches t == r)
-			if (st + lane == r) { F.yA = 0; F.uA = r ? C.q8 : 0; }
+			const bool tr = st + lane == r;
+			F.yA = tr ? 0u : F.yA; F.uA = tr ? (r ? C.q8 : 0u) : F.uA;
 		}
-		if (STEADY || lane <= nTop) {                        // a steady band always covers blocks 0..3
-			unsigned xn, vn, un, yn, d;
-			ksw_cell<RIGHT>(F.sA, xpA, vpA, F.uA, F.yA, C, xn, vn, un, yn, d);
+		unsigned xn, vn, un, yn, d;
+		ksw_cell<RIGHT>(F.sA, xpA, vpA, F.uA, F.yA, C, xn, vn, un, yn, d);
+		const bool act = STEADY || lane <= nTop;             // a steady band always covers blocks 0..3
+		const bool inT = act & (lane >= loA) & (lane <= hiT);
+		int h;
+		if (STEADY || r > 0) h = (lane == spec ? HpA + (int)un : F.HA + (int)vn) - E.qe;   // :318, :323-329
+		else h = (int)vn - E.qe - E.qe;                      // :349
+		if (STEADY) {
 			F.xA = xn; F.vA = vn; F.uA = un; F.yA = yn;
 			if (E.with_cigar) pr[lane] = (uint8_t)d;
-			if (lane >= loA && lane <= hiT) {
-				if (STEADY || r > 0) hA = (lane == spec ? HpA + (int)un : F.HA + (int)vn) - E.qe;
-				else hA = (int)vn - E.qe - E.qe;                 // :349
-				F.HA = hA;
-			}
+		} else {
+			F.xA = act ? xn : F.xA; F.vA = act ? vn : F.vA; F.uA = act ? un : F.uA; F.yA = act ? yn : F.yA;
+			if (E.with_cigar && act) pr[lane] = (uint8_t)d;
 		}
+		hA = inT ? h : INTMIN;
+		F.HA = inT ? h : F.HA;
 	}
 	// ---- exact max (:320-348) ----------------------------------------------------------
 	int max_H = wave_max_i32(hA), max_t;
