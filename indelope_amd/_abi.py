@@ -165,6 +165,7 @@ _PRODUCT_ONLY = {
     "batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
+    "debug_last_ksw_mode": (C.c_int, []),
 }
 
 KSW_ARGTYPES = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,

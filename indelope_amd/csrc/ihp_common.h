@@ -87,6 +87,7 @@ struct DevEvent {
 
 struct KswParams {
 	int m; int sc_mch, sc_mis; int min_sc; int q, e, w, zdrop, flag; int encode_ascii;
+	int codes_ok;                             // host: every base code is < m (always so after ASCII encoding)
 };
 
 }  // namespace ihp

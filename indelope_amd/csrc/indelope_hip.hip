@@ -78,13 +78,23 @@ int grid_for(int items, int waves_per_cu)
 int ksw_mode(const KswParams &P)
 {
 	if (P.w < 0 || P.w > 62) return 2;
-	return (P.flag & KSW_EZ_RIGHT) ? 1 : 0;
+	const int right = (P.flag & KSW_EZ_RIGHT) ? 1 : 0;
+	return (ksw_narrow_ok(P) && P.codes_ok) ? 3 + right : right;
+}
+
+int g_last_ksw_mode = -1;
+
+size_t ksw_mode_lds(int mode, int qlen, int tlen)
+{
+	return mode >= 3 ? ksw_narrow_lds_bytes(qlen, tlen) : mode != 2 ? ksw_fast_lds_bytes(qlen, tlen) : ksw_lds_bytes(qlen, tlen);
 }
 
 template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStream_t s, const KswArgs &a)
 {
 	if (mode == 0) hipLaunchKernelGGL(k_ksw<0>, grid, dim3(64), lds, s, a);
 	else if (mode == 1) hipLaunchKernelGGL(k_ksw<1>, grid, dim3(64), lds, s, a);
+	else if (mode == 3) hipLaunchKernelGGL(k_ksw<3>, grid, dim3(64), lds, s, a);
+	else if (mode == 4) hipLaunchKernelGGL(k_ksw<4>, grid, dim3(64), lds, s, a);
 	else hipLaunchKernelGGL(k_ksw<2>, grid, dim3(64), lds, s, a);
 }
 
@@ -94,7 +104,7 @@ KswParams make_ksw_params(int8_t m, const int8_t *mat, int8_t q, int8_t e, int w
 	P.m = m; P.sc_mch = mat[0]; P.sc_mis = mat[1];
 	int mn = mat[1];
 	for (int t = 1; t < m * m; ++t) mn = mn < mat[t] ? mn : mat[t];      // ksw2_extz2_sse.c:167-170
-	P.min_sc = mn; P.q = q; P.e = e; P.w = w; P.zdrop = zdrop; P.flag = flag; P.encode_ascii = ascii;
+	P.min_sc = mn; P.q = q; P.e = e; P.w = w; P.zdrop = zdrop; P.flag = flag; P.encode_ascii = ascii; P.codes_ok = ascii;
 	return P;
 }
 
@@ -142,6 +152,8 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_ksw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_ksw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 	}
 	g.ready = true;
 	return 0;
@@ -222,6 +234,16 @@ extern "C" double ihp_genotype_qual(const ihp_genotype_t *g_)
 }
 
 // ----------------------------------------------------------------- ksw2 batch
+// diagnostics: which k_ksw<MODE> the last ksw_extz2_sse / ihp_ksw_extz2_batch / ihp_batch_run call used
+extern "C" int ihp_debug_last_ksw_mode(void) { return g_last_ksw_mode; }
+
+static int codes_below(const uint8_t *s, size_t n, int m)
+{
+	uint8_t mx = 0;
+	for (size_t i = 0; i < n; ++i) mx = mx > s[i] ? mx : s[i];
+	return (int)mx < m;
+}
+
 static int ksw_flags_supported(int flag)
 {
 	return !(flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP));
@@ -239,7 +261,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	size_t lds_need = 0, p_need = 0; long long cig_bound = 0; int cig_cap = 0;
 	for (const AlnJob &j : jobs) {
 		if (j.qlen <= 0 || j.tlen <= 0) continue;
-		lds_need = std::max(lds_need, (P.w >= 0 && P.w <= 62) ? ksw_fast_lds_bytes(j.qlen, j.tlen) : ksw_lds_bytes(j.qlen, j.tlen));
+		lds_need = std::max(lds_need, (P.w >= 0 && P.w <= 62) ? ksw_narrow_lds_bytes(j.qlen, j.tlen) : ksw_lds_bytes(j.qlen, j.tlen));
 		int w = P.w < 0 ? std::max(j.qlen, j.tlen) : P.w;
 		int nc = (std::min(std::min(j.qlen, j.tlen), w + 1) + 15) / 16 + 1;
 		p_need = std::max(p_need, ((size_t)(j.qlen + j.tlen - 1) * nc + 1) * 16);
@@ -268,7 +290,8 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
 	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
 	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr;
-	launch_ksw(ksw_mode(P), dim3(grid), lds_need + 64, g.stream, a);
+	g_last_ksw_mode = ksw_mode(P);
+	launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
 	HIPC(hipMemcpyAsync(ez.data(), d_ez.p, sizeof(KswOut) * n, hipMemcpyDeviceToHost, g.stream));
@@ -306,7 +329,9 @@ extern "C" int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int6
 	if ((rc = d_q.upload(queries, (size_t)q_off[n], g.stream))) return rc;
 	if ((rc = d_t.upload(targets, (size_t)t_off[n], g.stream))) return rc;
 	std::vector<KswOut> out; std::vector<long long> coff; std::vector<uint32_t> pool;
-	rc = run_ksw_jobs(jobs, d_q.as<uint8_t>(), d_t.as<uint8_t>(), make_ksw_params(m, mat, q, e, w, zdrop, flag, 0), out, coff, pool);
+	KswParams P = make_ksw_params(m, mat, q, e, w, zdrop, flag, 0);
+	P.codes_ok = codes_below(queries, (size_t)q_off[n], m) && codes_below(targets, (size_t)t_off[n], m);
+	rc = run_ksw_jobs(jobs, d_q.as<uint8_t>(), d_t.as<uint8_t>(), P, out, coff, pool);
 	if (rc) return rc;
 	int64_t used = 0; int ret = 0;
 	for (int i = 0; i < n; ++i) {
@@ -589,10 +614,10 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	const int qmax = std::min(MAXLEN, b->max_region_bases), tmax = b->max_ref_len;
 	{
 		const bool fastp = p->bw >= 0 && p->bw <= 62;
-		size_t need = (fastp ? ksw_fast_lds_bytes(qmax, tmax) : ksw_lds_bytes(qmax, tmax)) + 64;
+		size_t need = (fastp ? ksw_narrow_lds_bytes(qmax, tmax) : ksw_lds_bytes(qmax, tmax)) + 64;
 		// contigs are rarely longer than the reference window + band; cap the LDS request there and let the
 		// kernel flag anything larger (reported as IHP_E_CAPACITY for that batch)
-		const size_t typical = (fastp ? ksw_fast_lds_bytes(tmax + 64, tmax) : ksw_lds_bytes(tmax + 64, tmax)) + 64;
+		const size_t typical = (fastp ? ksw_narrow_lds_bytes(tmax + 64, tmax) : ksw_lds_bytes(tmax + 64, tmax)) + 64;
 		need = std::min(need, std::max(typical, (size_t)(fastp ? 2048 : 8192)));
 		need = std::min(need, (size_t)g.max_lds - 2048);
 		b->lds_ksw = (int)need;
@@ -707,7 +732,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
 		a.cig_pool_cap = b->cig_pool_cap; a.cig_bump_cap = b->cig_bump_cap; a.overflow = misc + M_OVF; a.work_counter = wq + 4 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
-		launch_ksw(ksw_mode(a.P), dim3(b->grid_ksw), b->lds_ksw, s, a);
+		g_last_ksw_mode = ksw_mode(a.P);
+		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[2], s));
@@ -772,6 +798,7 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	out[7] = nretry;                                  // ... on to the third LDS pass
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY3, sizeof(int), hipMemcpyDeviceToHost));
 	out[11] = nretry;                                 // ... and to the HBM-arena pass
+	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
 	return 0;
 }
 

@@ -3,7 +3,7 @@
 #pragma once
 #include "contig_dev.h"
 #include "ksw_dev.h"
-#include "ksw_fast.h"
+#include "ksw_narrow.h"
 #include "tally_dev.h"
 
 namespace ihp {
@@ -380,71 +380,96 @@ struct KswArgs {
 	long long *prof;                           // optional cycle counters (diagnostics)
 };
 
-// MODE 0: register-resident sweep, left-aligned gaps; 1: same, KSW_EZ_RIGHT; 2: generic LDS sweep (any band).
-// Separate instantiations keep each kernel's register footprint to what its sweep needs.
+// MODE 3: top-byte register-resident sweep (ksw_narrow.h), left-aligned gaps; 4: same, KSW_EZ_RIGHT -- the
+// production kernels.  0/1: the masked register-resident sweep (ksw_fast.h) for scoring schemes or alphabets
+// ksw_narrow_ok() rejects; 2: generic LDS sweep (any band).  Separate instantiations keep each kernel's
+// register footprint to what its sweep needs.
+// The launch arguments are read through the kernarg segment pointer, re-derived behind an empty asm at the top
+// of every job and again after the sweep: the ~40 SGPRs of pointers and capacities are then loaded where they are
+// used instead of staying live (and being spilled to VGPR lanes) across the sweep's inner loop.
+typedef const __attribute__((address_space(4))) KswArgs *KswArgsK;
+__device__ __forceinline__ KswArgsK ksw_args_again(KswArgsK p) { asm volatile("" : "+s"(p)); return p; }
+
 template <int MODE>
-__global__ __launch_bounds__(64) void k_ksw(const KswArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE >= 3 ? 8 : 1))) void k_ksw(const KswArgs)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_item;
 	__shared__ long long s_off;
 	const int lane = lane_id();
-	const int njobs = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
-	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
-	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
-	long long *pacc = (long long *)(lds + a.lds_budget + 16);   // per-wave cycle counters live past the sweep's LDS
-	if (a.prof && lane < 4) pacc[lane] = 0;
+	const KswArgsK a0 = (KswArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+	{
+		const KswArgsK a = a0;
+		if (a->prof && lane < 4) ((long long *)(lds + a->lds_budget + 16))[lane] = 0;   // per-wave cycle counters live past the sweep's LDS
+	}
 	WSYNC();
 	unsigned wq_dead = 0;
 	for (;;) {
-		if (lane == 0) s_item = wq_next(a.work_counter, njobs, (int)blockIdx.x, wq_dead);
+		KswArgsK a = ksw_args_again(a0);
+		const int njobs = a->n_jobs ? *a->n_jobs : a->n_jobs_host;
+		if (lane == 0) s_item = wq_next(a->work_counter, njobs, (int)blockIdx.x, wq_dead);
 		WSYNC();
-		const int j = s_item;
+		const int j = __builtin_amdgcn_readfirstlane(s_item);   // wave-uniform by construction; tells the compiler so
 		WSYNC();
 		if (j < 0) break;
-		const AlnJob jb = a.jobs[j];
+		const AlnJob jb = a->jobs[j];
 		KswOut out;
-		int w = a.P.w;
-		if (w < 0) w = jb.tlen > jb.qlen ? jb.tlen : jb.qlen;
-		int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
-		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
-		const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
-		constexpr bool fast = MODE != 2;
-		const size_t lneed = fast ? ksw_fast_lds_bytes(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen);
-		if (jb.qlen > 0 && jb.tlen > 0 && (lneed > (size_t)a.lds_budget || pneed > a.p_cap)) {
-			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
-			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
-			if (lane == 0) atomicExch(&a.overflow[1], 1);
-		} else if (MODE == 0) {
-			ksw_wave_fast<false>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
-		} else if (MODE == 1) {
-			ksw_wave_fast<true>(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
-		} else {
-			ksw_wave(a.qbase + jb.q_off, jb.qlen, a.tbase + jb.t_off, jb.tlen, a.P, lds, p, ct, a.cig_cap, out, a.prof ? pacc : nullptr);
+		{
+			uint8_t *p = a->p_scratch + (size_t)blockIdx.x * a->p_cap;
+			uint32_t *ct = a->cig_tmp + (size_t)blockIdx.x * a->cig_cap;
+			long long *pacc = a->prof ? (long long *)(lds + a->lds_budget + 16) : nullptr;
+			const KswParams P = {a->P.m, a->P.sc_mch, a->P.sc_mis, a->P.min_sc, a->P.q, a->P.e, a->P.w, a->P.zdrop, a->P.flag,
+			                     a->P.encode_ascii, a->P.codes_ok};
+			int w = P.w;
+			if (w < 0) w = jb.tlen > jb.qlen ? jb.tlen : jb.qlen;
+			int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
+			ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
+			const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
+			const size_t lneed = MODE >= 3 ? ksw_narrow_lds_bytes(jb.qlen, jb.tlen) : MODE != 2 ? ksw_fast_lds_bytes(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen);
+			const uint8_t *qy = a->qbase + jb.q_off, *tg = a->tbase + jb.t_off;
+			const int cig_cap = a->cig_cap;
+			if (jb.qlen > 0 && jb.tlen > 0 && (lneed > (size_t)a->lds_budget || pneed > a->p_cap)) {
+				out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
+				out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
+			} else if (MODE == 3 || MODE == 4) {
+				if (!ksw_wave_narrow<MODE == 4>(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc))
+					out.n_cigar = -1;                                  // a code outside the alphabet: the host never sends those here
+			} else if (MODE == 0 || MODE == 1) {
+				ksw_wave_fast<MODE == 1>(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
+			} else {
+				ksw_wave(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
+			}
 		}
+		a = ksw_args_again(a0);
+		const uint32_t *ct = a->cig_tmp + (size_t)blockIdx.x * a->cig_cap;
 		long long off = -1;
 		if (out.n_cigar > 0) {
-			if (out.n_cigar <= CIG_SLOT) off = a.cig_bump_cap + (long long)j * CIG_SLOT;   // the job's own slot: no atomic
+			if (out.n_cigar <= CIG_SLOT) off = a->cig_bump_cap + (long long)j * CIG_SLOT;   // the job's own slot: no atomic
 			else {
-				if (lane == 0) s_off = (long long)atomicAdd(a.cig_cursor, (unsigned long long)out.n_cigar);
+				if (lane == 0) s_off = (long long)atomicAdd(a->cig_cursor, (unsigned long long)out.n_cigar);
 				WSYNC();
 				off = s_off;
-				if (off + out.n_cigar > a.cig_bump_cap) off = a.cig_pool_cap;     // bump region exhausted
+				if (off + out.n_cigar > a->cig_bump_cap) off = a->cig_pool_cap;     // bump region exhausted
 			}
-			if (off + out.n_cigar <= a.cig_pool_cap) {
-				for (int i = lane; i < out.n_cigar; i += 64) a.cig_pool[off + i] = ct[i];
+			if (off + out.n_cigar <= a->cig_pool_cap) {
+				uint32_t *pool = a->cig_pool;
+				for (int i = lane; i < out.n_cigar; i += 64) pool[off + i] = ct[i];
 			} else {
-				if (lane == 0) atomicExch(&a.overflow[0], 1);
+				if (lane == 0) atomicExch(&a->overflow[0], 1);
 				off = -1;
 			}
 		} else if (out.n_cigar < 0) {
-			if (lane == 0) atomicExch(&a.overflow[1], 1);
+			if (lane == 0) atomicExch(&a->overflow[1], 1);             // LDS / traceback scratch budget
 		}
-		if (lane == 0) { a.ez[jb.out] = out; a.cig_off[jb.out] = off; }
+		if (lane == 0) { a->ez[jb.out] = out; a->cig_off[jb.out] = off; }
 		WSYNC();
 	}
 	WSYNC();
-	if (a.prof && lane < 4) atomicAdd((unsigned long long *)&a.prof[8 + lane], (unsigned long long)pacc[lane]);
+	{
+		const KswArgsK a = ksw_args_again(a0);
+		if (a->prof && lane < 4)
+			atomicAdd((unsigned long long *)&a->prof[8 + lane], (unsigned long long)((long long *)(lds + a->lds_budget + 16))[lane]);
+	}
 }
 
 // --------------------------------------------------------------------- tally
