@@ -105,7 +105,7 @@ struct NarrowState {
 	const unsigned *qptr;                                // LDS: this lane's selector word for the coming diagonal
 	unsigned T1B, T0B;
 	// wave-uniform
-	int st, edge_h, last_st, last_en, last_sc;
+	int st, edge_h, last_sc;
 	int ez_max, ez_max_t, ez_max_q, mqe, mqe_t, mte, mte_q, score;
 };
 
@@ -122,29 +122,43 @@ struct NarrowEnv {
 __device__ __forceinline__ int narrow_z(unsigned T0, unsigned T1, unsigned sel) { return (int)__builtin_amdgcn_perm(T0, T1, sel); }
 
 // One anti-diagonal; same contract as fast_diag() in ksw_fast.h (returns true when the sweep must stop; every such
-// exit is a z-drop for the caller, :98-101 and :200-203).  STEADY: the caller supplies the band [st0, en0] (it advances
-// it incrementally) and guarantees w in [49, 62]: en0-st0 is in [48, 62], so the refreshed scores end exactly 63
-// cells after st0, blocks 0..3 are always computed and en0 is never on lane 0.
+// exit is a z-drop for the caller, :98-101 and :200-203).  KIND selects what the diagonal can be:
+//   ND_ANY    any r >= 1;
+//   ND_FIRST  r == 0 (the same code with r folded);
+//   ND_EARLY  1 <= r <= w+30 of a job with qlen, tlen >= w+32: the band starts in block 0 (st == 0, no move), is
+//             not yet cut by the sequence ends, and grows: st0 = max(0,(r-w+1)>>1), en0 = min(r,(r+w)>>1);
+//   ND_STEADY w in [49, 62] and the band limited by w on both sides with en < r (the caller supplies [st0, en0] and
+//             advances it): en0-st0 is in [48, 62], so the refreshed scores end exactly 63 cells after st0, blocks
+//             0..3 are always computed and en0 is never on lane 0.
+// A block edge x[st-1], v[st-1] is taken (:207-208) exactly on the diagonal where st moves: then st-1 = old st+15
+// lies in [last_st, last_en]; without a move st-1 < last_st and the edge is 0 (:210).
 // Slot B's score bytes are not tracked per diagonal while the refreshed range only grows (st0, en0 and en0-st0
-// non-decreasing: every diagonal before the band reaches the last target base): then a B lane is "refreshed on
-// the previous diagonal" up to last_sc-64 and "never" above, which is all its lazily formed value needs.
-template <bool RIGHT, bool STEADY, bool CIGAR>
+// non-decreasing, i.e. ND_EARLY and ND_STEADY): then a B lane is "refreshed on the previous diagonal" up to
+// last_sc-64 and "never" above, which is all its lazily formed value needs.
+enum { ND_ANY = 0, ND_STEADY = 1, ND_EARLY = 2, ND_FIRST = 3 };
+
+template <bool RIGHT, int KIND>
 __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, const int r, int st0 = 0, int en0 = 0)
 {
+	constexpr bool STEADY = KIND == ND_STEADY, EARLY = KIND == ND_EARLY, GROWING = STEADY || EARLY;
+	constexpr bool ENDS = KIND == ND_ANY || KIND == ND_FIRST;          // the band may touch the sequence ends
 	const int lane = lane_id();
 	const int INTMIN = -0x7fffffff - 1;
 	int nst, en;
 	if (STEADY) { nst = st0 & ~15; en = en0 | 15; }
-	else if (!ksw_band(r, E.qlen, E.tlen, E.w, st0, en0, nst, en)) return true;   // :200-203
+	else if (EARLY) {
+		st0 = (r - E.w + 1) >> 1; st0 = st0 > 0 ? st0 : 0;
+		en0 = (r + E.w) >> 1; en0 = en0 < r ? en0 : r;
+		nst = 0; en = en0 | 15;
+	} else if (!ksw_band(r, E.qlen, E.tlen, E.w, st0, en0, nst, en)) return true;   // :200-203
 	int ex = 0, ev = 0;
-	if (nst != F.st) {
+	if (!EARLY && nst != F.st) {
 		// the band origin moved one block right: rotate the registers 16 lanes, re-seed slot B
-		const bool valid = STEADY || (F.st + 15 >= F.last_st && F.st + 15 <= F.last_en);
-		ex = valid ? __builtin_amdgcn_readlane(F.XA, 15) : 0;
-		ev = valid ? __builtin_amdgcn_readlane(F.VA, 15) : 0;
+		ex = __builtin_amdgcn_readlane(F.XA, 15);
+		ev = __builtin_amdgcn_readlane(F.VA, 15);
 		F.edge_h = __builtin_amdgcn_readlane(F.HA, 15);
 		int zB;
-		if (STEADY) {
+		if (GROWING) {
 			const int zf = narrow_z(F.T0B, F.T1B, E.qs[E.qlen - r + F.st + 64 + (lane & 15)]);   // scores of diagonal r-1
 			zB = lane_in(lane_range(0, F.last_sc - 64)) ? zf : E.ZW24;
 		} else zB = F.rlB < 0 ? E.ZW24 : narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - F.rlB + F.st + 64 + (lane & 15)]);
@@ -155,39 +169,40 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		F.st = nst;
 		F.qptr += 16;
 		F.XB = F.VB = F.UB = F.YB = 0; F.HB = KSW_NEG_INF;
-		if (!STEADY) F.rlB = -1;
+		if (!GROWING) F.rlB = -1;
 		const uint2 ta = E.tbl[E.tg[nst + lane]], tb = E.tbl[E.tg[nst + 64 + (lane & 15)]];
 		F.T1A = ta.x; F.T0A = ta.y; F.T1B = tb.x; F.T0B = tb.y;
-	} else if (!STEADY && F.st == 0) { ev = r ? E.q24 : 0; }     // :211; for st > 0 without a move x1 = v1 = 0 (:210)
+	} else if (EARLY || (!STEADY && F.st == 0)) { ev = r ? E.q24 : 0; }     // :211
 	// neighbours of r-1 (taken before anything is overwritten); lane 0 gets the block edge x1, v1 (:207-211)
-	const int xpA = set_lane0(ex, 0, dppz_shr1(F.XA)), vpA = set_lane0(ev, 0, dppz_shr1(F.VA));
+	const int xpA = EARLY ? dppz_shr1(F.XA) : set_lane0(ex, 0, dppz_shr1(F.XA)), vpA = set_lane0(ev, 0, dppz_shr1(F.VA));
 	int HpA = dppz_shr1(F.HA);
-	if (!STEADY) HpA = set_lane0(F.edge_h, 0, HpA);    // a steady band never has en0 on lane 0
-	const int st = F.st;
+	if (ENDS) HpA = set_lane0(F.edge_h, 0, HpA);        // otherwise en0 is never on lane 0
+	const int st = EARLY ? 0 : F.st;
 	const int loA = st0 - st;                            // first true-band lane (<= 15)
 	const int hiT = en0 - st;                            // last true-band lane (may be >= 64: slot B)
 	const int nTop = en - st;                            // last computed lane: 15, 31, 47, 63 or 79
-	const int sc = STEADY ? loA + 63 : st0 + ((en0 - st0) / 16 + 1) * 16 - 1 - st;   // last refreshed score lane (:215)
+	const int sc = STEADY ? loA + 63 : st0 + ((en0 - st0) / 16 + 1) * 16 - 1 - st;   // last refreshed score lane (:215), > loA
 	const bool hasB = nTop >= 64;
 	uint8_t *pr = E.p + (size_t)r * E.ncol;
-	const int spec = (STEADY || (r > 0 && en0 > 0)) ? hiT : -1000;      // lane of the H[en0] special case (:318)
-	const unsigned long long mRefA = STEADY ? ~0ull << loA : lane_range(loA, sc < 63 ? sc : 63);
-	const unsigned long long mInA = STEADY ? mRefA & (~0ull >> (63 - (hiT < 63 ? hiT : 63))) : lane_range(loA, hiT < 63 ? hiT : 63);
-	unsigned long long mSpecA = STEADY ? mInA & ~(mInA >> 1)            // the top lane of the band ...
-	                                   : (spec >= 0 && spec < 64) ? 1ull << spec : 0ull;
+	const bool has_spec = !ENDS || (r > 0 && en0 > 0);   // H[en0] comes from H[en0-1] + u (:318)
+	const unsigned long long mLo = ~0ull << loA;
+	const unsigned long long mRefA = STEADY ? mLo : mLo & (~0ull >> (63 - (sc < 63 ? sc : 63)));
+	const unsigned long long mInA = mLo & (~0ull >> (63 - (hiT < 63 ? hiT : 63)));      // hiT >= loA
+	unsigned long long mSpecA = mInA & ~(mInA >> 1);    // the top lane of the band ...
+	if (ENDS && !has_spec) mSpecA = 0;
 	int hB = INTMIN, hA;
 	unsigned long long mInB = 0;
 	// ---- slot B (block 4) ------------------------------------------------------------
-	if (!STEADY) F.rlB = lane_in(lane_range(0, sc - 64)) ? r : F.rlB;  // :214-228 runs past en; value formed on use
+	if (!GROWING) F.rlB = lane_in(sc >= 64 ? ~0ull >> (127 - sc) : 0ull) ? r : F.rlB;  // :214-228 runs past en; value formed on use
 	if (hasB) {                                                        // nTop == 79: the whole block
-		if (STEADY && hiT >= 64) mSpecA = 0;                           // ... unless the band ends in block 4
+		if (hiT >= 64) mSpecA = 0;                                     // ... unless the band ends in block 4
 		const int exB = __builtin_amdgcn_readlane(F.XA, 63), evB = __builtin_amdgcn_readlane(F.VA, 63);
 		const int HeB = __builtin_amdgcn_readlane(F.HA, 63);
 		int xpB = dppz_shr1(F.XB), vpB = dppz_shr1(F.VB), HpB = dppz_shr1(F.HB);
 		xpB = set_lane0(exB, 0, xpB); vpB = set_lane0(evB, 0, vpB);
 		HpB = set_lane0(HeB, 0, HpB);
 		int zB;
-		if (STEADY) {
+		if (GROWING) {
 			const int zf = narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - r + st + 64 + (lane & 15)]);
 			zB = lane_in(lane_range(0, sc - 64)) ? zf : E.ZW24;
 		} else zB = F.rlB < 0 ? E.ZW24 : narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - F.rlB + st + 64 + (lane & 15)]);
@@ -198,8 +213,8 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 			int xn, vn, un, yn; unsigned d;
 			narrow_cell<RIGHT>(zB, xpB, vpB, ut, yt, E.M24, E.q24, xn, vn, un, yn, d);
 			F.XB = xn; F.VB = vn; F.UB = un; F.YB = yn;
-			if (CIGAR) pr[64 + lane] = (uint8_t)d;                     // :283
-			const bool sp = 64 + lane == spec;
+			pr[64 + lane] = (uint8_t)d;                                // :283
+			const bool sp = has_spec && 64 + lane == hiT;
 			const int h = (sp ? HpB : F.HB) + (int)((unsigned)(sp ? un : vn) >> 24) - E.qe;   // :318, :323-329 (u8, v8 are uint8_t: :193)
 			const bool inT = lane_in(mInB);
 			hB = inT ? h : INTMIN;
@@ -219,21 +234,21 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		narrow_cell<RIGHT>(F.ZA, xpA, vpA, F.UA, F.YA, E.M24, E.q24, xn, vn, un, yn, d);
 		int h;
 		const bool sp = lane_in(mSpecA);
-		if (STEADY || r > 0) h = (sp ? HpA : F.HA) + (int)((unsigned)(sp ? un : vn) >> 24) - E.qe;   // :318, :323-329
+		if (KIND != ND_FIRST) h = (sp ? HpA : F.HA) + (int)((unsigned)(sp ? un : vn) >> 24) - E.qe;   // :318, :323-329
 		else h = (int)((unsigned)vn >> 24) - E.qe - E.qe;              // :349
 		if (STEADY) {                                                  // a steady band always covers blocks 0..3
 			F.XA = xn; F.VA = vn; F.UA = un; F.YA = yn;
-			if (CIGAR) pr[lane] = (uint8_t)d;
+			pr[lane] = (uint8_t)d;
 		} else {
-			const bool act = lane_in(lane_range(0, nTop < 63 ? nTop : 63));
+			const bool act = lane_in(~0ull >> (63 - (nTop < 63 ? nTop : 63)));
 			F.XA = act ? xn : F.XA; F.VA = act ? vn : F.VA; F.UA = act ? un : F.UA; F.YA = act ? yn : F.YA;
-			if (CIGAR && act) pr[lane] = (uint8_t)d;
+			if (act) pr[lane] = (uint8_t)d;
 		}
 		const bool inT = lane_in(mInA);
 		hA = inT ? h : INTMIN;
 		F.HA = inT ? h : F.HA;
 	}
-	F.last_st = st; F.last_en = en; F.last_sc = sc;
+	F.last_sc = sc;
 	// ---- exact max (:320-348) ----------------------------------------------------------
 	int max_H = wave_max_i32_keep(hA), max_t;
 	unsigned long long mB = 0;
@@ -267,14 +282,16 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		}
 	}
 	// ---- ez updates (:351-357) -----------------------------------------------------------
-	int Hen0 = 0;
-	if (!STEADY && (en0 == E.tlen - 1 || r - st0 == E.qlen - 1)) {
-		Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
-		const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
-		if (en0 == E.tlen - 1 && Hen0 > F.mte) { F.mte = Hen0; F.mte_q = r - en; }        // rounded en (:352)
-		if (r - st0 == E.qlen - 1 && Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st0; }
+	if (ENDS) {
+		int Hen0 = 0;
+		if (en0 == E.tlen - 1 || r - st0 == E.qlen - 1) {
+			Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
+			const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
+			if (en0 == E.tlen - 1 && Hen0 > F.mte) { F.mte = Hen0; F.mte_q = r - en; }        // rounded en (:352)
+			if (r - st0 == E.qlen - 1 && Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st0; }
+		}
+		if (r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;                  // :356-357
 	}
-	if (!STEADY && r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;           // :356-357
 	{                                                                             // ksw_apply_zdrop :88-104
 		const int t = max_t;
 		if (max_H > F.ez_max) { F.ez_max = max_H; F.ez_max_t = t; F.ez_max_q = r - t; }
@@ -346,29 +363,36 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 		F.T1A = ta.x; F.T0A = ta.y; F.T1B = tb.x; F.T0B = tb.y;
 	}
 	F.rlB = -1; F.HA = F.HB = KSW_NEG_INF; F.st = 0; F.qptr = qs + (qlen - 1 + lane);
-	F.edge_h = KSW_NEG_INF; F.last_st = F.last_en = -1; F.last_sc = -1;
+	F.edge_h = KSW_NEG_INF; F.last_sc = -1;
 	F.ez_max = 0; F.ez_max_t = F.ez_max_q = -1; F.mqe = F.mte = F.score = KSW_NEG_INF; F.mqe_t = F.mte_q = -1;
 	NarrowEnv E;
 	E.tg = tg; E.qs = qs; E.tbl = tbl; E.p = p; E.qlen = qlen; E.tlen = tlen; E.w = w; E.ncol = ncol; E.qe = qe; E.e = e;
 	E.zdrop = P.zdrop; E.ZW24 = (int)(ZW << 24); E.M24 = ZM << 24; E.q24 = (int)(((unsigned)q & 0xff) << 24);
 	const int total = qlen + tlen - 1;
 	// steady diagonals: st0 = (r-w+1)>>1 > r-qlen+1, en0 = (r+w)>>1 < tlen-1, en < r
-	const int r_lo = w + 32;
+	const bool roomy = qlen >= w + 32 && tlen >= w + 32;   // the first w+31 diagonals stay clear of the sequence ends
 	int r_hi = 2 * tlen - 3 - w < 2 * qlen - w - 3 ? 2 * tlen - 3 - w : 2 * qlen - w - 3;
 	r_hi = r_hi + 1 < total ? r_hi + 1 : total;
-	int r = 0;
-	bool stop = false;
-	for (; r < total && r < r_lo && !stop; ++r) stop = narrow_diag<RIGHT, false, true>(F, E, r);
+	bool stop = narrow_diag<RIGHT, ND_FIRST>(F, E, 0);
+	int r = 1;
+	bool tracked = true;                                 // F.rlB is up to date
+	if (roomy) {
+		for (; r < w + 31 && !stop; ++r) stop = narrow_diag<RIGHT, ND_EARLY>(F, E, r);
+		tracked = false;
+	} else {
+		for (; r < total && r < w + 32 && !stop; ++r) stop = narrow_diag<RIGHT, ND_ANY>(F, E, r);
+	}
 	if (w >= 49 && !stop && r < r_hi) {                  // w >= 49: a steady band spans blocks 0..3
 		int st0 = (r - w + 1) >> 1, en0 = (r + w) >> 1;
 		for (; r < r_hi && !stop; ++r) {
-			stop = narrow_diag<RIGHT, true, true>(F, E, r, st0, en0);
+			stop = narrow_diag<RIGHT, ND_STEADY>(F, E, r, st0, en0);
 			const int up = (r + w) & 1;                  // (r+w)>>1 grows on the step from an odd r+w, (r-w+1)>>1 otherwise
 			en0 += up; st0 += 1 - up;
 		}
-		F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;     // what the steady diagonals did not track (see narrow_diag)
+		tracked = false;
 	}
-	for (; r < total && !stop; ++r) stop = narrow_diag<RIGHT, false, true>(F, E, r);
+	if (!tracked) F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;   // what the growing diagonals did not track (see narrow_diag)
+	for (; r < total && !stop; ++r) stop = narrow_diag<RIGHT, ND_ANY>(F, E, r);
 	WSYNC();
 	out.max = F.ez_max; out.zdropped = stop ? 1 : 0; out.max_q = F.ez_max_q; out.max_t = F.ez_max_t;   // every early exit is a z-drop (:98-101, :200-203)
 	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.score;

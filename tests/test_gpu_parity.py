@@ -152,6 +152,38 @@ def test_ksw2_random_vs_oracle(hip, oracle):
         assert [c.tolist() for c in cg] == [c.tolist() for c in cg2], pi
 
 
+def test_ksw2_kernel_modes(hip, oracle):
+    """Every ksw2 kernel (ihp_debug_last_ksw_mode: 3/4 top-byte sweep, 0/1 masked sweep, 2 LDS sweep) gives the
+    reference's result; scoring schemes whose int8 work values wrap (gap costs near 64) go through the top-byte
+    sweep, those with a non-positive s+2(q+e) or base codes outside the alphabet through the masked one."""
+    import test_oracle_ksw2 as tk
+    R = A.KSW_EZ_RIGHT
+    sets = [  # match, mismatch, gapo, gape, w, zdrop, flag, raw codes up to, expected kernel
+        (1, -2, 4, 1, 50, 400, 0, None, 3), (1, -2, 4, 2, 50, 100, R, None, 4), (1, -2, 4, 1, 10, 30, 0, None, 3),
+        (2, -4, 40, 10, 50, 400, 0, None, 3), (1, -3, 50, 12, 62, -1, R, None, 4), (3, -6, 30, 25, 49, 900, 0, None, 3),
+        (1, -10, 4, 1, 50, 400, 0, None, 0), (1, -10, 4, 1, 50, 400, R, None, 1), (1, -2, 60, 4, 50, 400, 0, None, 0),
+        (1, -2, 4, 1, 50, 400, 0, 6, 0), (1, -2, 4, 1, 50, 400, R, 7, 1), (1, -2, 4, 1, 50, 400, 0, 4, 3),
+        (1, -2, 4, 1, 63, 400, 0, None, 2), (1, -2, 5, 1, -1, -1, 0, None, 2)]
+    for si, (ma, mi, go, ge, w, z, flag, raw, mode) in enumerate(sets):
+        pairs = list(tk.cases(500 + si, 60))
+        qs, ts = [q for q, t in pairs], [t for q, t in pairs]
+        kw = dict(match=ma, mismatch=mi, gap_open=go, gap_ext=ge, bw=w, z=z, flag=flag)
+        if raw is not None:
+            rng = np.random.default_rng(si)
+            def codes(s):
+                c = hip.encode(s)
+                hit = rng.random(len(c)) < 0.03
+                c[hit] = rng.integers(0, raw + 1, int(hit.sum()))
+                return c
+            qs, ts = [codes(s) for s in qs], [codes(s) for s in ts]
+            kw["encoded"] = True
+        ez, cg = hip.align_batch(qs, ts, **kw)
+        assert hip.b.debug_last_ksw_mode() == mode, (si, hip.b.debug_last_ksw_mode())
+        ez2, cg2 = oracle.align_batch(qs, ts, **kw)
+        assert ez.tolist() == ez2.tolist(), si
+        assert [c.tolist() for c in cg] == [c.tolist() for c in cg2], si
+
+
 def test_ksw_extz2_sse_symbol_is_a_drop_in(hip, oracle):
     """The reference's FFI seam (ksw2_c.nim:53-55) served by the HIP library, incl. cigar buffer reuse."""
     import ctypes as C

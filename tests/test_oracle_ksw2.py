@@ -69,6 +69,32 @@ def test_restatement_equals_compiled_reference(oracle, variant, pi):
         oracle.set_variant(0)
 
 
+WRAP_SETS = [  # match, mismatch, gapo, gape, w, zdrop, flag, raw codes up to
+    (2, -4, 40, 10, 50, 400, 0, None), (1, -3, 50, 12, 62, -1, A.KSW_EZ_RIGHT, None), (3, -6, 30, 25, 49, 900, 0, None),
+    (1, -10, 4, 1, 50, 400, 0, None), (1, -2, 60, 4, 50, 400, 0, None), (1, -2, 4, 1, 50, 400, 0, 6),
+    (1, -2, 4, 1, 50, 400, A.KSW_EZ_RIGHT, 7)]
+
+
+@pytest.mark.parametrize("si", range(len(WRAP_SETS)))
+def test_restatement_on_wrapping_schemes_and_foreign_codes(oracle, si):
+    """Gap costs near 64 make the int8 work arrays wrap; codes >= m take the plain equal/unequal scores.  The GPU
+    kernels are checked against the restatement on these, so pin the restatement to the compiled reference first."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    ma, mi, go, ge, w, z, flag, raw = WRAP_SETS[si]
+    rng = np.random.default_rng(si)
+    mat = oracle.matrix(ma, mi)
+    for q, t in cases(900 + si, 40):
+        qe, te = oracle.encode(q), oracle.encode(t)
+        if raw is not None:
+            for c in (qe, te):
+                hit = rng.random(len(c)) < 0.03
+                c[hit] = rng.integers(0, raw + 1, int(hit.sum()))
+        got, gc = oracle.ksw(qe, te, mat=mat, gapo=go, gape=ge, w=w, zdrop=z, flag=flag)
+        exp, ec = oracle.ksw_ref(qe, te, mat=mat, gapo=go, gape=ge, w=w, zdrop=z, flag=flag)
+        assert got == exp and gc.tolist() == ec.tolist(), (si, q, t)
+
+
 def test_sse2_and_sse41_reference_builds_agree(oracle):
     """both code paths of the reference give identical results (production settings)."""
     if oracle.ref_lib() is None:
