@@ -41,8 +41,13 @@ __device__ __forceinline__ int dppz_shr1(int v)
 
 __device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-// v with lane 0 replaced by the wave-uniform s
-__device__ __forceinline__ int set_lane0(int s, int /*lane*/, int v) { return lane_in(1ull) ? s : v; }
+// v with lane 0 replaced by the wave-uniform s (v_writelane_b32: one VALU slot; a v_cndmask would need the mask
+// and the value on the constant bus at once)
+__device__ __forceinline__ int set_lane0(int s, int /*lane*/, int v)
+{
+	asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(s));
+	return v;
+}
 
 // lanes [lo, hi] of the wave, 0 <= lo, hi <= 63; empty when hi < lo
 __device__ __forceinline__ unsigned long long lane_range(int lo, int hi)
@@ -103,6 +108,7 @@ struct NarrowState {
 	unsigned T1A, T0A;
 	int XB, VB, UB, YB, HB, rlB;
 	const unsigned *qptr;                                // LDS: this lane's selector word for the coming diagonal
+	int qoffB;                                           // 64 + (lane & 15) - lane: from qptr to the lane's slot-B word
 	unsigned T1B, T0B;
 	// wave-uniform
 	int st, edge_h, last_sc;
@@ -159,8 +165,8 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		F.edge_h = __builtin_amdgcn_readlane(F.HA, 15);
 		int zB;
 		if (GROWING) {
-			const int zf = narrow_z(F.T0B, F.T1B, E.qs[E.qlen - r + F.st + 64 + (lane & 15)]);   // scores of diagonal r-1
-			zB = lane_in(lane_range(0, F.last_sc - 64)) ? zf : E.ZW24;
+			const int zf = narrow_z(F.T0B, F.T1B, F.qptr[F.qoffB + 1]);    // qs[qlen-r+st+64+lane]: scores of diagonal r-1
+			zB = lane_in(STEADY ? 0x7fffull : lane_range(0, F.last_sc - 64)) ? zf : E.ZW24;   // steady: st0 was 16k+15, so last_sc = 78
 		} else zB = F.rlB < 0 ? E.ZW24 : narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - F.rlB + F.st + 64 + (lane & 15)]);
 		F.XA = (int)rot16((unsigned)F.XA, (unsigned)F.XB, lane); F.VA = (int)rot16((unsigned)F.VA, (unsigned)F.VB, lane);
 		F.UA = (int)rot16((unsigned)F.UA, (unsigned)F.UB, lane); F.YA = (int)rot16((unsigned)F.YA, (unsigned)F.YB, lane);
@@ -203,7 +209,7 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		HpB = set_lane0(HeB, 0, HpB);
 		int zB;
 		if (GROWING) {
-			const int zf = narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - r + st + 64 + (lane & 15)]);
+			const int zf = narrow_z(F.T0B, F.T1B, F.qptr[F.qoffB]);        // qs[qlen-1-r+st+64+lane]
 			zB = lane_in(lane_range(0, sc - 64)) ? zf : E.ZW24;
 		} else zB = F.rlB < 0 ? E.ZW24 : narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - F.rlB + st + 64 + (lane & 15)]);
 		mInB = lane_range(0, hiT - 64 < 15 ? hiT - 64 : 15);           // loA <= 15, so block 4 is never below the band
@@ -248,18 +254,20 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		hA = inT ? h : INTMIN;
 		F.HA = inT ? h : F.HA;
 	}
-	F.last_sc = sc;
+	if (!STEADY) F.last_sc = sc;
 	// ---- exact max (:320-348) ----------------------------------------------------------
 	int max_H = wave_max_i32_keep(hA), max_t;
 	unsigned long long mB = 0;
+	int nB = 0;
 	if (hasB) {
 		const int mb = wave_max_i32_keep(hB);
 		max_H = mb > max_H ? mb : max_H;
 		mB = ballot(hB == max_H) & mInB;
+		nB = popc64(mB);
 	}
 	{
-		const unsigned long long mA = ballot(hA == max_H) & mInA;
-		if (popc64(mA) + popc64(mB) == 1) {
+		const unsigned long long mA = ballot(hA == max_H);             // lanes outside the band hold INT_MIN
+		if (popc64(mA) + nB == 1) {
 			max_t = mA ? st + ctz64(mA) : st + 64 + ctz64(mB);
 		} else {
 			// ties: en0 first, then stride classes of the vector part, then the scalar tail
@@ -292,16 +300,13 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		}
 		if (r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;                  // :356-357
 	}
-	{                                                                             // ksw_apply_zdrop :88-104
-		const int t = max_t;
-		if (max_H > F.ez_max) { F.ez_max = max_H; F.ez_max_t = t; F.ez_max_q = r - t; }
-		else if (t >= F.ez_max_t && r - t >= F.ez_max_q) {
-			const int tl = t - F.ez_max_t, ql = (r - t) - F.ez_max_q;
-			const int l = tl > ql ? tl - ql : ql - tl;
-			if (E.zdrop >= 0 && F.ez_max - max_H > E.zdrop + l * E.e) return true;
-		}
-	}
-	return false;
+	// ksw_apply_zdrop (:88-104), written as a chain of exits
+	const int t = max_t, dq = r - max_t;
+	if (max_H > F.ez_max) { F.ez_max = max_H; F.ez_max_t = t; F.ez_max_q = dq; return false; }
+	if (t < F.ez_max_t || dq < F.ez_max_q || E.zdrop < 0) return false;
+	const int tl = t - F.ez_max_t, ql = dq - F.ez_max_q;
+	const int l = tl > ql ? tl - ql : ql - tl;
+	return F.ez_max - max_H > E.zdrop + l * E.e;
 }
 
 // Returns false when the job is not for this sweep (a code outside the 5-letter alphabet; nothing useful in
@@ -362,7 +367,7 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 		const uint2 ta = tbl[tg[lane]], tb = tbl[tg[64 + (lane & 15)]];
 		F.T1A = ta.x; F.T0A = ta.y; F.T1B = tb.x; F.T0B = tb.y;
 	}
-	F.rlB = -1; F.HA = F.HB = KSW_NEG_INF; F.st = 0; F.qptr = qs + (qlen - 1 + lane);
+	F.rlB = -1; F.HA = F.HB = KSW_NEG_INF; F.st = 0; F.qptr = qs + (qlen - 1 + lane); F.qoffB = 64 + (lane & 15) - lane;
 	F.edge_h = KSW_NEG_INF; F.last_sc = -1;
 	F.ez_max = 0; F.ez_max_t = F.ez_max_q = -1; F.mqe = F.mte = F.score = KSW_NEG_INF; F.mqe_t = F.mte_q = -1;
 	NarrowEnv E;
@@ -376,23 +381,26 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	bool stop = narrow_diag<RIGHT, ND_FIRST>(F, E, 0);
 	int r = 1;
 	bool tracked = true;                                 // F.rlB is up to date
-	if (roomy) {
-		for (; r < w + 31 && !stop; ++r) stop = narrow_diag<RIGHT, ND_EARLY>(F, E, r);
+	if (!stop && roomy) {
+		do { if (narrow_diag<RIGHT, ND_EARLY>(F, E, r)) { stop = true; break; } } while (++r < w + 31);
 		tracked = false;
-	} else {
-		for (; r < total && r < w + 32 && !stop; ++r) stop = narrow_diag<RIGHT, ND_ANY>(F, E, r);
+	} else if (!stop) {
+		for (; r < total && r < w + 32; ++r) if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) { stop = true; break; }
 	}
 	if (w >= 49 && !stop && r < r_hi) {                  // w >= 49: a steady band spans blocks 0..3
 		int st0 = (r - w + 1) >> 1, en0 = (r + w) >> 1;
-		for (; r < r_hi && !stop; ++r) {
-			stop = narrow_diag<RIGHT, ND_STEADY>(F, E, r, st0, en0);
+		do {
+			if (narrow_diag<RIGHT, ND_STEADY>(F, E, r, st0, en0)) { stop = true; break; }
 			const int up = (r + w) & 1;                  // (r+w)>>1 grows on the step from an odd r+w, (r-w+1)>>1 otherwise
 			en0 += up; st0 += 1 - up;
-		}
+		} while (++r < r_hi);
+		F.last_sc = ((r - w) >> 1) - F.st + 63;          // of diagonal r-1 (st0 - st + 63)
 		tracked = false;
 	}
-	if (!tracked) F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;   // what the growing diagonals did not track (see narrow_diag)
-	for (; r < total && !stop; ++r) stop = narrow_diag<RIGHT, ND_ANY>(F, E, r);
+	if (!stop) {
+		if (!tracked) F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;   // what the growing diagonals did not track (see narrow_diag)
+		for (; r < total; ++r) if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) { stop = true; break; }
+	}
 	WSYNC();
 	out.max = F.ez_max; out.zdropped = stop ? 1 : 0; out.max_q = F.ez_max_q; out.max_t = F.ez_max_t;   // every early exit is a z-drop (:98-101, :200-203)
 	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.score;
