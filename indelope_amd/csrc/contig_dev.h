@@ -27,7 +27,8 @@ struct RegionStateT {
 	int lo3[MC + 1], hi3[MC + 1];                 // every base in [lo3, hi3) has support >= 3 (empty if lo3 >= hi3)
 	unsigned char alive[MC + 1];
 	short listA[MC], listB[MC];
-	unsigned bitmap[MAXLEN / 32];
+	static constexpr int BMLEN = MC <= 64 ? 2048 : MAXLEN;   // longest contig insert_dev can merge into (longer: next pass)
+	unsigned bitmap[BMLEN / 32];
 	int bump;
 	int err;
 	long long prof[16];
@@ -56,12 +57,6 @@ __device__ __forceinline__ long long wave_min_ll(long long v)
 		long long o = __shfl_xor(v, d, 64);
 		v = o < v ? o : v;
 	}
-	return v;
-}
-
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
 	return v;
 }
 
@@ -254,7 +249,7 @@ __device__ inline int insert_dev(ST &S, Arena &A, int ts, int qs, int off, int n
 	int newlen;
 	if (off < 0) { newlen = aoff + tlen; if (qlen > newlen) newlen = qlen; }
 	else { newlen = tlen; if (off + qlen > newlen) newlen = off + qlen; }
-	if (newlen > MAXLEN) return IHP_E_CAPACITY;
+	if (newlen > ST::BMLEN) return IHP_E_CAPACITY;
 	// room first: compaction moves contigs, so pointers are taken afterwards
 	const bool reloc = off < 0 || newlen > S.cap[ts];
 	int ncap = align4(newlen + headroom(newlen));
@@ -439,9 +434,10 @@ __device__ __forceinline__ bool may_allow(const ST &S, int qs, int ts)
 	return p1 || p2;
 }
 
-// slide_align for max_mismatch == 0 without votes (contig.nim:70-141), same total order as slide_scan.
+// slide_align for max_mismatch == 0 without votes (contig.nim:70-141), same total order as slide_scan:
+// one offset per lane, any lengths (the general form; slide_scan_exact below is the usual one).
 template <class ST>
-__device__ inline void slide_scan_exact(const ST &S, const Arena &A, int qs, int ts, int pos, int min_overlap, Best &best)
+__device__ inline void slide_scan_exact_small(const ST &S, const Arena &A, int qs, int ts, int pos, int min_overlap, Best &best)
 {
 	const int lane = lane_id();
 	const uint32_t *a32 = (const uint32_t *)A.seq;
@@ -502,37 +498,118 @@ __device__ inline void slide_scan_exact(const ST &S, const Arena &A, int qs, int
 	}
 }
 
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ unsigned wave_scan_add(unsigned v)
+// ---- exact scan, four offsets per lane ------------------------------------------------------
+// Everything about the two contigs is passed in wave-uniform (scalar) form: arena byte offsets qb/tb, lengths,
+// the first 8 bases of each.  An offset phase looks at offsets o in [o_lo, o_hi] of a `stream` (byte offset sb,
+// slen bases) against the first bases of the `other` contig (ob, olen); its overlap n(o) = min(olen, slen - o) is
+// >= 8 for every o in range.  Each lane filters FOUR consecutive offsets from one 16-byte read of the stream
+// (funnel shifts give the four 8-byte windows), so a 150-base read against a 250-base contig is one LDS round trip
+// per phase instead of five.  Survivors are verified in ascending offset order (first-wins tie rule of
+// contig.nim:107).
+struct ScanSide { int b, len; unsigned h0, h1; };            // arena byte offset, bases, first 8 bases
+
+// window filter of one 256-offset chunk: bit j of the result <-> offset o_lo + base + 4*lane + j matches on 8 bases
+__device__ __forceinline__ unsigned exact_hits(const uint32_t *a32, int sb, int o_lo, int o_hi, int base, unsigned p0, unsigned p1)
 {
 	const int lane = lane_id();
-	for (int d = 1; d < 64; d <<= 1) {
-		const unsigned o = (unsigned)__shfl_up((int)v, d, 64);
-		if (lane >= d) v += o;
+	const int a0 = sb + o_lo;
+	const unsigned sh = (unsigned)(a0 & 3) * 8u;
+	const int ofs = base + 4 * lane;                         // this lane's first offset, relative to o_lo
+	unsigned hits = 0;
+	if (o_lo + ofs <= o_hi) {
+		const int d = (a0 >> 2) + (ofs >> 2);
+		const unsigned w0 = a32[d], w1 = a32[d + 1], w2 = a32[d + 2], w3 = a32[d + 3];
+		const unsigned u0 = __builtin_amdgcn_alignbit(w1, w0, sh), u1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+		const unsigned u2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+		const unsigned x0 = (u0 ^ p0) | (u1 ^ p1);
+		const unsigned x1 = (__builtin_amdgcn_alignbit(u1, u0, 8) ^ p0) | (__builtin_amdgcn_alignbit(u2, u1, 8) ^ p1);
+		const unsigned x2 = (__builtin_amdgcn_alignbit(u1, u0, 16) ^ p0) | (__builtin_amdgcn_alignbit(u2, u1, 16) ^ p1);
+		const unsigned x3 = (__builtin_amdgcn_alignbit(u1, u0, 24) ^ p0) | (__builtin_amdgcn_alignbit(u2, u1, 24) ^ p1);
+		if (min(min(x0, x1), min(x2, x3)) == 0) {            // rare: form the per-offset bits (offsets past o_hi excluded)
+			const int left = o_hi - (o_lo + ofs);            // >= 0
+			hits = (x0 == 0 ? 1u : 0u) | (x1 == 0 && left >= 1 ? 2u : 0u) | (x2 == 0 && left >= 2 ? 4u : 0u) | (x3 == 0 && left >= 3 ? 8u : 0u);
+		}
 	}
-	return v;
+	return hits;
 }
 
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+// verify the survivors of one chunk in ascending offset order and keep the best (contig.nim:103-111, :128-135)
+__device__ __forceinline__ void exact_verify(const uint32_t *a32, unsigned hits, int sb, int slen, int ob, int olen, int o_base,
+                                              bool neg, int min_overlap, int pos, int ts, Best &best)
 {
-	for (int d = 32; d >= 1; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
-	return v;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
-{
-	for (int d = 32; d >= 1; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
-	return v;
+	const int lane = lane_id();
+	unsigned long long mask = ballot(hits != 0);
+	while (mask) {                                           // lanes ascending, then j ascending: ascending offsets
+		const int sl = ctz64(mask);
+		mask &= mask - 1;
+		unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)hits, sl);
+		while (bits) {
+			const int j = __builtin_ctz(bits);
+			bits &= bits - 1;
+			const int co = o_base + 4 * sl + j;
+			int cn = slen - co; cn = cn < olen ? cn : olen;
+			if (best.found && cn <= best.ma) continue;       // accepted offsets have mm == 0: only strictly more matches win (:107)
+			bool ok = true;
+			for (int k0 = 0; k0 < cn; k0 += 256) {
+				const int k = k0 + 4 * lane;
+				bool bad = false;
+				if (k < cn) {
+					unsigned x = ld32u(a32, ob + k) ^ ld32u(a32, sb + co + k);
+					const int rem = cn - k;
+					if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+					bad = x != 0;
+				}
+				if (ballot(bad)) { ok = false; break; }
+			}
+			if (ok && cn >= min_overlap - 1) {
+				best.found = 1; best.ma = cn; best.mm = 0; best.pos = pos; best.slot = ts;
+				best.off = neg ? -co : co;                   // the offset is on the query (contig.nim:114-135): reported as -o
+			}
+		}
+	}
 }
 
-__device__ __forceinline__ int wave_min_i32(int v)
+// slide_align for max_mismatch == 0 without votes (contig.nim:70-141), same total order as slide_scan.
+// Preconditions (else slide_scan_exact_small): min_overlap >= 9, q.len >= min_overlap, t.len >= 8.
+__device__ __forceinline__ void slide_scan_exact_u(const Arena &A, const ScanSide q, const ScanSide t, int pos, int ts, int min_overlap, Best &best)
 {
-	for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
-	return v;
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	const int omax = t.len - min_overlap;                    // :79: offsets 0..omax on the target (:81-111)
+	const int omin = q.len - min_overlap;                    // :78: then offsets 1..omin on the query (:114-135)
+	if (omax < 256 && omin <= 256) {                         // the usual sizes: both filters issued back to back
+		const unsigned h1 = omax >= 0 ? exact_hits(a32, t.b, 0, omax, 0, q.h0, q.h1) : 0u;
+		const unsigned h2 = omin >= 1 ? exact_hits(a32, q.b, 1, omin, 0, t.h0, t.h1) : 0u;
+		exact_verify(a32, h1, t.b, t.len, q.b, q.len, 0, false, min_overlap, pos, ts, best);
+		exact_verify(a32, h2, q.b, q.len, t.b, t.len, 1, true, min_overlap, pos, ts, best);
+		return;
+	}
+	for (int base = 0; base <= omax; base += 256)
+		exact_verify(a32, exact_hits(a32, t.b, 0, omax, base, q.h0, q.h1), t.b, t.len, q.b, q.len, base, false, min_overlap, pos, ts, best);
+	for (int base = 0; 1 + base <= omin; base += 256)
+		exact_verify(a32, exact_hits(a32, q.b, 1, omin, base, t.h0, t.h1), q.b, q.len, t.b, t.len, 1 + base, true, min_overlap, pos, ts, best);
 }
-__device__ __forceinline__ int wave_max_i32s(int v)
+
+__device__ __forceinline__ ScanSide scan_side_uni(const uint32_t *a32, int b, int len)
 {
-	for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-	return v;
+	ScanSide s;
+	s.b = uni(b); s.len = uni(len);
+	unsigned h0, h1;
+	ld64u(a32, s.b, h0, h1);
+	s.h0 = (unsigned)uni((int)h0); s.h1 = (unsigned)uni((int)h1);
+	return s;
+}
+
+template <class ST>
+__device__ inline void slide_scan_exact(const ST &S, const Arena &A, int qs, int ts, int pos, int min_overlap, Best &best)
+{
+	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
+	min_overlap = uni(min_overlap);
+	if (min_overlap < 9 || qlen < min_overlap || tlen < 8) {  // windows shorter than 8 bases, or the abs(omin) oddity of :114
+		slide_scan_exact_small(S, A, qs, ts, pos, min_overlap, best);
+		return;
+	}
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	slide_scan_exact_u(A, scan_side_uni(a32, S.off[qs], qlen), scan_side_uni(a32, S.off[ts], tlen), uni(pos), uni(ts), min_overlap, best);
 }
 
 // Support extrema and the clean zone [lo3, hi3) (every support >= 3) of one contig.
@@ -725,12 +802,38 @@ __device__ inline int insert_read(ST &S, Arena &A, int ts, int off)
 	return 0;
 }
 
-// best_match (contig.nim:224-240) for a fresh read against list[0..n): always the exact scan.
+// best_match (contig.nim:224-240) for a fresh read against list[0..n): always the exact scan.  The slot
+// metadata and first 8 bases of up to 64 contigs are gathered lane-parallel (three LDS round trips per read
+// instead of per contig) and handed to the scan through v_readlane.
 template <class ST>
 __device__ inline Best best_match_read(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
 {
+	const int lane = lane_id();
 	Best best = {0, 0, 0, -1, -1, 0};
-	for (int i = 0; i < n; ++i) slide_scan_exact(S, A, ST::QSLOT, list[i], i, min_overlap, best);
+	n = uni(n); min_overlap = uni(min_overlap);
+	const int qlen = uni(S.len[ST::QSLOT]);
+	if (min_overlap < 9 || qlen < min_overlap) {
+		for (int i = 0; i < n; ++i) slide_scan_exact_small(S, A, ST::QSLOT, list[i], i, min_overlap, best);
+		return best;
+	}
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	const ScanSide q = scan_side_uni(a32, S.off[ST::QSLOT], qlen);
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		int m_ts = 0, m_off = 0, m_len = 0; unsigned m_h0 = 0, m_h1 = 0;
+		if (c0 + lane < n) {
+			m_ts = list[c0 + lane]; m_off = S.off[m_ts]; m_len = S.len[m_ts];
+			ld64u(a32, m_off, m_h0, m_h1);
+		}
+		const int m = n - c0 < 64 ? n - c0 : 64;
+		for (int i = 0; i < m; ++i) {
+			ScanSide t;
+			t.b = __builtin_amdgcn_readlane(m_off, i); t.len = __builtin_amdgcn_readlane(m_len, i);
+			t.h0 = (unsigned)__builtin_amdgcn_readlane((int)m_h0, i); t.h1 = (unsigned)__builtin_amdgcn_readlane((int)m_h1, i);
+			const int ts = __builtin_amdgcn_readlane(m_ts, i);
+			if (t.len < 8) { slide_scan_exact_small(S, A, ST::QSLOT, ts, c0 + i, min_overlap, best); continue; }
+			slide_scan_exact_u(A, q, t, c0 + i, ts, min_overlap, best);
+		}
+	}
 	return best;
 }
 

@@ -27,7 +27,50 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int clz64(unsigned long long m) { return __clzll((long long)m); }
-__device__ __forceinline__ int bcast(int v, int src) { return __shfl(v, src, 64); }
+// Value of lane `src` (wave-uniform index) for every lane: v_readlane, not a trip through the LDS crossbar; the
+// result is in an SGPR, so everything computed from it stays on the scalar unit.
+__device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+
+// Wave-wide reductions on the DPP network (xor 1, xor 2, 8-lane mirror, 16-lane mirror, then row_bcast 15/31
+// fold the four rows into lane 63): six VALU instructions, against six LDS-crossbar round trips for a shuffle loop.
+#define IHP_WAVE_REDUCE(NAME, TYPE, OP)                                                                    \
+	__device__ __forceinline__ TYPE NAME(TYPE v)                                                           \
+	{                                                                                                      \
+		int t;                                                                                             \
+		asm("s_nop 4\n\t"                                                                                  \
+		    OP " %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                   \
+		    OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                   \
+		    OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                       \
+		    OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                            \
+		    OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                          \
+		    OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"                               \
+		    : "=&v"(t) : "v"((int)v));                                                                     \
+		return (TYPE)__builtin_amdgcn_readlane(t, 63);                                                     \
+	}
+IHP_WAVE_REDUCE(wave_min_u32, unsigned, "v_min_u32_dpp")
+IHP_WAVE_REDUCE(wave_max_u32, unsigned, "v_max_u32_dpp")
+IHP_WAVE_REDUCE(wave_min_i32, int, "v_min_i32_dpp")
+IHP_WAVE_REDUCE(wave_max_i32s, int, "v_max_i32_dpp")
+IHP_WAVE_REDUCE(wave_sum_i, int, "v_add_u32_dpp")
+IHP_WAVE_REDUCE(wave_or_u32, unsigned, "v_or_b32_dpp")
+
+// Inclusive prefix sum over the 64 lanes, the DPP scan: 4-wide sums from three row shifts of the input, then
+// row_shr 4 / 8 on the lanes that have such a neighbour, then the row broadcasts.
+__device__ __forceinline__ unsigned wave_scan_add(unsigned v)
+{
+	unsigned t;
+	asm("s_nop 4\n\t"
+	    "v_mov_b32 %0, %1\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+	    : "=&v"(t) : "v"(v));
+	return t;
+}
 __device__ __forceinline__ int first_lane_val(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // A wave-uniform value that was loaded through the vector memory path sits in a VGPR, and the compiler then
 // does all the scalar arithmetic and branching that depends on it on the vector ALU.  uni() moves it to an SGPR.

@@ -595,9 +595,9 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
 #undef UP
 	// scratch sizing
-	b->grid_asm = grid_for(R, 16);
+	b->grid_asm = grid_for(R, 18);
 	b->grid_retry = grid_for(R, 2);
-	b->lds_arena1 = 6144;                                           // + 4.4 KB of state: 15 workgroups per CU
+	b->lds_arena1 = 5120;                                           // + 3.7 KB of state: 18 workgroups per CU
 	b->lds_arena2 = 12288;                                          // + 7.5 KB (RegionStateT<128>): 8 per CU
 	{
 		long long want = ((long long)b->max_region_bases * 4 / 5 + 4 * ((b->max_read_len + 15) / 16 * 16 + 16) + 1024 + 15) / 16 * 16;

@@ -181,8 +181,7 @@ __device__ __forceinline__ int count_events(const uint32_t *cigar, int n_cigar, 
 // OR-reduce a 64-bit value over the wave
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
 {
-	unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-	for (int d = 32; d >= 1; d >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, d, 64); hi |= (unsigned)__shfl_xor((int)hi, d, 64); }
+	const unsigned lo = wave_or_u32((unsigned)v), hi = wave_or_u32((unsigned)(v >> 32));
 	return ((unsigned long long)hi << 32) | lo;
 }
 
