@@ -802,11 +802,11 @@ __device__ inline int insert_read(ST &S, Arena &A, int ts, int off)
 	return 0;
 }
 
-// best_match (contig.nim:224-240) for a fresh read against list[0..n): always the exact scan.  The slot
-// metadata and first 8 bases of up to 64 contigs are gathered lane-parallel (three LDS round trips per read
-// instead of per contig) and handed to the scan through v_readlane.
+// best_match (contig.nim:224-240) for a fresh read against list[0..n), one contig after the other: the slot
+// metadata and first 8 bases of up to 64 contigs are gathered lane-parallel and handed to the scan through
+// v_readlane.  The general form (any lengths); best_match_read below is the usual one.
 template <class ST>
-__device__ inline Best best_match_read(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
+__device__ inline Best best_match_read_seq(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
 {
 	const int lane = lane_id();
 	Best best = {0, 0, 0, -1, -1, 0};
@@ -835,6 +835,146 @@ __device__ inline Best best_match_read(const ST &S, const Arena &A, const short 
 		}
 	}
 	return best;
+}
+
+// Candidate (cn bases of the arena at xb and yb equal?) against the best so far under the reference's total
+// order: more matches win (contig.nim:107), ties go to the earlier contig (match_sort :32-36, :239), within a
+// contig to the target-offset phase (:81-111) before the query-offset phase (:114-135), then the smaller offset.
+struct BestOrd { Best b; int ph, o; };
+__device__ __forceinline__ void consider(const uint32_t *a32, BestOrd &B, int cn, int pos, int ph, int o, int slot, int xb, int yb, int min_overlap)
+{
+	const int lane = lane_id();
+	if (cn < min_overlap - 1) return;
+	if (B.b.found) {
+		if (cn < B.b.ma) return;
+		if (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (ph > B.ph || (ph == B.ph && o >= B.o))))) return;
+	}
+	for (int k0 = 0; k0 < cn; k0 += 256) {
+		const int k = k0 + 4 * lane;
+		bool bad = false;
+		if (k < cn) {
+			unsigned x = ld32u(a32, xb + k) ^ ld32u(a32, yb + k);
+			const int rem = cn - k;
+			if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+			bad = x != 0;
+		}
+		if (ballot(bad)) return;
+	}
+	B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = slot; B.b.off = ph ? -o : o;
+	B.ph = ph; B.o = o;
+}
+
+// best_match (contig.nim:224-240) for a fresh read, all contigs of the list at once.
+//   Target-offset phase (:81-111): the valid offsets [0, len - min_overlap] of the contigs are laid end to end in
+//   groups of four; a lane takes one group (its contig found by walking the scalar prefix sums), reads 16 bytes of
+//   that contig and filters four 8-base windows against the head of the read.
+//   Query-offset phase (:114-135): one lane per contig holds the contig's first 8 bases; the <= 63 windows of the
+//   read are broadcast one after the other.
+// Survivors are verified on the full overlap and ranked by consider().
+template <class ST>
+__device__ inline Best best_match_read(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
+{
+	const int lane = lane_id();
+	n = uni(n); min_overlap = uni(min_overlap);
+	const int qlen = uni(S.len[ST::QSLOT]);
+	const int omin = qlen - min_overlap;                     // :78
+	if (min_overlap < 9 || omin < 0 || omin > 63) return best_match_read_seq(S, A, list, n, min_overlap);
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	const int qb = uni(S.off[ST::QSLOT]);
+	unsigned rw0, rw1;                                       // lane o: the read's 8 bases from offset o
+	ld64u(a32, qb + (lane <= omin ? lane : 0), rw0, rw1);
+	const unsigned qh0 = (unsigned)__builtin_amdgcn_readlane((int)rw0, 0), qh1 = (unsigned)__builtin_amdgcn_readlane((int)rw1, 0);
+	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int m = n - c0 < 64 ? n - c0 : 64;
+		int m_ts = 0, m_off = 0, m_len = 0; unsigned m_h0 = 0, m_h1 = 0;
+		if (lane < m) {
+			m_ts = list[c0 + lane]; m_off = S.off[m_ts]; m_len = S.len[m_ts];
+			ld64u(a32, m_off, m_h0, m_h1);
+		}
+		if (ballot(lane < m && m_len < 8)) return best_match_read_seq(S, A, list, n, min_overlap);   // windows shorter than 8 bases
+		// ---- offsets on the contigs
+		const int n1 = m_len - min_overlap + 1;              // offsets 0 .. len - min_overlap (:79)
+		const unsigned nq = lane < m && n1 > 0 ? (unsigned)(n1 + 3) >> 2 : 0u;
+		const unsigned incl = wave_scan_add(nq), excl = incl - nq;
+		const int Q = __builtin_amdgcn_readlane((int)incl, 63);
+		int i0 = 0;                                          // first contig whose groups are not all behind us
+		for (int g0 = 0; g0 < Q; g0 += 64) {
+			const int g = g0 + lane;
+			int c_i = 0;
+			for (int i = i0; i < m; ++i) {                   // contigs in list order have ascending group ranges
+				const int ei = __builtin_amdgcn_readlane((int)excl, i);
+				if (ei >= g0 + 64) break;
+				c_i = g >= ei ? i : c_i;                     // the last contig that starts at or before g owns it
+				if (__builtin_amdgcn_readlane((int)incl, i) <= g0 + 64) i0 = i + 1;
+			}
+			// (contigs with no valid offset have empty ranges: a later contig with the same start overrides them)
+			const int c_off = __builtin_amdgcn_ds_bpermute(c_i << 2, m_off), c_n1 = __builtin_amdgcn_ds_bpermute(c_i << 2, n1);
+			const int c_ex = __builtin_amdgcn_ds_bpermute(c_i << 2, (int)excl);
+			const int o1 = 4 * (g - c_ex);                   // first of this lane's four offsets
+			unsigned hits = 0;
+			if (g < Q && o1 < c_n1) {
+				const int ab = c_off + o1;
+				const unsigned sh = (unsigned)(ab & 3) * 8u;
+				const int d = ab >> 2;
+				const unsigned w0 = a32[d], w1 = a32[d + 1], w2 = a32[d + 2], w3 = a32[d + 3];
+				const unsigned u0 = __builtin_amdgcn_alignbit(w1, w0, sh), u1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+				const unsigned u2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+				const unsigned x0 = (u0 ^ qh0) | (u1 ^ qh1);
+				const unsigned x1 = (__builtin_amdgcn_alignbit(u1, u0, 8) ^ qh0) | (__builtin_amdgcn_alignbit(u2, u1, 8) ^ qh1);
+				const unsigned x2 = (__builtin_amdgcn_alignbit(u1, u0, 16) ^ qh0) | (__builtin_amdgcn_alignbit(u2, u1, 16) ^ qh1);
+				const unsigned x3 = (__builtin_amdgcn_alignbit(u1, u0, 24) ^ qh0) | (__builtin_amdgcn_alignbit(u2, u1, 24) ^ qh1);
+				if (min(min(x0, x1), min(x2, x3)) == 0) {
+					const int left = c_n1 - 1 - o1;          // >= 0: offsets past len - min_overlap are not candidates
+					hits = (x0 == 0 ? 1u : 0u) | (x1 == 0 && left >= 1 ? 2u : 0u) | (x2 == 0 && left >= 2 ? 4u : 0u) | (x3 == 0 && left >= 3 ? 8u : 0u);
+				}
+			}
+			unsigned long long mask = ballot(hits != 0);
+			while (mask) {
+				const int sl = ctz64(mask);
+				mask &= mask - 1;
+				unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)hits, sl);
+				const int i = __builtin_amdgcn_readlane(c_i, sl), ob = __builtin_amdgcn_readlane(o1, sl);
+				const int tb = __builtin_amdgcn_readlane(m_off, i), tlen = __builtin_amdgcn_readlane(m_len, i);
+				const int ts = __builtin_amdgcn_readlane(m_ts, i);
+				while (bits) {
+					const int o = ob + __builtin_ctz(bits);
+					bits &= bits - 1;
+					const int cn = qlen < tlen - o ? qlen : tlen - o;
+					consider(a32, B, cn, c0 + i, 0, o, ts, qb, tb + o, min_overlap);
+				}
+			}
+		}
+		// ---- offsets on the read: lanes are contigs and the windows are broadcast, or the other way round
+		if (omin < m) {
+			for (int o = 1; o <= omin; ++o) {
+				const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)rw0, o), s1 = (unsigned)__builtin_amdgcn_readlane((int)rw1, o);
+				unsigned long long mask = ballot(lane < m && ((m_h0 ^ s0) | (m_h1 ^ s1)) == 0);
+				while (mask) {
+					const int i = ctz64(mask);
+					mask &= mask - 1;
+					const int tb = __builtin_amdgcn_readlane(m_off, i), tlen = __builtin_amdgcn_readlane(m_len, i);
+					const int cn = qlen - o < tlen ? qlen - o : tlen;
+					consider(a32, B, cn, c0 + i, 1, o, __builtin_amdgcn_readlane(m_ts, i), qb + o, tb, min_overlap);
+				}
+			}
+		} else {
+			for (int i = 0; i < m; ++i) {
+				const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)m_h0, i), t1 = (unsigned)__builtin_amdgcn_readlane((int)m_h1, i);
+				unsigned long long mask = ballot(lane >= 1 && lane <= omin && ((rw0 ^ t0) | (rw1 ^ t1)) == 0);
+				if (!mask) continue;
+				const int tb = __builtin_amdgcn_readlane(m_off, i), tlen = __builtin_amdgcn_readlane(m_len, i);
+				const int ts = __builtin_amdgcn_readlane(m_ts, i);
+				while (mask) {
+					const int o = ctz64(mask);
+					mask &= mask - 1;
+					const int cn = qlen - o < tlen ? qlen - o : tlen;
+					consider(a32, B, cn, c0 + i, 1, o, ts, qb + o, tb, min_overlap);
+				}
+			}
+		}
+	}
+	return B.b;
 }
 
 // best_match for the combine phase: exact scan when the vote rule cannot fire for the pair.
