@@ -595,18 +595,42 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
 #undef UP
 	// scratch sizing
-	b->grid_asm = grid_for(R, 18);
+	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
 	b->grid_retry = grid_for(R, 2);
-	b->lds_arena1 = 5120;                                           // + 3.7 KB of state: 18 workgroups per CU
-	b->lds_arena2 = 12288;                                          // + 7.5 KB (RegionStateT<128>): 8 per CU
+	{
+		// First-pass LDS arena: a small arena runs more waves per CU (state 3.7 KB + arena, at most 16 waves: 128
+		// VGPRs) but sends the regions that do not fit on to the second pass, which runs at the occupancy of its
+		// own, larger arena.  A region needs about half its read bases (live contigs stay below ~30%; headroom
+		// and relocated copies take the rest) plus the staging areas, and costs about its read bases: pick the
+		// arena that minimises  sum(cost / occupancy)  over the two passes.
+		std::vector<std::pair<long long, long long>> need((size_t)R);          // (bytes needed, cost)
+		for (long long r = 0; r < R; ++r) {
+			const long long nb = in->read_off[in->region_read_off[r + 1]] - in->read_off[in->region_read_off[r]];
+			need[(size_t)r] = {nb / 2 + 2 * b->stage_cap, nb + 1};
+		}
+		std::sort(need.begin(), need.end());
+		std::vector<double> pre((size_t)R + 1, 0.0);
+		for (size_t i = 0; i < (size_t)R; ++i) pre[i + 1] = pre[i] + (double)need[i].second;
+		double best_t = 1e300; long long a1 = 5120;
+		for (long long a = 3072; a <= 24576; a += 512) {
+			const size_t fit = (size_t)(std::upper_bound(need.begin(), need.end(), std::make_pair(a - 16, (long long)1 << 60)) - need.begin());
+			const double occ1 = (double)std::max(1, std::min(16, g.max_lds / ((int)a + 3840)));
+			const long long a2 = std::max<long long>(12288, std::min<long long>(2 * a, g.max_lds - 24576));
+			const double occ2 = (double)std::max(1, std::min(16, g.max_lds / ((int)a2 + 8192)));
+			const double t = pre[fit] / occ1 + (pre[(size_t)R] - pre[fit]) / occ2;
+			if (t < best_t) { best_t = t; a1 = a; }
+		}
+		b->lds_arena1 = (int)a1;
+		b->grid_asm = grid_for(R, std::max(1, std::min(16, g.max_lds / (b->lds_arena1 + 3840))));
+	}
+	b->lds_arena2 = std::max(12288, std::min(2 * b->lds_arena1, g.max_lds - 24576));   // + 7.5 KB (RegionStateT<128>)
 	{
 		long long want = ((long long)b->max_region_bases * 4 / 5 + 4 * ((b->max_read_len + 15) / 16 * 16 + 16) + 1024 + 15) / 16 * 16;
 		const long long cap = (long long)g.max_lds - 16384;          // RegionStateT<256> is ~13.7 KB of static LDS
-		b->lds_arena3 = (int)std::max<long long>(16384, std::min(want, cap));
+		b->lds_arena3 = (int)std::max<long long>(std::max(16384, b->lds_arena2), std::min(want, cap));
 	}
 	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
 	b->grid_asm3 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena3 + 14336)));
-	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
 	b->arena_cap = (3 * b->max_region_bases + 4 * b->stage_cap + 2048 + 15) / 16 * 16;
 	b->corr_cap = std::min(MAXLEN, b->max_region_bases) + 16;
 	const long long slots = NR;
