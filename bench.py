@@ -134,8 +134,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
         if args.config == "C2" and R == 10_000 and os.path.exists(pmc):
             k = json.load(open(pmc))["kernels"]
-            key = {"k_assemble": "k_assemble<128, true>", "k_ksw": "k_ksw", "k_tally": "k_tally"}[KERNELS[dom]]
-            traffic = k.get(key, {}).get("traffic")
+            # the stage is one launch of each of these (the later assembly passes are empty on this workload)
+            names = {"k_assemble": ("k_assemble<64, true, 4>",), "k_ksw": ("k_ksw<3>", "k_ksw<4>"), "k_tally": ("k_tally",)}[KERNELS[dom]]
+            t = [k[n]["traffic"] for n in names if n in k]
+            traffic = int(sum(t)) if t else None
         out = {
             "metric": "candidate regions/sec (assemble+ksw2+kmer-genotype), 150bp x 64-read batches",
             "value": round(world * R * args.steps / dt, 1), "unit": "regions/s",
