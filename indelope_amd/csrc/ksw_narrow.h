@@ -256,18 +256,29 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 	}
 	if (!STEADY) F.last_sc = sc;
 	// ---- exact max (:320-348) ----------------------------------------------------------
-	int max_H = wave_max_i32_keep(hA), max_t;
-	unsigned long long mB = 0;
-	int nB = 0;
-	if (hasB) {
-		const int mb = wave_max_i32_keep(hB);
-		max_H = mb > max_H ? mb : max_H;
-		mB = ballot(hB == max_H) & mInB;
-		nB = popc64(mB);
+	int max_H = wave_max_i32_keep(hA);
+	if (hasB) { const int mb = wave_max_i32_keep(hB); max_H = mb > max_H ? mb : max_H; }
+	// ---- ez updates (:351-357) -----------------------------------------------------------
+	if (ENDS) {
+		int Hen0 = 0;
+		if (en0 == E.tlen - 1 || r - st0 == E.qlen - 1) {
+			Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
+			const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
+			if (en0 == E.tlen - 1 && Hen0 > F.mte) { F.mte = Hen0; F.mte_q = r - en; }        // rounded en (:352)
+			if (r - st0 == E.qlen - 1 && Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st0; }
+		}
+		if (r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;                  // :356-357
 	}
+	// ksw_apply_zdrop (:88-104) only looks at max_t when the maximum improves or has fallen more than zdrop below
+	// the best one (the test of :98 cannot hold otherwise): everything about max_t, ties included, is skipped on
+	// the other diagonals.
+	const bool improves = max_H > F.ez_max;
+	if (!improves && (E.zdrop < 0 || F.ez_max - max_H <= E.zdrop)) return false;
+	int max_t;
 	{
-		const unsigned long long mA = ballot(hA == max_H);             // lanes outside the band hold INT_MIN
-		if (popc64(mA) + nB == 1) {
+		const unsigned long long mA = ballot(hA == max_H);                 // lanes outside the band hold INT_MIN
+		const unsigned long long mB = hasB ? ballot(hB == max_H) & mInB : 0ull;
+		if (popc64(mA) + popc64(mB) == 1) {
 			max_t = mA ? st + ctz64(mA) : st + 64 + ctz64(mB);
 		} else {
 			// ties: en0 first, then stride classes of the vector part, then the scalar tail
@@ -289,21 +300,9 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 			}
 		}
 	}
-	// ---- ez updates (:351-357) -----------------------------------------------------------
-	if (ENDS) {
-		int Hen0 = 0;
-		if (en0 == E.tlen - 1 || r - st0 == E.qlen - 1) {
-			Hen0 = hiT < 64 ? __builtin_amdgcn_readlane(hA, hiT & 63) : __builtin_amdgcn_readlane(hB, (hiT - 64) & 63);
-			const int Hst0 = __builtin_amdgcn_readlane(hA, loA);
-			if (en0 == E.tlen - 1 && Hen0 > F.mte) { F.mte = Hen0; F.mte_q = r - en; }        // rounded en (:352)
-			if (r - st0 == E.qlen - 1 && Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st0; }
-		}
-		if (r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;                  // :356-357
-	}
-	// ksw_apply_zdrop (:88-104), written as a chain of exits
 	const int t = max_t, dq = r - max_t;
-	if (max_H > F.ez_max) { F.ez_max = max_H; F.ez_max_t = t; F.ez_max_q = dq; return false; }
-	if (t < F.ez_max_t || dq < F.ez_max_q || E.zdrop < 0) return false;
+	if (improves) { F.ez_max = max_H; F.ez_max_t = t; F.ez_max_q = dq; return false; }
+	if (t < F.ez_max_t || dq < F.ez_max_q) return false;
 	const int tl = t - F.ez_max_t, ql = dq - F.ez_max_q;
 	const int l = tl > ql ? tl - ql : ql - tl;
 	return F.ez_max - max_H > E.zdrop + l * E.e;
