@@ -637,26 +637,36 @@ __device__ inline void recompute_minmax(ST &S, const Arena &A, int s)
 	WSYNC();
 }
 
-// Difference arrays -> supports, in place, plus the support extrema (end of the read phase).
+// Difference arrays -> supports, in place, plus the support extrema and clean zone of recompute_minmax()
+// from the values while they are in registers (end of the read phase).
 template <class ST>
 __device__ inline void materialize_supports(ST &S, Arena &A, const short *list, int n)
 {
 	const int lane = lane_id();
+	n = uni(n);
 	for (int c = 0; c < n; ++c) {
-		const int s = list[c];
-		uint32_t *d = A.sup + S.off[s];
-		const int len = S.len[s];
+		const int s = uni((int)list[c]);
+		uint32_t *d = A.sup + uni(S.off[s]);
+		const int len = uni(S.len[s]);
 		unsigned carry = 0, mn = 0xffffffffu, mx = 0;
+		int first = 0x7fffffff, last = -1, cnt = 0;
 		for (int i0 = 0; i0 < len; i0 += 64) {
 			const int i = i0 + lane;
 			unsigned v = i < len ? ld_l2(&d[i]) : 0u;
 			v = wave_scan_add(v) + carry;
-			if (i < len) { d[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-			carry = (unsigned)__shfl((int)v, 63, 64);
+			if (i < len) {
+				d[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+				if (v >= 3u) { first = i < first ? i : first; last = i; cnt++; }
+			}
+			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 		}
-		(void)mn; (void)mx;
-		WSYNC();
-		recompute_minmax(S, A, s);
+		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+		first = wave_min_i32(first); last = wave_max_i32s(last); cnt = wave_sum_i(cnt);
+		if (lane == 0) {
+			S.smin[s] = mn; S.smax[s] = mx;
+			const bool clean = last >= first && cnt == last - first + 1;    // no dip below 3 inside
+			S.lo3[s] = clean ? first : 0x3fffffff; S.hi3[s] = clean ? last + 1 : 0;
+		}
 	}
 	WSYNC();
 }
