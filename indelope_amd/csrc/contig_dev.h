@@ -874,38 +874,72 @@ __device__ __forceinline__ void consider(const uint32_t *a32, BestOrd &B, int cn
 	B.ph = ph; B.o = o;
 }
 
-// best_match (contig.nim:224-240) for a fresh read, all contigs of the list at once.
+// best_match for the combine phase, one contig after the other: exact scan when the vote rule cannot fire for
+// the pair, else the generic scan.  The general form; best_match_combine below is the usual one.
+template <class ST>
+__device__ inline Best best_match_combine_seq(const ST &S, const Arena &A, int qs, const short *list, int n,
+                                          int min_overlap, int max_mm)
+{
+	Best best = {0, 0, 0, -1, -1, 0};
+	for (int i = 0; i < n; ++i) {
+		const int ts = list[i];
+		if (ts == qs) continue;                                    // :227
+		if (max_mm == 0 && !may_allow(S, qs, ts)) { IHP_T0(A); slide_scan_exact(S, A, qs, ts, i, min_overlap, best); IHP_T1(A, 5); }
+		else { IHP_T0(A); slide_scan(S, A, qs, ts, i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, best); IHP_T1(A, 4); }
+	}
+	return best;
+}
+
+// best_match (contig.nim:224-240) against all contigs of the list at once, for queries the exact scan is valid
+// for: a fresh read (COMBINE = false) or, in the combine phase, a contig for which may_allow() is false against
+// every contig of the list (anything else goes to the one-after-the-other forms).
 //   Target-offset phase (:81-111): the valid offsets [0, len - min_overlap] of the contigs are laid end to end in
 //   groups of four; a lane takes one group (its contig found by walking the scalar prefix sums), reads 16 bytes of
-//   that contig and filters four 8-base windows against the head of the read.
-//   Query-offset phase (:114-135): one lane per contig holds the contig's first 8 bases; the <= 63 windows of the
-//   read are broadcast one after the other.
+//   that contig and filters four 8-base windows against the head of the query.
+//   Query-offset phase (:114-135): lane o holds the query's 8 bases from offset o (64 offsets at a time) and the
+//   contigs' first 8 bases are broadcast one after the other -- or, when there are fewer offsets than contigs, one
+//   lane per contig and the windows are broadcast.
 // Survivors are verified on the full overlap and ranked by consider().
-template <class ST>
-__device__ inline Best best_match_read(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
+template <class ST, bool COMBINE>
+__device__ inline Best best_match_all(const ST &S, const Arena &A, int qs, const short *list, int n, int min_overlap, int max_mm)
 {
 	const int lane = lane_id();
-	n = uni(n); min_overlap = uni(min_overlap);
-	const int qlen = uni(S.len[ST::QSLOT]);
+	n = uni(n); min_overlap = uni(min_overlap); qs = uni(qs);
+	const int qlen = uni(S.len[qs]);
 	const int omin = qlen - min_overlap;                     // :78
-	if (min_overlap < 9 || omin < 0 || omin > 63) return best_match_read_seq(S, A, list, n, min_overlap);
+	if (min_overlap < 9 || omin < 0 || (COMBINE && max_mm != 0))
+		return COMBINE ? best_match_combine_seq(S, A, qs, list, n, min_overlap, max_mm) : best_match_read_seq(S, A, list, n, min_overlap);
 	const uint32_t *a32 = (const uint32_t *)A.seq;
-	const int qb = uni(S.off[ST::QSLOT]);
-	unsigned rw0, rw1;                                       // lane o: the read's 8 bases from offset o
+	const int qb = uni(S.off[qs]);
+	unsigned rw0, rw1;                                       // lane o: the query's 8 bases from offset o
 	ld64u(a32, qb + (lane <= omin ? lane : 0), rw0, rw1);
 	const unsigned qh0 = (unsigned)__builtin_amdgcn_readlane((int)rw0, 0), qh1 = (unsigned)__builtin_amdgcn_readlane((int)rw1, 0);
+	unsigned qmin = 0, qmax = 0; long long qreads = 0;
+	if (COMBINE) { qmin = (unsigned)uni((int)S.smin[qs]); qmax = (unsigned)uni((int)S.smax[qs]); qreads = uni(S.nreads[qs]); }
 	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
 	for (int c0 = 0; c0 < n; c0 += 64) {
 		const int m = n - c0 < 64 ? n - c0 : 64;
 		int m_ts = 0, m_off = 0, m_len = 0; unsigned m_h0 = 0, m_h1 = 0;
-		if (lane < m) {
+		bool use = lane < m;
+		if (use) {
 			m_ts = list[c0 + lane]; m_off = S.off[m_ts]; m_len = S.len[m_ts];
 			ld64u(a32, m_off, m_h0, m_h1);
 		}
-		if (ballot(lane < m && m_len < 8)) return best_match_read_seq(S, A, list, n, min_overlap);   // windows shorter than 8 bases
+		bool odd = use && m_len < 8;                         // windows shorter than 8 bases
+		if (COMBINE && use) {
+			if (m_ts == qs) use = false;                     // :227
+			else {                                           // may_allow(): can the vote rule fire for this pair at all?
+				const unsigned tmin = S.smin[m_ts], tmax = S.smax[m_ts];
+				const long long treads = S.nreads[m_ts];
+				odd |= (qmin < 3u && tmax > 3u * qmin && qreads > 3ll * (long long)qmin) ||
+				       (tmin < 3u && qmax > 3u * tmin && treads > 3ll * (long long)tmin);
+			}
+		}
+		if (ballot(odd))
+			return COMBINE ? best_match_combine_seq(S, A, qs, list, n, min_overlap, max_mm) : best_match_read_seq(S, A, list, n, min_overlap);
 		// ---- offsets on the contigs
 		const int n1 = m_len - min_overlap + 1;              // offsets 0 .. len - min_overlap (:79)
-		const unsigned nq = lane < m && n1 > 0 ? (unsigned)(n1 + 3) >> 2 : 0u;
+		const unsigned nq = use && n1 > 0 ? (unsigned)(n1 + 3) >> 2 : 0u;
 		const unsigned incl = wave_scan_add(nq), excl = incl - nq;
 		const int Q = __builtin_amdgcn_readlane((int)incl, 63);
 		int i0 = 0;                                          // first contig whose groups are not all behind us
@@ -955,11 +989,11 @@ __device__ inline Best best_match_read(const ST &S, const Arena &A, const short 
 				}
 			}
 		}
-		// ---- offsets on the read: lanes are contigs and the windows are broadcast, or the other way round
-		if (omin < m) {
+		// ---- offsets on the query: lanes are contigs and the windows are broadcast, or the other way round
+		if (omin < m && omin <= 63) {
 			for (int o = 1; o <= omin; ++o) {
 				const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)rw0, o), s1 = (unsigned)__builtin_amdgcn_readlane((int)rw1, o);
-				unsigned long long mask = ballot(lane < m && ((m_h0 ^ s0) | (m_h1 ^ s1)) == 0);
+				unsigned long long mask = ballot(use && ((m_h0 ^ s0) | (m_h1 ^ s1)) == 0);
 				while (mask) {
 					const int i = ctz64(mask);
 					mask &= mask - 1;
@@ -969,17 +1003,24 @@ __device__ inline Best best_match_read(const ST &S, const Arena &A, const short 
 				}
 			}
 		} else {
-			for (int i = 0; i < m; ++i) {
-				const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)m_h0, i), t1 = (unsigned)__builtin_amdgcn_readlane((int)m_h1, i);
-				unsigned long long mask = ballot(lane >= 1 && lane <= omin && ((rw0 ^ t0) | (rw1 ^ t1)) == 0);
-				if (!mask) continue;
-				const int tb = __builtin_amdgcn_readlane(m_off, i), tlen = __builtin_amdgcn_readlane(m_len, i);
-				const int ts = __builtin_amdgcn_readlane(m_ts, i);
-				while (mask) {
-					const int o = ctz64(mask);
-					mask &= mask - 1;
-					const int cn = qlen - o < tlen ? qlen - o : tlen;
-					consider(a32, B, cn, c0 + i, 1, o, ts, qb + o, tb, min_overlap);
+			const unsigned long long usem = ballot(use);
+			for (int ob = 0; ob <= omin; ob += 64) {         // lane <-> offset ob + lane
+				unsigned w0 = rw0, w1 = rw1;
+				if (ob) ld64u(a32, qb + (ob + lane <= omin ? ob + lane : 0), w0, w1);
+				const bool valid = ob + lane >= 1 && ob + lane <= omin;
+				for (int i = 0; i < m; ++i) {
+					if (!((usem >> i) & 1)) continue;
+					const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)m_h0, i), t1 = (unsigned)__builtin_amdgcn_readlane((int)m_h1, i);
+					unsigned long long mask = ballot(valid && ((w0 ^ t0) | (w1 ^ t1)) == 0);
+					if (!mask) continue;
+					const int tb = __builtin_amdgcn_readlane(m_off, i), tlen = __builtin_amdgcn_readlane(m_len, i);
+					const int ts = __builtin_amdgcn_readlane(m_ts, i);
+					while (mask) {
+						const int o = ob + ctz64(mask);
+						mask &= mask - 1;
+						const int cn = qlen - o < tlen ? qlen - o : tlen;
+						consider(a32, B, cn, c0 + i, 1, o, ts, qb + o, tb, min_overlap);
+					}
 				}
 			}
 		}
@@ -987,19 +1028,20 @@ __device__ inline Best best_match_read(const ST &S, const Arena &A, const short 
 	return B.b;
 }
 
-// best_match for the combine phase: exact scan when the vote rule cannot fire for the pair.
+template <class ST>
+__device__ inline Best best_match_read(const ST &S, const Arena &A, const short *list, int n, int min_overlap)
+{
+	return best_match_all<ST, false>(S, A, ST::QSLOT, list, n, min_overlap, 0);
+}
+
 template <class ST>
 __device__ inline Best best_match_combine(const ST &S, const Arena &A, int qs, const short *list, int n,
                                           int min_overlap, int max_mm)
 {
-	Best best = {0, 0, 0, -1, -1, 0};
-	for (int i = 0; i < n; ++i) {
-		const int ts = list[i];
-		if (ts == qs) continue;                                    // :227
-		if (max_mm == 0 && !may_allow(S, qs, ts)) { IHP_T0(A); slide_scan_exact(S, A, qs, ts, i, min_overlap, best); IHP_T1(A, 5); }
-		else { IHP_T0(A); slide_scan(S, A, qs, ts, i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, best); IHP_T1(A, 4); }
-	}
-	return best;
+	IHP_T0(A);
+	const Best b = best_match_all<ST, true>(S, A, qs, list, n, min_overlap, max_mm);
+	IHP_T1(A, 5);
+	return b;
 }
 
 }  // namespace ihp
