@@ -917,6 +917,7 @@ __device__ inline Best best_match_all(const ST &S, const Arena &A, int qs, const
 	unsigned qmin = 0, qmax = 0; long long qreads = 0;
 	if (COMBINE) { qmin = (unsigned)uni((int)S.smin[qs]); qmax = (unsigned)uni((int)S.smax[qs]); qreads = uni(S.nreads[qs]); }
 	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
+	Best G = {0, 0, 0, -1, -1, 0};                           // best of the pairs that need the generic scan
 	for (int c0 = 0; c0 < n; c0 += 64) {
 		const int m = n - c0 < 64 ? n - c0 : 64;
 		int m_ts = 0, m_off = 0, m_len = 0; unsigned m_h0 = 0, m_h1 = 0;
@@ -925,18 +926,30 @@ __device__ inline Best best_match_all(const ST &S, const Arena &A, int qs, const
 			m_ts = list[c0 + lane]; m_off = S.off[m_ts]; m_len = S.len[m_ts];
 			ld64u(a32, m_off, m_h0, m_h1);
 		}
-		bool odd = use && m_len < 8;                         // windows shorter than 8 bases
-		if (COMBINE && use) {
-			if (m_ts == qs) use = false;                     // :227
-			else {                                           // may_allow(): can the vote rule fire for this pair at all?
-				const unsigned tmin = S.smin[m_ts], tmax = S.smax[m_ts];
-				const long long treads = S.nreads[m_ts];
-				odd |= (qmin < 3u && tmax > 3u * qmin && qreads > 3ll * (long long)qmin) ||
-				       (tmin < 3u && qmax > 3u * tmin && treads > 3ll * (long long)tmin);
+		if (ballot(use && m_len < 8))                        // windows shorter than 8 bases
+			return COMBINE ? best_match_combine_seq(S, A, qs, list, n, min_overlap, max_mm) : best_match_read_seq(S, A, list, n, min_overlap);
+		if (COMBINE) {
+			bool votes = false;                              // may_allow(): can the vote rule fire for this pair at all?
+			if (use) {
+				if (m_ts == qs) use = false;                 // :227
+				else {
+					const unsigned tmin = S.smin[m_ts], tmax = S.smax[m_ts];
+					const long long treads = S.nreads[m_ts];
+					votes = (qmin < 3u && tmax > 3u * qmin && qreads > 3ll * (long long)qmin) ||
+					        (tmin < 3u && qmax > 3u * tmin && treads > 3ll * (long long)tmin);
+					if (votes) use = false;
+				}
+			}
+			// those pairs get the generic scan, one after the other; its best joins the ranking at the end
+			unsigned long long gm = ballot(votes);
+			while (gm) {
+				const int i = ctz64(gm);
+				gm &= gm - 1;
+				IHP_T0(A);
+				slide_scan(S, A, qs, __builtin_amdgcn_readlane(m_ts, i), c0 + i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, G);
+				IHP_T1(A, 4);
 			}
 		}
-		if (ballot(odd))
-			return COMBINE ? best_match_combine_seq(S, A, qs, list, n, min_overlap, max_mm) : best_match_read_seq(S, A, list, n, min_overlap);
 		// ---- offsets on the contigs
 		const int n1 = m_len - min_overlap + 1;              // offsets 0 .. len - min_overlap (:79)
 		const unsigned nq = use && n1 > 0 ? (unsigned)(n1 + 3) >> 2 : 0u;
@@ -1025,6 +1038,8 @@ __device__ inline Best best_match_all(const ST &S, const Arena &A, int qs, const
 			}
 		}
 	}
+	// more matches, then fewer mismatches, then the earlier contig (contig.nim:32-36, :107, :239)
+	if (COMBINE && G.found && (!B.b.found || G.ma > B.b.ma || (G.ma == B.b.ma && (G.mm < B.b.mm || (G.mm == B.b.mm && G.pos < B.b.pos))))) return G;
 	return B.b;
 }
 
