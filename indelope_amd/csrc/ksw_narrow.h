@@ -191,17 +191,17 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 	const bool hasB = nTop >= 64;
 	uint8_t *pr = E.p + (size_t)r * E.ncol;
 	const bool has_spec = !ENDS || (r > 0 && en0 > 0);   // H[en0] comes from H[en0-1] + u (:318)
-	const unsigned long long mLo = ~0ull << loA;
-	const unsigned long long mRefA = STEADY ? mLo : mLo & (~0ull >> (63 - (sc < 63 ? sc : 63)));
-	const unsigned long long mInA = mLo & (~0ull >> (63 - (hiT < 63 ? hiT : 63)));      // hiT >= loA
-	unsigned long long mSpecA = mInA & ~(mInA >> 1);    // the top lane of the band ...
-	if (ENDS && !has_spec) mSpecA = 0;
+	// lane predicates of slot A: compares against the scalar limits (three VALU compares; as scalar shift/and
+	// chains they would cost twice as many instructions on the busier scalar unit)
+	const bool geLo = lane >= loA;
+	const bool refA = STEADY ? geLo : (geLo && lane <= sc);             // refreshed score lanes (:214-228); sc > loA
+	const bool inTA = geLo && lane <= hiT;                              // inside the true band (hiT >= loA)
+	const bool spA = (ENDS ? has_spec : true) && lane == hiT;           // H[en0] comes from H[en0-1] + u (:318); in slot B if hiT >= 64
 	int hB = INTMIN, hA;
 	unsigned long long mInB = 0;
 	// ---- slot B (block 4) ------------------------------------------------------------
 	if (!GROWING) F.rlB = lane_in(sc >= 64 ? ~0ull >> (127 - sc) : 0ull) ? r : F.rlB;  // :214-228 runs past en; value formed on use
 	if (hasB) {                                                        // nTop == 79: the whole block
-		if (hiT >= 64) mSpecA = 0;                                     // ... unless the band ends in block 4
 		const int exB = __builtin_amdgcn_readlane(F.XA, 63), evB = __builtin_amdgcn_readlane(F.VA, 63);
 		const int HeB = __builtin_amdgcn_readlane(F.HA, 63);
 		int xpB = dppz_shr1(F.XB), vpB = dppz_shr1(F.VB), HpB = dppz_shr1(F.HB);
@@ -231,7 +231,7 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 	{
 		const int znew = narrow_z(F.T0A, F.T1A, *F.qptr);            // qs[qlen-1-r+st+lane]
 		F.qptr -= 1;
-		F.ZA = lane_in(mRefA) ? znew : F.ZA;                            // :214-228
+		F.ZA = refA ? znew : F.ZA;                                      // :214-228
 		if (!STEADY && r <= en && r - st < 64) {                       // :212 (only while the band still touches t == r)
 			const bool tr = lane_in(1ull << (r - st));
 			F.YA = tr ? 0 : F.YA; F.UA = tr ? (r ? E.q24 : 0) : F.UA;
@@ -239,7 +239,7 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 		int xn, vn, un, yn; unsigned d;
 		narrow_cell<RIGHT>(F.ZA, xpA, vpA, F.UA, F.YA, E.M24, E.q24, xn, vn, un, yn, d);
 		int h;
-		const bool sp = lane_in(mSpecA);
+		const bool sp = spA;
 		if (KIND != ND_FIRST) h = (sp ? HpA : F.HA) + (int)((unsigned)(sp ? un : vn) >> 24) - E.qe;   // :318, :323-329
 		else h = (int)((unsigned)vn >> 24) - E.qe - E.qe;              // :349
 		if (STEADY) {                                                  // a steady band always covers blocks 0..3
@@ -250,9 +250,8 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 			F.XA = act ? xn : F.XA; F.VA = act ? vn : F.VA; F.UA = act ? un : F.UA; F.YA = act ? yn : F.YA;
 			if (act) pr[lane] = (uint8_t)d;
 		}
-		const bool inT = lane_in(mInA);
-		hA = inT ? h : INTMIN;
-		F.HA = inT ? h : F.HA;
+		hA = inTA ? h : INTMIN;
+		F.HA = inTA ? h : F.HA;
 	}
 	if (!STEADY) F.last_sc = sc;
 	// ---- exact max (:320-348) ----------------------------------------------------------
