@@ -188,7 +188,8 @@ __device__ __forceinline__ bool narrow_diag(NarrowState &F, const NarrowEnv &E, 
 	const int hiT = en0 - st;                            // last true-band lane (may be >= 64: slot B)
 	const int nTop = en - st;                            // last computed lane: 15, 31, 47, 63 or 79
 	const int sc = STEADY ? loA + 63 : st0 + ((en0 - st0) / 16 + 1) * 16 - 1 - st;   // last refreshed score lane (:215), > loA
-	const bool hasB = nTop >= 64;
+	const int hasB = (nTop >> 6) & 1;                    // block 4 is computed (an integer: a bool carried across the
+	                                                     // DPP asm below is materialised per lane and tested again)
 	uint8_t *pr = E.p + (size_t)r * E.ncol;
 	const bool has_spec = !ENDS || (r > 0 && en0 > 0);   // H[en0] comes from H[en0-1] + u (:318)
 	// lane predicates of slot A: compares against the scalar limits (three VALU compares; as scalar shift/and
