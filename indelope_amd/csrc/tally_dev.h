@@ -80,6 +80,14 @@ __device__ inline void tally_reads(const uint8_t *bases, const long long *read_o
 	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
 }
 
+// reverse complement of a K-mer's 2-bit code
+__device__ __forceinline__ unsigned long long revcomp_code(unsigned long long code, int K)
+{
+	unsigned long long rc = 0;
+	for (int i = 0; i < K; ++i) { rc = (rc << 2) | (3ull - (code & 3ull)); code >>= 2; }
+	return rc;
+}
+
 // The same tally with the reads staged through LDS: 64 reads at a time are copied with coalesced dword
 // loads (they are contiguous in `bases`), then each lane walks its own read out of LDS.  A lane-per-read
 // walk straight from HBM touches 64 different cache lines per load instruction.
@@ -90,7 +98,8 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 {
 	const int lane = lane_id();
 	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
-	const int hs = 2 * (K - 1);
+	// forward and reverse-complement codes of the two k-mers (refe/alte are the smaller of each pair)
+	const unsigned long long ref_f = refe, ref_r = revcomp_code(refe, K), alt_f = alte, alt_r = revcomp_code(alte, K);
 	int nref = 0, nalt = 0, nboth = 0;
 	for (long long b = r0; b < r1; b += 64) {
 		const long long e = b + 64 < r1 ? b + 64 : r1;
@@ -106,37 +115,36 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 		for (int i = 4 * lane; i < nbytes; i += 256) lds32[i >> 2] = *(const tally_u32u *)(bases + base0 + i);
 		WSYNC();
 		const long long ri = b + lane;
-		bool rf = false, af = false;
-		if (ri < e && !(mapq && mapq[ri] < min_mapq)) {          // :294
-			const int off = (int)(read_off[ri] - base0);
-			const int n = (int)(read_off[ri + 1] - read_off[ri]);
-			unsigned long long f = 0, rc = 0;
-			int valid = 0;
-			for (int i0 = 0; i0 < n; i0 += 4) {
-				const int bo = off + i0, w = bo >> 2;
-				const unsigned wv = __builtin_amdgcn_alignbit(lds32[w + 1], lds32[w], (unsigned)(bo & 3) * 8u);
-				const int m = n - i0 < 4 ? n - i0 : 4;
+		// Branch-free walk: a window's canonical code equals the k-mer's iff its forward code equals the k-mer's
+		// forward or reverse-complement code, so only the forward code is rolled and compared with four constants;
+		// a base that is not upper-case ACGT zeroes the run length (:300 never sees such a window) and the K-1
+		// windows it taints are masked by the run length alone.
+		const bool use = ri < e && !(mapq && mapq[ri] < min_mapq);   // :294
+		int off = 0, n = 0;
+		if (use) { off = (int)(read_off[ri] - base0); n = (int)(read_off[ri + 1] - read_off[ri]); }
+		const int nmax = wave_max_i32s(n);
+		unsigned long long f = 0, rfm = 0, afm = 0;
+		int run = 0;
+		for (int i0 = 0; i0 < nmax; i0 += 4) {
+			const int bo = off + i0, w = bo >> 2;
+			const unsigned wv = __builtin_amdgcn_alignbit(lds32[w + 1], lds32[w], (unsigned)(bo & 3) * 8u);
 #pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					if (j < m) {
-						const int c = base2((uint8_t)(wv >> (8 * j)));
-						if (c < 0) { valid = 0; f = rc = 0; }
-						else {
-							f = ((f << 2) | (unsigned long long)c) & mask;
-							rc = (rc >> 2) | ((unsigned long long)(3 - c) << hs);
-							if (++valid >= K) {
-								const unsigned long long ee = f < rc ? f : rc;
-								rf |= ee == refe;                        // :301-309
-								af |= ee == alte;
-							}
-						}
-					}
-				}
+			for (int j = 0; j < 4; ++j) {
+				const unsigned ch = (wv >> (8 * j)) & 0xffu;
+				const unsigned x = (ch >> 1) & 3u, c = x ^ (x >> 1);          // A C G T -> 0 1 2 3 (and something for the rest)
+				const bool acgt = __builtin_amdgcn_perm(0u, 0x54474341u, c | 0x0c0c0c00u) == ch && i0 + j < n;   // selector 0x0c: zero byte
+				run = acgt ? run + 1 : 0;
+				f = ((f << 2) | (unsigned long long)c) & mask;
+				const unsigned long long full = ballot(run >= K);
+				rfm |= full & (ballot(f == ref_f) | ballot(f == ref_r));      // :301-309
+				afm |= full & (ballot(f == alt_f) | ballot(f == alt_r));
 			}
 		}
-		nref += popc64(ballot(rf));
-		nalt += popc64(ballot(af));
-		nboth += popc64(ballot(rf && af));                       // :310-311
+		const unsigned long long usem = ballot(use);
+		rfm &= usem; afm &= usem;
+		nref += popc64(rfm);
+		nalt += popc64(afm);
+		nboth += popc64(rfm & afm);                               // :310-311
 	}
 	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
 }
