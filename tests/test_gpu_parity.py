@@ -60,6 +60,21 @@ def test_regions_match_oracle(hip, oracle, cfg):
     assert (got.status == 0).all()
 
 
+def test_regions_with_n_and_lower_case_bases(hip, oracle):
+    """Bytes other than upper-case ACGT in the reads: they assemble as plain bytes (contig.nim compares chars), align
+    as the wildcard (ksw2.nim:127-132) and never count in a k-mer (the tally restarts its window)."""
+    b, _ = synth.generate(150, n_reads=(24, 64), err_rate=1e-3, config_id=25)
+    rng = np.random.default_rng(11)
+    bases = b.bases.copy()
+    hit = rng.random(len(bases)) < 0.004
+    bases[hit] = rng.choice(np.frombuffer(b"NNacgtn", np.uint8), int(hit.sum()))
+    b.bases = bases
+    got = hip.run_regions(b, hip.params())
+    exp = oracle.run_regions(b, oracle.params())
+    assert_same(got, exp)
+    assert (got.events["status"] != 0).any() or got.n_events > 0
+
+
 def test_cli_defaults_and_filters(hip, oracle):
     """CLI defaults (indelope.nim:568-570) and mapq / skip / quality-trim inputs."""
     b, _ = synth.generate(120, n_reads=(12, 64), err_rate=2e-3, config_id=24)
