@@ -178,6 +178,11 @@ typedef struct {
 	int8_t  match, mismatch, gap_open, gap_ext; /* 1,-2,4,1  ksw2.nim:142        */
 	int32_t bw, zdrop, ksw_flag;  /* 50,400,0  indelope.nim:221                  */
 	double  error;                /* 1e-3   indelope.nim:379                     */
+	/* alignment-fallback genotyper (indelope.nim:312-372): when an event's k-mer tally
+	 * has both_found > 0 every read is aligned to the reference window and to the contig */
+	int32_t fallback;             /* 1      run it (0: only flag fallback_needed)  */
+	int8_t  fb_match, fb_mismatch, fb_gap_open, fb_gap_ext; /* 1,-2,5,1 indelope.nim:318-319 */
+	int32_t fb_bw, fb_zdrop, fb_flag;  /* -1,-1,0  align_to defaults ksw2.nim:159 */
 } ihp_params;
 
 void ihp_params_default(ihp_params *p);
@@ -223,12 +228,17 @@ typedef struct {
 	uint32_t len;
 	uint8_t  type;                /* 0 Insertion, 1 Deletion     ksw2.nim:65-67  */
 	uint8_t  status;              /* IHP_EV_*                                    */
-	uint8_t  fallback_needed;     /* both_found > 0 (indelope.nim:313)           */
-	uint8_t  _pad;
+	uint8_t  fallback_needed;     /* k-mer both_found > 0 (indelope.nim:313)     */
+	uint8_t  aligned;             /* `aligned`: the fallback ran (indelope.nim:372) */
 	int32_t  cf_offset;           /* `offset`, indelope.nim:243                  */
-	int32_t  ref_support, alt_support, both_found;   /* indelope.nim:285-311     */
+	/* the reference's variables as they stand at indelope.nim:375: the k-mer tally
+	 * (:285-311), or the alignment votes (:353-356) with both_found reset (:316)
+	 * when `aligned`                                                              */
+	int32_t  ref_support, alt_support, both_found;
 	char     ref_kmer[32], alt_kmer[32];             /* NUL padded               */
 	int32_t  gt;                  /* genotype(ref,alt,error) indelope.nim:379    */
+	int32_t  kmer_ref_support, kmer_alt_support, kmer_both_found;  /* the k-mer tally
+	                                 itself (:285-311), kept when the fallback ran */
 	double   gl[3];
 	double   qual;
 } ihp_event;
@@ -278,6 +288,9 @@ void ihp_batch_free(ihp_batch *b);
 /* Per-stage device time of the most recent ihp_batch_run+sync, from HIP events
  * on the batch stream: ms[0] assemble, ms[1] ksw2, ms[2] tally, ms[3] total.  */
 int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);
+/* Device time of the alignment-fallback kernel (indelope.nim:312-372) in the same run; it is
+ * included in ms[3] and runs between the tally and the summary.                               */
+int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
 /* Diagnostics: with IHP_PROFILE=1 in the environment the kernels sum shader-clock cycles
  * per phase over all waves: [0] assemble, [1] combine, [2] assemble+output, [3] regions;
  * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments.  Always filled:

@@ -79,7 +79,10 @@ class Params(C.Structure):
                 ("K", C.c_int32), ("max_events", C.c_int32), ("ref_pad", C.c_int32),
                 ("match", C.c_int8), ("mismatch", C.c_int8), ("gap_open", C.c_int8), ("gap_ext", C.c_int8),
                 ("bw", C.c_int32), ("zdrop", C.c_int32), ("ksw_flag", C.c_int32),
-                ("error", C.c_double)]
+                ("error", C.c_double),
+                ("fallback", C.c_int32),
+                ("fb_match", C.c_int8), ("fb_mismatch", C.c_int8), ("fb_gap_open", C.c_int8), ("fb_gap_ext", C.c_int8),
+                ("fb_bw", C.c_int32), ("fb_zdrop", C.c_int32), ("fb_flag", C.c_int32)]
 
 
 class BatchIn(C.Structure):
@@ -92,23 +95,25 @@ class BatchIn(C.Structure):
 class Event(C.Structure):
     _fields_ = [("tstart", C.c_int64), ("tstop", C.c_int64), ("qstart", C.c_int64), ("qstop", C.c_int64),
                 ("len", C.c_uint32), ("type", C.c_uint8), ("status", C.c_uint8),
-                ("fallback_needed", C.c_uint8), ("_pad", C.c_uint8),
+                ("fallback_needed", C.c_uint8), ("aligned", C.c_uint8),
                 ("cf_offset", C.c_int32), ("ref_support", C.c_int32), ("alt_support", C.c_int32),
                 ("both_found", C.c_int32), ("ref_kmer", C.c_char * 32), ("alt_kmer", C.c_char * 32),
-                ("gt", C.c_int32), ("gl", C.c_double * 3), ("qual", C.c_double)]
+                ("gt", C.c_int32), ("kmer_ref_support", C.c_int32), ("kmer_alt_support", C.c_int32),
+                ("kmer_both_found", C.c_int32), ("gl", C.c_double * 3), ("qual", C.c_double)]
 
 
 EVENT_DTYPE = np.dtype({
-    "names": ["tstart", "tstop", "qstart", "qstop", "len", "type", "status", "fallback_needed",
+    "names": ["tstart", "tstop", "qstart", "qstop", "len", "type", "status", "fallback_needed", "aligned",
               "cf_offset", "ref_support", "alt_support", "both_found", "ref_kmer", "alt_kmer",
-              "gt", "gl", "qual"],
-    "formats": ["<i8", "<i8", "<i8", "<i8", "<u4", "u1", "u1", "u1",
-                "<i4", "<i4", "<i4", "<i4", "S32", "S32", "<i4", ("<f8", 3), "<f8"],
+              "gt", "kmer_ref_support", "kmer_alt_support", "kmer_both_found", "gl", "qual"],
+    "formats": ["<i8", "<i8", "<i8", "<i8", "<u4", "u1", "u1", "u1", "u1",
+                "<i4", "<i4", "<i4", "<i4", "S32", "S32", "<i4", "<i4", "<i4", "<i4", ("<f8", 3), "<f8"],
     "offsets": [Event.tstart.offset, Event.tstop.offset, Event.qstart.offset, Event.qstop.offset,
                 Event.len.offset, Event.type.offset, Event.status.offset, Event.fallback_needed.offset,
-                Event.cf_offset.offset, Event.ref_support.offset, Event.alt_support.offset,
+                Event.aligned.offset, Event.cf_offset.offset, Event.ref_support.offset, Event.alt_support.offset,
                 Event.both_found.offset, Event.ref_kmer.offset, Event.alt_kmer.offset,
-                Event.gt.offset, Event.gl.offset, Event.qual.offset],
+                Event.gt.offset, Event.kmer_ref_support.offset, Event.kmer_alt_support.offset,
+                Event.kmer_both_found.offset, Event.gl.offset, Event.qual.offset],
     "itemsize": C.sizeof(Event)})
 
 
@@ -163,6 +168,7 @@ _PRODUCT_ONLY = {
     "batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(BatchOut)]),
     "batch_free": (None, [C.c_void_p]),
     "batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "batch_fallback_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
     "debug_last_ksw_mode": (C.c_int, []),

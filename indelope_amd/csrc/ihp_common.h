@@ -122,11 +122,16 @@ struct DevEvent {
 	int tstart_rel, tstop_rel;   // relative to ctg.start's region origin (int64 added on host)
 	int qstart, qstop;
 	unsigned len;
-	unsigned char type, status, fallback, pad;
+	unsigned char type, status, fallback, aligned;
 	int cf_offset;
-	int ref_support, alt_support, both_found;
+	int ref_support, alt_support, both_found;   // as at indelope.nim:375 (alignment votes when `aligned`)
 	char ref_kmer[32], alt_kmer[32];
+	int kmer_ref, kmer_alt, kmer_both;          // the k-mer tally itself (indelope.nim:285-311)
 };
+
+// One event whose k-mer tally found both k-mers in some read (indelope.nim:313): the alignment fallback
+// kernel aligns every read of the region for it.
+struct FbItem { int job; int ev; };             // AlnJob index, event pool index
 
 struct KswParams {
 	int m; int sc_mch, sc_mis; int min_sc; int q, e, w, zdrop, flag; int encode_ascii;

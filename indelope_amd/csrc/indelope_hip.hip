@@ -152,6 +152,7 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 	}
@@ -205,6 +206,9 @@ extern "C" void ihp_params_default(ihp_params *p)
 	p->match = 1; p->mismatch = -2; p->gap_open = 4; p->gap_ext = 1;
 	p->bw = 50; p->zdrop = 400; p->ksw_flag = 0;
 	p->error = 1e-3;
+	p->fallback = 1;
+	p->fb_match = 1; p->fb_mismatch = -2; p->fb_gap_open = 5; p->fb_gap_ext = 1;   // indelope.nim:318-319
+	p->fb_bw = -1; p->fb_zdrop = -1; p->fb_flag = 0;                                // ksw2.nim:159
 }
 
 // ------------------------------------------------------------- genotyper.nim
@@ -537,23 +541,28 @@ struct ihp_batch {
 	size_t p_cap = 0;
 	long long cig_pool_cap = 0, cig_bump_cap = 0, ev_pool_cap = 0, njobs_cap = 0;
 	DBuf queues;
+	// alignment fallback (indelope.nim:312-372)
+	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
+	int grid_fb = 0, lds_fb = 0, fb_cig_cap = 0, max_region_reads = 0;
+	size_t fb_p_cap = 0;
 	// outputs
 	DBuf status, n_pre, n_final, ctg_start, ctg_nreads, ctg_seq_off, ctg_len, aln_flags, aln_ref_len, aln_ref_start;
 	DBuf out_seq, out_sup, jobs, ez, cig_off, cig_pool, ev_off, n_ev, ev_pool, summary;
-	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool ran = false;
 	~ihp_batch() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
 };
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_WORDS = 20 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_WORDS = 20 };
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
 	if (!p || !in || !bout || p->struct_size != (int32_t)sizeof(ihp_params)) return IHP_E_ARG;
 	if (p->K < 1 || p->K > 31 || in->n_regions < 0 || in->n_reads < 0) return IHP_E_ARG;
 	if (!ksw_flags_supported(p->ksw_flag)) return IHP_E_UNSUPPORTED;
+	if (p->fallback && !ksw_flags_supported(p->fb_flag)) return IHP_E_UNSUPPORTED;
 	if (in->n_regions && (!in->region_read_off || !in->ref_off || !in->ref_origin)) return IHP_E_ARG;
 	if (in->n_reads && (!in->read_off || !in->bases || !in->read_start || !in->read_stop || !in->mapq)) return IHP_E_ARG;
 	int rc = ensure_init();
@@ -571,6 +580,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		const int64_t nb = ro[rro[r + 1]] - ro[rro[r]];
 		if (nb > (1 << 30) || fo[r + 1] - fo[r] > (1 << 30)) { delete b; return IHP_E_CAPACITY; }
 		b->max_region_bases = std::max(b->max_region_bases, (int)nb);
+		b->max_region_reads = (int)std::max<int64_t>(b->max_region_reads, std::min<int64_t>(rro[r + 1] - rro[r], 1 << 30));
 		b->max_ref_len = std::max(b->max_ref_len, (int)(fo[r + 1] - fo[r]));
 	}
 	for (long long i = 0; i < NR; ++i) {
@@ -658,6 +668,18 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	b->cig_bump_cap = 8 * njobs_cap + 4096;                      // CIGARs longer than CIG_SLOT words
 	b->cig_pool_cap = b->cig_bump_cap + (long long)CIG_SLOT * njobs_cap;
 	b->ev_pool_cap = (long long)std::max(1, p->max_events) * njobs_cap + 16;
+	if (p->fallback) {
+		// a read against the rest of the reference window / of the contig from the read's start.  Contigs are rarely
+		// longer than the window; the scratch is sized for that and the kernel flags anything larger (IHP_E_CAPACITY).
+		const int ql = std::max(1, b->max_read_len), tl = std::max(1, std::min(qmax, tmax + 128));
+		const int tt = std::max(tl, tmax);
+		const int w = p->fb_bw < 0 ? std::max(ql, tt) : p->fb_bw;
+		const int nc = (std::min(std::min(ql, tt), w + 1) + 15) / 16 + 1;
+		b->fb_p_cap = ((size_t)(ql + tt) * nc + 1) * 16 + 64;
+		b->fb_cig_cap = ql + tt + 16;
+		b->lds_fb = (int)std::min<size_t>(ksw_lds_bytes(ql, tt) + 64, (size_t)g.max_lds - 2048);
+		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(8, g.max_lds / (b->lds_fb + 256))));
+	}
 #define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
 	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);
 	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_retry);
@@ -670,7 +692,12 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(misc, sizeof(int) * M_WORDS);
-	AL(queues, sizeof(int) * WQ_WORDS * 6);
+	AL(queues, sizeof(int) * WQ_WORDS * 7);
+	if (p->fallback) {
+		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
+		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
+		AL(fb_cig_tmp, sizeof(uint32_t) * (size_t)b->fb_cig_cap * b->grid_fb);
+	}
 	AL(prof, sizeof(long long) * 32);
 	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
 	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
@@ -693,7 +720,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	hipStream_t s = g.stream;
 	const ihp_params &p = b->P;
 	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
-	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * 6, s));
+	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * 7, s));
 	int *wq = b->queues.as<int>();
 	const bool profiling = getenv("IHP_PROFILE") != nullptr;
 	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
@@ -770,6 +797,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.ref_origin = b->ref_origin.as<long long>(); a.ctg_start = b->ctg_start.as<long long>();
 		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>(); a.cig_pool = b->cig_pool.as<uint32_t>();
 		a.P.K = p.K; a.P.min_event_len = p.min_event_len; a.P.max_events = p.max_events; a.P.min_mapq_tally = p.min_mapq_tally;
+		a.P.fallback = p.fallback; a.fb_items = p.fallback ? b->fb_items.as<FbItem>() : nullptr; a.fb_count = misc + M_NFB;
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
 		a.overflow = misc + M_OVF; a.work_counter = wq + 5 * WQ_WORDS;
@@ -779,6 +807,28 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[3], s));
+	if (b->R > 0 && b->n_reads > 0 && p.fallback) {
+		int8_t mat[25];
+		ihp_matrix(p.fb_match, p.fb_mismatch, mat);                  // new_ez(mismatch=-2, gap_open=5, gap_ext=1), indelope.nim:318-319
+		FbArgs a;
+		a.items = b->fb_items.as<FbItem>(); a.n_items = misc + M_NFB; a.max_region_reads = std::max(1, b->max_region_reads);
+		a.jobs = b->jobs.as<AlnJob>();
+		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>(); a.bases = b->bases.as<uint8_t>();
+		a.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr; a.mapq = b->mapq.as<uint8_t>();
+		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();
+		a.read_start = b->read_start.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
+		a.ctg_start = b->ctg_start.as<long long>();
+		a.ev_pool = b->ev_pool.as<DevEvent>();
+		a.P = make_ksw_params(5, mat, (int8_t)std::abs((int)p.fb_gap_open), (int8_t)std::abs((int)p.fb_gap_ext), p.fb_bw, p.fb_zdrop, p.fb_flag, 1);
+		a.min_mapq = p.min_mapq_tally; a.trim_min_qual = p.trim_min_qual;
+		a.lds_budget = b->lds_fb - 64;
+		a.p_scratch = b->fb_p_scratch.as<uint8_t>(); a.p_cap = b->fb_p_cap;
+		a.cig_tmp = b->fb_cig_tmp.as<uint32_t>(); a.cig_cap = b->fb_cig_cap;
+		a.overflow = misc + M_OVF; a.work_counter = wq + 6 * WQ_WORDS;
+		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
+		HIPC(hipGetLastError());
+	}
+	HIPC(hipEventRecord(b->ev[5], s));
 	if (b->R > 0) {
 		SummaryArgs a;
 		a.n_regions = b->R; a.region_read_off = b->region_read_off.as<long long>();
@@ -823,6 +873,14 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY3, sizeof(int), hipMemcpyDeviceToHost));
 	out[11] = nretry;                                 // ... and to the HBM-arena pass
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
+	return 0;
+}
+
+extern "C" int ihp_batch_fallback_ms(ihp_batch *b, float *ms)
+{
+	if (!b || !b->ran || !ms) return IHP_E_ARG;
+	HIPC(hipEventSynchronize(b->ev[4]));
+	HIPC(hipEventElapsedTime(ms, b->ev[3], b->ev[5]));
 	return 0;
 }
 
@@ -922,7 +980,8 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 				const DevEvent &d = evp[(size_t)ev_off[sl] + e];
 				ihp_event &x = out->events[ev];
 				x.tstart = origin + d.tstart_rel; x.tstop = origin + d.tstop_rel; x.qstart = d.qstart; x.qstop = d.qstop;
-				x.len = d.len; x.type = d.type; x.status = d.status; x.fallback_needed = d.fallback; x._pad = 0;
+				x.len = d.len; x.type = d.type; x.status = d.status; x.fallback_needed = d.fallback; x.aligned = d.aligned;
+				x.kmer_ref_support = d.kmer_ref; x.kmer_alt_support = d.kmer_alt; x.kmer_both_found = d.kmer_both;
 				x.cf_offset = d.cf_offset; x.ref_support = d.ref_support; x.alt_support = d.alt_support; x.both_found = d.both_found;
 				memcpy(x.ref_kmer, d.ref_kmer, 32); memcpy(x.alt_kmer, d.alt_kmer, 32);
 				x.gt = IHP_GT_UNKNOWN; x.gl[0] = x.gl[1] = x.gl[2] = 0; x.qual = 0;

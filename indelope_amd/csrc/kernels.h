@@ -485,6 +485,7 @@ struct TallyArgs {
 	int *work_counter;
 	long long *prof;                           // optional cycle counters (diagnostics)
 	int lds_bytes;                             // dynamic LDS for staging 64 reads
+	FbItem *fb_items; int *fb_count;           // events handed to the alignment fallback (one slot per event)
 };
 
 __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 				fill_events(a.cig_pool + coff, ntrunc, a.out_seq + jb.q_off, jb.qlen,
 				            (int)(a.ctg_start[jb.out] - a.ref_origin[r]), a.ref_bases + jb.t_off, jb.tlen,
 				            a.bases, a.read_off, a.mapq, a.region_read_off[r], a.region_read_off[r + 1],
-				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes);
+				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count);
 			} else {
 				if (lane == 0) atomicExch(&a.overflow[2], 1);
 				eoff = -1; nev = 0;
@@ -529,6 +530,112 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 		if (a.prof && lane == 0) {
 			atomicAdd((unsigned long long *)&a.prof[nev ? 16 : 17], (unsigned long long)((long long)clock64() - tj0));
 			atomicAdd((unsigned long long *)&a.prof[nev ? 18 : 19], 1ull);
+		}
+	}
+}
+
+// --------------------------------------------------------- alignment fallback
+// indelope.nim:312-372.  For an event whose k-mer tally found both k-mers in one read, every read of the region
+// (mapq >= 10, quality-trimmed) is aligned -- gap open 5, unbanded, no z-drop (ksw2.nim:159 defaults) -- to the
+// reference window and to the contig, both cut at the read's start; count_flanked_cigar (:185-199) of the two
+// truncated CIGARs decides the vote.  One wave per (event, read): work item j = event * max_region_reads + read.
+struct FbArgs {
+	const FbItem *items; const int *n_items; int max_region_reads;
+	const AlnJob *jobs;
+	const uint8_t *out_seq, *ref_bases, *bases, *quals, *mapq;
+	const long long *read_off, *region_read_off, *read_start, *ref_origin, *ctg_start;
+	DevEvent *ev_pool;
+	KswParams P; int min_mapq, trim_min_qual;
+	int lds_budget;
+	uint8_t *p_scratch; size_t p_cap;          // per workgroup
+	uint32_t *cig_tmp; int cig_cap;            // per workgroup
+	int *overflow;                             // [1] LDS / traceback scratch budget
+	int *work_counter;
+};
+
+// count_flanked_cigar (indelope.nim:185-199) over Ez.cigar (ksw2.nim:22-33); wave-uniform
+__device__ __forceinline__ int count_flanked_cigar_dev(const uint32_t *cigar, int n_cigar, int max_q)
+{
+	const uint32_t max_off = (uint32_t)max_q;
+	uint32_t off = 0;
+	int matched = 0, n = 0, last_op = 0;
+	for (int i = 0; i < n_cigar; ++i) {
+		if (off >= max_off) break;
+		const uint32_t c = (uint32_t)uni((int)cigar[i]), op = c & 0xf, len = c >> 4;
+		if (op != 2) off += len;
+		if (!matched) { if (op == 0) { n += 1; matched = 1; } }
+		else n += 1;
+		last_op = (int)op;
+	}
+	if (last_op != 0) n -= 1;
+	return n;
+}
+
+__global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	__shared__ int s_item;
+	const int lane = lane_id();
+	const int n_items = *a.n_items;
+	const long long total = (long long)n_items * a.max_region_reads;
+	const int n = total > 0x7fffffff ? 0x7fffffff : (int)total;
+	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
+	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
+	unsigned wq_dead = 0;
+	for (;;) {
+		if (lane == 0) s_item = wq_next(a.work_counter, n, (int)blockIdx.x, wq_dead);
+		WSYNC();
+		const int j = uni(s_item);
+		WSYNC();
+		if (j < 0) break;
+		const int f = j / a.max_region_reads, i = j - f * a.max_region_reads;
+		const FbItem it = a.items[f];
+		const AlnJob jb = a.jobs[it.job];
+		const int r = uni(jb.region);
+		const long long r0 = uni(a.region_read_off[r]), r1 = uni(a.region_read_off[r + 1]);
+		const long long ri = r0 + i;
+		if (ri >= r1) continue;
+		if ((int)a.mapq[ri] < a.min_mapq) continue;                    // :325
+		const long long off = uni(a.read_off[ri]);
+		const int len = (int)(uni(a.read_off[ri + 1]) - off);
+		int lo = 0, hi = len, ta = 0;
+		if (a.quals) ta = read_trim_dev(a.quals + off, len, a.trim_min_qual, lo, hi);   // :328
+		const long long origin = uni(a.ref_origin[r]);
+		DevEvent *E = a.ev_pool + it.ev;
+		const int tstart = uni(E->tstart_rel), tstop = uni(E->tstop_rel);
+		const long long rs = uni(a.read_start[ri]) + ta - origin;      // relative to the region origin, like tloc
+		const int rl = hi - lo;
+		if (rs > tstop) continue;                                      // :329
+		const int L = uni((int)E->type) == 0 ? uni((int)E->len) : 0;   // :330-332
+		if (rs + rl + L < tstart) continue;                            // :333
+		const long long ctg_rel = uni(a.ctg_start[jb.out]) - origin;
+		const long long start = (rs > ctg_rel ? rs : ctg_rel) - ctg_rel;   // :336
+		const int ctg_len = uni(jb.qlen), reflen = uni(jb.tlen);
+		const int rsub = start < reflen ? (int)(reflen - start) : 0;   // :337
+		const int csub = start < ctg_len ? (int)(ctg_len - start) : 0; // :338
+		const int tmax = rsub > csub ? rsub : csub;
+		int w = a.P.w;
+		if (w < 0) w = tmax > rl ? tmax : rl;
+		int ncol_ = rl < tmax ? rl : tmax;
+		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
+		const size_t pneed = ((size_t)(rl + tmax - 1 > 0 ? rl + tmax - 1 : 0) * ncol_ + 1) * 16;
+		if (rl > 0 && tmax > 0 && (ksw_lds_bytes(rl, tmax) > (size_t)a.lds_budget || pneed > a.p_cap || rl + tmax + 8 > a.cig_cap)) {
+			if (lane == 0) atomicExch(&a.overflow[1], 1);
+			continue;
+		}
+		const uint8_t *qy = a.bases + off + lo;
+		KswOut o;
+		ksw_wave(qy, rl, a.ref_bases + uni(jb.t_off) + (rsub ? start : 0), rsub, a.P, lds, p, ct, a.cig_cap, o);   // :340
+		WSYNC();
+		const int rn = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;                       // :343
+		WSYNC();
+		ksw_wave(qy, rl, a.out_seq + uni(jb.q_off) + (csub ? start : 0), csub, a.P, lds, p, ct, a.cig_cap, o);     // :341
+		WSYNC();
+		const int an = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;                       // :344
+		WSYNC();
+		if (lane == 0) {
+			if (rn == 1 && an > 1) atomicAdd(&E->ref_support, 1);      // :353-354
+			else if (an == 1 && rn > 1) atomicAdd(&E->alt_support, 1); // :355-356
 		}
 	}
 }

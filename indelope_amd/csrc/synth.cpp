@@ -31,6 +31,10 @@ typedef struct {
 	double   err_rate;
 	int64_t  origin0;          // genomic origin of region 0's window
 	int64_t  origin_step;
+	double   dup_frac;         // fraction of events planted as tandem duplications (an insertion of >= 24 bp
+	                           // that repeats the reference bases to its right): the alt k-mer then also
+	                           // occurs in the reference haplotype, reads carry both k-mers and the
+	                           // alignment fallback of indelope.nim:312-372 has to decide
 } ihp_synth_cfg;
 
 struct Rng {
@@ -100,13 +104,18 @@ int ihp_synth_fill(const ihp_synth_cfg *c, int64_t *region_read_off, int64_t *re
 		// alt haplotype + map alt position -> W position
 		const int p0 = c->event_pos ? c->event_pos : L / 2;
 		int ev_pos[2] = {p0, p0 + 250}, ev_type[2] = {-1, -1}, ev_len[2] = {0, 0};
-		for (int e = 0; e < c->n_events && e < 2; ++e) { ev_type[e] = (int)g.below(2); ev_len[e] = 5 + (int)g.below(36); }
+		int ev_dup[2] = {0, 0};
+		for (int e = 0; e < c->n_events && e < 2; ++e) {
+			ev_type[e] = (int)g.below(2); ev_len[e] = 5 + (int)g.below(36);
+			if (c->dup_frac > 0 && g.unit() < c->dup_frac) { ev_dup[e] = 1; ev_type[e] = 0; ev_len[e] = 24 + (int)g.below(17); }
+		}
 		alt.clear(); amap.clear();
 		int w = 0;
 		for (int e = 0; e < 2; ++e) {
 			if (ev_type[e] < 0) continue;
 			for (; w < ev_pos[e]; ++w) { alt.push_back(W[w]); amap.push_back(w); }
 			if (ev_type[e] == 1) w += ev_len[e];                       // deletion: skip W bases
+			else if (ev_dup[e]) for (int k = 0; k < ev_len[e]; ++k) { alt.push_back(W[w + k]); amap.push_back(w); }
 			else for (int k = 0; k < ev_len[e]; ++k) { alt.push_back((uint8_t)ACGT[g.below(4)]); amap.push_back(w); }
 		}
 		for (; w < L; ++w) { alt.push_back(W[w]); amap.push_back(w); }

@@ -166,7 +166,7 @@ __device__ __forceinline__ bool same_bytes(const char *a, const char *b, int n)
 	return true;
 }
 
-struct TallyParams { int K, min_event_len, max_events, min_mapq_tally; };
+struct TallyParams { int K, min_event_len, max_events, min_mapq_tally, fallback; };
 
 // Ez.cigar truncation (ksw2.nim:22-33): number of events (I/D ops) among the ops the
 // iterator yields; *ntrunc = number of ops yielded.
@@ -226,7 +226,8 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
                                    const uint8_t *reference, int reflen,
                                    const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                    long long r0, long long r1, const TallyParams P, DevEvent *ev,
-                                   uint32_t *lds32, int lds_bytes)
+                                   uint32_t *lds32, int lds_bytes,
+                                   int job, int ev_index0, FbItem *fb_items, int *fb_count)
 {
 	const int lane = lane_id();
 	const int K = P.K;
@@ -286,9 +287,18 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
 		if (lane == 0) {
 			o->tstart_rel = e_ts; o->tstop_rel = e_te; o->qstart = e_qs; o->qstop = e_qe;
 			o->len = len; o->type = (unsigned char)e_type; o->status = (unsigned char)status;
-			o->fallback = status == IHP_EV_TALLIED && counts[2] > 0;     // :313
-			o->pad = 0; o->cf_offset = cf;
-			o->ref_support = counts[0]; o->alt_support = counts[1]; o->both_found = counts[2];
+			const bool fb = status == IHP_EV_TALLIED && counts[2] > 0;   // :313
+			const bool run_fb = fb && P.fallback && fb_items;
+			o->fallback = fb;
+			o->aligned = run_fb; o->cf_offset = cf;                      // :372
+			o->kmer_ref = counts[0]; o->kmer_alt = counts[1]; o->kmer_both = counts[2];
+			// the fallback kernel counts its votes into the zeroed fields (:316, :320-321)
+			o->ref_support = run_fb ? 0 : counts[0]; o->alt_support = run_fb ? 0 : counts[1];
+			o->both_found = run_fb ? 0 : counts[2];
+			if (run_fb) {
+				const int k = atomicAdd(fb_count, 1);
+				fb_items[k].job = job; fb_items[k].ev = ev_index0 + ii;
+			}
 		}
 		if (lane < 32) { o->ref_kmer[lane] = (char)(lane < K ? rk : 0); o->alt_kmer[lane] = (char)(lane < K ? ak : 0); }
 	}

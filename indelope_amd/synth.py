@@ -14,7 +14,8 @@ class SynthCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_regions", C.c_int32), ("first_region", C.c_int32),
                 ("read_len", C.c_int32), ("n_reads_min", C.c_int32), ("n_reads_max", C.c_int32),
                 ("n_events", C.c_int32), ("window_len", C.c_int32), ("event_pos", C.c_int32),
-                ("err_rate", C.c_double), ("origin0", C.c_int64), ("origin_step", C.c_int64)]
+                ("err_rate", C.c_double), ("origin0", C.c_int64), ("origin_step", C.c_int64),
+                ("dup_frac", C.c_double)]
 
 
 # BASELINE.json configs.  K is a path parameter, carried here for convenience.
@@ -45,11 +46,13 @@ def _lib():
 
 
 def generate(n_regions, read_len=150, n_reads=(64, 64), err_rate=0.0, n_events=1, config_id=0,
-             first_region=0, window_len=0, event_pos=0, seed=None, origin0=1_000_000, origin_step=10_000, **_):
-    """Returns (RegionBatch, truth[n_regions, 4])."""
+             first_region=0, window_len=0, event_pos=0, seed=None, origin0=1_000_000, origin_step=10_000,
+             dup_frac=0.0, **_):
+    """Returns (RegionBatch, truth[n_regions, 4]).  dup_frac > 0 plants that fraction of the events as tandem
+    duplications, which send the k-mer tally to the alignment fallback (indelope.nim:312-372)."""
     lib = _lib()
     cfg = SynthCfg(SEED0 ^ config_id if seed is None else seed, n_regions, first_region, read_len,
-                   n_reads[0], n_reads[1], n_events, window_len, event_pos, err_rate, origin0, origin_step)
+                   n_reads[0], n_reads[1], n_events, window_len, event_pos, err_rate, origin0, origin_step, dup_frac)
     nr, nb, nf = C.c_int64(), C.c_int64(), C.c_int64()
     lib.ihp_synth_sizes(C.byref(cfg), C.byref(nr), C.byref(nb), C.byref(nf))
     nr, nb, nf = nr.value, nb.value, nf.value

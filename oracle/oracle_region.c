@@ -31,6 +31,9 @@ void orc_params_default(ihp_params *p)
 	p->match = 1; p->mismatch = -2; p->gap_open = 4; p->gap_ext = 1;
 	p->bw = 50; p->zdrop = 400; p->ksw_flag = 0;
 	p->error = 1e-3;
+	p->fallback = 1;
+	p->fb_match = 1; p->fb_mismatch = -2; p->fb_gap_open = 5; p->fb_gap_ext = 1;   /* indelope.nim:318-319 */
+	p->fb_bw = -1; p->fb_zdrop = -1; p->fb_flag = 0;                                /* ksw2.nim:159 */
 }
 
 /* ---- k-mers (G1, G2) ------------------------------------------------------ */
@@ -138,6 +141,73 @@ static int distinct_bytes(const char *s, int n)
 	return d;
 }
 
+/* count_flanked_cigar, indelope.nim:185-199, over Ez.cigar (ksw2.nim:22-33: the CIGAR
+ * truncated at max_q) */
+static int count_flanked_cigar(const ksw_extz_t *ez)
+{
+	int matched = 0, n = 0, last_op = 0;
+	uint32_t max_off = (uint32_t)ez->max_q, off = 0;
+	for (int i = 0; i < ez->n_cigar; ++i) {
+		if (off >= max_off) break;
+		uint32_t op = ez->cigar[i] & 0xf, len = ez->cigar[i] >> 4;
+		if (op != 2) off += len;
+		if (!matched) { if (op == 0) { n += 1; matched = 1; } }
+		else n += 1;
+		last_op = (int)op;
+	}
+	if (last_op != 0) n -= 1;
+	return n;
+}
+
+/* The alignment fallback of indelope.nim:312-372 for one event: every read with mapq >= 10
+ * is quality-trimmed and aligned (gap open 5, unbanded, no z-drop) to the reference window
+ * and to the contig, both cut at the read's start; a read votes for the side whose
+ * alignment is a single M run while the other side needs more ops.
+ * Degenerate cases the Nim code would trap on (an emptied read: `query[0].addr` on an empty
+ * seq, ksw2.nim:155; a start beyond the contig: negative slice) are aligned as empty strings,
+ * i.e. ksw returns with n_cigar = 0 (ksw2_extz2_sse.c:146-147) and the read cannot vote.   */
+static void fallback_align(const ihp_params *p, const ihp_batch_in *in, int64_t r0, int64_t r1,
+                           const ihp_contig *ctg, const uint8_t *reference, int64_t reflen,
+                           ihp_event *ev, ksw_extz_t *ez_ref, ksw_extz_t *ez_alt)
+{
+	int8_t mat[25];
+	orc_matrix(p->fb_match, p->fb_mismatch, mat);
+	int8_t gapo = p->fb_gap_open < 0 ? -p->fb_gap_open : p->fb_gap_open;
+	int8_t gape = p->fb_gap_ext < 0 ? -p->fb_gap_ext : p->fb_gap_ext;
+	uint8_t *renc = (uint8_t *)malloc((size_t)reflen + 1), *cenc = (uint8_t *)malloc((size_t)ctg->len + 1);
+	orc_encode(reference, reflen, renc);
+	orc_encode(ctg->sequence, ctg->len, cenc);
+	uint8_t *qenc = 0;
+	int ref_support = 0, alt_support = 0;
+	for (int64_t ri = r0; ri < r1; ++ri) {
+		if (in->mapq[ri] < p->min_mapq_tally) continue;             /* :325 */
+		const int64_t n = in->read_off[ri + 1] - in->read_off[ri];
+		int64_t lo = 0, hi = n, a = 0;
+		if (in->quals) a = orc_read_trim(in->quals + in->read_off[ri], n, p->trim_min_qual, &lo, &hi);
+		const int64_t rs = in->read_start[ri] + a, rl = hi - lo;    /* :328 */
+		if (rs > ev->tstop) continue;                               /* :329 */
+		const int64_t L = ev->type == 0 ? (int64_t)ev->len : 0;     /* :330-332 */
+		if (rs + rl + L < ev->tstart) continue;                     /* :333 */
+		int64_t start = (rs > ctg->start ? rs : ctg->start) - ctg->start;   /* :336 */
+		int64_t rsub = reflen - start, csub = ctg->len - start;     /* :337-338 */
+		if (rsub < 0) rsub = 0;
+		if (csub < 0) csub = 0;
+		qenc = (uint8_t *)realloc(qenc, (size_t)rl + 1);
+		orc_encode(in->bases + in->read_off[ri] + lo, rl, qenc);
+		ez_ref->n_cigar = 0; ez_alt->n_cigar = 0;                   /* ksw2.nim:153 */
+		orc_ksw_dispatch((int)rl, qenc, (int)rsub, renc + (rsub ? start : 0), 5, mat, gapo, gape,
+		                 p->fb_bw, p->fb_zdrop, p->fb_flag, ez_ref);   /* :340 */
+		orc_ksw_dispatch((int)rl, qenc, (int)csub, cenc + (csub ? start : 0), 5, mat, gapo, gape,
+		                 p->fb_bw, p->fb_zdrop, p->fb_flag, ez_alt);   /* :341 */
+		const int rn = count_flanked_cigar(ez_ref), an = count_flanked_cigar(ez_alt);   /* :343-344 */
+		if (rn == 1 && an > 1) ref_support += 1;                    /* :353-356 */
+		else if (an == 1 && rn > 1) alt_support += 1;
+	}
+	free(renc); free(cenc); free(qenc);
+	ev->ref_support = ref_support; ev->alt_support = alt_support; ev->both_found = 0;   /* :316,:320-321 */
+	ev->aligned = 1;                                                /* :372 */
+}
+
 /* indelope.nim:157-183 */
 static orc_list assemble(const ihp_params *p, const ihp_batch_in *in, int64_t r0, int64_t r1, int32_t *n_pre)
 {
@@ -169,6 +239,7 @@ static void run_region(const ihp_params *p, const ihp_batch_in *in, int32_t r, r
 	int8_t mat[25];
 	orc_matrix(p->match, p->mismatch, mat);
 	ksw_extz_t ez; memset(&ez, 0, sizeof(ez));
+	ksw_extz_t ez_ref, ez_alt; memset(&ez_ref, 0, sizeof(ez_ref)); memset(&ez_alt, 0, sizeof(ez_alt));
 	uint8_t *qenc = 0, *tenc = 0;
 	for (int64_t ci = 0; ci < out->contigs.n; ++ci) {
 		ihp_contig *ctg = out->contigs.v[ci];
@@ -284,13 +355,17 @@ static void run_region(const ihp_params *p, const ihp_batch_in *in, int32_t r, r
 			}
 			ev->status = IHP_EV_TALLIED;
 			ev->fallback_needed = ev->both_found > 0;              /* :313 */
+			ev->kmer_ref_support = ev->ref_support; ev->kmer_alt_support = ev->alt_support;
+			ev->kmer_both_found = ev->both_found;
+			if (ev->fallback_needed && p->fallback)
+				fallback_align(p, in, r0, r1, ctg, reference, reflen, ev, &ez_ref, &ez_alt);   /* :313-372 */
 			ihp_genotype_t g;
 			orc_genotype(ev->ref_support, ev->alt_support, p->error, &g);   /* :379 */
 			ev->gt = g.gt; ev->gl[0] = g.gl[0]; ev->gl[1] = g.gl[1]; ev->gl[2] = g.gl[2];
 			ev->qual = orc_genotype_qual(&g);
 		}
 	}
-	free(ez.cigar); free(qenc); free(tenc);
+	free(ez.cigar); free(ez_ref.cigar); free(ez_alt.cigar); free(qenc); free(tenc);
 }
 
 /* ---- batch driver ----------------------------------------------------------- */

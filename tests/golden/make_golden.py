@@ -69,7 +69,9 @@ def regions():
     sets = {"c1": synth.config("C1")[0],
             "small": synth.generate(24, read_len=150, n_reads=(8, 40), err_rate=2e-3, config_id=91)[0],
             "long": synth.generate(4, read_len=300, n_reads=(40, 40), err_rate=1e-3, n_events=2, window_len=1400,
-                                   event_pos=500, config_id=95)[0]}
+                                   event_pos=500, config_id=95)[0],
+            # tandem duplications: reads carry both k-mers, the alignment fallback (indelope.nim:312-372) votes
+            "dup": synth.generate(10, read_len=150, n_reads=(12, 40), err_rate=1e-3, config_id=97, dup_frac=0.7)[0]}
     for name, b in sets.items():
         K = 31 if name == "long" else 27
         res = o.run_regions(b, o.params(K=K))

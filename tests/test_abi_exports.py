@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(A.KswExtz) == 48            # ksw2.h:22-30 on LP64
     assert C.sizeof(A.Ez) == 40
-    assert C.sizeof(A.Event) == 160 and A.EVENT_DTYPE.itemsize == 160
-    assert C.sizeof(A.Params) == 96
+    assert C.sizeof(A.Event) == 168 and A.EVENT_DTYPE.itemsize == 168
+    assert C.sizeof(A.Params) == 120
     lib = indelope_amd.load_library()
     p = A.Params()
     lib.ihp_params_default.argtypes = [C.POINTER(A.Params)]
@@ -39,6 +39,9 @@ def test_struct_layouts_match_header():
     assert (p.K, p.bw, p.zdrop, p.min_reads, p.min_ctg_len, p.combine_min_overlap) == (27, 50, 400, 4, 74, 65)
     assert (p.match, p.mismatch, p.gap_open, p.gap_ext) == (1, -2, 4, 1)
     assert abs(p.min_overlap_pct - 0.88) < 1e-15 and abs(p.error - 1e-3) < 1e-18
+    # alignment fallback: new_ez(mismatch=-2, gap_open=5, gap_ext=1) indelope.nim:318-319, align_to defaults ksw2.nim:159
+    assert (p.fallback, p.fb_match, p.fb_mismatch, p.fb_gap_open, p.fb_gap_ext) == (1, 1, -2, 5, 1)
+    assert (p.fb_bw, p.fb_zdrop, p.fb_flag) == (-1, -1, 0)
 
 
 def test_host_helpers_need_no_gpu(oracle):

@@ -30,7 +30,7 @@ def test_golden_ksw2(hip):
     assert golden_util.check_ksw2(hip) >= 200
 
 
-@pytest.mark.parametrize("name", ["c1", "small", "long"])
+@pytest.mark.parametrize("name", ["c1", "small", "long", "dup"])
 def test_golden_regions(hip, name):
     golden_util.check_regions(hip, name)
 
@@ -58,6 +58,49 @@ def test_regions_match_oracle(hip, oracle, cfg):
     exp = oracle.run_regions(b, oracle.params(K=K))
     assert_same(got, exp)
     assert (got.status == 0).all()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_regions=60, n_reads=(24, 64), err_rate=1e-3, config_id=41, dup_frac=0.6),
+    dict(n_regions=30, n_reads=(16, 200), err_rate=2e-3, config_id=42, dup_frac=0.5),
+    dict(n_regions=16, read_len=300, n_reads=(48, 64), err_rate=1e-3, n_events=2, window_len=1400, event_pos=500,
+         config_id=43, K=31, dup_frac=0.5),
+    dict(n_regions=30, read_len=100, n_reads=(20, 60), err_rate=2e-3, config_id=44, K=21, dup_frac=0.8),
+])
+def test_alignment_fallback_matches_oracle(hip, oracle, cfg):
+    """indelope.nim:312-372: events whose k-mers are not unique go through per-read alignments (k_fallback)."""
+    b, _ = synth.generate(**cfg)
+    K = cfg.get("K", 27)
+    got = hip.run_regions(b, hip.params(K=K))
+    exp = oracle.run_regions(b, oracle.params(K=K))
+    assert_same(got, exp)
+    assert (got.events["aligned"] == 1).sum() >= (20 if cfg["config_id"] == 41 else 1)
+    # fallback off: the k-mer tally is the result and nothing is aligned
+    got0 = hip.run_regions(b, hip.params(K=K, fallback=0))
+    assert_same(got0, oracle.run_regions(b, oracle.params(K=K, fallback=0)))
+    assert (got0.events["aligned"] == 0).all()
+
+
+def test_alignment_fallback_filters(hip, oracle):
+    """mapq < 10 reads skipped (:325), quality trim moves the read start (:328), emptied reads, CLI defaults."""
+    b, _ = synth.generate(50, n_reads=(16, 64), err_rate=1e-3, config_id=45, dup_frac=0.7)
+    rng = np.random.default_rng(3)
+    b.mapq = rng.choice(np.array([0, 9, 10, 19, 20, 60], np.uint8), b.n_reads)
+    q = b.quals.copy()
+    for i in range(b.n_reads):
+        lo, hi = b.read_off[i], b.read_off[i + 1]
+        k = rng.integers(0, 5)
+        if k == 1:
+            q[lo:lo + rng.integers(1, 40)] = 2
+        elif k == 2:
+            q[hi - rng.integers(1, 40):hi] = 2
+        elif k == 3 and rng.random() < 0.3:
+            q[lo:hi] = 2
+    b.quals = q
+    kw = dict(min_reads=3, min_ctg_len=73, min_event_len=4)
+    got = hip.run_regions(b, hip.params(**kw))
+    assert_same(got, oracle.run_regions(b, oracle.params(**kw)))
+    assert (got.events["aligned"] == 1).sum() >= 3
 
 
 def test_regions_with_n_and_lower_case_bases(hip, oracle):

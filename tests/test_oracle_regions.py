@@ -8,7 +8,7 @@ from indelope_amd import _abi as A
 from indelope_amd.host import BatchResult
 
 
-@pytest.mark.parametrize("name", ["c1", "small", "long"])
+@pytest.mark.parametrize("name", ["c1", "small", "long", "dup"])
 def test_golden_regions(oracle, name):
     golden_util.check_regions(oracle, name)
 
@@ -39,6 +39,38 @@ def test_error_free_regions_recover_truth(oracle):
             evs += [e for e in res.events[res.event_off[c]:res.event_off[c + 1]] if e["status"] == 0]
         hits += any(e["type"] == truth[r, 0] and e["len"] == truth[r, 1] for e in evs)
     assert hits >= 36          # a few regions lose the event to coverage / band limits
+
+
+def test_alignment_fallback(oracle):
+    """indelope.nim:312-372: tandem duplications put the alt k-mer into the reference haplotype too, so reference
+    reads carry both k-mers (both_found > 0) and the per-read alignments decide.  fallback=0 keeps the k-mer counts."""
+    b, truth = synth.generate(30, n_reads=(24, 64), err_rate=1e-3, config_id=41, dup_frac=0.6)
+    res = oracle.run_regions(b)
+    off = oracle.run_regions(b, oracle.params(fallback=0))
+    ev, ev0 = res.events, off.events
+    fb = ev["aligned"] == 1
+    assert fb.sum() >= 10 and (ev0["aligned"] == 0).all()
+    assert np.array_equal(ev["fallback_needed"], ev0["fallback_needed"]) and np.array_equal(fb, ev["fallback_needed"] == 1)
+    # the k-mer tally is kept beside the votes; without the fallback it is the result
+    for k in ("ref_support", "alt_support", "both_found"):
+        assert np.array_equal(ev["kmer_" + k], ev0[k])
+        assert np.array_equal(ev[k][~fb], ev0[k][~fb])
+    assert (ev["kmer_both_found"][fb] > 0).all() and (ev["both_found"][fb] == 0).all()
+    # a read votes at most once, and the votes separate the haplotypes where the k-mers could not
+    nreads = np.diff(b.region_read_off).max()
+    assert ((ev["ref_support"] + ev["alt_support"])[fb] <= nreads).all()
+    assert (ev["alt_support"][fb] < ev["kmer_alt_support"][fb]).all()
+    assert (ev["gt"][fb] == A.IHP_GT_HET).sum() >= 0.7 * fb.sum()
+    # mapq < 10 reads do not vote (:325); quality-trimmed starts shift the window (:328)
+    b.mapq = b.mapq.copy()
+    b.mapq[::3] = 9
+    b.quals = b.quals.copy()
+    for i in range(0, b.n_reads, 5):
+        b.quals[b.read_off[i]:b.read_off[i] + 7] = 2
+    low = oracle.run_regions(b)
+    fb2 = low.events["aligned"] == 1
+    assert fb2.sum() >= 5
+    assert ((low.events["ref_support"] + low.events["alt_support"])[fb2] <= nreads - nreads // 3).all()
 
 
 def test_threads_do_not_change_results(oracle):
