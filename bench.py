@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--config", default="C2", help="BASELINE config id (C2, C3, C5) for the per-GPU batch")
     ap.add_argument("--regions", type=int, default=0, help="override regions per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dup-frac", type=float, default=0.0,
+                    help="fraction of planted events that are tandem duplications (these send the k-mer tally to the "
+                         "alignment fallback, indelope.nim:312-372); 0 = the BASELINE workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +92,7 @@ def main():
     R = args.regions or min(cfg["n_regions"], 200_000)
     cfg["n_regions"] = R
     K = cfg["K"]
-    batch, _ = synth.generate(first_region=rank * R, **cfg)
+    batch, _ = synth.generate(first_region=rank * R, dup_frac=args.dup_frac, **cfg)
     params = api.params(K=K)
     h = api.batch_upload(batch, params)
     sptr, sn = api.batch_summary_dev(h)
@@ -106,6 +109,7 @@ def main():
     for _ in range(args.warmup):
         step()
     stage = np.zeros(4)
+    fb_ms = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -113,6 +117,7 @@ def main():
     for _ in range(args.steps):
         step()
         stage += api.batch_stage_ms(h)
+        fb_ms += api.batch_fallback_ms(h)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -122,14 +127,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stage /= max(args.steps, 1)
+    fb_ms /= max(args.steps, 1)
 
     if rank == 0:
         res = api.batch_fetch(h)
         assert (res.status == 0).all(), "regions failed on the device"
         # B = sum_reads(len+9) + len_refwindow + sum_contigs(5 len+16) + sum_aln(44+4 n_cigar) + sum_events(2K+12)
         alg_bytes = batch.algorithmic_input_bytes() + res.algorithmic_output_bytes(K)
+        by_kernel = res.algorithmic_bytes_by_kernel(batch, K)     # the same terms, split by the kernel that moves them
         dom = int(np.argmax(stage[:3]))
-        achieved = alg_bytes / (stage[dom] * 1e-3) / 1e9
+        achieved = by_kernel[KERNELS[dom]] / (stage[dom] * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
         if args.config == "C2" and R == 10_000 and os.path.exists(pmc):
@@ -146,16 +153,22 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %d regions/GPU x %s reads x %d bp, K=%d, err %g (SURVEY 8d generator, seed 0x1DE10BE^%d)"
                                    % (args.config, R, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
-                                      else str(cfg["n_reads"][0]), cfg["read_len"], K, cfg["err_rate"], cfg["config_id"]),
+                                      else str(cfg["n_reads"][0]), cfg["read_len"], K, cfg["err_rate"], cfg["config_id"])
+                                   + (", %g of events tandem duplications" % args.dup_frac if args.dup_frac else ""),
                        "regions_per_gpu": R, "sharding": "contiguous region ranges per rank, one RCCL gather of "
                        "per-region result records per step" if world > 1 else "single GPU"},
-            "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)},
+            "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "algorithmic_bytes_per_region": round(alg_bytes / R, 1)},
+                         "algorithmic_bytes_per_launch": int(by_kernel[KERNELS[dom]]),
+                         "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] / R, 1),
+                         "algorithmic_bytes_by_kernel": by_kernel,
+                         "whole_path": {"algorithmic_bytes_per_step": int(alg_bytes),
+                                        "achieved": round(alg_bytes / (stage[3] * 1e-3) / 1e9, 2),
+                                        "frac": round(alg_bytes / (stage[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
             "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),
-                        "tallied": int((res.events["status"] == 0).sum())},
+                        "tallied": int((res.events["status"] == 0).sum()),
+                        "fallback_events": int((res.events["aligned"] == 1).sum())},
         }
         if os.environ.get("IHP_PROFILE"):
             out["profile_cycles"] = [int(x) for x in api.batch_profile(h)]

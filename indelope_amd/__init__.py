@@ -70,6 +70,11 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_stage_ms(h, ms), "batch_stage_ms")
         return [float(x) for x in ms]
 
+    def batch_fallback_ms(self, h):
+        ms = C.c_float()
+        self._chk_hip(self.b.batch_fallback_ms(h, C.byref(ms)), "batch_fallback_ms")
+        return float(ms.value)
+
     def batch_summary_dev(self, h):
         p, n = C.c_void_p(), C.c_int64()
         self._chk_hip(self.b.batch_summary_dev(h, C.byref(p), C.byref(n)), "batch_summary_dev")

@@ -180,6 +180,21 @@ class BatchResult:
         return int(5 * len(self.ctg_seq) + 16 * self.n_contigs + 44 * naln + 4 * len(self.cigar)
                    + (2 * K + 12) * self.n_events)
 
+    def algorithmic_bytes_by_kernel(self, batch, K):
+        """The same SURVEY.md §8d terms split by the kernel that moves them: assemble = reads in
+        + final contigs out; ksw2 = contig + window in, result record + CIGAR out; tally = the region's read bases
+        once per tallied event + the event record out."""
+        done = self.aln_flags & A.IHP_ALN_DONE != 0
+        clen = np.diff(self.ctg_seq_off)
+        asm = int(len(batch.bases) + 9 * batch.n_reads + 5 * len(self.ctg_seq) + 16 * self.n_contigs)
+        ksw = int(clen[done].sum() + self.aln_ref_len[done].sum() + 44 * int(done.sum()) + 4 * len(self.cigar))
+        region_bases = np.diff(batch.read_off[batch.region_read_off])
+        ctg_region = np.repeat(np.arange(self.n_regions), np.diff(self.contig_off))
+        ev_ctg = np.repeat(np.arange(self.n_contigs), np.diff(self.event_off))
+        tallied = self.events["status"] == A.IHP_EV_TALLIED
+        tally = int(region_bases[ctg_region[ev_ctg[tallied]]].sum() + (2 * K + 12) * self.n_events)
+        return {"k_assemble": asm, "k_ksw": ksw, "k_tally": tally}
+
     def first_difference(self, other):
         """None if bit-identical to `other`, else a description (integer fields only;
         GL/qual are floating point and compared with a tolerance by the caller)."""
