@@ -677,8 +677,15 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		const int nc = (std::min(std::min(ql, tt), w + 1) + 15) / 16 + 1;
 		b->fb_p_cap = ((size_t)(ql + tt) * nc + 1) * 16 + 64;
 		b->fb_cig_cap = ql + tt + 16;
-		b->lds_fb = (int)std::min<size_t>(ksw_lds_bytes(ql, tt) + 64, (size_t)g.max_lds - 2048);
-		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(8, g.max_lds / (b->lds_fb + 256))));
+		int8_t fmat[25];
+		ihp_matrix(p->fb_match, p->fb_mismatch, fmat);
+		const KswParams FP = make_ksw_params(5, fmat, (int8_t)std::abs((int)p->fb_gap_open), (int8_t)std::abs((int)p->fb_gap_ext),
+		                                     p->fb_bw, p->fb_zdrop, p->fb_flag, 1);
+		size_t lneed = ksw_lds_bytes(ql, tt);                        // the generic LDS sweep always fits this
+		if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<3>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<3>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
+		else if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<6>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<6>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
+		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
+		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(12, g.max_lds / (b->lds_fb + 256))));
 	}
 #define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
 	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);

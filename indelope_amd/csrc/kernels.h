@@ -4,6 +4,7 @@
 #include "contig_dev.h"
 #include "ksw_dev.h"
 #include "ksw_narrow.h"
+#include "ksw_wide.h"
 #include "tally_dev.h"
 
 namespace ihp {
@@ -619,20 +620,36 @@ __global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
 		int ncol_ = rl < tmax ? rl : tmax;
 		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
 		const size_t pneed = ((size_t)(rl + tmax - 1 > 0 ? rl + tmax - 1 : 0) * ncol_ + 1) * 16;
-		if (rl > 0 && tmax > 0 && (ksw_lds_bytes(rl, tmax) > (size_t)a.lds_budget || pneed > a.p_cap || rl + tmax + 8 > a.cig_cap)) {
+		if (rl > 0 && tmax > 0 && (pneed > a.p_cap || rl + tmax + 8 > a.cig_cap)) {
 			if (lane == 0) atomicExch(&a.overflow[1], 1);
 			continue;
 		}
 		const uint8_t *qy = a.bases + off + lo;
-		KswOut o;
-		ksw_wave(qy, rl, a.ref_bases + uni(jb.t_off) + (rsub ? start : 0), rsub, a.P, lds, p, ct, a.cig_cap, o);   // :340
-		WSYNC();
-		const int rn = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;                       // :343
-		WSYNC();
-		ksw_wave(qy, rl, a.out_seq + uni(jb.q_off) + (csub ? start : 0), csub, a.P, lds, p, ct, a.cig_cap, o);     // :341
-		WSYNC();
-		const int an = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;                       // :344
-		WSYNC();
+		// read vs reference window (:340), then read vs contig (:341); the register-resident ring sweep (ksw_wide.h)
+		// when the read fits it, the generic LDS sweep otherwise
+		const bool wide_ok = !(a.P.flag & KSW_EZ_RIGHT);
+		int cnt[2];
+		bool over = false;
+		for (int side = 0; side < 2; ++side) {
+			const int tl = side ? csub : rsub;
+			const uint8_t *tg = side ? a.out_seq + uni(jb.q_off) + (csub ? start : 0) : a.ref_bases + uni(jb.t_off) + (rsub ? start : 0);
+			KswOut o;
+			o.n_cigar = 0; o.max_q = -1;
+			if (rl > 0 && tl > 0) {
+				if (wide_ok && ksw_wide_ok<3>(a.P, rl, tl) && ksw_wide_lds_bytes<3>(rl, tl) <= (size_t)a.lds_budget)
+					ksw_wave_wide<3, false>(qy, rl, tg, tl, a.P, lds, p, ct, a.cig_cap, o);
+				else if (wide_ok && ksw_wide_ok<6>(a.P, rl, tl) && ksw_wide_lds_bytes<6>(rl, tl) <= (size_t)a.lds_budget)
+					ksw_wave_wide<6, false>(qy, rl, tg, tl, a.P, lds, p, ct, a.cig_cap, o);
+				else if (ksw_lds_bytes(rl, tl) <= (size_t)a.lds_budget)
+					ksw_wave(qy, rl, tg, tl, a.P, lds, p, ct, a.cig_cap, o);
+				else over = true;
+			}
+			WSYNC();
+			cnt[side] = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;   // :343-344
+			WSYNC();
+		}
+		if (over) { if (lane == 0) atomicExch(&a.overflow[1], 1); continue; }
+		const int rn = cnt[0], an = cnt[1];
 		if (lane == 0) {
 			if (rn == 1 && an > 1) atomicAdd(&E->ref_support, 1);      // :353-354
 			else if (an == 1 && rn > 1) atomicAdd(&E->alt_support, 1); // :355-356
