@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 #include "kernels.h"
@@ -44,13 +45,58 @@ int ensure_init()
 	return ihp_init(0);
 }
 
-// device buffer; freed on scope exit / batch free
+// Device memory comes from a caching pool: a BAM sweep uploads batch after batch of similar shape, and hipMalloc /
+// hipFree (which synchronises the device) of ~50 buffers per batch would cost more than the kernels.  Freed blocks are
+// kept (up to a byte budget) and handed out again to requests of similar size.
+struct DevPool {
+	std::mutex mu;
+	std::vector<std::pair<void *, size_t>> free_list;
+	size_t cached = 0;
+	static constexpr size_t BUDGET = (size_t)24 << 30;
+	void *get(size_t bytes, size_t *cap) {
+		{
+			std::lock_guard<std::mutex> l(mu);
+			int best = -1;
+			for (int i = 0; i < (int)free_list.size(); ++i)
+				if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = i;
+			if (best >= 0 && free_list[best].second <= 2 * bytes + 4096) {
+				void *p = free_list[best].first;
+				*cap = free_list[best].second;
+				cached -= *cap;
+				free_list.erase(free_list.begin() + best);
+				return p;
+			}
+		}
+		void *p = nullptr;
+		if (hipMalloc(&p, bytes) != hipSuccess) {
+			clear();                                           // give the cached blocks back and try once more
+			if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+		}
+		*cap = bytes;
+		return p;
+	}
+	void put(void *p, size_t cap) {
+		std::lock_guard<std::mutex> l(mu);
+		if (cached + cap > BUDGET) { (void)hipFree(p); return; }
+		free_list.push_back({p, cap});
+		cached += cap;
+	}
+	void clear() {
+		std::lock_guard<std::mutex> l(mu);
+		for (auto &e : free_list) (void)hipFree(e.first);
+		free_list.clear(); cached = 0;
+	}
+};
+DevPool g_pool;
+
+// device buffer; returned to the pool on scope exit / batch free
 struct DBuf {
-	void *p = nullptr; size_t n = 0;
+	void *p = nullptr; size_t n = 0, cap = 0;
 	int alloc(size_t bytes) {
+		release();
 		n = bytes;
-		hipError_t e = hipMalloc(&p, bytes + 64);          // +64: kernels read whole dwords at the tail of byte arrays
-		if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __LINE__) == IHP_E_HIP ? IHP_E_NOMEM : IHP_E_NOMEM; }
+		p = g_pool.get(bytes + 64, &cap);                    // +64: kernels read whole dwords at the tail of byte arrays
+		if (!p) { n = cap = 0; snprintf(g.err, sizeof(g.err), "hipMalloc of %zu bytes failed", bytes + 64); return IHP_E_NOMEM; }
 		return 0;
 	}
 	int upload(const void *src, size_t bytes, hipStream_t s) {
@@ -61,7 +107,8 @@ struct DBuf {
 	}
 	int zero(hipStream_t s) { if (n) HIPC(hipMemsetAsync(p, 0, n, s)); return 0; }
 	template <class T> T *as() const { return (T *)p; }
-	~DBuf() { if (p) (void)hipFree(p); }
+	void release() { if (p) g_pool.put(p, cap); p = nullptr; n = cap = 0; }
+	~DBuf() { release(); }
 	DBuf() = default;
 	DBuf(const DBuf &) = delete;
 	DBuf &operator=(const DBuf &) = delete;
@@ -170,9 +217,12 @@ extern "C" int ihp_device_info(int *cu_count, int *wave_size, int64_t *hbm_bytes
 	return 0;
 }
 
+static void slab_cache_clear();
 extern "C" void ihp_shutdown(void)
 {
 	if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
+	slab_cache_clear();
+	g_pool.clear();
 	g.ready = false; g.device = -1;
 }
 
@@ -543,6 +593,7 @@ struct ihp_batch {
 	DBuf queues;
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
+	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
 	int grid_fb = 0, lds_fb = 0, fb_cig_cap = 0, max_region_reads = 0;
 	size_t fb_p_cap = 0;
 	// outputs
@@ -900,110 +951,165 @@ extern "C" int ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n)
 
 extern "C" void ihp_batch_free(ihp_batch *b) { delete b; }
 
+// ---- host result slabs ---------------------------------------------------------------
+// Every array of an ihp_batch_out lives in ONE pinned host allocation (64-byte header + sections), so that
+// the packed device results arrive in a single hipMemcpy at PCIe rate.  Pinning is expensive, so freed slabs
+// are kept and reused by later fetches.
+namespace {
+struct SlabHdr { uint64_t magic; size_t cap; uint64_t pad[6]; };
+static_assert(sizeof(SlabHdr) == 64, "slab header");
+constexpr uint64_t SLAB_MAGIC = 0x49485053'4c414231ull;
+struct SlabCache {
+	std::mutex mu;
+	std::vector<std::pair<void *, size_t>> free_list;      // (base, capacity)
+	void *get(size_t bytes) {
+		{
+			std::lock_guard<std::mutex> l(mu);
+			int best = -1;
+			for (int i = 0; i < (int)free_list.size(); ++i)
+				if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = i;
+			if (best >= 0 && free_list[best].second <= 4 * bytes + (1u << 20)) {
+				void *p = free_list[best].first;
+				free_list.erase(free_list.begin() + best);
+				return p;
+			}
+		}
+		const size_t cap = bytes + bytes / 4 + 4096;
+		void *p = nullptr;
+		if (hipHostMalloc(&p, cap + sizeof(SlabHdr), hipHostMallocDefault) != hipSuccess) return nullptr;
+		SlabHdr *h = (SlabHdr *)p;
+		h->magic = SLAB_MAGIC; h->cap = cap;
+		return p;
+	}
+	void put(void *base) {
+		std::lock_guard<std::mutex> l(mu);
+		free_list.push_back({base, ((SlabHdr *)base)->cap});
+		while (free_list.size() > 4) {                       // keep a few; drop the smallest
+			int w = 0;
+			for (int i = 1; i < (int)free_list.size(); ++i) if (free_list[i].second < free_list[w].second) w = i;
+			(void)hipHostFree(free_list[w].first);
+			free_list.erase(free_list.begin() + w);
+		}
+	}
+	void clear() {
+		std::lock_guard<std::mutex> l(mu);
+		for (auto &e : free_list) (void)hipHostFree(e.first);
+		free_list.clear();
+	}
+};
+SlabCache g_slabs;
+
+// section offsets of the flat result arrays inside a slab (the same on the device and on the host)
+struct OutLayout {
+	size_t status, n_pre, contig_off, ctg_start, ctg_nreads, ctg_seq_off, aln_ref_start, cigar_off, event_off, events,
+	       aln_ez, aln_flags, aln_ref_len, ctg_support, cigar, ctg_seq, bytes;
+	OutLayout(long long R, long long C, long long B, long long W, long long E) {
+		size_t o = 0;
+		auto sec = [&](size_t elem, long long n) { const size_t at = o; o += ((size_t)(n > 0 ? n : 1) * elem + 15) / 16 * 16; return at; };
+		contig_off = sec(8, R + 1); ctg_start = sec(8, C); ctg_nreads = sec(8, C); ctg_seq_off = sec(8, C + 1);
+		aln_ref_start = sec(8, C); cigar_off = sec(8, C + 1); event_off = sec(8, C + 1); events = sec(sizeof(ihp_event), E);
+		aln_ez = sec(sizeof(ihp_ez), C); status = sec(4, R); n_pre = sec(4, R); aln_flags = sec(4, C); aln_ref_len = sec(4, C);
+		ctg_support = sec(4, B); cigar = sec(4, W); ctg_seq = sec(1, B);
+		bytes = o;
+	}
+};
+}  // namespace
+
 extern "C" void ihp_free_out(ihp_batch_out *o)
 {
 	if (!o) return;
-	free(o->status); free(o->n_contigs_pre); free(o->contig_off);
-	free(o->ctg_start); free(o->ctg_nreads); free(o->ctg_seq_off); free(o->ctg_seq); free(o->ctg_support);
-	free(o->aln_flags); free(o->aln_ref_start); free(o->aln_ref_len); free(o->aln_ez);
-	free(o->cigar_off); free(o->cigar); free(o->event_off); free(o->events);
+	if (o->contig_off) {
+		SlabHdr *h = (SlabHdr *)((char *)o->contig_off - sizeof(SlabHdr));   // contig_off is the slab's first section
+		if (h->magic == SLAB_MAGIC) g_slabs.put(h);
+	}
 	memset(o, 0, sizeof(*o));
-}
-
-template <class T> static int fetch(std::vector<T> &h, const DBuf &d, size_t n)
-{
-	h.resize(n);
-	if (n) HIPC(hipMemcpyAsync(h.data(), d.p, sizeof(T) * n, hipMemcpyDeviceToHost, g.stream));
-	return 0;
 }
 
 extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 {
 	if (!b || !out || !b->ran) return IHP_E_ARG;
 	memset(out, 0, sizeof(*out));
-	const int R = b->R; const size_t S = (size_t)b->n_reads;
+	const int R = b->R;
+	hipStream_t s = g.stream;
 	int misc[M_WORDS];
-	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, g.stream));
-	HIPC(hipStreamSynchronize(g.stream));
+	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, s));
+	// per-region counts and their prefix sums (k_pack_count, k_pack_scan)
+	const size_t S = (size_t)R + 1;
+	if (!b->pack_cnt.p) { int rc = b->pack_cnt.alloc(sizeof(long long) * 4 * S); if (rc) return rc; }
+	long long *cnt = b->pack_cnt.as<long long>();
+	if (R > 0) {
+		PackCountArgs a;
+		a.R = R; a.region_read_off = b->region_read_off.as<long long>(); a.n_final = b->n_final.as<int>();
+		a.ctg_len = b->ctg_len.as<int>(); a.aln_flags = b->aln_flags.as<int>(); a.n_ev = b->n_ev.as<int>();
+		a.ez = b->ez.as<KswOut>(); a.cnt = cnt;
+		hipLaunchKernelGGL(k_pack_count, dim3((R + 255) / 256), dim3(256), 0, s, a);
+		HIPC(hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, R, cnt);
+	HIPC(hipGetLastError());
+	long long tot[4];
+	for (int k = 0; k < 4; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+	HIPC(hipStreamSynchronize(s));
 	if (misc[M_OVF] || misc[M_OVF + 1] || misc[M_OVF + 2]) {
 		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d", misc[M_OVF], misc[M_OVF + 1], misc[M_OVF + 2]);
 		return IHP_E_CAPACITY;
 	}
-	const long long njobs = misc[M_NJOBS];
-	const unsigned long long ncig = (unsigned long long)(b->cig_bump_cap + njobs * CIG_SLOT);
-	const unsigned long long nev = (unsigned long long)(njobs * std::max(1, b->P.max_events));
-	std::vector<int> status, n_pre, n_final, ctg_len, aln_flags, aln_ref_len, n_ev;
-	std::vector<long long> ctg_start, ctg_nreads, ctg_seq_off, aln_ref_start, cig_off, ev_off;
-	std::vector<uint8_t> seq; std::vector<uint32_t> sup, pool; std::vector<KswOut> ez; std::vector<DevEvent> evp;
-	int rc;
-	if ((rc = fetch(status, b->status, R)) || (rc = fetch(n_pre, b->n_pre, R)) || (rc = fetch(n_final, b->n_final, R)) ||
-	    (rc = fetch(ctg_len, b->ctg_len, S)) || (rc = fetch(aln_flags, b->aln_flags, S)) ||
-	    (rc = fetch(aln_ref_len, b->aln_ref_len, S)) || (rc = fetch(n_ev, b->n_ev, S)) ||
-	    (rc = fetch(ctg_start, b->ctg_start, S)) || (rc = fetch(ctg_nreads, b->ctg_nreads, S)) ||
-	    (rc = fetch(ctg_seq_off, b->ctg_seq_off, S)) || (rc = fetch(aln_ref_start, b->aln_ref_start, S)) ||
-	    (rc = fetch(cig_off, b->cig_off, S)) || (rc = fetch(ev_off, b->ev_off, S)) ||
-	    (rc = fetch(seq, b->out_seq, (size_t)b->n_bases)) || (rc = fetch(sup, b->out_sup, (size_t)b->n_bases)) ||
-	    (rc = fetch(pool, b->cig_pool, (size_t)ncig)) || (rc = fetch(ez, b->ez, S)) || (rc = fetch(evp, b->ev_pool, (size_t)nev)))
-		return rc;
-	HIPC(hipStreamSynchronize(g.stream));
-	// repack slot-indexed device results into the flat output
-	long long C = 0, B = 0, W = 0, E = 0;
-	for (int r = 0; r < R; ++r) {
-		const long long base = b->h_region_read_off[r];
-		for (int k = 0; k < n_final[r]; ++k) {
-			const long long sl = base + k;
-			C++; B += ctg_len[sl];
-			if (aln_flags[sl] & IHP_ALN_DONE) { W += ez[sl].n_cigar > 0 ? ez[sl].n_cigar : 0; E += n_ev[sl]; }
-		}
+	const long long C = tot[0], B = tot[1], W = tot[2], E = tot[3];
+	const OutLayout L(R, C, B, W, E);
+	if (b->pack_slab.n < L.bytes) {
+		int rc = b->pack_slab.alloc(L.bytes + L.bytes / 8);
+		if (rc) return rc;
+	}
+	char *dev = b->pack_slab.as<char>();
+	void *slab = g_slabs.get(L.bytes);
+	if (!slab) { snprintf(g.err, sizeof(g.err), "hipHostMalloc of %zu bytes failed", L.bytes); return IHP_E_NOMEM; }
+	char *host = (char *)slab + sizeof(SlabHdr);
+	{
+		PackArgs a;
+		a.R = R; a.region_read_off = b->region_read_off.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
+		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
+		a.ctg_len = b->ctg_len.as<int>(); a.aln_flags = b->aln_flags.as<int>(); a.aln_ref_len = b->aln_ref_len.as<int>();
+		a.n_ev = b->n_ev.as<int>();
+		a.ctg_start = b->ctg_start.as<long long>(); a.ctg_nreads = b->ctg_nreads.as<long long>();
+		a.ctg_seq_off = b->ctg_seq_off.as<long long>(); a.aln_ref_start = b->aln_ref_start.as<long long>();
+		a.cig_off = b->cig_off.as<long long>(); a.ev_off = b->ev_off.as<long long>();
+		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>(); a.ez = b->ez.as<KswOut>();
+		a.cig_pool = b->cig_pool.as<uint32_t>(); a.ev_pool = b->ev_pool.as<DevEvent>(); a.cnt = cnt;
+		a.o_status = (int32_t *)(dev + L.status); a.o_n_pre = (int32_t *)(dev + L.n_pre); a.o_contig_off = (int64_t *)(dev + L.contig_off);
+		a.o_ctg_start = (int64_t *)(dev + L.ctg_start); a.o_ctg_nreads = (int64_t *)(dev + L.ctg_nreads);
+		a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off); a.o_seq = (uint8_t *)(dev + L.ctg_seq); a.o_sup = (uint32_t *)(dev + L.ctg_support);
+		a.o_aln_flags = (int32_t *)(dev + L.aln_flags); a.o_aln_ref_start = (int64_t *)(dev + L.aln_ref_start);
+		a.o_aln_ref_len = (int32_t *)(dev + L.aln_ref_len); a.o_ez = (ihp_ez *)(dev + L.aln_ez);
+		a.o_cigar_off = (int64_t *)(dev + L.cigar_off); a.o_cigar = (uint32_t *)(dev + L.cigar);
+		a.o_event_off = (int64_t *)(dev + L.event_off); a.o_events = (ihp_event *)(dev + L.events);
+		hipLaunchKernelGGL(k_pack, dim3(grid_for(R + 1, 16)), dim3(64), 0, s, a);
+		hipError_t e = hipGetLastError();
+		if (e == hipSuccess) e = hipMemcpyAsync(host, dev, L.bytes, hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess) e = hipStreamSynchronize(s);
+		if (e != hipSuccess) { g_slabs.put(slab); return hip_fail(e, "pack / copy of the results", __LINE__); }
 	}
 	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B;
-#define ALLOC(T, n) ((T *)calloc((size_t)((n) ? (n) : 1), sizeof(T)))
-	out->status = ALLOC(int32_t, R); out->n_contigs_pre = ALLOC(int32_t, R); out->contig_off = ALLOC(int64_t, R + 1);
-	out->ctg_start = ALLOC(int64_t, C); out->ctg_nreads = ALLOC(int64_t, C); out->ctg_seq_off = ALLOC(int64_t, C + 1);
-	out->ctg_seq = ALLOC(uint8_t, B); out->ctg_support = ALLOC(uint32_t, B);
-	out->aln_flags = ALLOC(int32_t, C); out->aln_ref_start = ALLOC(int64_t, C); out->aln_ref_len = ALLOC(int32_t, C);
-	out->aln_ez = ALLOC(ihp_ez, C); out->cigar_off = ALLOC(int64_t, C + 1); out->cigar = ALLOC(uint32_t, W);
-	out->event_off = ALLOC(int64_t, C + 1); out->events = ALLOC(ihp_event, E);
-#undef ALLOC
-	long long c = 0, bb = 0, wd = 0, ev = 0;
-	for (int r = 0; r < R; ++r) {
-		out->status[r] = status[r]; out->n_contigs_pre[r] = n_pre[r]; out->contig_off[r] = c;
-		const long long base = b->h_region_read_off[r], origin = b->h_ref_origin[r];
-		for (int k = 0; k < n_final[r]; ++k, ++c) {
-			const long long sl = base + k;
-			out->ctg_start[c] = ctg_start[sl]; out->ctg_nreads[c] = ctg_nreads[sl]; out->ctg_seq_off[c] = bb;
-			memcpy(out->ctg_seq + bb, seq.data() + ctg_seq_off[sl], (size_t)ctg_len[sl]);
-			memcpy(out->ctg_support + bb, sup.data() + ctg_seq_off[sl], sizeof(uint32_t) * (size_t)ctg_len[sl]);
-			bb += ctg_len[sl];
-			out->aln_flags[c] = aln_flags[sl]; out->aln_ref_start[c] = aln_ref_start[sl]; out->aln_ref_len[c] = aln_ref_len[sl];
-			out->cigar_off[c] = wd; out->event_off[c] = ev;
-			if (!(aln_flags[sl] & IHP_ALN_DONE)) continue;
-			const KswOut &z = ez[sl];
-			ihp_ez &o = out->aln_ez[c];
-			o.max = z.max; o.zdropped = z.zdropped; o.max_q = z.max_q; o.max_t = z.max_t; o.mqe = z.mqe; o.mqe_t = z.mqe_t;
-			o.mte = z.mte; o.mte_q = z.mte_q; o.score = z.score; o.n_cigar = z.n_cigar;
-			if (z.n_cigar > 0) { memcpy(out->cigar + wd, pool.data() + cig_off[sl], sizeof(uint32_t) * (size_t)z.n_cigar); wd += z.n_cigar; }
-			for (int e = 0; e < n_ev[sl]; ++e, ++ev) {
-				const DevEvent &d = evp[(size_t)ev_off[sl] + e];
-				ihp_event &x = out->events[ev];
-				x.tstart = origin + d.tstart_rel; x.tstop = origin + d.tstop_rel; x.qstart = d.qstart; x.qstop = d.qstop;
-				x.len = d.len; x.type = d.type; x.status = d.status; x.fallback_needed = d.fallback; x.aligned = d.aligned;
-				x.kmer_ref_support = d.kmer_ref; x.kmer_alt_support = d.kmer_alt; x.kmer_both_found = d.kmer_both;
-				x.cf_offset = d.cf_offset; x.ref_support = d.ref_support; x.alt_support = d.alt_support; x.both_found = d.both_found;
-				memcpy(x.ref_kmer, d.ref_kmer, 32); memcpy(x.alt_kmer, d.alt_kmer, 32);
-				x.gt = IHP_GT_UNKNOWN; x.gl[0] = x.gl[1] = x.gl[2] = 0; x.qual = 0;
-				if (d.status == IHP_EV_TALLIED) {                  // indelope.nim:379
-					ihp_genotype_t gt;
-					ihp_genotype(d.ref_support, d.alt_support, b->P.error, &gt);
-					x.gt = gt.gt; x.gl[0] = gt.gl[0]; x.gl[1] = gt.gl[1]; x.gl[2] = gt.gl[2];
-					x.qual = ihp_genotype_qual(&gt);
-				}
-			}
-		}
+	out->status = (int32_t *)(host + L.status); out->n_contigs_pre = (int32_t *)(host + L.n_pre);
+	out->contig_off = (int64_t *)(host + L.contig_off);
+	out->ctg_start = (int64_t *)(host + L.ctg_start); out->ctg_nreads = (int64_t *)(host + L.ctg_nreads);
+	out->ctg_seq_off = (int64_t *)(host + L.ctg_seq_off); out->ctg_seq = (uint8_t *)(host + L.ctg_seq);
+	out->ctg_support = (uint32_t *)(host + L.ctg_support);
+	out->aln_flags = (int32_t *)(host + L.aln_flags); out->aln_ref_start = (int64_t *)(host + L.aln_ref_start);
+	out->aln_ref_len = (int32_t *)(host + L.aln_ref_len); out->aln_ez = (ihp_ez *)(host + L.aln_ez);
+	out->cigar_off = (int64_t *)(host + L.cigar_off); out->cigar = (uint32_t *)(host + L.cigar);
+	out->event_off = (int64_t *)(host + L.event_off); out->events = (ihp_event *)(host + L.events);
+	for (long long e = 0; e < E; ++e) {                        // indelope.nim:379: genotype(ref_support, alt_support, 1e-3), fp64 on the host
+		ihp_event &x = out->events[e];
+		if (x.status != IHP_EV_TALLIED) continue;
+		ihp_genotype_t gt;
+		ihp_genotype(x.ref_support, x.alt_support, b->P.error, &gt);
+		x.gt = gt.gt; x.gl[0] = gt.gl[0]; x.gl[1] = gt.gl[1]; x.gl[2] = gt.gl[2];
+		x.qual = ihp_genotype_qual(&gt);
 	}
-	out->contig_off[R] = c; out->ctg_seq_off[C] = bb; out->cigar_off[C] = wd; out->event_off[C] = ev;
 	return 0;
 }
+
+static void slab_cache_clear() { g_slabs.clear(); }
 
 extern "C" int ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out)
 {

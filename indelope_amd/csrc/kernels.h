@@ -692,6 +692,132 @@ __global__ void k_summary(const SummaryArgs a)
 	a.out[r] = s;
 }
 
+// ---------------------------------------------------------------------- pack
+// Results are produced slot-indexed (contig k of region r at region_read_off[r] + k, bases at the region's read
+// offset, ...), so that no kernel needs a data-dependent size.  Fetching that layout would move the read-sized
+// arrays over PCIe; instead three small kernels compact it on the device into the flat `ihp_batch_out` arrays,
+// laid out in one slab that is copied to the host in one piece.
+//   k_pack_count: per region -> contigs, bases, CIGAR words, events;  k_pack_scan: exclusive prefix sums;
+//   k_pack: one wave per region copies its contigs to their final places.
+struct PackCountArgs {
+	int R;
+	const long long *region_read_off;
+	const int *n_final, *ctg_len, *aln_flags, *n_ev;
+	const KswOut *ez;
+	long long *cnt;                 // [4][R+1]: contigs, bases, cigar words, events
+};
+
+__global__ void k_pack_count(const PackCountArgs a)
+{
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.R) return;
+	const long long base = a.region_read_off[r];
+	const int n = a.n_final[r];
+	long long B = 0, W = 0, E = 0;
+	for (int k = 0; k < n; ++k) {
+		const long long sl = base + k;
+		B += a.ctg_len[sl];
+		if (a.aln_flags[sl] & IHP_ALN_DONE) { const int nc = a.ez[sl].n_cigar; W += nc > 0 ? nc : 0; E += a.n_ev[sl]; }
+	}
+	const size_t S = (size_t)a.R + 1;
+	a.cnt[r] = n; a.cnt[S + r] = B; a.cnt[2 * S + r] = W; a.cnt[3 * S + r] = E;
+}
+
+// in place: counts -> exclusive prefix sums, totals at index R.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_pack_scan(int R, long long *cnt)
+{
+	__shared__ long long part[4][1024];
+	const int t = (int)threadIdx.x;
+	const long long per = ((long long)R + 1023) / 1024;
+	const long long lo = (long long)t * per < R ? (long long)t * per : R, hi = lo + per < R ? lo + per : R;
+	const size_t S = (size_t)R + 1;
+	for (int a = 0; a < 4; ++a) {
+		long long s = 0;
+		for (long long i = lo; i < hi; ++i) s += cnt[a * S + i];
+		part[a][t] = s;
+	}
+	__syncthreads();
+	if (t < 4) {
+		long long run = 0;
+		for (int i = 0; i < 1024; ++i) { const long long c = part[t][i]; part[t][i] = run; run += c; }
+		cnt[t * S + R] = run;
+	}
+	__syncthreads();
+	for (int a = 0; a < 4; ++a) {
+		long long run = part[a][t];
+		for (long long i = lo; i < hi; ++i) { const long long c = cnt[a * S + i]; cnt[a * S + i] = run; run += c; }
+	}
+}
+
+struct PackArgs {
+	int R;
+	const long long *region_read_off, *ref_origin;
+	const int *status, *n_pre, *n_final, *ctg_len, *aln_flags, *aln_ref_len, *n_ev;
+	const long long *ctg_start, *ctg_nreads, *ctg_seq_off, *aln_ref_start, *cig_off, *ev_off;
+	const uint8_t *out_seq; const uint32_t *out_sup; const KswOut *ez; const uint32_t *cig_pool; const DevEvent *ev_pool;
+	const long long *cnt;           // prefix sums of k_pack_scan
+	// the flat arrays of ihp_batch_out (device slab)
+	int32_t *o_status, *o_n_pre; int64_t *o_contig_off;
+	int64_t *o_ctg_start, *o_ctg_nreads, *o_ctg_seq_off; uint8_t *o_seq; uint32_t *o_sup;
+	int32_t *o_aln_flags; int64_t *o_aln_ref_start; int32_t *o_aln_ref_len; ihp_ez *o_ez;
+	int64_t *o_cigar_off; uint32_t *o_cigar; int64_t *o_event_off; ihp_event *o_events;
+};
+
+__global__ __launch_bounds__(64) void k_pack(const PackArgs a)
+{
+	const int lane = lane_id();
+	const size_t S = (size_t)a.R + 1;
+	for (int r = (int)blockIdx.x; r <= a.R; r += (int)gridDim.x) {
+		long long c = a.cnt[r], bb = a.cnt[S + r], wd = a.cnt[2 * S + r], ev = a.cnt[3 * S + r];
+		if (r == a.R) {                                       // the closing entries of the offset arrays
+			if (lane == 0) { a.o_contig_off[r] = c; a.o_ctg_seq_off[c] = bb; a.o_cigar_off[c] = wd; a.o_event_off[c] = ev; }
+			break;
+		}
+		const long long base = a.region_read_off[r], origin = a.ref_origin[r];
+		const int n = a.n_final[r];
+		if (lane == 0) { a.o_status[r] = a.status[r]; a.o_n_pre[r] = a.n_pre[r]; a.o_contig_off[r] = c; }
+		for (int k = 0; k < n; ++k, ++c) {
+			const long long sl = base + k;
+			const int len = a.ctg_len[sl], flags = a.aln_flags[sl];
+			const bool done = (flags & IHP_ALN_DONE) != 0;
+			const long long so = a.ctg_seq_off[sl];
+			for (int i = lane; i < len; i += 64) { a.o_seq[bb + i] = a.out_seq[so + i]; a.o_sup[bb + i] = a.out_sup[so + i]; }
+			KswOut z;
+			z.max = z.zdropped = z.max_q = z.max_t = z.mqe = z.mqe_t = z.mte = z.mte_q = z.score = z.n_cigar = 0;
+			if (done) z = a.ez[sl];
+			if (lane == 0) {
+				a.o_ctg_start[c] = a.ctg_start[sl]; a.o_ctg_nreads[c] = a.ctg_nreads[sl]; a.o_ctg_seq_off[c] = bb;
+				a.o_aln_flags[c] = flags; a.o_aln_ref_start[c] = a.aln_ref_start[sl]; a.o_aln_ref_len[c] = a.aln_ref_len[sl];
+				a.o_cigar_off[c] = wd; a.o_event_off[c] = ev;
+				ihp_ez o;
+				o.max = z.max; o.zdropped = z.zdropped; o.max_q = z.max_q; o.max_t = z.max_t; o.mqe = z.mqe; o.mqe_t = z.mqe_t;
+				o.mte = z.mte; o.mte_q = z.mte_q; o.score = z.score; o.n_cigar = z.n_cigar;
+				a.o_ez[c] = o;
+			}
+			bb += len;
+			if (!done) continue;
+			if (z.n_cigar > 0) {
+				const long long co = a.cig_off[sl];
+				for (int i = lane; i < z.n_cigar; i += 64) a.o_cigar[wd + i] = a.cig_pool[co + i];
+				wd += z.n_cigar;
+			}
+			const int ne = a.n_ev[sl];
+			for (int en = lane; en < ne; en += 64) {
+				const DevEvent d = a.ev_pool[a.ev_off[sl] + en];
+				ihp_event x;
+				x.tstart = origin + d.tstart_rel; x.tstop = origin + d.tstop_rel; x.qstart = d.qstart; x.qstop = d.qstop;
+				x.len = d.len; x.type = d.type; x.status = d.status; x.fallback_needed = d.fallback; x.aligned = d.aligned;
+				x.cf_offset = d.cf_offset; x.ref_support = d.ref_support; x.alt_support = d.alt_support; x.both_found = d.both_found;
+				for (int i = 0; i < 32; ++i) { x.ref_kmer[i] = d.ref_kmer[i]; x.alt_kmer[i] = d.alt_kmer[i]; }
+				x.gt = IHP_GT_UNKNOWN; x.kmer_ref_support = d.kmer_ref; x.kmer_alt_support = d.kmer_alt; x.kmer_both_found = d.kmer_both;
+				x.gl[0] = x.gl[1] = x.gl[2] = 0; x.qual = 0;         // genotype(): host, fp64 (genotyper.nim:36-47)
+				a.o_events[ev + en] = x;
+			}
+			ev += ne;
+		}
+	}
+}
+
 // ------------------------------------------------ single-op kernels (Contig API)
 struct OpArgs {
 	int op;                      // 0 slide_align, 1 insert, 2 trim
