@@ -21,6 +21,9 @@ type
     match*, mismatch*, gap_open*, gap_ext*: int8
     bw*, zdrop*, ksw_flag*: int32
     error*: float64
+    fallback*: int32                      # run the alignment fallback of indelope.nim:312-372 on the GPU (default 1)
+    fb_match*, fb_mismatch*, fb_gap_open*, fb_gap_ext*: int8   # new_ez(mismatch = -2, gap_open = 5, gap_ext = 1), :318-319
+    fb_bw*, fb_zdrop*, fb_flag*: int32    # align_to defaults (-1, -1, 0), ksw2.nim:159
 
   IhpBatchIn* {.importc: "ihp_batch_in", header: "indelope_hip.h", bycopy.} = object
     n_regions*: int32
@@ -39,10 +42,11 @@ type
   IhpEvent* {.importc: "ihp_event", header: "indelope_hip.h", bycopy.} = object
     tstart*, tstop*, qstart*, qstop*: int64
     len*: uint32
-    `type`*, status*, fallback_needed*, pad: uint8
-    cf_offset*, ref_support*, alt_support*, both_found*: int32
+    `type`*, status*, fallback_needed*, aligned*: uint8   # aligned = `aligned` of indelope.nim:372
+    cf_offset*, ref_support*, alt_support*, both_found*: int32   # as they stand at indelope.nim:375
     ref_kmer*, alt_kmer*: array[32, char]
     gt*: int32
+    kmer_ref_support*, kmer_alt_support*, kmer_both_found*: int32   # the k-mer tally itself (:285-311)
     gl*: array[3, float64]
     qual*: float64
 
