@@ -13,6 +13,7 @@
 #ifndef INDELOPE_HIP_H_
 #define INDELOPE_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -272,6 +273,13 @@ typedef struct {
 	int64_t *event_off;           /* [C+1] into events                           */
 	ihp_event *events;
 } ihp_batch_out;
+
+/* Page-locked host memory for the caller's flat batch arrays: uploads from it are DMA
+ * transfers that overlap other batches' kernels (every batch runs on its own stream, and
+ * batches may be driven from several host threads at once).  Pageable memory works too,
+ * through the runtime's staging copies.  NULL on failure.                                 */
+void *ihp_host_alloc(size_t bytes);
+void  ihp_host_free(void *p);
 
 /* Host buffers in, host buffers out (upload + run + fetch).                   */
 int  ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out);

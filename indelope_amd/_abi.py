@@ -162,6 +162,8 @@ _PRODUCT_ONLY = {
     "init": (C.c_int, [C.c_int]),
     "device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), i64p]),
     "shutdown": (None, []),
+    "host_alloc": (C.c_void_p, [C.c_size_t]),
+    "host_free": (None, [C.c_void_p]),
     "batch_upload": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(C.c_void_p)]),
     "batch_run": (C.c_int, [C.c_void_p]),
     "batch_sync": (C.c_int, [C.c_void_p]),

@@ -89,6 +89,29 @@ struct DevPool {
 };
 DevPool g_pool;
 
+// Every device-resident batch runs on a stream of its own, so batches in flight from different host threads (one
+// uploading, one running, one fetching) overlap on the copy engines and the CUs.  Streams are reused.
+struct StreamCache {
+	std::mutex mu;
+	std::vector<hipStream_t> free_list;
+	hipStream_t get() {
+		{
+			std::lock_guard<std::mutex> l(mu);
+			if (!free_list.empty()) { hipStream_t s = free_list.back(); free_list.pop_back(); return s; }
+		}
+		hipStream_t s = nullptr;
+		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+		return s;
+	}
+	void put(hipStream_t s) { std::lock_guard<std::mutex> l(mu); free_list.push_back(s); }
+	void clear() {
+		std::lock_guard<std::mutex> l(mu);
+		for (auto s : free_list) (void)hipStreamDestroy(s);
+		free_list.clear();
+	}
+};
+StreamCache g_streams;
+
 // device buffer; returned to the pool on scope exit / batch free
 struct DBuf {
 	void *p = nullptr; size_t n = 0, cap = 0;
@@ -223,6 +246,7 @@ extern "C" void ihp_shutdown(void)
 	if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
 	slab_cache_clear();
 	g_pool.clear();
+	g_streams.clear();
 	g.ready = false; g.device = -1;
 }
 
@@ -600,8 +624,13 @@ struct ihp_batch {
 	DBuf status, n_pre, n_final, ctg_start, ctg_nreads, ctg_seq_off, ctg_len, aln_flags, aln_ref_len, aln_ref_start;
 	DBuf out_seq, out_sup, jobs, ez, cig_off, cig_pool, ev_off, n_ev, ev_pool, summary;
 	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipStream_t stream = nullptr;
 	bool ran = false;
-	~ihp_batch() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+	~ihp_batch() {
+		// the buffers go back to the pool (the members are released after this body): nothing of this batch may still be running
+		if (stream) { (void)hipStreamSynchronize(stream); g_streams.put(stream); }
+		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+	}
 };
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
@@ -640,7 +669,9 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	}
 	b->h_region_read_off.assign(rro, rro + R + 1);
 	b->h_ref_origin.assign(in->ref_origin, in->ref_origin + R);
-	hipStream_t s = g.stream;
+	b->stream = g_streams.get();
+	if (!b->stream) { delete b; snprintf(g.err, sizeof(g.err), "hipStreamCreate failed"); return IHP_E_HIP; }
+	hipStream_t s = b->stream;
 #define UP(buf, ptr, bytes) do { if ((rc = b->buf.upload(ptr, (size_t)(bytes), s))) { delete b; return rc; } } while (0)
 	UP(region_read_off, rro, sizeof(int64_t) * (R + 1));
 	UP(read_off, ro, sizeof(int64_t) * (NR + 1));
@@ -775,7 +806,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 extern "C" int ihp_batch_run(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
-	hipStream_t s = g.stream;
+	hipStream_t s = b->stream;
 	const ihp_params &p = b->P;
 	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
 	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * 7, s));
@@ -904,7 +935,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 extern "C" int ihp_batch_sync(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
-	HIPC(hipStreamSynchronize(g.stream));
+	HIPC(hipStreamSynchronize(b->stream));
 	return 0;
 }
 
@@ -1030,7 +1061,7 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 	if (!b || !out || !b->ran) return IHP_E_ARG;
 	memset(out, 0, sizeof(*out));
 	const int R = b->R;
-	hipStream_t s = g.stream;
+	hipStream_t s = b->stream;
 	int misc[M_WORDS];
 	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, s));
 	// per-region counts and their prefix sums (k_pack_count, k_pack_scan)
@@ -1110,6 +1141,16 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 }
 
 static void slab_cache_clear() { g_slabs.clear(); }
+
+extern "C" void *ihp_host_alloc(size_t bytes)
+{
+	if (ensure_init()) return nullptr;
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+	return p;
+}
+
+extern "C" void ihp_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out)
 {
