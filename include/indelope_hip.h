@@ -254,7 +254,7 @@ typedef struct {
  */
 typedef struct {
 	int32_t  n_regions;
-	int64_t  n_contigs, n_events, n_cigar_words, n_bases;
+	int64_t  n_contigs, n_events, n_cigar_words, n_bases, n_hits;
 	int32_t *status;              /* [R] IHP_OK or IHP_E_*                       */
 	int32_t *n_contigs_pre;       /* [R] assemble's n_contigs, indelope.nim:171  */
 	int64_t *contig_off;          /* [R+1]                                       */
@@ -272,6 +272,14 @@ typedef struct {
 	uint32_t *cigar;
 	int64_t *event_off;           /* [C+1] into events                           */
 	ihp_event *events;
+	/* Per tallied event, one entry per read of its region (BAM order): the start index in the
+	 * (untrimmed) read of the first k-mer whose canonical code is the ref / alt k-mer
+	 * (indelope.nim:301-309), or -1 (no such k-mer, or the read was not examined: mapq < 10,
+	 * :294).  This is what `rdists/adists/rmapqs/amapqs` (:302-309) are built from: the `kmer`
+	 * package's distance `d` is a property of that window, the mapq is the read's.  Events
+	 * that were not tallied have no entries.                                               */
+	int64_t *hit_off;             /* [E+1] into ref_hit / alt_hit                */
+	int32_t *ref_hit, *alt_hit;
 } ihp_batch_out;
 
 /* Page-locked host memory for the caller's flat batch arrays: uploads from it are DMA

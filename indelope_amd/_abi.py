@@ -119,13 +119,14 @@ EVENT_DTYPE = np.dtype({
 
 class BatchOut(C.Structure):
     _fields_ = [("n_regions", C.c_int32), ("n_contigs", C.c_int64), ("n_events", C.c_int64),
-                ("n_cigar_words", C.c_int64), ("n_bases", C.c_int64),
+                ("n_cigar_words", C.c_int64), ("n_bases", C.c_int64), ("n_hits", C.c_int64),
                 ("status", i32p), ("n_contigs_pre", i32p), ("contig_off", i64p),
                 ("ctg_start", i64p), ("ctg_nreads", i64p), ("ctg_seq_off", i64p),
                 ("ctg_seq", u8p), ("ctg_support", u32p),
                 ("aln_flags", i32p), ("aln_ref_start", i64p), ("aln_ref_len", i32p),
                 ("aln_ez", C.POINTER(Ez)), ("cigar_off", i64p), ("cigar", u32p),
-                ("event_off", i64p), ("events", C.POINTER(Event))]
+                ("event_off", i64p), ("events", C.POINTER(Event)),
+                ("hit_off", i64p), ("ref_hit", i32p), ("alt_hit", i32p)]
 
 
 class RegionSummary(C.Structure):

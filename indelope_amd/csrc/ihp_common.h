@@ -127,6 +127,8 @@ struct DevEvent {
 	int ref_support, alt_support, both_found;   // as at indelope.nim:375 (alignment votes when `aligned`)
 	char ref_kmer[32], alt_kmer[32];
 	int kmer_ref, kmer_alt, kmer_both;          // the k-mer tally itself (indelope.nim:285-311)
+	int pad2;
+	long long hit_off;                          // into the hit pool: nreads ref positions, then nreads alt positions; -1 none
 };
 
 // One event whose k-mer tally found both k-mers in some read (indelope.nim:313): the alignment fallback

@@ -618,6 +618,7 @@ struct ihp_batch {
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
+	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
 	int grid_fb = 0, lds_fb = 0, fb_cig_cap = 0, max_region_reads = 0;
 	size_t fb_p_cap = 0;
 	// outputs
@@ -635,7 +636,7 @@ struct ihp_batch {
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_WORDS = 20 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_HIT = 20, M_WORDS = 24 };
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
@@ -796,6 +797,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(cig_pool, 4 * (size_t)b->cig_pool_cap);
 	AL(ev_off, 8 * slots); AL(n_ev, 4 * slots); AL(ev_pool, sizeof(DevEvent) * (size_t)b->ev_pool_cap);
 	AL(summary, sizeof(ihp_region_summary) * R);
+	b->hit_cap = 2 * (4 * NR + 64 * (long long)std::max(1, b->max_region_reads));   // room for 4 tallied events per region on average
+	AL(hit_pool, sizeof(int) * (size_t)b->hit_cap);
 #undef AL
 	for (auto &e : b->ev) HIPC(hipEventCreate(&e));
 	HIPC(hipStreamSynchronize(s));
@@ -887,6 +890,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>(); a.cig_pool = b->cig_pool.as<uint32_t>();
 		a.P.K = p.K; a.P.min_event_len = p.min_event_len; a.P.max_events = p.max_events; a.P.min_mapq_tally = p.min_mapq_tally;
 		a.P.fallback = p.fallback; a.fb_items = p.fallback ? b->fb_items.as<FbItem>() : nullptr; a.fb_count = misc + M_NFB;
+		a.hit_pool = b->hit_pool.as<int>(); a.hit_cursor = (unsigned long long *)(misc + M_HIT); a.hit_cap = b->hit_cap;
+		a.hit_overflow = misc + M_OVF_HIT;
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
 		a.overflow = misc + M_OVF; a.work_counter = wq + 5 * WQ_WORDS;
@@ -1033,14 +1038,15 @@ SlabCache g_slabs;
 // section offsets of the flat result arrays inside a slab (the same on the device and on the host)
 struct OutLayout {
 	size_t status, n_pre, contig_off, ctg_start, ctg_nreads, ctg_seq_off, aln_ref_start, cigar_off, event_off, events,
-	       aln_ez, aln_flags, aln_ref_len, ctg_support, cigar, ctg_seq, bytes;
-	OutLayout(long long R, long long C, long long B, long long W, long long E) {
+	       aln_ez, aln_flags, aln_ref_len, ctg_support, cigar, ctg_seq, hit_off, ref_hit, alt_hit, bytes;
+	OutLayout(long long R, long long C, long long B, long long W, long long E, long long Hn) {
 		size_t o = 0;
 		auto sec = [&](size_t elem, long long n) { const size_t at = o; o += ((size_t)(n > 0 ? n : 1) * elem + 15) / 16 * 16; return at; };
 		contig_off = sec(8, R + 1); ctg_start = sec(8, C); ctg_nreads = sec(8, C); ctg_seq_off = sec(8, C + 1);
-		aln_ref_start = sec(8, C); cigar_off = sec(8, C + 1); event_off = sec(8, C + 1); events = sec(sizeof(ihp_event), E);
+		aln_ref_start = sec(8, C); cigar_off = sec(8, C + 1); event_off = sec(8, C + 1); hit_off = sec(8, E + 1);
+		events = sec(sizeof(ihp_event), E);
 		aln_ez = sec(sizeof(ihp_ez), C); status = sec(4, R); n_pre = sec(4, R); aln_flags = sec(4, C); aln_ref_len = sec(4, C);
-		ctg_support = sec(4, B); cigar = sec(4, W); ctg_seq = sec(1, B);
+		ctg_support = sec(4, B); cigar = sec(4, W); ref_hit = sec(4, Hn); alt_hit = sec(4, Hn); ctg_seq = sec(1, B);
 		bytes = o;
 	}
 };
@@ -1066,27 +1072,28 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, s));
 	// per-region counts and their prefix sums (k_pack_count, k_pack_scan)
 	const size_t S = (size_t)R + 1;
-	if (!b->pack_cnt.p) { int rc = b->pack_cnt.alloc(sizeof(long long) * 4 * S); if (rc) return rc; }
+	if (!b->pack_cnt.p) { int rc = b->pack_cnt.alloc(sizeof(long long) * 5 * S); if (rc) return rc; }
 	long long *cnt = b->pack_cnt.as<long long>();
 	if (R > 0) {
 		PackCountArgs a;
 		a.R = R; a.region_read_off = b->region_read_off.as<long long>(); a.n_final = b->n_final.as<int>();
 		a.ctg_len = b->ctg_len.as<int>(); a.aln_flags = b->aln_flags.as<int>(); a.n_ev = b->n_ev.as<int>();
-		a.ez = b->ez.as<KswOut>(); a.cnt = cnt;
+		a.ez = b->ez.as<KswOut>(); a.ev_off = b->ev_off.as<long long>(); a.ev_pool = b->ev_pool.as<DevEvent>(); a.cnt = cnt;
 		hipLaunchKernelGGL(k_pack_count, dim3((R + 255) / 256), dim3(256), 0, s, a);
 		HIPC(hipGetLastError());
 	}
 	hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, R, cnt);
 	HIPC(hipGetLastError());
-	long long tot[4];
-	for (int k = 0; k < 4; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+	long long tot[5];
+	for (int k = 0; k < 5; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
 	HIPC(hipStreamSynchronize(s));
-	if (misc[M_OVF] || misc[M_OVF + 1] || misc[M_OVF + 2]) {
-		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d", misc[M_OVF], misc[M_OVF + 1], misc[M_OVF + 2]);
+	if (misc[M_OVF] || misc[M_OVF + 1] || misc[M_OVF + 2] || misc[M_OVF_HIT]) {
+		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d hits=%d", misc[M_OVF], misc[M_OVF + 1],
+		         misc[M_OVF + 2], misc[M_OVF_HIT]);
 		return IHP_E_CAPACITY;
 	}
-	const long long C = tot[0], B = tot[1], W = tot[2], E = tot[3];
-	const OutLayout L(R, C, B, W, E);
+	const long long C = tot[0], B = tot[1], W = tot[2], E = tot[3], Hn = tot[4];
+	const OutLayout L(R, C, B, W, E, Hn);
 	if (b->pack_slab.n < L.bytes) {
 		int rc = b->pack_slab.alloc(L.bytes + L.bytes / 8);
 		if (rc) return rc;
@@ -1106,6 +1113,8 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 		a.cig_off = b->cig_off.as<long long>(); a.ev_off = b->ev_off.as<long long>();
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>(); a.ez = b->ez.as<KswOut>();
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.ev_pool = b->ev_pool.as<DevEvent>(); a.cnt = cnt;
+		a.hit_pool = b->hit_pool.as<int>();
+		a.o_hit_off = (int64_t *)(dev + L.hit_off); a.o_ref_hit = (int32_t *)(dev + L.ref_hit); a.o_alt_hit = (int32_t *)(dev + L.alt_hit);
 		a.o_status = (int32_t *)(dev + L.status); a.o_n_pre = (int32_t *)(dev + L.n_pre); a.o_contig_off = (int64_t *)(dev + L.contig_off);
 		a.o_ctg_start = (int64_t *)(dev + L.ctg_start); a.o_ctg_nreads = (int64_t *)(dev + L.ctg_nreads);
 		a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off); a.o_seq = (uint8_t *)(dev + L.ctg_seq); a.o_sup = (uint32_t *)(dev + L.ctg_support);
@@ -1119,7 +1128,8 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 		if (e == hipSuccess) e = hipStreamSynchronize(s);
 		if (e != hipSuccess) { g_slabs.put(slab); return hip_fail(e, "pack / copy of the results", __LINE__); }
 	}
-	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B;
+	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B; out->n_hits = Hn;
+	out->hit_off = (int64_t *)(host + L.hit_off); out->ref_hit = (int32_t *)(host + L.ref_hit); out->alt_hit = (int32_t *)(host + L.alt_hit);
 	out->status = (int32_t *)(host + L.status); out->n_contigs_pre = (int32_t *)(host + L.n_pre);
 	out->contig_off = (int64_t *)(host + L.contig_off);
 	out->ctg_start = (int64_t *)(host + L.ctg_start); out->ctg_nreads = (int64_t *)(host + L.ctg_nreads);

@@ -487,6 +487,7 @@ struct TallyArgs {
 	long long *prof;                           // optional cycle counters (diagnostics)
 	int lds_bytes;                             // dynamic LDS for staging 64 reads
 	FbItem *fb_items; int *fb_count;           // events handed to the alignment fallback (one slot per event)
+	int *hit_pool; unsigned long long *hit_cursor; long long hit_cap; int *hit_overflow;   // first-hit positions per (tallied event, read)
 };
 
 __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 				fill_events(a.cig_pool + coff, ntrunc, a.out_seq + jb.q_off, jb.qlen,
 				            (int)(a.ctg_start[jb.out] - a.ref_origin[r]), a.ref_bases + jb.t_off, jb.tlen,
 				            a.bases, a.read_off, a.mapq, a.region_read_off[r], a.region_read_off[r + 1],
-				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count);
+				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count,
+				            a.hit_pool, a.hit_cursor, a.hit_cap, a.hit_overflow);
 			} else {
 				if (lane == 0) atomicExch(&a.overflow[2], 1);
 				eoff = -1; nev = 0;
@@ -704,7 +706,8 @@ struct PackCountArgs {
 	const long long *region_read_off;
 	const int *n_final, *ctg_len, *aln_flags, *n_ev;
 	const KswOut *ez;
-	long long *cnt;                 // [4][R+1]: contigs, bases, cigar words, events
+	const long long *ev_off; const DevEvent *ev_pool;
+	long long *cnt;                 // [5][R+1]: contigs, bases, cigar words, events, hit entries
 };
 
 __global__ void k_pack_count(const PackCountArgs a)
@@ -713,37 +716,42 @@ __global__ void k_pack_count(const PackCountArgs a)
 	if (r >= a.R) return;
 	const long long base = a.region_read_off[r];
 	const int n = a.n_final[r];
-	long long B = 0, W = 0, E = 0;
+	const long long nr = a.region_read_off[r + 1] - base;
+	long long B = 0, W = 0, E = 0, Hn = 0;
 	for (int k = 0; k < n; ++k) {
 		const long long sl = base + k;
 		B += a.ctg_len[sl];
-		if (a.aln_flags[sl] & IHP_ALN_DONE) { const int nc = a.ez[sl].n_cigar; W += nc > 0 ? nc : 0; E += a.n_ev[sl]; }
+		if (a.aln_flags[sl] & IHP_ALN_DONE) {
+			const int nc = a.ez[sl].n_cigar, ne = a.n_ev[sl];
+			W += nc > 0 ? nc : 0; E += ne;
+			for (int e = 0; e < ne; ++e) if (a.ev_pool[a.ev_off[sl] + e].hit_off >= 0) Hn += nr;
+		}
 	}
 	const size_t S = (size_t)a.R + 1;
-	a.cnt[r] = n; a.cnt[S + r] = B; a.cnt[2 * S + r] = W; a.cnt[3 * S + r] = E;
+	a.cnt[r] = n; a.cnt[S + r] = B; a.cnt[2 * S + r] = W; a.cnt[3 * S + r] = E; a.cnt[4 * S + r] = Hn;
 }
 
 // in place: counts -> exclusive prefix sums, totals at index R.  One workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void k_pack_scan(int R, long long *cnt)
 {
-	__shared__ long long part[4][1024];
+	__shared__ long long part[5][1024];
 	const int t = (int)threadIdx.x;
 	const long long per = ((long long)R + 1023) / 1024;
 	const long long lo = (long long)t * per < R ? (long long)t * per : R, hi = lo + per < R ? lo + per : R;
 	const size_t S = (size_t)R + 1;
-	for (int a = 0; a < 4; ++a) {
+	for (int a = 0; a < 5; ++a) {
 		long long s = 0;
 		for (long long i = lo; i < hi; ++i) s += cnt[a * S + i];
 		part[a][t] = s;
 	}
 	__syncthreads();
-	if (t < 4) {
+	if (t < 5) {
 		long long run = 0;
 		for (int i = 0; i < 1024; ++i) { const long long c = part[t][i]; part[t][i] = run; run += c; }
 		cnt[t * S + R] = run;
 	}
 	__syncthreads();
-	for (int a = 0; a < 4; ++a) {
+	for (int a = 0; a < 5; ++a) {
 		long long run = part[a][t];
 		for (long long i = lo; i < hi; ++i) { const long long c = cnt[a * S + i]; cnt[a * S + i] = run; run += c; }
 	}
@@ -755,12 +763,14 @@ struct PackArgs {
 	const int *status, *n_pre, *n_final, *ctg_len, *aln_flags, *aln_ref_len, *n_ev;
 	const long long *ctg_start, *ctg_nreads, *ctg_seq_off, *aln_ref_start, *cig_off, *ev_off;
 	const uint8_t *out_seq; const uint32_t *out_sup; const KswOut *ez; const uint32_t *cig_pool; const DevEvent *ev_pool;
+	const int *hit_pool;
 	const long long *cnt;           // prefix sums of k_pack_scan
 	// the flat arrays of ihp_batch_out (device slab)
 	int32_t *o_status, *o_n_pre; int64_t *o_contig_off;
 	int64_t *o_ctg_start, *o_ctg_nreads, *o_ctg_seq_off; uint8_t *o_seq; uint32_t *o_sup;
 	int32_t *o_aln_flags; int64_t *o_aln_ref_start; int32_t *o_aln_ref_len; ihp_ez *o_ez;
 	int64_t *o_cigar_off; uint32_t *o_cigar; int64_t *o_event_off; ihp_event *o_events;
+	int64_t *o_hit_off; int32_t *o_ref_hit, *o_alt_hit;
 };
 
 __global__ __launch_bounds__(64) void k_pack(const PackArgs a)
@@ -768,12 +778,13 @@ __global__ __launch_bounds__(64) void k_pack(const PackArgs a)
 	const int lane = lane_id();
 	const size_t S = (size_t)a.R + 1;
 	for (int r = (int)blockIdx.x; r <= a.R; r += (int)gridDim.x) {
-		long long c = a.cnt[r], bb = a.cnt[S + r], wd = a.cnt[2 * S + r], ev = a.cnt[3 * S + r];
+		long long c = a.cnt[r], bb = a.cnt[S + r], wd = a.cnt[2 * S + r], ev = a.cnt[3 * S + r], hn = a.cnt[4 * S + r];
 		if (r == a.R) {                                       // the closing entries of the offset arrays
-			if (lane == 0) { a.o_contig_off[r] = c; a.o_ctg_seq_off[c] = bb; a.o_cigar_off[c] = wd; a.o_event_off[c] = ev; }
+			if (lane == 0) { a.o_contig_off[r] = c; a.o_ctg_seq_off[c] = bb; a.o_cigar_off[c] = wd; a.o_event_off[c] = ev; a.o_hit_off[ev] = hn; }
 			break;
 		}
 		const long long base = a.region_read_off[r], origin = a.ref_origin[r];
+		const long long nr = a.region_read_off[r + 1] - base;
 		const int n = a.n_final[r];
 		if (lane == 0) { a.o_status[r] = a.status[r]; a.o_n_pre[r] = a.n_pre[r]; a.o_contig_off[r] = c; }
 		for (int k = 0; k < n; ++k, ++c) {
@@ -812,6 +823,13 @@ __global__ __launch_bounds__(64) void k_pack(const PackArgs a)
 				x.gt = IHP_GT_UNKNOWN; x.kmer_ref_support = d.kmer_ref; x.kmer_alt_support = d.kmer_alt; x.kmer_both_found = d.kmer_both;
 				x.gl[0] = x.gl[1] = x.gl[2] = 0; x.qual = 0;         // genotype(): host, fp64 (genotyper.nim:36-47)
 				a.o_events[ev + en] = x;
+			}
+			for (int e = 0; e < ne; ++e) {                     // first-hit positions, in event order
+				const long long ho = a.ev_pool[a.ev_off[sl] + e].hit_off;
+				if (lane == 0) a.o_hit_off[ev + e] = hn;
+				if (ho < 0) continue;
+				for (long long i = lane; i < nr; i += 64) { a.o_ref_hit[hn + i] = a.hit_pool[ho + i]; a.o_alt_hit[hn + i] = a.hit_pool[ho + nr + i]; }
+				hn += nr;
 			}
 			ev += ne;
 		}

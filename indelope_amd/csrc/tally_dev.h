@@ -33,13 +33,17 @@ __device__ inline bool mincode_dev(const char *kmer, int K, unsigned long long &
 
 typedef uint32_t tally_u32u __attribute__((aligned(1)));
 
+__device__ __forceinline__ bool lane_in_mask(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // indelope.nim:293-311: lanes = reads.  counts[0..3) = ref_support, alt_support, both_found.
 // Each lane walks its read four bases per (unaligned) dword load; the byte arrays are padded so the last
 // partial dword of the last read is readable.
 __device__ inline void tally_reads(const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                    long long r0, long long r1, int min_mapq, int K,
-                                   unsigned long long refe, unsigned long long alte, int counts[3])
+                                   unsigned long long refe, unsigned long long alte, int counts[3],
+                                   int *ref_hit = nullptr, int *alt_hit = nullptr)
 {
+	// ref_hit / alt_hit (optional): per read, the start index of the first window that matched (-1: none), entry ri - r0
 	const int lane = lane_id();
 	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
 	const int hs = 2 * (K - 1);
@@ -47,6 +51,7 @@ __device__ inline void tally_reads(const uint8_t *bases, const long long *read_o
 	for (long long b = r0; b < r1; b += 64) {
 		const long long ri = b + lane;
 		bool rf = false, af = false;
+		int rpos = -1, apos = -1;
 		if (ri < r1 && !(mapq && mapq[ri] < min_mapq)) {     // :294
 			const uint8_t *seq = bases + read_off[ri];
 			const int n = (int)(read_off[ri + 1] - read_off[ri]);
@@ -65,8 +70,8 @@ __device__ inline void tally_reads(const uint8_t *bases, const long long *read_o
 							rc = (rc >> 2) | ((unsigned long long)(3 - c) << hs);
 							if (++valid >= K) {
 								const unsigned long long e = f < rc ? f : rc;
-								rf |= e == refe;                         // :301-309
-								af |= e == alte;
+								if (e == refe && !rf) { rf = true; rpos = i0 + j - (K - 1); }   // :301-304
+								if (e == alte && !af) { af = true; apos = i0 + j - (K - 1); }   // :306-309
 							}
 						}
 					}
@@ -76,6 +81,7 @@ __device__ inline void tally_reads(const uint8_t *bases, const long long *read_o
 		nref += popc64(ballot(rf));
 		nalt += popc64(ballot(af));
 		nboth += popc64(ballot(rf && af));                       // :310-311
+		if (ref_hit && ri < r1) { ref_hit[ri - r0] = rpos; alt_hit[ri - r0] = apos; }
 	}
 	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
 }
@@ -94,7 +100,7 @@ __device__ __forceinline__ unsigned long long revcomp_code(unsigned long long co
 __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                        long long r0, long long r1, int min_mapq, int K,
                                        unsigned long long refe, unsigned long long alte, int counts[3],
-                                       uint32_t *lds32, int lds_bytes)
+                                       uint32_t *lds32, int lds_bytes, int *ref_hit = nullptr, int *alt_hit = nullptr)
 {
 	const int lane = lane_id();
 	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
@@ -107,7 +113,8 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 		const int nbytes = (int)(read_off[e] - base0);
 		if (nbytes + 8 > lds_bytes) {                            // does not fit: walk HBM directly (rare)
 			int c[3];
-			tally_reads(bases, read_off, mapq, b, e, min_mapq, K, refe, alte, c);
+			tally_reads(bases, read_off, mapq, b, e, min_mapq, K, refe, alte, c,
+			            ref_hit ? ref_hit + (b - r0) : nullptr, alt_hit ? alt_hit + (b - r0) : nullptr);
 			nref += c[0]; nalt += c[1]; nboth += c[2];
 			continue;
 		}
@@ -124,7 +131,7 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 		if (use) { off = (int)(read_off[ri] - base0); n = (int)(read_off[ri + 1] - read_off[ri]); }
 		const int nmax = wave_max_i32s(n);
 		unsigned long long f = 0, rfm = 0, afm = 0;
-		int run = 0;
+		int run = 0, rpos = -1, apos = -1;
 		for (int i0 = 0; i0 < nmax; i0 += 4) {
 			const int bo = off + i0, w = bo >> 2;
 			const unsigned wv = __builtin_amdgcn_alignbit(lds32[w + 1], lds32[w], (unsigned)(bo & 3) * 8u);
@@ -136,12 +143,17 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 				run = acgt ? run + 1 : 0;
 				f = ((f << 2) | (unsigned long long)c) & mask;
 				const unsigned long long full = ballot(run >= K);
-				rfm |= full & (ballot(f == ref_f) | ballot(f == ref_r));      // :301-309
-				afm |= full & (ballot(f == alt_f) | ballot(f == alt_r));
+				const unsigned long long hr = full & (ballot(f == ref_f) | ballot(f == ref_r));   // :301-309
+				const unsigned long long ha = full & (ballot(f == alt_f) | ballot(f == alt_r));
+				const int wpos = i0 + j - (K - 1);                            // start of this window: the first hit is kept
+				rpos = lane_in_mask(hr & ~rfm) ? wpos : rpos;
+				apos = lane_in_mask(ha & ~afm) ? wpos : apos;
+				rfm |= hr; afm |= ha;
 			}
 		}
 		const unsigned long long usem = ballot(use);
 		rfm &= usem; afm &= usem;
+		if (ref_hit && ri < e) { ref_hit[ri - r0] = use ? rpos : -1; alt_hit[ri - r0] = use ? apos : -1; }
 		nref += popc64(rfm);
 		nalt += popc64(afm);
 		nboth += popc64(rfm & afm);                               // :310-311
@@ -227,7 +239,8 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
                                    const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                    long long r0, long long r1, const TallyParams P, DevEvent *ev,
                                    uint32_t *lds32, int lds_bytes,
-                                   int job, int ev_index0, FbItem *fb_items, int *fb_count)
+                                   int job, int ev_index0, FbItem *fb_items, int *fb_count,
+                                   int *hit_pool, unsigned long long *hit_cursor, long long hit_cap, int *hit_overflow)
 {
 	const int lane = lane_id();
 	const int K = P.K;
@@ -279,8 +292,18 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
 				else if (!mincode_lanes(rk, K, refe) || !mincode_lanes(ak, K, alte)) status = IHP_EV_NON_ACGT;
 			}
 		}
+		long long hoff = -1;
 		if (status < 0) {
-			tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes);
+			// first-hit positions of every read (the side data of :302-309): 2 x nreads ints from a bump pool
+			const long long nr = r1 - r0;
+			if (hit_pool && nr > 0) {
+				long long o = 0;
+				if (lane == 0) o = (long long)atomicAdd(hit_cursor, (unsigned long long)(2 * nr));
+				hoff = uni(o);
+				if (hoff + 2 * nr > hit_cap) { hoff = -1; if (lane == 0) atomicExch(hit_overflow, 1); }
+			}
+			tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
+			                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr);
 			status = IHP_EV_TALLIED;
 		}
 		DevEvent *o = ev + ii;
@@ -292,6 +315,7 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
 			o->fallback = fb;
 			o->aligned = run_fb; o->cf_offset = cf;                      // :372
 			o->kmer_ref = counts[0]; o->kmer_alt = counts[1]; o->kmer_both = counts[2];
+			o->hit_off = hoff;
 			// the fallback kernel counts its votes into the zeroed fields (:316, :320-321)
 			o->ref_support = run_fb ? 0 : counts[0]; o->alt_support = run_fb ? 0 : counts[1];
 			o->both_found = run_fb ? 0 : counts[2];

@@ -142,7 +142,7 @@ class BatchResult:
     """numpy copy of `ihp_batch_out` (the C buffers are freed right after)."""
     FIELDS = ("status", "n_contigs_pre", "contig_off", "ctg_start", "ctg_nreads", "ctg_seq_off",
               "ctg_seq", "ctg_support", "aln_flags", "aln_ref_start", "aln_ref_len", "aln_ez",
-              "cigar_off", "cigar", "event_off", "events")
+              "cigar_off", "cigar", "event_off", "events", "hit_off", "ref_hit", "alt_hit")
 
     def __init__(self, o):
         R, Cn, E, W, B = o.n_regions, o.n_contigs, o.n_events, o.n_cigar_words, o.n_bases
@@ -163,6 +163,10 @@ class BatchResult:
         self.cigar = _np(o.cigar, W, np.uint32)
         self.event_off = _np(o.event_off, Cn + 1, np.int64)
         self.events = _np(o.events, E, A.EVENT_DTYPE)
+        self.n_hits = o.n_hits
+        self.hit_off = _np(o.hit_off, E + 1, np.int64)
+        self.ref_hit = _np(o.ref_hit, o.n_hits, np.int32)
+        self.alt_hit = _np(o.alt_hit, o.n_hits, np.int32)
 
     def contig_sequence(self, c):
         return self.ctg_seq[self.ctg_seq_off[c]:self.ctg_seq_off[c + 1]].tobytes().decode("latin1")

@@ -52,7 +52,7 @@ type
 
   IhpBatchOut* {.importc: "ihp_batch_out", header: "indelope_hip.h", bycopy.} = object
     n_regions*: int32
-    n_contigs*, n_events*, n_cigar_words*, n_bases*: int64
+    n_contigs*, n_events*, n_cigar_words*, n_bases*, n_hits*: int64
     status*, n_contigs_pre*: ptr int32
     contig_off*, ctg_start*, ctg_nreads*, ctg_seq_off*: ptr int64
     ctg_seq*: ptr uint8
@@ -65,6 +65,8 @@ type
     cigar*: ptr uint32
     event_off*: ptr int64
     events*: ptr IhpEvent
+    hit_off*: ptr int64                   # [E+1]; per tallied event one entry per read of its region:
+    ref_hit*, alt_hit*: ptr int32         # start of the first ref / alt k-mer window in the read, -1 = none (indelope.nim:301-309)
 
 proc ihp_init*(device: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_strerror*(code: cint): cstring {.importc, cdecl, header: "indelope_hip.h".}

@@ -60,12 +60,13 @@ static int mincode(const char *kmer, int K, uint64_t *code)
 
 /* indelope.nim:293-311 for one read: rolling canonical code over every k-mer */
 static void tally_read(const uint8_t *seq, int64_t n, int K, uint64_t refe, uint64_t alte,
-                       int *ref_found, int *alt_found)
+                       int *ref_found, int *alt_found, int32_t *ref_pos, int32_t *alt_pos)
 {
 	const uint64_t mask = K < 32 ? (((uint64_t)1 << (2 * K)) - 1) : ~(uint64_t)0;
 	uint64_t f = 0, rc = 0;
 	int valid = 0;
 	*ref_found = *alt_found = 0;
+	*ref_pos = *alt_pos = -1;
 	for (int64_t i = 0; i < n; ++i) {
 		int b = base2(seq[i]);
 		if (b < 0) { valid = 0; f = rc = 0; continue; }
@@ -74,8 +75,8 @@ static void tally_read(const uint8_t *seq, int64_t n, int K, uint64_t refe, uint
 		if (++valid < K) continue;
 		orc_cnt_kmers++;
 		uint64_t e = f < rc ? f : rc;
-		if (!*ref_found && e == refe) *ref_found = 1;
-		if (!*alt_found && e == alte) *alt_found = 1;
+		if (!*ref_found && e == refe) { *ref_found = 1; *ref_pos = (int32_t)(i - K + 1); }   /* :301-304 */
+		if (!*alt_found && e == alte) { *alt_found = 1; *alt_pos = (int32_t)(i - K + 1); }   /* :306-309 */
 	}
 }
 
@@ -89,8 +90,8 @@ int orc_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64_t *read_of
 	if (!mincode(ref_kmer, K, &refe) || !mincode(alt_kmer, K, &alte)) return IHP_E_UNSUPPORTED;
 	for (int32_t i = 0; i < n_reads; ++i) {
 		if (mapq && mapq[i] < min_mapq) continue;    /* :294 */
-		int rf, af;
-		tally_read(bases + read_off[i], read_off[i + 1] - read_off[i], K, refe, alte, &rf, &af);
+		int rf, af; int32_t rp, apos;
+		tally_read(bases + read_off[i], read_off[i + 1] - read_off[i], K, refe, alte, &rf, &af, &rp, &apos);
 		counts[0] += rf; counts[1] += af;
 		if (rf && af) counts[2] += 1;
 	}
@@ -126,6 +127,7 @@ double orc_genotype_qual(const ihp_genotype_t *g)
 typedef struct {
 	int32_t flags; int64_t ref_start; int32_t ref_len;
 	ihp_ez ez; uint32_t *cigar; int32_t n_events; ihp_event *events;
+	int32_t **hits;              /* per event: NULL, or [2 * n_reads of the region]: ref then alt first-hit positions */
 } ctg_res;
 
 typedef struct {
@@ -291,6 +293,7 @@ static void run_region(const ihp_params *p, const ihp_batch_in *in, int32_t r, r
 		}
 		if (nev == 0 || nev > p->max_events) continue;             /* :229 */
 		cr->events = (ihp_event *)calloc((size_t)nev, sizeof(ihp_event));
+		cr->hits = (int32_t **)calloc((size_t)nev, sizeof(int32_t *));
 		cr->n_events = nev;
 		int64_t toff = ctg->start, qoff = 0;
 		int ii = -1;
@@ -345,11 +348,14 @@ static void run_region(const ihp_params *p, const ihp_batch_in *in, int32_t r, r
 			if (!mincode(ev->ref_kmer, K, &refe) || !mincode(ev->alt_kmer, K, &alte)) {
 				ev->status = IHP_EV_NON_ACGT; continue;
 			}
+			int32_t *hits = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(r1 - r0 ? r1 - r0 : 1));
+			cr->hits[ii] = hits;
 			for (int64_t ri = r0; ri < r1; ++ri) {                 /* :293-311 */
+				hits[ri - r0] = hits[(r1 - r0) + ri - r0] = -1;
 				if (in->mapq[ri] < p->min_mapq_tally) continue;
 				int rf, af;
 				tally_read(in->bases + in->read_off[ri], in->read_off[ri + 1] - in->read_off[ri],
-				           K, refe, alte, &rf, &af);
+				           K, refe, alte, &rf, &af, &hits[ri - r0], &hits[(r1 - r0) + ri - r0]);
 				ev->ref_support += rf; ev->alt_support += af;
 				if (rf && af) ev->both_found += 1;
 			}
@@ -410,16 +416,18 @@ int orc_run_regions_mt(const ihp_params *p, const ihp_batch_in *in, ihp_batch_ou
 	free(jobs); free(th);
 
 	/* flatten */
-	int64_t C = 0, E = 0, W = 0, B = 0;
+	int64_t C = 0, E = 0, W = 0, B = 0, Hn = 0;
 	for (int32_t r = 0; r < R; ++r) {
 		C += res[r].contigs.n;
+		const int64_t nr = in->region_read_off[r + 1] - in->region_read_off[r];
 		for (int64_t c = 0; c < res[r].contigs.n; ++c) {
 			B += res[r].contigs.v[c]->len;
 			W += res[r].res[c].ez.n_cigar;
 			E += res[r].res[c].n_events;
+			for (int e = 0; e < res[r].res[c].n_events; ++e) if (res[r].res[c].hits[e]) Hn += nr;
 		}
 	}
-	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B;
+	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B; out->n_hits = Hn;
 #define ALLOC(T, n) ((T *)calloc((size_t)((n) ? (n) : 1), sizeof(T)))
 	out->status = ALLOC(int32_t, R); out->n_contigs_pre = ALLOC(int32_t, R);
 	out->contig_off = ALLOC(int64_t, R + 1);
@@ -430,9 +438,11 @@ int orc_run_regions_mt(const ihp_params *p, const ihp_batch_in *in, ihp_batch_ou
 	out->aln_ref_len = ALLOC(int32_t, C); out->aln_ez = ALLOC(ihp_ez, C);
 	out->cigar_off = ALLOC(int64_t, C + 1); out->cigar = ALLOC(uint32_t, W);
 	out->event_off = ALLOC(int64_t, C + 1); out->events = ALLOC(ihp_event, E);
+	out->hit_off = ALLOC(int64_t, E + 1); out->ref_hit = ALLOC(int32_t, Hn); out->alt_hit = ALLOC(int32_t, Hn);
 #undef ALLOC
-	int64_t c = 0, b = 0, wd = 0, ev = 0;
+	int64_t c = 0, b = 0, wd = 0, ev = 0, hn = 0;
 	for (int32_t r = 0; r < R; ++r) {
+		const int64_t nr = in->region_read_off[r + 1] - in->region_read_off[r];
 		out->status[r] = res[r].status; out->n_contigs_pre[r] = res[r].n_pre;
 		out->contig_off[r] = c;
 		for (int64_t k = 0; k < res[r].contigs.n; ++k, ++c) {
@@ -450,13 +460,22 @@ int orc_run_regions_mt(const ihp_params *p, const ihp_batch_in *in, ihp_batch_ou
 			wd += cr->ez.n_cigar;
 			out->event_off[c] = ev;
 			if (cr->n_events) memcpy(out->events + ev, cr->events, (size_t)cr->n_events * sizeof(ihp_event));
+			for (int e = 0; e < cr->n_events; ++e) {
+				out->hit_off[ev + e] = hn;
+				if (!cr->hits[e]) continue;
+				memcpy(out->ref_hit + hn, cr->hits[e], sizeof(int32_t) * (size_t)nr);
+				memcpy(out->alt_hit + hn, cr->hits[e] + nr, sizeof(int32_t) * (size_t)nr);
+				hn += nr;
+				free(cr->hits[e]);
+			}
 			ev += cr->n_events;
-			free(cr->cigar); free(cr->events);
+			free(cr->cigar); free(cr->events); free(cr->hits);
 			orc_contig_free(g);
 		}
 		free(res[r].contigs.v); free(res[r].res);
 	}
 	out->contig_off[R] = c; out->ctg_seq_off[C] = b; out->cigar_off[C] = wd; out->event_off[C] = ev;
+	out->hit_off[E] = hn;
 	free(res);
 	return 0;
 }
@@ -468,7 +487,8 @@ typedef struct { const ihp_params *p; const ihp_batch_in *in; int32_t lo, hi; in
 static void free_region(region_res *rr)
 {
 	for (int64_t k = 0; k < rr->contigs.n; ++k) {
-		free(rr->res[k].cigar); free(rr->res[k].events);
+		for (int e = 0; e < rr->res[k].n_events; ++e) free(rr->res[k].hits[e]);
+		free(rr->res[k].cigar); free(rr->res[k].events); free(rr->res[k].hits);
 		orc_contig_free(rr->contigs.v[k]);
 	}
 	free(rr->contigs.v); free(rr->res);
@@ -515,5 +535,6 @@ void orc_free_out(ihp_batch_out *out)
 	free(out->ctg_seq); free(out->ctg_support);
 	free(out->aln_flags); free(out->aln_ref_start); free(out->aln_ref_len); free(out->aln_ez);
 	free(out->cigar_off); free(out->cigar); free(out->event_off); free(out->events);
+	free(out->hit_off); free(out->ref_hit); free(out->alt_hit);
 	memset(out, 0, sizeof(*out));
 }

@@ -327,3 +327,44 @@ def test_device_summary_records(hip):
         hip.batch_free(h)
     exp = idist.summaries_from_result(res).view(np.int32).reshape(-1, idist.SUMMARY_WORDS)
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
+def test_concurrent_batches_from_host_threads(hip, oracle):
+    """Batches driven from several host threads at once (each on its own stream, sharing the device and host pools)
+    give the same results as one at a time; inputs staged in ihp_host_alloc memory work like pageable ones."""
+    import ctypes as C
+    import threading
+    batches = [synth.generate(120, n_reads=(8, 64), err_rate=1e-3, config_id=60 + i, dup_frac=0.1 * (i % 2))[0] for i in range(4)]
+    # one batch staged in pinned memory
+    pinned = []
+    b0 = batches[0]
+    for f in ("bases", "quals", "read_start", "read_stop", "mapq", "read_off", "region_read_off", "ref_bases", "ref_off", "ref_origin"):
+        a = np.ascontiguousarray(getattr(b0, f))
+        ptr = hip.b.host_alloc(max(1, a.nbytes))
+        assert ptr
+        pinned.append(ptr)
+        v = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (max(1, a.nbytes),))[:a.nbytes].view(a.dtype)
+        v[...] = a
+        setattr(b0, f, v)
+    expected = [oracle.run_regions(b) for b in batches]
+    got = [[None] * 3 for _ in batches]
+    errs = []
+
+    def worker(i):
+        try:
+            for rep in range(3):
+                got[i][rep] = hip.run_regions(batches[i])
+        except Exception as e:            # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(batches))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i, exp in enumerate(expected):
+        for rep in range(3):
+            assert_same(got[i][rep], exp)
+    for ptr in pinned:
+        hip.b.host_free(ptr)

@@ -73,6 +73,43 @@ def test_alignment_fallback(oracle):
     assert ((low.events["ref_support"] + low.events["alt_support"])[fb2] <= nreads - nreads // 3).all()
 
 
+def test_first_hit_positions_are_consistent_with_the_counts(oracle):
+    """hit_off/ref_hit/alt_hit: per tallied event one entry per read of the region; the counts of indelope.nim:301-311
+    are the numbers of non-negative entries, and the window at a reported index is the k-mer or its reverse complement."""
+    b, _ = synth.generate(40, n_reads=(12, 64), err_rate=1e-3, config_id=46, dup_frac=0.3)
+    b.mapq = b.mapq.copy()
+    b.mapq[::7] = 5
+    res = oracle.run_regions(b)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    assert res.n_hits == res.hit_off[-1] and len(res.ref_hit) == res.n_hits == len(res.alt_hit)
+    seen = 0
+    for c in range(res.n_contigs):
+        r = int(np.searchsorted(res.contig_off, c, side="right") - 1)
+        r0, r1 = b.region_read_off[r], b.region_read_off[r + 1]
+        for e in range(res.event_off[c], res.event_off[c + 1]):
+            ev = res.events[e]
+            h0, h1 = res.hit_off[e], res.hit_off[e + 1]
+            if ev["status"] != A.IHP_EV_TALLIED:
+                assert h0 == h1
+                continue
+            assert h1 - h0 == r1 - r0
+            rh, ah = res.ref_hit[h0:h1], res.alt_hit[h0:h1]
+            assert (rh >= 0).sum() == ev["kmer_ref_support"] and (ah >= 0).sum() == ev["kmer_alt_support"]
+            assert ((rh >= 0) & (ah >= 0)).sum() == ev["kmer_both_found"]
+            assert (rh[b.mapq[r0:r1] < 10] == -1).all() and (ah[b.mapq[r0:r1] < 10] == -1).all()
+            for k, pos in ((ev["ref_kmer"], rh), (ev["alt_kmer"], ah)):
+                for i in np.flatnonzero(pos >= 0)[:6]:
+                    lo = b.read_off[r0 + i] + pos[i]
+                    w = b.bases[lo:lo + len(k)].tobytes()
+                    assert w == k or w == k.translate(comp)[::-1]
+                    # first hit: no earlier window of the read matches
+                    rd = b.bases[b.read_off[r0 + i]:b.read_off[r0 + i + 1]].tobytes()
+                    first = min(x for x in (rd.find(k), rd.find(k.translate(comp)[::-1])) if x >= 0)
+                    assert first == pos[i]
+            seen += 1
+    assert seen >= 20
+
+
 def test_threads_do_not_change_results(oracle):
     b, _ = synth.generate(64, n_reads=(16, 64), err_rate=1e-3, config_id=8)
     a = oracle.run_regions(b)
