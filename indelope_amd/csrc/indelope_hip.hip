@@ -609,7 +609,9 @@ struct ihp_batch {
 	// scratch
 	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
-	DBuf lds_sup3;
+	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
+	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
+	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
@@ -629,13 +631,17 @@ struct ihp_batch {
 	bool ran = false;
 	~ihp_batch() {
 		// the buffers go back to the pool (the members are released after this body): nothing of this batch may still be running
+		if (stream2) { (void)hipStreamSynchronize(stream2); g_streams.put(stream2); }
 		if (stream) { (void)hipStreamSynchronize(stream); g_streams.put(stream); }
+		if (ev_fork) (void)hipEventDestroy(ev_fork);
+		if (ev_join) (void)hipEventDestroy(ev_join);
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	}
 };
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
+enum { WQ_SETS = 10 };      // work-queue counter sets: 7 assembly launches, ksw2, tally, fallback
 enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_HIT = 20, M_WORDS = 24 };
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
@@ -671,7 +677,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	b->h_region_read_off.assign(rro, rro + R + 1);
 	b->h_ref_origin.assign(in->ref_origin, in->ref_origin + R);
 	b->stream = g_streams.get();
-	if (!b->stream) { delete b; snprintf(g.err, sizeof(g.err), "hipStreamCreate failed"); return IHP_E_HIP; }
+	b->stream2 = g_streams.get();
+	if (!b->stream || !b->stream2) { delete b; snprintf(g.err, sizeof(g.err), "hipStreamCreate failed"); return IHP_E_HIP; }
 	hipStream_t s = b->stream;
 #define UP(buf, ptr, bytes) do { if ((rc = b->buf.upload(ptr, (size_t)(bytes), s))) { delete b; return rc; } } while (0)
 	UP(region_read_off, rro, sizeof(int64_t) * (R + 1));
@@ -722,6 +729,32 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		const long long cap = (long long)g.max_lds - 16384;          // RegionStateT<256> is ~13.7 KB of static LDS
 		b->lds_arena3 = (int)std::max<long long>(std::max(16384, b->lds_arena2), std::min(want, cap));
 	}
+	{
+		// Assembly class of every region, predicted from its read bases exactly as the kernels' own up-front test
+		// does (live contig bytes stay below ~30% of the read bases): class k runs in pass k's kernel from the start,
+		// on a second stream beside pass 1, instead of waiting for pass 1 to forward it.  Within a class the regions
+		// with the most reads go first (their serial latency is what the launch waits for at the end).
+		std::vector<std::pair<long long, int>> cls[4];
+		const long long lim[3] = {b->lds_arena1, b->lds_arena2, b->lds_arena3};
+		for (int r = 0; r < R; ++r) {
+			const long long nb = ro[rro[r + 1]] - ro[rro[r]];
+			const long long want = nb * 3 / 10 + 2 * b->stage_cap;
+			int k = 0;
+			while (k < 3 && want > lim[k]) ++k;
+			cls[k].push_back({-nb, r});
+		}
+		std::vector<int> order;
+		order.reserve((size_t)R);
+		for (int k = 0; k < 4; ++k) {
+			std::sort(cls[k].begin(), cls[k].end());
+			b->n_cls[k] = (int)cls[k].size();
+			for (auto &e : cls[k]) order.push_back(e.second);
+		}
+		if ((rc = b->cls_list.upload(order.data(), sizeof(int) * (size_t)R, s))) { delete b; return rc; }
+		if ((rc = b->cls_n.upload(b->n_cls, sizeof(b->n_cls), s))) { delete b; return rc; }
+		HIPC(hipStreamSynchronize(s));                         // `order` goes out of scope
+	}
+	b->grid_asm = std::min(b->grid_asm, std::max(1, b->n_cls[0]));
 	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
 	b->grid_asm3 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena3 + 14336)));
 	b->arena_cap = (3 * b->max_region_bases + 4 * b->stage_cap + 2048 + 15) / 16 * 16;
@@ -778,11 +811,13 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
 	AL(retry_list2, sizeof(int) * (size_t)R);
+	AL(retry_list3, sizeof(int) * (size_t)R);
+	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
 	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm, b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(misc, sizeof(int) * M_WORDS);
-	AL(queues, sizeof(int) * WQ_WORDS * 7);
+	AL(queues, sizeof(int) * WQ_WORDS * WQ_SETS);
 	if (p->fallback) {
 		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
@@ -801,6 +836,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(hit_pool, sizeof(int) * (size_t)b->hit_cap);
 #undef AL
 	for (auto &e : b->ev) HIPC(hipEventCreate(&e));
+	HIPC(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+	HIPC(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
 	HIPC(hipStreamSynchronize(s));
 	*bout = b;
 	return 0;
@@ -812,7 +849,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	hipStream_t s = b->stream;
 	const ihp_params &p = b->P;
 	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
-	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * 7, s));
+	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * WQ_SETS, s));
 	int *wq = b->queues.as<int>();
 	const bool profiling = getenv("IHP_PROFILE") != nullptr;
 	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
@@ -840,24 +877,51 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
-		// passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  A region
-		// moves on when it is predicted not to fit, or when it runs out of arena / contig slots.
-		int *l1 = b->retry_list.as<int>(), *l2 = b->retry_list2.as<int>();
-		a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
-		a.in_list = nullptr; a.n_in = nullptr; a.out_list = l1; a.n_out = misc + M_NRETRY;
-		hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
-		HIPC(hipGetLastError());
-		a.arena_sup = b->lds_sup2.as<uint32_t>(); a.arena_cap = b->lds_arena2; a.lds_arena = b->lds_arena2;
-		a.in_list = l1; a.n_in = misc + M_NRETRY; a.out_list = l2; a.n_out = misc + M_NRETRY2; a.work_counter = wq + WQ_WORDS;
-		hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(b->grid_asm2), dim3(64), b->lds_arena2, s, a);
-		HIPC(hipGetLastError());
-		a.arena_sup = b->lds_sup3.as<uint32_t>(); a.arena_cap = b->lds_arena3; a.lds_arena = b->lds_arena3;
-		a.in_list = l2; a.n_in = misc + M_NRETRY2; a.out_list = l1; a.n_out = misc + M_NRETRY3; a.work_counter = wq + 2 * WQ_WORDS;
-		hipLaunchKernelGGL((k_assemble<256, true, 1>), dim3(b->grid_asm3), dim3(64), b->lds_arena3, s, a);
-		HIPC(hipGetLastError());
-		a.arena_seq = b->arena_seq.as<uint8_t>(); a.arena_sup = b->arena_sup.as<uint32_t>(); a.arena_cap = b->arena_cap; a.lds_arena = 0;
-		a.in_list = l1; a.n_in = misc + M_NRETRY3; a.out_list = nullptr; a.n_out = nullptr; a.work_counter = wq + 3 * WQ_WORDS;
-		hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(b->grid_retry), dim3(64), 0, s, a);
+		// Passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  Every region
+		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
+		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
+		// overlaps pass 1 instead of following it.  A region that still runs out of arena / contig slots is
+		// forwarded at run time to the next pass's overflow list; those lists (normally empty) are processed after
+		// both streams have joined.
+		int *o2 = b->retry_list.as<int>(), *o3 = b->retry_list2.as<int>(), *o4 = b->retry_list3.as<int>();
+		const int *cl = b->cls_list.as<int>(), *cn = b->cls_n.as<int>();
+		const int n1 = b->n_cls[0], n2 = b->n_cls[1], n3 = b->n_cls[2], n4 = b->n_cls[3];
+		hipStream_t s2 = b->stream2;
+		const bool side = n2 + n3 + n4 > 0;
+		auto pass2 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
+			x.arena_seq = nullptr; x.arena_sup = b->lds_sup2.as<uint32_t>(); x.arena_cap = b->lds_arena2; x.lds_arena = b->lds_arena2;
+			x.in_list = in; x.n_in = n_in; x.out_list = o3; x.n_out = misc + M_NRETRY2; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
+			hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(b->grid_asm2), dim3(64), b->lds_arena2, st, x);
+		};
+		auto pass3 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
+			x.arena_seq = nullptr; x.arena_sup = b->lds_sup3.as<uint32_t>(); x.arena_cap = b->lds_arena3; x.lds_arena = b->lds_arena3;
+			x.in_list = in; x.n_in = n_in; x.out_list = o4; x.n_out = misc + M_NRETRY3; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
+			hipLaunchKernelGGL((k_assemble<256, true, 1>), dim3(b->grid_asm3), dim3(64), b->lds_arena3, st, x);
+		};
+		auto pass4 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
+			x.arena_seq = b->arena_seq.as<uint8_t>(); x.arena_sup = b->arena_sup.as<uint32_t>(); x.arena_cap = b->arena_cap; x.lds_arena = 0;
+			x.in_list = in; x.n_in = n_in; x.out_list = nullptr; x.n_out = nullptr; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
+			hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(b->grid_retry), dim3(64), 0, st, x);
+		};
+		if (side) {
+			HIPC(hipEventRecord(b->ev_fork, s));                   // the counters are cleared
+			HIPC(hipStreamWaitEvent(s2, b->ev_fork, 0));
+			if (n2) pass2(a, s2, cl + n1, cn + 1, 1, b->corr2.as<Corr>());
+			if (n3) pass3(a, s2, cl + n1 + n2, cn + 2, 2, b->corr2.as<Corr>());
+			if (n4) pass4(a, s2, cl + n1 + n2 + n3, cn + 3, 3, b->corr2.as<Corr>());
+			HIPC(hipGetLastError());
+			HIPC(hipEventRecord(b->ev_join, s2));
+		}
+		if (n1) {
+			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
+			a.in_list = cl; a.n_in = cn; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
+			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
+			HIPC(hipGetLastError());
+		}
+		if (side) HIPC(hipStreamWaitEvent(s, b->ev_join, 0));
+		pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>());
+		pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>());
+		pass4(a, s, o4, misc + M_NRETRY3, 6, b->corr.as<Corr>());
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[1], s));
@@ -873,7 +937,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_tmp = b->cig_tmp.as<uint32_t>(); a.cig_cap = b->cig_cap;
 		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>();
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
-		a.cig_pool_cap = b->cig_pool_cap; a.cig_bump_cap = b->cig_bump_cap; a.overflow = misc + M_OVF; a.work_counter = wq + 4 * WQ_WORDS;
+		a.cig_pool_cap = b->cig_pool_cap; a.cig_bump_cap = b->cig_bump_cap; a.overflow = misc + M_OVF; a.work_counter = wq + 7 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		g_last_ksw_mode = ksw_mode(a.P);
 		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
@@ -894,7 +958,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.hit_overflow = misc + M_OVF_HIT;
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
-		a.overflow = misc + M_OVF; a.work_counter = wq + 5 * WQ_WORDS;
+		a.overflow = misc + M_OVF; a.work_counter = wq + 8 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.lds_bytes = std::min(g.max_lds - 4096, 64 * ((b->max_read_len + 3) / 4 * 4) + 64);
 		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
@@ -918,7 +982,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.lds_budget = b->lds_fb - 64;
 		a.p_scratch = b->fb_p_scratch.as<uint8_t>(); a.p_cap = b->fb_p_cap;
 		a.cig_tmp = b->fb_cig_tmp.as<uint32_t>(); a.cig_cap = b->fb_cig_cap;
-		a.overflow = misc + M_OVF; a.work_counter = wq + 6 * WQ_WORDS;
+		a.overflow = misc + M_OVF; a.work_counter = wq + 9 * WQ_WORDS;
 		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
 		HIPC(hipGetLastError());
 	}
