@@ -315,7 +315,8 @@ int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
  * ihp_batch_run used: 3/4 = top-byte register sweep (left/right gaps; the production
  * kernels), 0/1 = masked register sweep (scoring schemes or base codes the former does
- * not cover), 2 = LDS sweep (band > 62).  Results are identical in every mode.            */
+ * not cover), 5 = ring sweep for bands > 62 or unbanded (ksw_wide.h; per job the LDS sweep
+ * where the ring does not fit), 2 = LDS sweep.  Results are identical in every mode.       */
 int  ihp_debug_last_ksw_mode(void);
 /* Fixed-size per-region summary record left on the device for the multi-GPU
  * gather (one RCCL gather of these at the end).     */

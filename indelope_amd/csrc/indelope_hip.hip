@@ -147,8 +147,11 @@ int grid_for(int items, int waves_per_cu)
 
 int ksw_mode(const KswParams &P)
 {
-	if (P.w < 0 || P.w > 62) return 2;
 	const int right = (P.flag & KSW_EZ_RIGHT) ? 1 : 0;
+	if (P.w < 0 || P.w > 62) {
+		KswParams Q = P; Q.w = 0;
+		return (!right && ksw_narrow_ok(Q)) ? 5 : 2;             // 5: ring sweep per job where it fits, LDS sweep otherwise
+	}
 	return (ksw_narrow_ok(P) && P.codes_ok) ? 3 + right : right;
 }
 
@@ -156,6 +159,7 @@ int g_last_ksw_mode = -1;
 
 size_t ksw_mode_lds(int mode, int qlen, int tlen)
 {
+	if (mode == 5) return std::max(ksw_lds_bytes(qlen, tlen), std::max(ksw_wide_lds_bytes<3>(qlen, tlen), ksw_wide_lds_bytes<6>(qlen, tlen)));
 	return mode >= 3 ? ksw_narrow_lds_bytes(qlen, tlen) : mode != 2 ? ksw_fast_lds_bytes(qlen, tlen) : ksw_lds_bytes(qlen, tlen);
 }
 
@@ -165,6 +169,7 @@ template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStr
 	else if (mode == 1) hipLaunchKernelGGL(k_ksw<1>, grid, dim3(64), lds, s, a);
 	else if (mode == 3) hipLaunchKernelGGL(k_ksw<3>, grid, dim3(64), lds, s, a);
 	else if (mode == 4) hipLaunchKernelGGL(k_ksw<4>, grid, dim3(64), lds, s, a);
+	else if (mode == 5) hipLaunchKernelGGL(k_ksw<5>, grid, dim3(64), lds, s, a);
 	else hipLaunchKernelGGL(k_ksw<2>, grid, dim3(64), lds, s, a);
 }
 
@@ -225,6 +230,7 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
+		(void)hipFuncSetAttribute((const void *)k_ksw<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 	}
 	g.ready = true;
 	return 0;
@@ -339,7 +345,9 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	size_t lds_need = 0, p_need = 0; long long cig_bound = 0; int cig_cap = 0;
 	for (const AlnJob &j : jobs) {
 		if (j.qlen <= 0 || j.tlen <= 0) continue;
-		lds_need = std::max(lds_need, (P.w >= 0 && P.w <= 62) ? ksw_narrow_lds_bytes(j.qlen, j.tlen) : ksw_lds_bytes(j.qlen, j.tlen));
+		lds_need = std::max(lds_need, (P.w >= 0 && P.w <= 62) ? ksw_narrow_lds_bytes(j.qlen, j.tlen)
+		                    : std::max(ksw_lds_bytes(j.qlen, j.tlen), ksw_wide_ok<3>(P, j.qlen, j.tlen) ? ksw_wide_lds_bytes<3>(j.qlen, j.tlen)
+		                               : ksw_wide_ok<6>(P, j.qlen, j.tlen) ? ksw_wide_lds_bytes<6>(j.qlen, j.tlen) : (size_t)0));
 		int w = P.w < 0 ? std::max(j.qlen, j.tlen) : P.w;
 		int nc = (std::min(std::min(j.qlen, j.tlen), w + 1) + 15) / 16 + 1;
 		p_need = std::max(p_need, ((size_t)(j.qlen + j.tlen - 1) * nc + 1) * 16);
@@ -764,10 +772,10 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	const int qmax = std::min(MAXLEN, b->max_region_bases), tmax = b->max_ref_len;
 	{
 		const bool fastp = p->bw >= 0 && p->bw <= 62;
-		size_t need = (fastp ? ksw_narrow_lds_bytes(qmax, tmax) : ksw_lds_bytes(qmax, tmax)) + 64;
+		size_t need = (fastp ? ksw_narrow_lds_bytes(qmax, tmax) : std::max(ksw_lds_bytes(qmax, tmax), ksw_wide_lds_bytes<6>(qmax, tmax))) + 64;
 		// contigs are rarely longer than the reference window + band; cap the LDS request there and let the
 		// kernel flag anything larger (reported as IHP_E_CAPACITY for that batch)
-		const size_t typical = (fastp ? ksw_narrow_lds_bytes(tmax + 64, tmax) : ksw_lds_bytes(tmax + 64, tmax)) + 64;
+		const size_t typical = (fastp ? ksw_narrow_lds_bytes(tmax + 64, tmax) : std::max(ksw_lds_bytes(tmax + 64, tmax), ksw_wide_lds_bytes<6>(tmax + 64, tmax))) + 64;
 		need = std::min(need, std::max(typical, (size_t)(fastp ? 2048 : 8192)));
 		need = std::min(need, (size_t)g.max_lds - 2048);
 		b->lds_ksw = (int)need;

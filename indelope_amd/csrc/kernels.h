@@ -392,7 +392,7 @@ typedef const __attribute__((address_space(4))) KswArgs *KswArgsK;
 __device__ __forceinline__ KswArgsK ksw_args_again(KswArgsK p) { asm volatile("" : "+s"(p)); return p; }
 
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE >= 3 ? 8 : 1))) void k_ksw(const KswArgs)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 || MODE == 4 ? 8 : 1))) void k_ksw(const KswArgs)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_item;
@@ -426,7 +426,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE >= 3 ? 
 			int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
 			ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
 			const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
-			const size_t lneed = MODE >= 3 ? ksw_narrow_lds_bytes(jb.qlen, jb.tlen) : MODE != 2 ? ksw_fast_lds_bytes(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen);
+			// MODE 5: bands wider than the register layouts of MODE 0-4 (w < 0 or w > 62): the ring sweep of ksw_wide.h when
+			// the job fits it (3 or 6 slots), the LDS sweep otherwise
+			const int wide = MODE != 5 ? 0 : ksw_wide_ok<3>(P, jb.qlen, jb.tlen) ? 3 : ksw_wide_ok<6>(P, jb.qlen, jb.tlen) ? 6 : 0;
+			const size_t lneed = MODE == 5 ? (wide == 3 ? ksw_wide_lds_bytes<3>(jb.qlen, jb.tlen) : wide == 6 ? ksw_wide_lds_bytes<6>(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen))
+			                     : MODE >= 3 ? ksw_narrow_lds_bytes(jb.qlen, jb.tlen) : MODE != 2 ? ksw_fast_lds_bytes(jb.qlen, jb.tlen) : ksw_lds_bytes(jb.qlen, jb.tlen);
 			const uint8_t *qy = a->qbase + jb.q_off, *tg = a->tbase + jb.t_off;
 			const int cig_cap = a->cig_cap;
 			if (jb.qlen > 0 && jb.tlen > 0 && (lneed > (size_t)a->lds_budget || pneed > a->p_cap)) {
@@ -437,6 +441,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE >= 3 ? 
 					out.n_cigar = -1;                                  // a code outside the alphabet: the host never sends those here
 			} else if (MODE == 0 || MODE == 1) {
 				ksw_wave_fast<MODE == 1>(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
+			} else if (MODE == 5) {
+				bool done = false;
+				if (wide == 3) done = ksw_wave_wide<3, false>(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out);
+				else if (wide == 6) done = ksw_wave_wide<6, false>(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out);
+				if (!done) {                                           // too wide for the ring, or a code outside the alphabet
+					if (ksw_lds_bytes(jb.qlen, jb.tlen) > (size_t)a->lds_budget) {
+						out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
+						out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
+					} else ksw_wave(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
+				}
 			} else {
 				ksw_wave(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
 			}

@@ -211,7 +211,8 @@ def test_ksw2_random_vs_oracle(hip, oracle):
 
 
 def test_ksw2_kernel_modes(hip, oracle):
-    """Every ksw2 kernel (ihp_debug_last_ksw_mode: 3/4 top-byte sweep, 0/1 masked sweep, 2 LDS sweep) gives the
+    """Every ksw2 kernel (ihp_debug_last_ksw_mode: 3/4 top-byte sweep, 0/1 masked sweep, 5 ring sweep for wide bands
+    with the LDS sweep per job where the ring does not fit, 2 LDS sweep) gives the
     reference's result; scoring schemes whose int8 work values wrap (gap costs near 64) go through the top-byte
     sweep, those with a non-positive s+2(q+e) or base codes outside the alphabet through the masked one."""
     import test_oracle_ksw2 as tk
@@ -221,7 +222,9 @@ def test_ksw2_kernel_modes(hip, oracle):
         (2, -4, 40, 10, 50, 400, 0, None, 3), (1, -3, 50, 12, 62, -1, R, None, 4), (3, -6, 30, 25, 49, 900, 0, None, 3),
         (1, -10, 4, 1, 50, 400, 0, None, 0), (1, -10, 4, 1, 50, 400, R, None, 1), (1, -2, 60, 4, 50, 400, 0, None, 0),
         (1, -2, 4, 1, 50, 400, 0, 6, 0), (1, -2, 4, 1, 50, 400, R, 7, 1), (1, -2, 4, 1, 50, 400, 0, 4, 3),
-        (1, -2, 4, 1, 63, 400, 0, None, 2), (1, -2, 5, 1, -1, -1, 0, None, 2)]
+        (1, -2, 4, 1, 63, 400, 0, None, 5), (1, -2, 5, 1, -1, -1, 0, None, 5), (1, -2, 4, 1, 120, 200, 0, None, 5),
+        (2, -4, 40, 10, -1, -1, 0, None, 5), (1, -2, 5, 1, -1, -1, R, None, 2), (1, -10, 4, 1, 100, 400, 0, None, 2),
+        (1, -2, 5, 1, -1, -1, 0, 6, 5)]
     for si, (ma, mi, go, ge, w, z, flag, raw, mode) in enumerate(sets):
         pairs = list(tk.cases(500 + si, 60))
         qs, ts = [q for q, t in pairs], [t for q, t in pairs]
@@ -368,3 +371,27 @@ def test_concurrent_batches_from_host_threads(hip, oracle):
             assert_same(got[i][rep], exp)
     for ptr in pinned:
         hip.b.host_free(ptr)
+
+
+def test_ksw2_wide_ring_boundaries(hip, oracle):
+    """ksw_wide.h: query/target lengths around the ring capacities (min(qlen, tlen, w+1) + 31 <= 192 / 384), targets
+    shorter than the query, tiny sequences, band origins that move every 16 diagonals, z-drop and band exits."""
+    import test_oracle_ksw2 as tk
+    rng = np.random.default_rng(77)
+    qs, ts = [], []
+    for ql in (1, 2, 15, 16, 17, 31, 64, 100, 150, 159, 160, 161, 162, 163, 200, 300, 352, 353, 354, 355, 400):
+        for tl in (ql // 2 + 1, ql, ql + 7, ql + 150, 3 * ql + 40):
+            t = kats.rand_dna(rng, tl)
+            base = (t * (ql // tl + 2))[:ql] if rng.random() < 0.7 else kats.rand_dna(rng, ql)
+            qs.append(tk.mutate(rng, base, 2) if ql > 20 else base)          # substitutions: the length stays exact
+            ts.append(t)
+            if ql > 40:
+                qs.append(tk.mutate(rng, base, int(rng.integers(0, 2))))      # a planted indel
+                ts.append(t)
+    for kw in (dict(gap_open=5, gap_ext=1, bw=-1, z=-1), dict(gap_open=4, gap_ext=1, bw=90, z=60),
+               dict(gap_open=4, gap_ext=2, bw=200, z=400), dict(gap_open=5, gap_ext=1, bw=-1, z=-1, flag=A.KSW_EZ_EXTZ_ONLY)):
+        ez, cg = hip.align_batch(qs, ts, **kw)
+        assert hip.b.debug_last_ksw_mode() == 5
+        ez2, cg2 = oracle.align_batch(qs, ts, **kw)
+        assert ez.tolist() == ez2.tolist(), kw
+        assert [c.tolist() for c in cg] == [c.tolist() for c in cg2], kw
