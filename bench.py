@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--config", default="C2", help="BASELINE config id (C2, C3, C5) for the per-GPU batch")
     ap.add_argument("--regions", type=int, default=0, help="override regions per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--quals", action="store_true",
+                    help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
+                         "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
     ap.add_argument("--dup-frac", type=float, default=0.0,
                     help="fraction of planted events that are tandem duplications (these send the k-mer tally to the "
                          "alignment fallback, indelope.nim:312-372); 0 = the BASELINE workload")
@@ -93,6 +96,8 @@ def main():
     cfg["n_regions"] = R
     K = cfg["K"]
     batch, _ = synth.generate(first_region=rank * R, dup_frac=args.dup_frac, **cfg)
+    if not args.quals:
+        batch = batch.with_trim_bounds()                     # A0 on the host (SURVEY 8a row A0, 8b "trim bounds (a,b)")
     params = api.params(K=K)
     h = api.batch_upload(batch, params)
     sptr, sn = api.batch_summary_dev(h)
@@ -155,6 +160,7 @@ def main():
                                    % (args.config, R, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
                                       else str(cfg["n_reads"][0]), cfg["read_len"], K, cfg["err_rate"], cfg["config_id"])
                                    + (", %g of events tandem duplications" % args.dup_frac if args.dup_frac else ""),
+                       "read_trim": "device, from base qualities" if args.quals else "stager (trim bounds in the batch)",
                        "regions_per_gpu": R, "sharding": "contiguous region ranges per rank, one RCCL gather of "
                        "per-region result records per step" if world > 1 else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),

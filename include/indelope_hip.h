@@ -210,6 +210,11 @@ typedef struct {
 	                                     requests (indelope.nim:220) are clamped to
 	                                     the slice the way faidx clamps to a
 	                                     chromosome, and flagged IHP_ALN_REF_CLAMPED */
+	/* Optional: the result of trim(sequence, base_qualities) (indelope.nim:23-38) computed by
+	 * the stager -- read i keeps bases [trim_lo[i], trim_hi[i]) and its start moves by
+	 * trim_lo[i] (an emptied read: lo == hi == the returned `a`).  When given, `quals` is not
+	 * read and need not be uploaded: half the bytes of a batch.  NULL: trim from `quals`.    */
+	const int32_t *trim_lo, *trim_hi; /* [n_reads]                               */
 } ihp_batch_in;
 
 /* event status: why the tally did or did not run for an alignment event.      */

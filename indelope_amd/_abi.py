@@ -89,7 +89,8 @@ class BatchIn(C.Structure):
     _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int64),
                 ("region_read_off", i64p), ("read_off", i64p), ("bases", u8p), ("quals", u8p),
                 ("read_start", i64p), ("read_stop", i64p), ("mapq", u8p), ("read_skip", u8p),
-                ("ref_off", i64p), ("ref_bases", u8p), ("ref_origin", i64p)]
+                ("ref_off", i64p), ("ref_bases", u8p), ("ref_origin", i64p),
+                ("trim_lo", i32p), ("trim_hi", i32p)]
 
 
 class Event(C.Structure):

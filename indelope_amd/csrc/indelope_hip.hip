@@ -613,7 +613,8 @@ struct ihp_batch {
 	std::vector<int64_t> h_region_read_off, h_ref_origin;
 	// inputs
 	DBuf region_read_off, read_off, bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin;
-	bool has_quals = false, has_skip = false;
+	DBuf trim_lo, trim_hi;
+	bool has_quals = false, has_skip = false, has_trim = false;
 	// scratch
 	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
@@ -692,8 +693,10 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	UP(region_read_off, rro, sizeof(int64_t) * (R + 1));
 	UP(read_off, ro, sizeof(int64_t) * (NR + 1));
 	UP(bases, in->bases, b->n_bases);
-	b->has_quals = in->quals != nullptr; b->has_skip = in->read_skip != nullptr;
+	b->has_trim = in->trim_lo != nullptr && in->trim_hi != nullptr;     // trim() done by the stager: qualities not needed
+	b->has_quals = in->quals != nullptr && !b->has_trim; b->has_skip = in->read_skip != nullptr;
 	if (b->has_quals) UP(quals, in->quals, b->n_bases);
+	if (b->has_trim) { UP(trim_lo, in->trim_lo, sizeof(int32_t) * NR); UP(trim_hi, in->trim_hi, sizeof(int32_t) * NR); }
 	UP(read_start, in->read_start, sizeof(int64_t) * NR);
 	UP(read_stop, in->read_stop, sizeof(int64_t) * NR);
 	UP(mapq, in->mapq, NR);
@@ -868,6 +871,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.n_regions = b->R;
 		a.region_read_off = b->region_read_off.as<long long>(); a.read_off = b->read_off.as<long long>();
 		a.bases = b->bases.as<uint8_t>(); a.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr;
+		a.trim_lo = b->has_trim ? b->trim_lo.as<int>() : nullptr; a.trim_hi = b->has_trim ? b->trim_hi.as<int>() : nullptr;
 		a.read_start = b->read_start.as<long long>(); a.read_stop = b->read_stop.as<long long>();
 		a.mapq = b->mapq.as<uint8_t>(); a.read_skip = b->has_skip ? b->read_skip.as<uint8_t>() : nullptr;
 		a.ref_off = b->ref_off.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
@@ -981,6 +985,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.jobs = b->jobs.as<AlnJob>();
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>(); a.bases = b->bases.as<uint8_t>();
 		a.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr; a.mapq = b->mapq.as<uint8_t>();
+		a.trim_lo = b->has_trim ? b->trim_lo.as<int>() : nullptr; a.trim_hi = b->has_trim ? b->trim_hi.as<int>() : nullptr;
 		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();
 		a.read_start = b->read_start.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
 		a.ctg_start = b->ctg_start.as<long long>();

@@ -14,6 +14,7 @@ struct AsmArgs {
 	int n_regions;
 	const long long *region_read_off, *read_off;
 	const uint8_t *bases, *quals;
+	const int *trim_lo, *trim_hi;                      // optional: trim() done by the stager (then quals is null)
 	const long long *read_start, *read_stop;
 	const uint8_t *mapq, *read_skip;
 	const long long *ref_off, *ref_origin;
@@ -156,9 +157,14 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 	for (long long g0 = r0; g0 < r1; g0 += 64) {               // indelope.nim:163-169, 64 reads of metadata at a time
 		const long long my = g0 + lane;
 		const bool in = my < r1;
-		long long moff = 0, mstart = 0; int mlen = 0; bool ok = false;
+		long long moff = 0, mstart = 0; int mlen = 0, mtlo = 0, mthi = 0; bool ok = false;
 		if (in) {
 			moff = a.read_off[my]; mlen = (int)(a.read_off[my + 1] - moff); mstart = a.read_start[my];
+			if (a.trim_lo) {                                   // clamped to the read
+				mtlo = a.trim_lo[my]; mthi = a.trim_hi[my];
+				mtlo = mtlo < 0 ? 0 : mtlo > mlen ? mlen : mtlo;
+				mthi = mthi > mlen ? mlen : mthi; mthi = mthi < mtlo ? mtlo : mthi;
+			}
 			ok = a.mapq[my] >= a.min_mapq_assemble && !(a.read_skip && a.read_skip[my]);   // :164-165
 		}
 		unsigned long long elig = ballot(ok);
@@ -184,7 +190,8 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 				read_prefetch(a, off2, len2 <= 512 ? len2 : 0, st2, nxt);
 			}
 			int lo = 0, hi = len, o = 0;
-			if (len <= 512) {
+			if (a.trim_lo) { lo = bcast(mtlo, k); hi = bcast(mthi, k); o = lo; }   // :168 done by the stager
+			else if (len <= 512) {
 				if (a.quals) o = read_trim_regs(cur, a.trim_min_qual, lo, hi);    // :168
 			} else if (a.quals) o = read_trim_dev(a.quals + b0, len, a.trim_min_qual, lo, hi);
 			const int tl = hi - lo;
@@ -560,6 +567,7 @@ struct FbArgs {
 	const FbItem *items; const int *n_items; int max_region_reads;
 	const AlnJob *jobs;
 	const uint8_t *out_seq, *ref_bases, *bases, *quals, *mapq;
+	const int *trim_lo, *trim_hi;
 	const long long *read_off, *region_read_off, *read_start, *ref_origin, *ctg_start;
 	DevEvent *ev_pool;
 	KswParams P; int min_mapq, trim_min_qual;
@@ -616,7 +624,11 @@ __global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
 		const long long off = uni(a.read_off[ri]);
 		const int len = (int)(uni(a.read_off[ri + 1]) - off);
 		int lo = 0, hi = len, ta = 0;
-		if (a.quals) ta = read_trim_dev(a.quals + off, len, a.trim_min_qual, lo, hi);   // :328
+		if (a.trim_lo) {
+			lo = uni(a.trim_lo[ri]); hi = uni(a.trim_hi[ri]);
+			lo = lo < 0 ? 0 : lo > len ? len : lo; hi = hi > len ? len : hi; hi = hi < lo ? lo : hi;
+			ta = lo;
+		} else if (a.quals) ta = read_trim_dev(a.quals + off, len, a.trim_min_qual, lo, hi);   // :328
 		const long long origin = uni(a.ref_origin[r]);
 		DevEvent *E = a.ev_pool + it.ev;
 		const int tstart = uni(E->tstart_rel), tstop = uni(E->tstop_rel);

@@ -86,6 +86,8 @@ class RegionBatch:
     ref_off: np.ndarray
     ref_bases: np.ndarray
     ref_origin: np.ndarray
+    trim_lo: np.ndarray = None        # optional: trim() done by the stager (then `quals` is not needed)
+    trim_hi: np.ndarray = None
 
     @property
     def n_regions(self):
@@ -111,7 +113,8 @@ class RegionBatch:
                       p(self.read_start, A.i64p, np.int64), p(self.read_stop, A.i64p, np.int64),
                       p(self.mapq, A.u8p, np.uint8), p(self.read_skip, A.u8p, np.uint8),
                       p(self.ref_off, A.i64p, np.int64), p(self.ref_bases, A.u8p, np.uint8),
-                      p(self.ref_origin, A.i64p, np.int64))
+                      p(self.ref_origin, A.i64p, np.int64),
+                      p(self.trim_lo, A.i32p, np.int32), p(self.trim_hi, A.i32p, np.int32))
         c._keep = keep
         return c
 
@@ -124,7 +127,36 @@ class RegionBatch:
                            self.bases[b0:b1], None if self.quals is None else self.quals[b0:b1],
                            self.read_start[r0:r1], self.read_stop[r0:r1], self.mapq[r0:r1],
                            None if self.read_skip is None else self.read_skip[r0:r1],
-                           self.ref_off[lo:hi + 1] - f0, self.ref_bases[f0:f1], self.ref_origin[lo:hi])
+                           self.ref_off[lo:hi + 1] - f0, self.ref_bases[f0:f1], self.ref_origin[lo:hi],
+                           None if self.trim_lo is None else self.trim_lo[r0:r1],
+                           None if self.trim_hi is None else self.trim_hi[r0:r1])
+
+    def with_trim_bounds(self, min_quality=15):
+        """The same batch with trim(sequence, base_qualities, min_quality) (indelope.nim:23-38) done here, the way a
+        stager would: per read the kept range [lo, hi) instead of the qualities."""
+        n = self.n_reads
+        ln = np.diff(self.read_off).astype(np.int64)
+        lo, hi = np.zeros(n, np.int32), ln.astype(np.int32)
+        if self.quals is not None and n and len(self.quals):
+            good = np.asarray(self.quals) >= min_quality
+            if not good.all():
+                idx = np.arange(len(good), dtype=np.int64)
+                off = np.asarray(self.read_off[:-1], np.int64)
+                nz = ln > 0
+                first = np.full(n, np.iinfo(np.int64).max)
+                last = np.full(n, -1, np.int64)
+                # reduceat over the non-empty reads only (their offsets are strictly increasing)
+                o = off[nz]
+                first[nz] = np.minimum.reduceat(np.where(good, idx, np.iinfo(np.int64).max), o)
+                last[nz] = np.maximum.reduceat(np.where(good, idx, -1), o)
+                high = ln - 1
+                a = np.where(first - off < high, first - off, high)          # :25 scans i < high only
+                emptied = a == high                                         # :28-30 returns a, sequence emptied
+                b = np.maximum(last - off, a)                               # :33 last i > a with q >= min, else a
+                lo = np.where(nz, a, 0).astype(np.int32)
+                hi = np.where(nz, np.where(emptied, a, b + 1), 0).astype(np.int32)
+        return RegionBatch(self.region_read_off, self.read_off, self.bases, None, self.read_start, self.read_stop,
+                           self.mapq, self.read_skip, self.ref_off, self.ref_bases, self.ref_origin, lo, hi)
 
     def algorithmic_input_bytes(self):
         """sum_reads(len + 4 start + 1 mapq + 4 trim) + len_refwindow."""

@@ -35,6 +35,7 @@ type
     ref_off*: ptr int64
     ref_bases*: ptr uint8
     ref_origin*: ptr int64
+    trim_lo*, trim_hi*: ptr int32         # optional: trim() of indelope.nim:23-38 done by the stager; quals then unused
 
   IhpEz* {.importc: "ihp_ez", header: "indelope_hip.h", bycopy.} = object
     max*, zdropped*, max_q*, max_t*, mqe*, mqe_t*, mte*, mte_q*, score*, n_cigar*: int32
@@ -79,6 +80,7 @@ proc ihp_free_out*(outp: ptr IhpBatchOut) {.importc, cdecl, header: "indelope_hi
 type Stager* = object
   region_read_off*, read_off*, read_start*, read_stop*, ref_off*, ref_origin*: seq[int64]
   bases*, quals*, mapq*, read_skip*, ref_bases*: seq[uint8]
+  trim_lo*, trim_hi*: seq[int32]        # what trim(read_seq, base_q) keeps: [lo, hi); start moves by lo
 
 proc init*(s: var Stager) =
   s.region_read_off = @[0'i64]; s.read_off = @[0'i64]; s.ref_off = @[0'i64]
@@ -89,7 +91,10 @@ proc init*(s: var Stager) =
 #   for read in r.reads:
 #     discard read.sequence(read_seq); discard read.base_qualities(base_q)
 #     for c in read_seq: s.bases.add(uint8(c))
-#     for q in base_q[0..<read_seq.len]: s.quals.add(q)
+#     # either hand over the qualities ...   for q in base_q[0..<read_seq.len]: s.quals.add(q)
+#     # ... or trim here (half the bytes to upload): a = first i < high with q >= 15 else high; emptied read: lo = hi = a;
+#     # else b = last i > a with q >= 15 else a; lo = a, hi = b + 1      (indelope.nim:23-38)
+#     let (lo, hi) = trim_bounds(base_q, read_seq.len); s.trim_lo.add(lo); s.trim_hi.add(hi)
 #     s.read_off.add(int64(s.bases.len))
 #     s.read_start.add(read.start); s.read_stop.add(read.stop)
 #     s.mapq.add(read.qual); s.read_skip.add(uint8(read.skippable(allow_unmapped=false)))
@@ -108,4 +113,5 @@ proc run*(s: var Stager, p: var IhpParams, outp: var IhpBatchOut): cint =
   b.read_start = addr s.read_start[0]; b.read_stop = addr s.read_stop[0]
   b.mapq = addr s.mapq[0]; b.read_skip = addr s.read_skip[0]
   b.ref_off = addr s.ref_off[0]; b.ref_bases = addr s.ref_bases[0]; b.ref_origin = addr s.ref_origin[0]
+  if s.trim_lo.len > 0: (b.trim_lo = addr s.trim_lo[0]; b.trim_hi = addr s.trim_hi[0]; b.quals = nil)
   result = ihp_run_regions(addr p, addr b, addr outp)

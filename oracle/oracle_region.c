@@ -143,6 +143,17 @@ static int distinct_bytes(const char *s, int n)
 	return d;
 }
 
+/* trim() done by the stager (ihp_batch_in.trim_lo/trim_hi), clamped to the read */
+static void trim_given(const ihp_batch_in *in, int64_t i, int64_t n, int64_t *lo, int64_t *hi)
+{
+	int64_t l = in->trim_lo[i], h = in->trim_hi[i];
+	if (l < 0) l = 0;
+	if (l > n) l = n;
+	if (h > n) h = n;
+	if (h < l) h = l;
+	*lo = l; *hi = h;
+}
+
 /* count_flanked_cigar, indelope.nim:185-199, over Ez.cigar (ksw2.nim:22-33: the CIGAR
  * truncated at max_q) */
 static int count_flanked_cigar(const ksw_extz_t *ez)
@@ -185,7 +196,8 @@ static void fallback_align(const ihp_params *p, const ihp_batch_in *in, int64_t 
 		if (in->mapq[ri] < p->min_mapq_tally) continue;             /* :325 */
 		const int64_t n = in->read_off[ri + 1] - in->read_off[ri];
 		int64_t lo = 0, hi = n, a = 0;
-		if (in->quals) a = orc_read_trim(in->quals + in->read_off[ri], n, p->trim_min_qual, &lo, &hi);
+		if (in->trim_lo) { trim_given(in, ri, n, &lo, &hi); a = lo; }
+		else if (in->quals) a = orc_read_trim(in->quals + in->read_off[ri], n, p->trim_min_qual, &lo, &hi);
 		const int64_t rs = in->read_start[ri] + a, rl = hi - lo;    /* :328 */
 		if (rs > ev->tstop) continue;                               /* :329 */
 		const int64_t L = ev->type == 0 ? (int64_t)ev->len : 0;     /* :330-332 */
@@ -219,7 +231,8 @@ static orc_list assemble(const ihp_params *p, const ihp_batch_in *in, int64_t r0
 		if (in->read_skip && in->read_skip[i]) continue;           /* :165 */
 		const uint8_t *seq = in->bases + in->read_off[i];
 		int64_t n = in->read_off[i + 1] - in->read_off[i], lo = 0, hi = n, o = 0;
-		if (in->quals) o = orc_read_trim(in->quals + in->read_off[i], n, p->trim_min_qual, &lo, &hi);  /* :168 */
+		if (in->trim_lo) { trim_given(in, i, n, &lo, &hi); o = lo; }
+		else if (in->quals) o = orc_read_trim(in->quals + in->read_off[i], n, p->trim_min_qual, &lo, &hi);  /* :168 */
 		int64_t tl = hi - lo;
 		int64_t min_overlap = (int64_t)(p->min_overlap_pct * (double)tl);   /* :169 */
 		ihp_contig *qc = orc_make_contig(seq + lo, tl, in->read_start[i] + o, 1);

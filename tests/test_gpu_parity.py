@@ -139,6 +139,41 @@ def test_cli_defaults_and_filters(hip, oracle):
     assert_same(hip.run_regions(b, hip.params(**kw)), oracle.run_regions(b, oracle.params(**kw)))
 
 
+def test_trim_done_by_the_stager(hip, oracle):
+    """ihp_batch_in.trim_lo/trim_hi: trim() (indelope.nim:23-38) computed on the host gives the results of the
+    qualities themselves -- in the assembly and in the alignment fallback -- and the qualities are not needed."""
+    b, _ = synth.generate(150, n_reads=(12, 64), err_rate=2e-3, config_id=47, dup_frac=0.3)
+    rng = np.random.default_rng(9)
+    q = b.quals.copy()
+    for i in range(b.n_reads):
+        lo, hi = b.read_off[i], b.read_off[i + 1]
+        k = rng.integers(0, 6)
+        if k == 1:
+            q[lo:lo + rng.integers(1, 30)] = 2
+        elif k == 2:
+            q[hi - rng.integers(1, 30):hi] = 2
+        elif k == 3 and rng.random() < 0.3:
+            q[lo:hi] = 2
+        elif k == 4:
+            q[lo:hi - 1] = 2
+    b.quals = q
+    tb = b.with_trim_bounds()
+    assert tb.quals is None and (tb.trim_lo > 0).any() and (tb.trim_lo == tb.trim_hi).any()
+    exp = oracle.run_regions(b)
+    assert_same(hip.run_regions(b), exp)
+    got = hip.run_regions(tb)
+    assert_same(got, exp)
+    assert_same(oracle.run_regions(tb), exp)
+    assert (got.events["aligned"] == 1).sum() >= 3
+    # out-of-range bounds are clamped to the read the same way on both sides
+    tb.trim_lo = tb.trim_lo.copy()
+    tb.trim_hi = tb.trim_hi.copy()
+    tb.trim_lo[::17] = -5
+    tb.trim_hi[::13] = 10_000
+    tb.trim_hi[5::29] = 0
+    assert_same(hip.run_regions(tb), oracle.run_regions(tb))
+
+
 def test_edge_batches(hip, oracle):
     b, _ = synth.generate(3, n_reads=(12, 12), config_id=10)
     b.mapq = b.mapq.copy()

@@ -110,6 +110,26 @@ def test_first_hit_positions_are_consistent_with_the_counts(oracle):
     assert seen >= 20
 
 
+def test_trim_bounds_equal_qualities(oracle):
+    """RegionBatch.with_trim_bounds (the stager's trim(), indelope.nim:23-38) against orc_read_trim on every read."""
+    b, _ = synth.generate(40, n_reads=(8, 40), err_rate=1e-3, config_id=48)
+    rng = np.random.default_rng(1)
+    q = rng.choice(np.array([2, 14, 15, 30], np.uint8), len(b.quals), p=[0.3, 0.1, 0.1, 0.5])
+    for i in range(0, b.n_reads, 9):
+        q[b.read_off[i]:b.read_off[i + 1]] = 2
+    for i in range(4, b.n_reads, 9):
+        q[b.read_off[i]:b.read_off[i + 1] - 1] = 2
+    b.quals = q
+    tb = b.with_trim_bounds()
+    for i in range(b.n_reads):
+        a, lo, hi = oracle.read_trim(q[b.read_off[i]:b.read_off[i + 1]])
+        if lo == hi:
+            assert tb.trim_lo[i] == tb.trim_hi[i] == a, i
+        else:
+            assert (tb.trim_lo[i], tb.trim_hi[i]) == (lo, hi) and a == lo, i
+    assert BatchResult.first_difference(oracle.run_regions(b), oracle.run_regions(tb)) is None
+
+
 def test_threads_do_not_change_results(oracle):
     b, _ = synth.generate(64, n_reads=(16, 64), err_rate=1e-3, config_id=8)
     a = oracle.run_regions(b)
