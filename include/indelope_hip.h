@@ -294,6 +294,56 @@ typedef struct {
 void *ihp_host_alloc(size_t bytes);
 void  ihp_host_free(void *p);
 
+/* ------------------------------------- post-tally filters and Variant records (row f2) */
+/* indelope.nim:375-428 (the filters and Variant fields that follow the tally inside
+ * callsemble) and :604-608 (the last-two-variants dedupe of the main loop), as host code over
+ * one batch's inputs and results.  Every tallied event yields one record; `filter` says
+ * whether the reference would have printed it, and if not which test dropped it (the first
+ * one in the reference's order).  AKE/RKE and the :412 filter use the `kmer` package's
+ * distance `d`, whose definition is not pinned here (indelope.nimble:10-11): it is taken as
+ * the distance of the k-mer window from the closer end of the read, min(i, len - K - i).      */
+#define IHP_VF_EMITTED      0
+#define IHP_VF_LOW_ALT      2   /* alt_support < min_reads                    :375 */
+#define IHP_VF_LOW_FRAC     3   /* alt_support / reads.len < 0.1              :377 */
+#define IHP_VF_HOM_REF      4   /*                                            :380 */
+#define IHP_VF_BOTH_AT_EDGE 5   /* offset == 0 and both_found >= 0.75 min(ref, alt)  :384 */
+#define IHP_VF_SMALL_FLANK  6   /* min_flank - 1 < event span                 :399 */
+#define IHP_VF_KMER_AT_END  7   /* mean(adists) < 5                           :412 */
+#define IHP_VF_HOMOPOLYMER  8   /* homopolymer insertion in homopolymer k-mers :423-427 */
+#define IHP_VF_DUPLICATE    9   /* same as one of the last two printed        :604-608 */
+#define IHP_VF_OOB         10   /* allele slice outside the contig / the region's reference slice
+                                   (the reference would raise); never printed */
+typedef struct {
+	int32_t region, contig;       /* indices into ihp_batch_out                  */
+	int64_t event;
+	int32_t filter;               /* IHP_VF_*                                    */
+	int32_t gt;                   /* IHP_GT_*                                    */
+	int64_t start;                /* Variant.start = tloc.start                  */
+	double  qual;                 /* genotype qual after the scalings of :386-404 */
+	double  gq, gl[3];            /* Genotype.qual, GL (the GT:GQ:GL sample column) */
+	double  ake, rke;             /* mean(adists), mean(rdists); NaN when empty  */
+	int32_t ad[2];                /* ref_support, alt_support                    */
+	int32_t dp, bs, mf, cf, nc;   /* DP, BS (0: absent), MF, CF, NC              */
+	int32_t amq, rmq;             /* median mapq of the alt / ref reads; -1: absent */
+	uint8_t lo, al, event_type, _pad;   /* LO and AL flags; 0 insertion, 1 deletion */
+	int32_t ref_len, alt_len, cc_len;   /* REF, ALT, CC strings in `chars`         */
+	int64_t ref_off, alt_off, cc_off;
+	char    ref_kmer[32], alt_kmer[32];
+} ihp_variant;
+
+typedef struct {
+	int64_t n;                    /* one record per tallied event, in output order */
+	ihp_variant *v;
+	int64_t n_chars;
+	char *chars;
+} ihp_variants;
+
+int  ihp_call_variants(const ihp_params *p, const ihp_batch_in *in, const ihp_batch_out *out, ihp_variants *vars);
+void ihp_free_variants(ihp_variants *vars);
+/* `$`(v) of indelope.nim:104-113: one VCF line (no newline) into buf; returns the length
+ * needed (excluding the NUL), or a negative IHP_E_* code.                                  */
+int64_t ihp_format_variant(const ihp_variant *v, const char *chars, const char *chrom, char *buf, int64_t cap);
+
 /* Host buffers in, host buffers out (upload + run + fetch).                   */
 int  ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out);
 void ihp_free_out(ihp_batch_out *out);

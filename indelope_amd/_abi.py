@@ -130,6 +130,26 @@ class BatchOut(C.Structure):
                 ("hit_off", i64p), ("ref_hit", i32p), ("alt_hit", i32p)]
 
 
+class Variant(C.Structure):           # ihp_variant
+    _fields_ = [("region", C.c_int32), ("contig", C.c_int32), ("event", C.c_int64), ("filter", C.c_int32), ("gt", C.c_int32),
+                ("start", C.c_int64), ("qual", C.c_double), ("gq", C.c_double), ("gl", C.c_double * 3),
+                ("ake", C.c_double), ("rke", C.c_double), ("ad", C.c_int32 * 2),
+                ("dp", C.c_int32), ("bs", C.c_int32), ("mf", C.c_int32), ("cf", C.c_int32), ("nc", C.c_int32),
+                ("amq", C.c_int32), ("rmq", C.c_int32),
+                ("lo", C.c_uint8), ("al", C.c_uint8), ("event_type", C.c_uint8), ("_pad", C.c_uint8),
+                ("ref_len", C.c_int32), ("alt_len", C.c_int32), ("cc_len", C.c_int32),
+                ("ref_off", C.c_int64), ("alt_off", C.c_int64), ("cc_off", C.c_int64),
+                ("ref_kmer", C.c_char * 32), ("alt_kmer", C.c_char * 32)]
+
+
+class Variants(C.Structure):          # ihp_variants
+    _fields_ = [("n", C.c_int64), ("v", C.POINTER(Variant)), ("n_chars", C.c_int64), ("chars", C.POINTER(C.c_char))]
+
+
+IHP_VF_EMITTED, IHP_VF_LOW_ALT, IHP_VF_LOW_FRAC, IHP_VF_HOM_REF, IHP_VF_BOTH_AT_EDGE = 0, 2, 3, 4, 5
+IHP_VF_SMALL_FLANK, IHP_VF_KMER_AT_END, IHP_VF_HOMOPOLYMER, IHP_VF_DUPLICATE, IHP_VF_OOB = 6, 7, 8, 9, 10
+
+
 class RegionSummary(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("status", "n_contigs_pre", "n_contigs", "n_aligned",
                                           "n_events", "n_tallied", "ref_support", "alt_support")]
@@ -155,6 +175,9 @@ _COMMON = {
     "params_default": (None, [C.POINTER(Params)]),
     "run_regions": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(BatchOut)]),
     "free_out": (None, [C.POINTER(BatchOut)]),
+    "call_variants": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(BatchOut), C.POINTER(Variants)]),
+    "free_variants": (None, [C.POINTER(Variants)]),
+    "format_variant": (C.c_int64, [C.POINTER(Variant), C.POINTER(C.c_char), C.c_char_p, C.c_char_p, C.c_int64]),
 }
 
 _PRODUCT_ONLY = {

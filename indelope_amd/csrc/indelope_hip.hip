@@ -15,6 +15,7 @@
 #include <new>
 #include <vector>
 #include "kernels.h"
+#include "variants_host.h"
 
 using namespace ihp;
 
@@ -1238,6 +1239,33 @@ extern "C" void *ihp_host_alloc(size_t bytes)
 }
 
 extern "C" void ihp_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// ---- post-tally filters and Variant records (host code, variants_host.h) ------------------
+extern "C" int ihp_call_variants(const ihp_params *p, const ihp_batch_in *in, const ihp_batch_out *out, ihp_variants *vars)
+{
+	if (!p || !in || !out || !vars || p->struct_size != (int32_t)sizeof(ihp_params)) return IHP_E_ARG;
+	if (out->n_regions != in->n_regions) return IHP_E_ARG;
+	memset(vars, 0, sizeof(*vars));
+	return ihp_host::call_variants(*p, *in, *out, vars);
+}
+
+extern "C" void ihp_free_variants(ihp_variants *vars)
+{
+	if (!vars) return;
+	free(vars->v); free(vars->chars);
+	memset(vars, 0, sizeof(*vars));
+}
+
+extern "C" int64_t ihp_format_variant(const ihp_variant *v, const char *chars, const char *chrom, char *buf, int64_t cap)
+{
+	if (!v || !chars || !chrom) return IHP_E_ARG;
+	const std::string line = ihp_host::vcf_line(*v, chars, chrom);
+	if (buf && cap > 0) {
+		const size_t m = std::min(line.size(), (size_t)cap - 1);
+		memcpy(buf, line.data(), m); buf[m] = 0;
+	}
+	return (int64_t)line.size();
+}
 
 extern "C" int ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out)
 {

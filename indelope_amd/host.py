@@ -200,6 +200,27 @@ class BatchResult:
         self.ref_hit = _np(o.ref_hit, o.n_hits, np.int32)
         self.alt_hit = _np(o.alt_hit, o.n_hits, np.int32)
 
+    def as_c(self):
+        """An `ihp_batch_out` view of these arrays (for the host-side entry points that take results as input)."""
+        o = A.BatchOut()
+        o.n_regions, o.n_contigs, o.n_events = self.n_regions, self.n_contigs, self.n_events
+        o.n_cigar_words, o.n_bases, o.n_hits = len(self.cigar), len(self.ctg_seq), len(self.ref_hit)
+        keep = []
+
+        def p(a, t):
+            b = np.ascontiguousarray(a if len(a) else np.zeros(1, a.dtype))
+            keep.append(b)
+            return C.cast(b.ctypes.data, t)
+        o.status, o.n_contigs_pre, o.contig_off = p(self.status, A.i32p), p(self.n_contigs_pre, A.i32p), p(self.contig_off, A.i64p)
+        o.ctg_start, o.ctg_nreads, o.ctg_seq_off = p(self.ctg_start, A.i64p), p(self.ctg_nreads, A.i64p), p(self.ctg_seq_off, A.i64p)
+        o.ctg_seq, o.ctg_support = p(self.ctg_seq, A.u8p), p(self.ctg_support, A.u32p)
+        o.aln_flags, o.aln_ref_start, o.aln_ref_len = p(self.aln_flags, A.i32p), p(self.aln_ref_start, A.i64p), p(self.aln_ref_len, A.i32p)
+        o.aln_ez, o.cigar_off, o.cigar = p(self.aln_ez, C.POINTER(A.Ez)), p(self.cigar_off, A.i64p), p(self.cigar, A.u32p)
+        o.event_off, o.events = p(self.event_off, A.i64p), p(self.events, C.POINTER(A.Event))
+        o.hit_off, o.ref_hit, o.alt_hit = p(self.hit_off, A.i64p), p(self.ref_hit, A.i32p), p(self.alt_hit, A.i32p)
+        o._keep = keep
+        return o
+
     def contig_sequence(self, c):
         return self.ctg_seq[self.ctg_seq_off[c]:self.ctg_seq_off[c + 1]].tobytes().decode("latin1")
 
@@ -402,3 +423,40 @@ class Api:
 
 
 GT_STR = ["0/0", "0/1", "1/1", "./."]             # genotyper.nim:17
+
+
+VARIANT_FIELDS = ("region", "contig", "event", "filter", "gt", "start", "qual", "gq", "ake", "rke", "dp", "bs", "mf", "cf",
+                  "nc", "amq", "rmq", "lo", "al", "event_type")
+
+
+def _variants(self, batch, result, params=None, chrom="chr1"):
+    """Api.call_variants: indelope.nim:375-428 + :604-608 over one batch -> list of dicts (one per tallied event), each
+    with the fields of `ihp_variant`, `ref`/`alt`/`cc` strings and, for printed variants, the VCF `line`."""
+    p = params if params is not None else self.params()
+    cin, cout = batch.as_c(), result.as_c()
+    vs = A.Variants()
+    self._chk(self.b.call_variants(C.byref(p), C.byref(cin), C.byref(cout), C.byref(vs)), "call_variants")
+    try:
+        chars = C.string_at(vs.chars, vs.n_chars) if vs.n_chars else b""
+        res = []
+        for i in range(vs.n):
+            v = vs.v[i]
+            d = {f: getattr(v, f) for f in VARIANT_FIELDS}
+            d["gl"], d["ad"] = list(v.gl), list(v.ad)
+            d["ref_kmer"], d["alt_kmer"] = v.ref_kmer.decode(), v.alt_kmer.decode()
+            d["ref"] = chars[v.ref_off:v.ref_off + v.ref_len].decode()
+            d["alt"] = chars[v.alt_off:v.alt_off + v.alt_len].decode()
+            d["cc"] = chars[v.cc_off:v.cc_off + v.cc_len].decode()
+            d["line"] = None
+            if v.filter == A.IHP_VF_EMITTED:
+                need = self.b.format_variant(C.byref(v), vs.chars, chrom.encode(), None, 0)
+                buf = C.create_string_buffer(need + 1)
+                self.b.format_variant(C.byref(v), vs.chars, chrom.encode(), buf, need + 1)
+                d["line"] = buf.value.decode()
+            res.append(d)
+        return res
+    finally:
+        self.b.free_variants(C.byref(vs))
+
+
+Api.call_variants = _variants

@@ -70,6 +70,10 @@ void orc_params_default(ihp_params *p);
 int  orc_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out);
 int  orc_run_regions_mt(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out, int nthreads);
 void orc_free_out(ihp_batch_out *out);
+/* indelope.nim:375-428 + :604-608 + `$`(Variant): mirrors of ihp_call_variants & co. (oracle_variants.c) */
+int  orc_call_variants(const ihp_params *p, const ihp_batch_in *in, const ihp_batch_out *out, ihp_variants *vars);
+void orc_free_variants(ihp_variants *vars);
+int64_t orc_format_variant(const ihp_variant *v, const char *chars, const char *chrom, char *buf, int64_t cap);
 /* cpu_baseline probe: each thread runs its share of the regions `reps` times, results discarded. */
 int  orc_bench_regions(const ihp_params *p, const ihp_batch_in *in, int nthreads, int reps);
 
