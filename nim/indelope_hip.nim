@@ -69,6 +69,33 @@ type
     hit_off*: ptr int64                   # [E+1]; per tallied event one entry per read of its region:
     ref_hit*, alt_hit*: ptr int32         # start of the first ref / alt k-mer window in the read, -1 = none (indelope.nim:301-309)
 
+  IhpVariant* {.importc: "ihp_variant", header: "indelope_hip.h", bycopy.} = object   # one per tallied event (indelope.nim:375-428)
+    region*, contig*: int32
+    event*: int64
+    filter*, gt*: int32                   # IHP_VF_* (0 = the reference prints it), IHP_GT_*
+    start*: int64
+    qual*, gq*: float64
+    gl*: array[3, float64]
+    ake*, rke*: float64
+    ad*: array[2, int32]
+    dp*, bs*, mf*, cf*, nc*, amq*, rmq*: int32
+    lo*, al*, event_type*, pad: uint8
+    ref_len*, alt_len*, cc_len*: int32
+    ref_off*, alt_off*, cc_off*: int64
+    ref_kmer*, alt_kmer*: array[32, char]
+
+  IhpVariants* {.importc: "ihp_variants", header: "indelope_hip.h", bycopy.} = object
+    n*: int64
+    v*: ptr IhpVariant
+    n_chars*: int64
+    chars*: cstring
+
+proc ihp_call_variants*(p: ptr IhpParams, inp: ptr IhpBatchIn, outp: ptr IhpBatchOut, vars: ptr IhpVariants): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_free_variants*(vars: ptr IhpVariants) {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_format_variant*(v: ptr IhpVariant, chars: cstring, chrom: cstring, buf: cstring, cap: int64): int64 {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_host_alloc*(bytes: csize_t): pointer {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
+
 proc ihp_init*(device: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_strerror*(code: cint): cstring {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_params_default*(p: ptr IhpParams) {.importc, cdecl, header: "indelope_hip.h".}
