@@ -431,7 +431,9 @@ VARIANT_FIELDS = ("region", "contig", "event", "filter", "gt", "start", "qual", 
 
 def _variants(self, batch, result, params=None, chrom="chr1"):
     """Api.call_variants: indelope.nim:375-428 + :604-608 over one batch -> list of dicts (one per tallied event), each
-    with the fields of `ihp_variant`, `ref`/`alt`/`cc` strings and, for printed variants, the VCF `line`."""
+    with the fields of `ihp_variant`, `ref`/`alt`/`cc` strings and, for variants that pass every test of :375-428
+    (printed, or dropped only as a duplicate of the last two), the VCF `line`.  `chrom`: a name, or region -> name."""
+    chrom_of = chrom if callable(chrom) else (lambda r: chrom)
     p = params if params is not None else self.params()
     cin, cout = batch.as_c(), result.as_c()
     vs = A.Variants()
@@ -448,10 +450,11 @@ def _variants(self, batch, result, params=None, chrom="chr1"):
             d["alt"] = chars[v.alt_off:v.alt_off + v.alt_len].decode()
             d["cc"] = chars[v.cc_off:v.cc_off + v.cc_len].decode()
             d["line"] = None
-            if v.filter == A.IHP_VF_EMITTED:
-                need = self.b.format_variant(C.byref(v), vs.chars, chrom.encode(), None, 0)
+            if v.filter in (A.IHP_VF_EMITTED, A.IHP_VF_DUPLICATE):
+                name = chrom_of(v.region).encode()
+                need = self.b.format_variant(C.byref(v), vs.chars, name, None, 0)
                 buf = C.create_string_buffer(need + 1)
-                self.b.format_variant(C.byref(v), vs.chars, chrom.encode(), buf, need + 1)
+                self.b.format_variant(C.byref(v), vs.chars, name, buf, need + 1)
                 d["line"] = buf.value.decode()
             res.append(d)
         return res

@@ -49,7 +49,7 @@ def test_product_equals_oracle_and_filters_fire(oracle):
         seen.update(v["filter"] for v in got)
         for v in got:
             if v["filter"] != A.IHP_VF_EMITTED:
-                assert v["line"] is None
+                assert (v["line"] is None) == (v["filter"] != A.IHP_VF_DUPLICATE)
                 continue
             lines += 1
             f = v["line"].split("\t")
@@ -98,3 +98,56 @@ def test_variants_from_device_results(hip, oracle):
     got = hip.call_variants(b, res, hip.params(**kw))
     same_records(got, oracle.call_variants(b, oracle.run_regions(b, oracle.params(**kw)), oracle.params(**kw)))
     assert sum(v["filter"] == A.IHP_VF_EMITTED for v in got) > 150
+
+
+def test_batching_adapter_is_batch_size_independent(oracle):
+    """Row f3: the sweep-side adapter (indelope_amd/sweep.py) prints the same VCF lines whatever the flush size, and
+    the last-two-printed window (indelope.nim:598-608) works across flushes."""
+    from indelope_amd import sweep
+    b, _ = synth.generate(90, n_reads=(12, 48), err_rate=1e-3, config_id=75, dup_frac=0.15)
+    rois = sweep.rois_from_batch(b)
+    # the same region three times in a row, and again two regions later: only the repeats inside the window are dropped
+    rois = rois[:10] + [rois[10]] * 3 + rois[11:13] + [rois[10]] + rois[13:]
+    kw = dict(min_reads=3, min_ctg_len=73)
+    outs = {}
+    for n in (1, 2, 7, 64, 10_000):
+        for on_host in (True, False):
+            c = sweep.BatchedCaller(oracle, oracle.params(**kw), batch_regions=n, trim_on_host=on_host)
+            lines = []
+            for roi in rois:
+                lines += c.add(roi)
+            lines += c.flush()
+            outs[(n, on_host)] = lines
+    ref = outs[(10_000, True)]
+    assert len(ref) > 60
+    for k, v in outs.items():
+        assert v == ref, k
+    # one flush == the library's own dedupe over the same regions
+    one = sweep.BatchedCaller(oracle, oracle.params(**kw), batch_regions=10_000)
+    for roi in rois:
+        one.add(roi)
+    batch = one._stage()
+    res = oracle.run_regions(batch, oracle.params(**kw))
+    direct = [v["line"] for v in oracle.call_variants(batch, res, oracle.params(**kw)) if v["filter"] == A.IHP_VF_EMITTED]
+    assert direct == ref
+    # the repeated region: printed once at its first occurrence, dropped while in the window
+    pos = str(int(b.ref_origin[10]))[:4]
+    assert sum(l.split("\t")[1].startswith(pos) for l in ref) <= 2
+
+
+@pytest.mark.gpu
+def test_batching_adapter_on_the_device(hip, oracle):
+    from indelope_amd import sweep
+    b, _ = synth.generate(120, n_reads=(12, 64), err_rate=1e-3, config_id=76, dup_frac=0.1)
+    rois = sweep.rois_from_batch(b)
+    kw = dict(min_reads=3, min_ctg_len=73)
+
+    def run(api, n):
+        c = sweep.BatchedCaller(api, api.params(**kw), batch_regions=n)
+        lines = []
+        for roi in rois:
+            lines += c.add(roi)
+        return lines + c.flush()
+    exp = run(oracle, 10_000)
+    assert len(exp) > 80
+    assert run(hip, 10_000) == exp and run(hip, 17) == exp
