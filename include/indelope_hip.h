@@ -344,6 +344,37 @@ void ihp_free_variants(ihp_variants *vars);
  * needed (excluding the NUL), or a negative IHP_E_* code.                                  */
 int64_t ihp_format_variant(const ihp_variant *v, const char *chars, const char *chrom, char *buf, int64_t cap);
 
+/* ------------------------------------------------ ROI evidence scan (row f4, the caller's side) */
+/* gen_roi / gen_roi_internal / event_locations (indelope.nim:430-445, :461-545) for one run of reads of
+ * one target, in BAM order: every non-match CIGAR op of a non-skippable read adds 1 (saturating at 255)
+ * to the positions it spans on the reference (1 position for ops that do not consume it), maximal runs of
+ * positions with evidence >= min_event_support become regions of interest -- cut at the read starts that
+ * follow a coverage gap, where the reference flushes its cache -- and a region keeps the first
+ * max_read_coverage + 1 non-skippable reads that overlap it; it is yielded when their number lies in
+ * [min_read_coverage, max_read_coverage].  Positions are relative to `origin`; evidence outside
+ * [origin, origin + span] is ignored (the reference indexes an array of target.length + 1 there).      */
+typedef struct {
+	int64_t n_reads;
+	const int64_t *read_start, *read_stop;    /* Record.start, Record.stop; sorted by start            */
+	const uint8_t *read_skip;                 /* skippable(r), indelope.nim:40-47                      */
+	const int64_t *cigar_off;                 /* [n_reads + 1] into cigar                              */
+	const uint32_t *cigar;                    /* BAM encoding: len << 4 | op, op in MIDNSHP=X          */
+	int64_t origin, span;
+	int32_t min_event_support;                /* gen_roi's min_event_support (uint8): 4, CLI max(3, min_reads - 2) */
+	int32_t min_read_coverage;                /* 4 (CLI: min_reads)                                    */
+	int32_t max_read_coverage;                /* 600                                                   */
+} ihp_roi_in;
+
+typedef struct {
+	int64_t n_roi, n_read_idx;
+	int64_t *roi_start, *roi_stop;            /* roi.start, roi.stop (inclusive), genomic              */
+	int64_t *read_off;                        /* [n_roi + 1] into reads                                */
+	int64_t *reads;                           /* indices of the region's reads in the input, BAM order */
+} ihp_roi_out;
+
+int  ihp_gen_roi(const ihp_roi_in *in, ihp_roi_out *out);
+void ihp_free_roi(ihp_roi_out *out);
+
 /* Host buffers in, host buffers out (upload + run + fetch).                   */
 int  ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_batch_out *out);
 void ihp_free_out(ihp_batch_out *out);

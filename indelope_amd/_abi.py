@@ -150,6 +150,17 @@ IHP_VF_EMITTED, IHP_VF_LOW_ALT, IHP_VF_LOW_FRAC, IHP_VF_HOM_REF, IHP_VF_BOTH_AT_
 IHP_VF_SMALL_FLANK, IHP_VF_KMER_AT_END, IHP_VF_HOMOPOLYMER, IHP_VF_DUPLICATE, IHP_VF_OOB = 6, 7, 8, 9, 10
 
 
+class RoiIn(C.Structure):             # ihp_roi_in
+    _fields_ = [("n_reads", C.c_int64), ("read_start", i64p), ("read_stop", i64p), ("read_skip", u8p),
+                ("cigar_off", i64p), ("cigar", u32p), ("origin", C.c_int64), ("span", C.c_int64),
+                ("min_event_support", C.c_int32), ("min_read_coverage", C.c_int32), ("max_read_coverage", C.c_int32)]
+
+
+class RoiOut(C.Structure):            # ihp_roi_out
+    _fields_ = [("n_roi", C.c_int64), ("n_read_idx", C.c_int64), ("roi_start", i64p), ("roi_stop", i64p),
+                ("read_off", i64p), ("reads", i64p)]
+
+
 class RegionSummary(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("status", "n_contigs_pre", "n_contigs", "n_aligned",
                                           "n_events", "n_tallied", "ref_support", "alt_support")]
@@ -175,6 +186,8 @@ _COMMON = {
     "params_default": (None, [C.POINTER(Params)]),
     "run_regions": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(BatchOut)]),
     "free_out": (None, [C.POINTER(BatchOut)]),
+    "gen_roi": (C.c_int, [C.POINTER(RoiIn), C.POINTER(RoiOut)]),
+    "free_roi": (None, [C.POINTER(RoiOut)]),
     "call_variants": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(BatchOut), C.POINTER(Variants)]),
     "free_variants": (None, [C.POINTER(Variants)]),
     "format_variant": (C.c_int64, [C.POINTER(Variant), C.POINTER(C.c_char), C.c_char_p, C.c_char_p, C.c_int64]),

@@ -1240,6 +1240,112 @@ extern "C" void *ihp_host_alloc(size_t bytes)
 
 extern "C" void ihp_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// ---- ROI evidence scan (roi_dev.h) ------------------------------------------------------------------
+extern "C" void ihp_free_roi(ihp_roi_out *out)
+{
+	if (!out) return;
+	free(out->roi_start); free(out->roi_stop); free(out->read_off); free(out->reads);
+	memset(out, 0, sizeof(*out));
+}
+
+extern "C" int ihp_gen_roi(const ihp_roi_in *in, ihp_roi_out *out)
+{
+	if (!in || !out || in->n_reads < 0 || in->span < 0 || in->max_read_coverage < 0) return IHP_E_ARG;
+	if (in->n_reads && (!in->read_start || !in->read_stop || !in->cigar_off || !in->cigar)) return IHP_E_ARG;
+	memset(out, 0, sizeof(*out));
+	int rc = ensure_init();
+	if (rc) return rc;
+	hipStream_t s = g.stream;
+	const long long N = in->n_reads, len = in->span + 1;
+	const long long n_cig = N ? in->cigar_off[N] : 0;
+	const long long rblocks = std::max<long long>(1, (N + ROI_BLOCK - 1) / ROI_BLOCK), pblocks = (len + ROI_BLOCK - 1) / ROI_BLOCK;
+	// positions relative to the origin
+	std::vector<long long> st((size_t)std::max<long long>(N, 1)), en((size_t)std::max<long long>(N, 1));
+	for (long long i = 0; i < N; ++i) { st[(size_t)i] = in->read_start[i] - in->origin; en[(size_t)i] = in->read_stop[i] - in->origin; }
+	DBuf d_st, d_en, d_skip, d_coff, d_cig, d_pmax, d_bmax, d_ev, d_cut, d_cnt, d_rs, d_re, d_rcnt, d_roff, d_reads;
+	if ((rc = d_st.upload(st.data(), sizeof(long long) * (size_t)N, s)) || (rc = d_en.upload(en.data(), sizeof(long long) * (size_t)N, s))) return rc;
+	if (in->read_skip && (rc = d_skip.upload(in->read_skip, (size_t)N, s))) return rc;
+	static const int64_t zero1[1] = {0};
+	if ((rc = d_coff.upload(N ? in->cigar_off : zero1, sizeof(long long) * (size_t)(N + 1), s))) return rc;
+	if ((rc = d_cig.upload(in->cigar, sizeof(uint32_t) * (size_t)n_cig, s))) return rc;
+	if ((rc = d_pmax.alloc(sizeof(long long) * (size_t)std::max<long long>(N, 1))) || (rc = d_bmax.alloc(sizeof(long long) * (size_t)rblocks))) return rc;
+	if ((rc = d_ev.alloc(sizeof(unsigned) * (size_t)len)) || (rc = d_cut.alloc((size_t)len + 2))) return rc;
+	if ((rc = d_cnt.alloc(sizeof(long long) * 2 * (size_t)(pblocks + 1)))) return rc;
+	if ((rc = d_ev.zero(s)) || (rc = d_cut.zero(s))) return rc;
+	RoiArgs a;
+	memset(&a, 0, sizeof(a));
+	a.n_reads = N; a.len = len; a.start = d_st.as<long long>(); a.stop = d_en.as<long long>();
+	a.skip = in->read_skip ? d_skip.as<uint8_t>() : nullptr;
+	a.cigar_off = d_coff.as<long long>(); a.cigar = d_cig.as<uint32_t>();
+	a.pmax_incl = d_pmax.as<long long>(); a.block_max = d_bmax.as<long long>();
+	a.evidence = d_ev.as<unsigned>(); a.cut = d_cut.as<uint8_t>();
+	a.min_evidence = in->min_event_support < 0 ? 0 : in->min_event_support > 255 ? 256 : in->min_event_support;
+	a.min_reads = in->min_read_coverage; a.max_reads = in->max_read_coverage;
+	a.block_cnt = d_cnt.as<long long>(); a.pos_blocks = pblocks;
+	if (N > 0) {
+		hipLaunchKernelGGL(k_roi_pmax_blocks, dim3((unsigned)rblocks), dim3(ROI_BLOCK), 0, s, a);
+		hipLaunchKernelGGL(k_roi_pmax_scan, dim3(1), dim3(ROI_BLOCK), 0, s, a.block_max, rblocks);
+		hipLaunchKernelGGL(k_roi_pmax_apply, dim3((unsigned)rblocks), dim3(ROI_BLOCK), 0, s, a);
+		hipLaunchKernelGGL(k_roi_evidence, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a);
+	}
+	hipLaunchKernelGGL(k_roi_count, dim3((unsigned)pblocks), dim3(ROI_BLOCK), 0, s, a);
+	hipLaunchKernelGGL(k_roi_count_scan, dim3(1), dim3(ROI_BLOCK), 0, s, a.block_cnt, pblocks);
+	HIPC(hipGetLastError());
+	long long tot[2] = {0, 0};
+	HIPC(hipMemcpyAsync(&tot[0], a.block_cnt + pblocks, sizeof(long long), hipMemcpyDeviceToHost, s));
+	HIPC(hipMemcpyAsync(&tot[1], a.block_cnt + 2 * pblocks + 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+	HIPC(hipStreamSynchronize(s));
+	if (tot[0] != tot[1]) { snprintf(g.err, sizeof(g.err), "roi scan: %lld starts, %lld ends", tot[0], tot[1]); return IHP_E_HIP; }
+	const long long R = tot[0];
+	std::vector<long long> h_rs((size_t)R), h_re((size_t)R), h_off((size_t)R, -1);
+	std::vector<int> h_cnt((size_t)R);
+	long long kept = 0, total_idx = 0;
+	if (R > 0) {
+		if ((rc = d_rs.alloc(sizeof(long long) * (size_t)R)) || (rc = d_re.alloc(sizeof(long long) * (size_t)R)) ||
+		    (rc = d_rcnt.alloc(sizeof(int) * (size_t)R)) || (rc = d_roff.alloc(sizeof(long long) * (size_t)R))) return rc;
+		a.roi_start = d_rs.as<long long>(); a.roi_end = d_re.as<long long>(); a.n_roi = R; a.roi_cnt = d_rcnt.as<int>();
+		hipLaunchKernelGGL(k_roi_emit, dim3((unsigned)pblocks), dim3(ROI_BLOCK), 0, s, a);
+		const int grid = grid_for((int)std::min<long long>(R, 1 << 30), 16);
+		hipLaunchKernelGGL(k_roi_reads<false>, dim3(grid), dim3(64), 0, s, a);
+		HIPC(hipGetLastError());
+		HIPC(hipMemcpyAsync(h_rs.data(), a.roi_start, sizeof(long long) * (size_t)R, hipMemcpyDeviceToHost, s));
+		HIPC(hipMemcpyAsync(h_re.data(), a.roi_end, sizeof(long long) * (size_t)R, hipMemcpyDeviceToHost, s));
+		HIPC(hipMemcpyAsync(h_cnt.data(), a.roi_cnt, sizeof(int) * (size_t)R, hipMemcpyDeviceToHost, s));
+		HIPC(hipStreamSynchronize(s));
+		for (long long k = 0; k < R; ++k)
+			if (h_cnt[(size_t)k] >= in->min_read_coverage && h_cnt[(size_t)k] <= in->max_read_coverage) {   // :485
+				h_off[(size_t)k] = total_idx; total_idx += h_cnt[(size_t)k]; kept++;
+			}
+	}
+	out->n_roi = kept; out->n_read_idx = total_idx;
+	out->roi_start = (int64_t *)calloc((size_t)std::max<long long>(kept, 1), 8);
+	out->roi_stop = (int64_t *)calloc((size_t)std::max<long long>(kept, 1), 8);
+	out->read_off = (int64_t *)calloc((size_t)kept + 1, 8);
+	out->reads = (int64_t *)calloc((size_t)std::max<long long>(total_idx, 1), 8);
+	if (!out->roi_start || !out->roi_stop || !out->read_off || !out->reads) { ihp_free_roi(out); return IHP_E_NOMEM; }
+	if (kept > 0) {
+		if (total_idx > 0) {
+			if ((rc = d_reads.alloc(sizeof(long long) * (size_t)total_idx))) { ihp_free_roi(out); return rc; }
+			HIPC(hipMemcpyAsync(d_roff.p, h_off.data(), sizeof(long long) * (size_t)R, hipMemcpyHostToDevice, s));
+			a.roi_off = d_roff.as<long long>(); a.roi_reads = d_reads.as<long long>();
+			const int grid = grid_for((int)std::min<long long>(R, 1 << 30), 16);
+			hipLaunchKernelGGL(k_roi_reads<true>, dim3(grid), dim3(64), 0, s, a);
+			HIPC(hipGetLastError());
+			HIPC(hipMemcpyAsync(out->reads, d_reads.p, sizeof(long long) * (size_t)total_idx, hipMemcpyDeviceToHost, s));
+			HIPC(hipStreamSynchronize(s));
+		}
+		long long w = 0;
+		for (long long k = 0; k < R; ++k) {
+			if (h_off[(size_t)k] < 0) continue;
+			out->roi_start[w] = h_rs[(size_t)k] + in->origin; out->roi_stop[w] = h_re[(size_t)k] + in->origin;
+			out->read_off[w] = h_off[(size_t)k];
+			++w;
+		}
+	}
+	out->read_off[kept] = total_idx;
+	return 0;
+}
+
 // ---- post-tally filters and Variant records (host code, variants_host.h) ------------------
 extern "C" int ihp_call_variants(const ihp_params *p, const ihp_batch_in *in, const ihp_batch_out *out, ihp_variants *vars)
 {

@@ -6,6 +6,7 @@
 #include "ksw_narrow.h"
 #include "ksw_wide.h"
 #include "tally_dev.h"
+#include "roi_dev.h"
 
 namespace ihp {
 

@@ -463,3 +463,34 @@ def _variants(self, batch, result, params=None, chrom="chr1"):
 
 
 Api.call_variants = _variants
+
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def _gen_roi(self, read_start, read_stop, cigars, read_skip=None, origin=0, span=None, min_event_support=4,
+             min_read_coverage=4, max_read_coverage=600):
+    """gen_roi (indelope.nim:515-545) over reads in BAM order.  `cigars`: one uint32 array (BAM encoding
+    len << 4 | op) per read.  Returns [(roi_start, roi_stop, [read indices])]."""
+    n = len(read_start)
+    st = np.ascontiguousarray(read_start, np.int64)
+    en = np.ascontiguousarray(read_stop, np.int64)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in cigars])
+    cig = np.ascontiguousarray(np.concatenate([np.asarray(c, np.uint32) for c in cigars]) if n and off[-1] else np.zeros(1, np.uint32))
+    sk = None if read_skip is None else np.ascontiguousarray(read_skip, np.uint8)
+    if span is None:
+        span = int(en.max() - origin + 1) if n else 0
+    rin = A.RoiIn(n, A.ptr(st if n else np.zeros(1, np.int64), A.i64p), A.ptr(en if n else np.zeros(1, np.int64), A.i64p),
+                  A.ptr(sk, A.u8p), A.ptr(off, A.i64p), A.ptr(cig, A.u32p), origin, span,
+                  min_event_support, min_read_coverage, max_read_coverage)
+    out = A.RoiOut()
+    self._chk(self.b.gen_roi(C.byref(rin), C.byref(out)), "gen_roi")
+    try:
+        rs, re = _np(out.roi_start, out.n_roi, np.int64), _np(out.roi_stop, out.n_roi, np.int64)
+        ro, rd = _np(out.read_off, out.n_roi + 1, np.int64), _np(out.reads, out.n_read_idx, np.int64)
+        return [(int(rs[k]), int(re[k]), rd[ro[k]:ro[k + 1]].tolist()) for k in range(out.n_roi)]
+    finally:
+        self.b.free_roi(C.byref(out))
+
+
+Api.gen_roi = _gen_roi

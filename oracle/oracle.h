@@ -73,6 +73,9 @@ void orc_free_out(ihp_batch_out *out);
 /* indelope.nim:375-428 + :604-608 + `$`(Variant): mirrors of ihp_call_variants & co. (oracle_variants.c) */
 int  orc_call_variants(const ihp_params *p, const ihp_batch_in *in, const ihp_batch_out *out, ihp_variants *vars);
 void orc_free_variants(ihp_variants *vars);
+/* gen_roi (indelope.nim:430-545): mirror of ihp_gen_roi (oracle_roi.c) */
+int  orc_gen_roi(const ihp_roi_in *in, ihp_roi_out *out);
+void orc_free_roi(ihp_roi_out *out);
 int64_t orc_format_variant(const ihp_variant *v, const char *chars, const char *chrom, char *buf, int64_t cap);
 /* cpu_baseline probe: each thread runs its share of the regions `reps` times, results discarded. */
 int  orc_bench_regions(const ihp_params *p, const ihp_batch_in *in, int nthreads, int reps);
