@@ -149,3 +149,29 @@ def rois_from_batch(batch, chrom="chr1"):
         e = max((rd.stop for rd in reads), default=s)
         out.append(Roi(s, e, reads, batch.ref_bases[f0:f1].tobytes(), int(batch.ref_origin[r]), chrom))
     return out
+
+
+def call_target(api, reads, cigars, fetch, params=None, chrom="chr1", batch_regions=4096, target_len=None,
+                min_event_support=None, max_read_coverage=600):
+    """The whole post-decode sweep of one target (indelope.nim:601-608): gen_roi over the decoded reads (`reads`: list
+    of `Read` in BAM order, `cigars`: their BAM CIGAR words), every region staged with the reference slice its reads
+    span (`fetch(start, stop)` -> bytes for [start, stop), clamped by the caller like faidx), batched through the
+    path, VCF lines out in order."""
+    p = params if params is not None else api.params()
+    if min_event_support is None:
+        min_event_support = max(3, p.min_reads - 2)            # indelope.nim:602
+    st = np.array([r.start for r in reads], np.int64)
+    en = np.array([r.stop for r in reads], np.int64)
+    sk = np.array([1 if r.skippable else 0 for r in reads], np.uint8)
+    span = (target_len if target_len is not None else int(en.max()) + 1) if len(reads) else 0
+    rois = api.gen_roi(st, en, cigars, read_skip=sk, origin=0, span=span, min_event_support=min_event_support,
+                       min_read_coverage=p.min_reads, max_read_coverage=max_read_coverage)
+    caller = BatchedCaller(api, p, batch_regions=batch_regions)
+    width = int((p.K + 1) / 2 - 1)                             # indelope.nim:218
+    lines = []
+    for rs, re, idx in rois:
+        rr = [reads[i] for i in idx]
+        lo = max(0, min(r.start for r in rr) - 1)              # REF alleles reach one base left of the event (:414, :421)
+        hi = max(r.stop for r in rr) + width + p.ref_pad + 1   # fai.get(chrom, ctg.start, max_stop + width + 50), :220
+        lines += caller.add(Roi(rs, re, rr, fetch(lo, hi), lo, chrom))
+    return lines + caller.flush(), rois

@@ -90,6 +90,21 @@ type
     n_chars*: int64
     chars*: cstring
 
+type
+  IhpRoiIn* {.importc: "ihp_roi_in", header: "indelope_hip.h", bycopy.} = object   # gen_roi (indelope.nim:515-545) over decoded reads
+    n_reads*: int64
+    read_start*, read_stop*: ptr int64
+    read_skip*: ptr uint8
+    cigar_off*: ptr int64
+    cigar*: ptr uint32                    # BAM encoding, as in bam1_t
+    origin*, span*: int64
+    min_event_support*, min_read_coverage*, max_read_coverage*: int32
+  IhpRoiOut* {.importc: "ihp_roi_out", header: "indelope_hip.h", bycopy.} = object
+    n_roi*, n_read_idx*: int64
+    roi_start*, roi_stop*, read_off*, reads*: ptr int64
+
+proc ihp_gen_roi*(inp: ptr IhpRoiIn, outp: ptr IhpRoiOut): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_free_roi*(outp: ptr IhpRoiOut) {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_call_variants*(p: ptr IhpParams, inp: ptr IhpBatchIn, outp: ptr IhpBatchOut, vars: ptr IhpVariants): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_free_variants*(vars: ptr IhpVariants) {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_format_variant*(v: ptr IhpVariant, chars: cstring, chrom: cstring, buf: cstring, cap: int64): int64 {.importc, cdecl, header: "indelope_hip.h".}
