@@ -15,7 +15,7 @@ from indelope_amd import _abi as A
 from indelope_amd.host import Api, BatchResult
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "liboracle.so")
+LIB = os.environ.get("IHP_ORACLE_LIB", os.path.join(HERE, "liboracle.so"))   # e.g. liboracle_asan.so (make asan)
 REF_DIR = os.path.join(HERE, "_ref")
 
 
