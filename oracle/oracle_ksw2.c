@@ -282,7 +282,7 @@ int orc_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int64_t *q_off,
 		ez[i].max = (int32_t)z.max; ez[i].zdropped = (int32_t)z.zdropped;
 		ez[i].max_q = z.max_q; ez[i].max_t = z.max_t; ez[i].mqe = z.mqe; ez[i].mqe_t = z.mqe_t;
 		ez[i].mte = z.mte; ez[i].mte_q = z.mte_q; ez[i].score = z.score; ez[i].n_cigar = z.n_cigar;
-		if (used + z.n_cigar <= cigar_cap) memcpy(cigar + used, z.cigar, (size_t)z.n_cigar * 4);
+		if (used + z.n_cigar <= cigar_cap) { if (z.n_cigar) memcpy(cigar + used, z.cigar, (size_t)z.n_cigar * 4); }
 		else rc = IHP_E_CAPACITY;
 		used += z.n_cigar;
 		cigar_off[i + 1] = used;
