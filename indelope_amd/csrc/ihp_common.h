@@ -89,22 +89,23 @@ __device__ __forceinline__ bool allowed(int rule, uint32_t qsup, uint32_t tsup, 
 	       (tsup < 3u && qsup > 3u * tsup && treads > 3ll * (long long)tsup);
 }
 
-// Work queue of a persistent grid: eight counters on separate cache lines (item j belongs to shard j & 7).
-// A single dequeue word saturates near 90 dequeues/us on this chip, which at ~20k short items per launch
-// costs more than the items themselves; a workgroup pulls from its home shard first and steals from the
-// others when it runs dry.  Call from lane 0 only.
-constexpr int WQ_WORDS = 8 * 16;
+// Work queue of a persistent grid: up to 64 counters on separate cache lines; item j belongs to shard j % S and a
+// workgroup serves its home shard (blockIdx % S) only, S = min(64, grid).  One address sustains only ~40 requests
+// per microsecond, loads included: a single counter makes 20 000 short items cost more than their work, and eight
+// counters with stealing made every wave sweep all eight at the end (65 000 requests per launch of 8192 waves,
+// ~0.27 ms).  With one atomic per item plus one per wave, spread over 64 lines, the queue disappears from the
+// profile; items are dealt round robin over the shards, so the shards hold equal shares and balancing inside a
+// shard (grid / S waves) is enough.  Call from lane 0 only; `dead` is the wave's "my shard is dry" flag.
+constexpr int WQ_SHARDS = 64;
+constexpr int WQ_WORDS = WQ_SHARDS * 16;
 __device__ __forceinline__ int wq_next(int *q, int n, int home, unsigned &dead)
 {
-	for (int t = 0; t < 8; ++t) {
-		const int s = (home + t) & 7;
-		if ((dead >> s) & 1) continue;
-		if (__hip_atomic_load(&q[s * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8 + s < n) {
-			const int j = atomicAdd(&q[s * 16], 1) * 8 + s;
-			if (j < n) return j;
-		}
-		dead |= 1u << s;
-	}
+	if (dead) return -1;
+	const int S = (int)gridDim.x < WQ_SHARDS ? (int)gridDim.x : WQ_SHARDS;
+	const int s = home % S;
+	const int j = atomicAdd(&q[s * 16], 1) * S + s;
+	if (j < n) return j;
+	dead = 1u;
 	return -1;
 }
 

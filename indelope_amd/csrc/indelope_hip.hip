@@ -630,7 +630,7 @@ struct ihp_batch {
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
-	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
+	DBuf hit_pool, hit_region_cnt; long long hit_cap = 0;  // first-hit k-mer positions per (tallied event, read)
 	int grid_fb = 0, lds_fb = 0, fb_cig_cap = 0, max_region_reads = 0;
 	size_t fb_p_cap = 0;
 	// outputs
@@ -790,7 +790,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		b->cig_cap = qeff + tmax + 8;
 	}
 	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_KSW_WAVES") ? atoi(getenv("IHP_KSW_WAVES")) : 32);
-	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), 32);
+	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_TALLY_WAVES") ? atoi(getenv("IHP_TALLY_WAVES")) : 32);
 	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
 	b->njobs_cap = njobs_cap;
 	b->cig_bump_cap = 8 * njobs_cap + 4096;                      // CIGARs longer than CIG_SLOT words
@@ -844,8 +844,11 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(cig_pool, 4 * (size_t)b->cig_pool_cap);
 	AL(ev_off, 8 * slots); AL(n_ev, 4 * slots); AL(ev_pool, sizeof(DevEvent) * (size_t)b->ev_pool_cap);
 	AL(summary, sizeof(ihp_region_summary) * R);
-	b->hit_cap = 2 * (4 * NR + 64 * (long long)std::max(1, b->max_region_reads));   // room for 4 tallied events per region on average
+	// HIT_SLOTS events per region at fixed places (2 x nreads ints each, region r at 8 x its first read index), then
+	// a bump region of the same size for regions with more tallied events
+	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
 	AL(hit_pool, sizeof(int) * (size_t)b->hit_cap);
+	AL(hit_region_cnt, sizeof(int) * (size_t)std::max(R, 1));
 #undef AL
 	for (auto &e : b->ev) HIPC(hipEventCreate(&e));
 	HIPC(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -968,7 +971,10 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.P.K = p.K; a.P.min_event_len = p.min_event_len; a.P.max_events = p.max_events; a.P.min_mapq_tally = p.min_mapq_tally;
 		a.P.fallback = p.fallback; a.fb_items = p.fallback ? b->fb_items.as<FbItem>() : nullptr; a.fb_count = misc + M_NFB;
 		a.hit_pool = b->hit_pool.as<int>(); a.hit_cursor = (unsigned long long *)(misc + M_HIT); a.hit_cap = b->hit_cap;
-		a.hit_overflow = misc + M_OVF_HIT;
+		a.hit_overflow = misc + M_OVF_HIT; a.hit_region_cnt = b->hit_region_cnt.as<int>();
+		HIPC(hipMemsetAsync(b->hit_region_cnt.p, 0, sizeof(int) * (size_t)std::max(b->R, 1), s));
+		a.hit_bump0 = 2ll * HIT_SLOTS * b->n_reads;
+		a.dbg = getenv("IHP_TALLY_DBG") ? atoi(getenv("IHP_TALLY_DBG")) : 0;                // the bump region lies behind the fixed slots
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
 		a.overflow = misc + M_OVF; a.work_counter = wq + 8 * WQ_WORDS;

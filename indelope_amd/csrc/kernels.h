@@ -510,41 +510,49 @@ struct TallyArgs {
 	int lds_bytes;                             // dynamic LDS for staging 64 reads
 	FbItem *fb_items; int *fb_count;           // events handed to the alignment fallback (one slot per event)
 	int *hit_pool; unsigned long long *hit_cursor; long long hit_cap; int *hit_overflow;   // first-hit positions per (tallied event, read)
+	int *hit_region_cnt;                       // [R] events of the region that took one of its own hit slots
+	long long hit_bump0;                       // start of the shared bump region
 };
 
 __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t tally_lds[];
-	__shared__ int s_item;
 	const int lane = lane_id();
-	const int njobs = *a.n_jobs;
-	unsigned wq_dead = 0;
-	for (;;) {
-		if (lane == 0) s_item = wq_next(a.work_counter, njobs, (int)blockIdx.x, wq_dead);
-		WSYNC();
-		const int j = s_item;
-		WSYNC();
-		if (j < 0) break;
+	const int njobs = uni(*a.n_jobs);
+	// Items are dealt round robin (wave w takes w, w + grid, ...): they are short and alike, and a shared queue costs
+	// every wave a sweep over its eight counters at the end -- 65 000 same-address requests per launch, which at the
+	// ~40 per microsecond one address sustains took longer than the items themselves.
+	for (int j = (int)blockIdx.x; j < njobs; j += (int)gridDim.x) {
 		const long long tj0 = a.prof ? (long long)clock64() : 0;
+		// A work item is a few microseconds of arithmetic behind a chain of dependent loads (job -> records -> CIGAR ->
+		// k-mer bytes -> reads); everything that depends on the same level is requested together.
 		const AlnJob jb = a.jobs[j];
+		const int r = jb.region;
 		const KswOut ez = a.ez[jb.out];
 		const long long coff = a.cig_off[jb.out];
+		const long long cstart = a.ctg_start[jb.out], origin = a.ref_origin[r];
+		const long long rr0 = a.region_read_off[r], rr1 = a.region_read_off[r + 1];
+		CigSrc cig;
+		cig.mem = a.cig_pool + (coff >= 0 ? coff : 0);
+		cig.in_lanes = ez.n_cigar <= 64;
+		cig.cw = (cig.in_lanes && coff >= 0 && lane < ez.n_cigar) ? cig.mem[lane] : 0u;
+		const long long ge0 = rr0 + 64 < rr1 ? rr0 + 64 : rr1;
+		const long long base0 = a.read_off[rr0], end0 = a.read_off[ge0];
 		int nev = 0, ntrunc = 0;
-		if (ez.n_cigar > 0 && coff >= 0) nev = count_events(a.cig_pool + coff, ez.n_cigar, ez.max_q, &ntrunc);
+		if (ez.n_cigar > 0 && coff >= 0) nev = count_events(cig, ez.n_cigar, ez.max_q, &ntrunc);
 		long long eoff = -1;
 		const long long tj1 = a.prof ? (long long)clock64() : 0;
 		if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[20], (unsigned long long)(tj1 - tj0));
 		if (nev > 0 && nev <= a.P.max_events) {                 // indelope.nim:229
 			eoff = (long long)j * a.P.max_events;               // the job's own slots: no atomic
-			if (lane == 0) atomicAdd(a.ev_cursor, (unsigned long long)nev);   // count only (result unused)
 			if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[21], (unsigned long long)((long long)clock64() - tj1));
 			if (eoff + nev <= a.ev_pool_cap) {
-				const int r = jb.region;
-				fill_events(a.cig_pool + coff, ntrunc, a.out_seq + jb.q_off, jb.qlen,
-				            (int)(a.ctg_start[jb.out] - a.ref_origin[r]), a.ref_bases + jb.t_off, jb.tlen,
-				            a.bases, a.read_off, a.mapq, a.region_read_off[r], a.region_read_off[r + 1],
+				fill_events(cig, ntrunc, a.out_seq + jb.q_off, jb.qlen,
+				            (int)(cstart - origin), a.ref_bases + jb.t_off, jb.tlen,
+				            a.bases, a.read_off, a.mapq, rr0, rr1,
 				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count,
-				            a.hit_pool, a.hit_cursor, a.hit_cap, a.hit_overflow);
+				            a.hit_pool, a.hit_cursor, a.hit_cap, a.hit_overflow, a.hit_region_cnt ? a.hit_region_cnt + r : nullptr,
+				            8 * rr0, a.hit_bump0, base0, end0);
 			} else {
 				if (lane == 0) atomicExch(&a.overflow[2], 1);
 				eoff = -1; nev = 0;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 // indelope.nim:312-372.  For an event whose k-mer tally found both k-mers in one read, every read of the region
 // (mapq >= 10, quality-trimmed) is aligned -- gap open 5, unbanded, no z-drop (ksw2.nim:159 defaults) -- to the
 // reference window and to the contig, both cut at the read's start; count_flanked_cigar (:185-199) of the two
-// truncated CIGARs decides the vote.  One wave per (event, read): work item j = event * max_region_reads + read.
+// truncated CIGARs decides the vote.  One wave per (event, read): work item j = read * n_events + event.
 struct FbArgs {
 	const FbItem *items; const int *n_items; int max_region_reads;
 	const AlnJob *jobs;
@@ -614,7 +622,9 @@ __global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
 		const int j = uni(s_item);
 		WSYNC();
 		if (j < 0) break;
-		const int f = j / a.max_region_reads, i = j - f * a.max_region_reads;
+		// item j = read * n_events + event: the queue deals items to its shards by j % 64, and "read i of every event"
+		// in one shard would put all the reads that start right of their event (skipped at once) together
+		const int i = j / n_items, f = j - i * n_items;
 		const FbItem it = a.items[f];
 		const AlnJob jb = a.jobs[it.job];
 		const int r = uni(jb.region);

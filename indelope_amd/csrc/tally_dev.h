@@ -100,8 +100,9 @@ __device__ __forceinline__ unsigned long long revcomp_code(unsigned long long co
 __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                        long long r0, long long r1, int min_mapq, int K,
                                        unsigned long long refe, unsigned long long alte, int counts[3],
-                                       uint32_t *lds32, int lds_bytes, int *ref_hit = nullptr, int *alt_hit = nullptr)
-{
+                                       uint32_t *lds32, int lds_bytes, int *ref_hit = nullptr, int *alt_hit = nullptr,
+                                       bool first_staged = false)
+{   // first_staged: the caller has already put the first 64 reads into LDS (tally_stage_first)
 	const int lane = lane_id();
 	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
 	// forward and reverse-complement codes of the two k-mers (refe/alte are the smaller of each pair)
@@ -118,8 +119,10 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 			nref += c[0]; nalt += c[1]; nboth += c[2];
 			continue;
 		}
-		WSYNC();
-		for (int i = 4 * lane; i < nbytes; i += 256) lds32[i >> 2] = *(const tally_u32u *)(bases + base0 + i);
+		if (!(first_staged && b == r0)) {
+			WSYNC();
+			for (int i = 4 * lane; i < nbytes; i += 256) lds32[i >> 2] = *(const tally_u32u *)(bases + base0 + i);
+		}
 		WSYNC();
 		const long long ri = b + lane;
 		// Branch-free walk: a window's canonical code equals the k-mer's iff its forward code equals the k-mer's
@@ -161,6 +164,17 @@ __device__ inline void tally_reads_lds(const uint8_t *bases, const long long *re
 	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
 }
 
+// The first (usually only) group of 64 reads of a region into LDS.  Returns false when it does not fit (the tally
+// then walks HBM directly).  No barrier: tally_reads_lds() waits before it reads.
+__device__ __forceinline__ bool tally_stage_first(const uint8_t *bases, long long base0, long long end0, uint32_t *lds32, int lds_bytes)
+{
+	const int lane = lane_id();
+	const int nbytes = (int)(end0 - base0);
+	if (nbytes + 8 > lds_bytes) return false;
+	for (int i = 4 * lane; i < nbytes; i += 256) lds32[i >> 2] = *(const tally_u32u *)(bases + base0 + i);
+	return true;
+}
+
 __device__ __forceinline__ int distinct_bytes(const char *s, int n)
 {
 	unsigned seen_lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -178,18 +192,28 @@ __device__ __forceinline__ bool same_bytes(const char *a, const char *b, int n)
 	return true;
 }
 
+constexpr int HIT_SLOTS = 4;      // tallied events per region with hit positions at a fixed place
+
 struct TallyParams { int K, min_event_len, max_events, min_mapq_tally, fallback; };
+
+// The CIGAR of one alignment: up to 64 words held one per lane (loaded with a single vector load, read back with
+// v_readlane), longer ones from memory.  Walking a CIGAR word by word from memory is a chain of dependent loads,
+// and this kernel's work items are short enough for such chains to be most of their time.
+struct CigSrc {
+	unsigned cw; const uint32_t *mem; bool in_lanes;
+	__device__ __forceinline__ uint32_t word(int i) const { return in_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)cw, i) : mem[i]; }
+};
 
 // Ez.cigar truncation (ksw2.nim:22-33): number of events (I/D ops) among the ops the
 // iterator yields; *ntrunc = number of ops yielded.
-__device__ __forceinline__ int count_events(const uint32_t *cigar, int n_cigar, int max_q, int *ntrunc)
+__device__ __forceinline__ int count_events(const CigSrc cigar, int n_cigar, int max_q, int *ntrunc)
 {
 	const uint32_t max_off = (uint32_t)max_q;
 	uint32_t off = 0;
 	int nev = 0, nt = 0;
 	for (int i = 0; i < n_cigar; ++i) {
 		if (off >= max_off) break;
-		const uint32_t op = cigar[i] & 0xf, len = cigar[i] >> 4;
+		const uint32_t w = cigar.word(i), op = w & 0xf, len = w >> 4;
 		if (op != 2) off += len;
 		nt++;
 		if (op == 1 || op == 2) nev++;
@@ -233,21 +257,24 @@ __device__ __forceinline__ bool mincode_lanes(unsigned byte, int K, unsigned lon
 // Events of one alignment (the caller has checked 0 < nev <= max_events, indelope.nim:229).
 // ctg_rel = ctg.start - region origin; reference points at the window the contig was
 // aligned to (length reflen).  The ref/alt k-mers are held one byte per lane (K <= 31).
-__device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
+__device__ inline void fill_events(const CigSrc cigar, int ntrunc,
                                    const uint8_t *ctg, int ctg_len, int ctg_rel,
                                    const uint8_t *reference, int reflen,
                                    const uint8_t *bases, const long long *read_off, const uint8_t *mapq,
                                    long long r0, long long r1, const TallyParams P, DevEvent *ev,
                                    uint32_t *lds32, int lds_bytes,
                                    int job, int ev_index0, FbItem *fb_items, int *fb_count,
-                                   int *hit_pool, unsigned long long *hit_cursor, long long hit_cap, int *hit_overflow)
-{
+                                   int *hit_pool, unsigned long long *hit_cursor, long long hit_cap, int *hit_overflow,
+                                   int *region_cnt, long long region_base, long long bump0,
+                                   long long base0, long long end0)
+{   // base0 / end0: read_off of the region's first read and of the end of its first group of 64 (loaded by the caller)
 	const int lane = lane_id();
 	const int K = P.K;
 	const int width = (int)((double)(K + 1) / 2.0 - 1.0);                // :218
 	int toff = ctg_rel, qoff = 0, ii = -1;
+	bool staged = false;
 	for (int i = 0; i < ntrunc; ++i) {
-		const uint32_t op = cigar[i] & 0xf, len = cigar[i] >> 4;
+		const uint32_t cwi = cigar.word(i), op = cwi & 0xf, len = cwi >> 4;
 		if (op == 0) { toff += (int)len; qoff += (int)len; continue; }
 		++ii;
 		int e_type, e_ts, e_te, e_qs, e_qe;
@@ -275,6 +302,8 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
 			if (qstart < 0) qstart = 0;
 			if (qstart + K > ctg_len) qstart = ctg_len - K;
 			if (lane < K) ak = ctg[qstart + lane];                       // :248
+			// the reads travel to LDS while the k-mer bytes are still on their way
+			if (!staged && r1 > r0) staged = tally_stage_first(bases, base0, end0, lds32, lds_bytes);
 			if (!ballot(lane < K && rk != ak)) {                         // :255-262
 				qstart = e_qs - 3;
 				if (qstart < 0) qstart = 0;
@@ -297,13 +326,22 @@ __device__ inline void fill_events(const uint32_t *cigar, int ntrunc,
 			// first-hit positions of every read (the side data of :302-309): 2 x nreads ints from a bump pool
 			const long long nr = r1 - r0;
 			if (hit_pool && nr > 0) {
-				long long o = 0;
-				if (lane == 0) o = (long long)atomicAdd(hit_cursor, (unsigned long long)(2 * nr));
-				hoff = uni(o);
-				if (hoff + 2 * nr > hit_cap) { hoff = -1; if (lane == 0) atomicExch(hit_overflow, 1); }
+				// the region's own slots first (HIT_SLOTS events of 2 x nr ints at 8 x its first read index: one atomic on
+				// a per-region word); further events take space from the shared bump region behind them.  A single bump
+				// cursor for everything serialises ten thousand waves on one address.
+				int k = HIT_SLOTS;
+				if (region_cnt) { if (lane == 0) k = atomicAdd(region_cnt, 1); k = uni(k); }
+				if (k < HIT_SLOTS) hoff = region_base + 2 * nr * k;
+				else {
+					long long o = 0;
+					if (lane == 0) o = (long long)atomicAdd(hit_cursor, (unsigned long long)(2 * nr));
+					hoff = bump0 + uni(o);
+					if (hoff + 2 * nr > hit_cap) { hoff = -1; if (lane == 0) atomicExch(hit_overflow, 1); }
+				}
 			}
 			tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
-			                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr);
+			                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr, staged);
+			if (r1 - r0 > 64) staged = false;                            // later groups have overwritten the first one
 			status = IHP_EV_TALLIED;
 		}
 		DevEvent *o = ev + ii;
