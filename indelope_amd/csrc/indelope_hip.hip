@@ -974,7 +974,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.hit_overflow = misc + M_OVF_HIT; a.hit_region_cnt = b->hit_region_cnt.as<int>();
 		HIPC(hipMemsetAsync(b->hit_region_cnt.p, 0, sizeof(int) * (size_t)std::max(b->R, 1), s));
 		a.hit_bump0 = 2ll * HIT_SLOTS * b->n_reads;
-		a.dbg = getenv("IHP_TALLY_DBG") ? atoi(getenv("IHP_TALLY_DBG")) : 0;                // the bump region lies behind the fixed slots
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
 		a.overflow = misc + M_OVF; a.work_counter = wq + 8 * WQ_WORDS;
