@@ -396,7 +396,7 @@ int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
 /* Diagnostics: with IHP_PROFILE=1 in the environment the kernels sum shader-clock cycles
  * per phase over all waves: [0] assemble, [1] combine, [2] assemble+output, [3] regions;
  * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments.  Always filled:
- * [11] regions forwarded at run time (arena / slot overflow) to the catch-all assembly pass, [22] ksw2 kernel mode. */
+ * [15]/[7]/[11] regions forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [22] ksw2 kernel mode. */
 int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
  * ihp_batch_run used: 3/4 = top-byte register sweep (left/right gaps; the production

@@ -897,16 +897,16 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
 		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
 		// overlaps pass 1 instead of following it.  A region that still runs out of arena / contig slots is
-		// forwarded at run time to the overflow list, which the catch-all pass (normally empty: one ~6 us launch)
-		// processes after both streams have joined.
-		int *o4 = b->retry_list3.as<int>();
+		// forwarded at run time to the next pass's overflow list; those lists (empty on pile-ups like C2, well used
+		// when long reads with errors leave many single-read contigs) are processed after both streams have joined.
+		int *o2 = b->retry_list.as<int>(), *o3 = b->retry_list2.as<int>(), *o4 = b->retry_list3.as<int>();
 		const int *cl = b->cls_list.as<int>(), *cn = b->cls_n.as<int>();
 		const int n1 = b->n_cls[0], n2 = b->n_cls[1], n3 = b->n_cls[2], n4 = b->n_cls[3];
 		hipStream_t s2 = b->stream2;
 		const bool side = n2 + n3 + n4 > 0;
 		auto pass2 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
 			x.arena_seq = nullptr; x.arena_sup = b->lds_sup2.as<uint32_t>(); x.arena_cap = b->lds_arena2; x.lds_arena = b->lds_arena2;
-			x.in_list = in; x.n_in = n_in; x.out_list = o4; x.n_out = misc + M_NRETRY3; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
+			x.in_list = in; x.n_in = n_in; x.out_list = o3; x.n_out = misc + M_NRETRY2; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
 			hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(b->grid_asm2), dim3(64), b->lds_arena2, st, x);
 		};
 		auto pass3 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
@@ -930,11 +930,13 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		}
 		if (n1) {
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
-			a.in_list = cl; a.n_in = cn; a.out_list = o4; a.n_out = misc + M_NRETRY3; a.work_counter = wq;
+			a.in_list = cl; a.n_in = cn; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
 			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
 			HIPC(hipGetLastError());
 		}
 		if (side) HIPC(hipStreamWaitEvent(s, b->ev_join, 0));
+		pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>());
+		pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>());
 		pass4(a, s, o4, misc + M_NRETRY3, 6, b->corr.as<Corr>());
 		HIPC(hipGetLastError());
 	}
@@ -1042,11 +1044,11 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
 	int nretry = 0;
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY, sizeof(int), hipMemcpyDeviceToHost));
-	out[15] = nretry;                                 // (unused since the overflow list became one: always 0)
+	out[15] = nretry;                                 // regions forwarded at run time to the second pass's overflow list
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY2, sizeof(int), hipMemcpyDeviceToHost));
-	out[7] = nretry;                                  // (unused: always 0)
+	out[7] = nretry;                                  // ... to the third pass's
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY3, sizeof(int), hipMemcpyDeviceToHost));
-	out[11] = nretry;                                 // regions forwarded at run time to the catch-all (HBM-arena) pass
+	out[11] = nretry;                                 // ... and to the catch-all (HBM-arena) pass
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
 	return 0;
 }
