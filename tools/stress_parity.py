@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (not part of the test suite): many synthetic configurations through the HIP path and the
+oracle, full result comparison.  usage: tools/stress_parity.py [n_configs] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import indelope_amd  # noqa: E402
+import oracle  # noqa: E402
+from indelope_amd import synth  # noqa: E402
+from indelope_amd.host import BatchResult  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    hip = indelope_amd.api()
+    hip.init(0)
+    orc = oracle.get()
+    bad = 0
+    t0 = time.time()
+    for it in range(n):
+        rl = int(rng.choice([75, 100, 125, 150, 151, 200, 250, 300]))
+        K = int(rng.choice([21, 25, 27, 31])) if rl >= 100 else 21
+        lo = int(rng.integers(2, 40))
+        hi = int(rng.integers(lo, min(300, lo + rng.choice([10, 60, 250]))))
+        cfg = dict(n_regions=int(rng.integers(5, 120)), read_len=rl, n_reads=(lo, hi), err_rate=float(rng.choice([0, 1e-3, 3e-3, 1e-2])),
+                   config_id=1000 + it, dup_frac=float(rng.choice([0, 0.2, 0.6])), seed=int(rng.integers(1, 2**31)))
+        if rl >= 250 and rng.random() < 0.5:
+            cfg.update(n_events=2, window_len=1400, event_pos=500)
+        b, _ = synth.generate(**cfg)
+        kw = dict(K=K)
+        if rng.random() < 0.5:
+            kw.update(min_reads=3, min_ctg_len=73)
+        if rng.random() < 0.3:
+            b.mapq = rng.choice(np.array([0, 5, 9, 10, 19, 20, 60], np.uint8), b.n_reads)
+        if rng.random() < 0.4:
+            q = b.quals.copy()
+            hit = rng.random(len(q)) < 0.02
+            q[hit] = 2
+            for i in range(0, b.n_reads, 7):
+                q[b.read_off[i]:b.read_off[i] + int(rng.integers(0, 40))] = 2
+            b.quals = q
+        if rng.random() < 0.5:
+            b = b.with_trim_bounds()
+        if rng.random() < 0.2:
+            bases = b.bases.copy()
+            hit = rng.random(len(bases)) < 0.003
+            bases[hit] = rng.choice(np.frombuffer(b"Nacgt", np.uint8), int(hit.sum()))
+            b.bases = bases
+        got = hip.run_regions(b, hip.params(**kw))
+        exp = orc.run_regions(b, orc.params(**kw))
+        d = BatchResult.first_difference(got, exp)
+        ok = d is None and np.allclose(got.events["gl"], exp.events["gl"], rtol=1e-12)
+        vg, ve = hip.call_variants(b, got, hip.params(**kw)), orc.call_variants(b, exp, orc.params(**kw))
+        okv = [(x["filter"], x["start"], x["ref"], x["alt"], x["line"]) for x in vg] == [(x["filter"], x["start"], x["ref"], x["alt"], x["line"]) for x in ve]
+        print("%3d %s rl=%d K=%d reads=%s err=%g dup=%g regions=%d contigs=%d events=%d fallback=%d variants=%d"
+              % (it, "ok " if ok and okv else "DIFF", rl, K, cfg["n_reads"], cfg["err_rate"], cfg["dup_frac"], b.n_regions,
+                 got.n_contigs, got.n_events, int((got.events["aligned"] == 1).sum()), sum(x["filter"] == 0 for x in vg)), d or "", flush=True)
+        bad += not (ok and okv)
+    print("done: %d configs, %d differences, %.1f s" % (n, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
