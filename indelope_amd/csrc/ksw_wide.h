@@ -161,7 +161,11 @@ __device__ __forceinline__ bool wide_diag(WideState<NS> &F, const NarrowEnv &E, 
 	int hm = hk[0];
 #pragma unroll
 	for (int k = 1; k < NS; ++k) hm = hk[k] > hm ? hk[k] : hm;
-	const int max_H = wave_max_i32_keep(hm);
+	// as in ksw_narrow.h: the reduction is needed only when the diagonal beats the running maximum or may have fallen
+	// more than zdrop below it
+	bool quiet = ballot(hm > F.ez_max) == 0ull;
+	if (quiet && E.zdrop >= 0) quiet = ballot(hm >= F.ez_max - E.zdrop) != 0ull;
+	const int max_H = quiet ? 0 : wave_max_i32_keep(hm);
 	// ---- ez updates (:351-357) -----------------------------------------------------------
 	{
 		int Hen0 = 0;
@@ -174,6 +178,7 @@ __device__ __forceinline__ bool wide_diag(WideState<NS> &F, const NarrowEnv &E, 
 		if (r == E.qlen + E.tlen - 2 && en0 == E.tlen - 1) F.score = Hen0;                  // :356-357
 	}
 	// ksw_apply_zdrop (:88-104) only looks at max_t when the maximum improves or has fallen more than zdrop below it
+	if (quiet) return false;
 	const bool improves = max_H > F.ez_max;
 	if (!improves && (E.zdrop < 0 || F.ez_max - max_H <= E.zdrop)) return false;
 	int max_t = en0;
