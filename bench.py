@@ -33,6 +33,11 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n_int32,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
+class _DevBytes:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
 def cpu_baseline(batch, K, want_seconds=12.0):
     """Oracle on the host cores over a bounded sample of the same workload."""
     import oracle
@@ -72,6 +77,10 @@ def main():
     ap.add_argument("--quals", action="store_true",
                     help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
                          "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
+    ap.add_argument("--payload", action="store_true",
+                    help="with --gpus N > 1: every step also packs the results on the device and sends each rank's slab "
+                         "to rank 0 (the variable-length half of the SURVEY 8e gather); off by default, the per-step "
+                         "collective is the gather of the fixed-size per-region records")
     ap.add_argument("--dup-frac", type=float, default=0.0,
                     help="fraction of planted events that are tandem duplications (these send the k-mer tally to the "
                          "alignment fallback, indelope.nim:312-372); 0 = the BASELINE workload")
@@ -110,6 +119,11 @@ def main():
         api.batch_sync(h)
         if world > 1:
             dist.gather(summary, gather_list, dst=0)
+            if args.payload:
+                from indelope_amd import dist as idist
+                ptr, nbytes, counts = api.batch_pack_dev(h)
+                slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
+                idist.gather_payload(slab, counts, rank, world, dst=0)
 
     for _ in range(args.warmup):
         step()

@@ -387,6 +387,15 @@ int  ihp_batch_run(ihp_batch *b);                     /* async on the batch stre
 int  ihp_batch_sync(ihp_batch *b);
 int  ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out);
 void ihp_batch_free(ihp_batch *b);
+/* The results of a batch compacted ON THE DEVICE into one slab that holds every array of ihp_batch_out (what
+ * ihp_batch_fetch copies to the host in one piece): device pointer, size, and the six counts {regions, contigs,
+ * bases, CIGAR words, events, hit entries} that define its layout.  Valid until the batch runs, packs or is freed
+ * again.  This is the variable-length payload of the multi-GPU gather: each rank sends its slab over xGMI, the root
+ * turns the copies back into ihp_batch_out views with ihp_unpack_slab (arrays point into the caller's buffer: do
+ * not pass them to ihp_free_out).  ihp_pack_out builds the same slab from host results (buf NULL: size query).     */
+int  ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6]);
+int  ihp_unpack_slab(void *slab, int64_t bytes, const int64_t counts[6], double error, ihp_batch_out *out);
+int  ihp_pack_out(const ihp_batch_out *src, void *buf, int64_t cap, int64_t *bytes, int64_t counts[6]);
 /* Per-stage device time of the most recent ihp_batch_run+sync, from HIP events
  * on the batch stream: ms[0] assemble, ms[1] ksw2, ms[2] tally, ms[3] total.  */
 int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);

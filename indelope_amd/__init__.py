@@ -70,6 +70,13 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_stage_ms(h, ms), "batch_stage_ms")
         return [float(x) for x in ms]
 
+    def batch_pack_dev(self, h):
+        """(device pointer, bytes, counts[6]) of the batch's results compacted on the device (no host copy)."""
+        import numpy as np
+        p, n, counts = C.c_void_p(), C.c_int64(), np.zeros(6, np.int64)
+        self._chk_hip(self.b.batch_pack_dev(h, C.byref(p), C.byref(n), _abi.ptr(counts, _abi.i64p)), "batch_pack_dev")
+        return p.value, n.value, counts
+
     def batch_fallback_ms(self, h):
         ms = C.c_float()
         self._chk_hip(self.b.batch_fallback_ms(h, C.byref(ms)), "batch_fallback_ms")

@@ -207,6 +207,9 @@ _PRODUCT_ONLY = {
     "batch_sync": (C.c_int, [C.c_void_p]),
     "batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(BatchOut)]),
     "batch_free": (None, [C.c_void_p]),
+    "batch_pack_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p, i64p]),
+    "unpack_slab": (C.c_int, [C.c_void_p, C.c_int64, i64p, C.c_double, C.POINTER(BatchOut)]),
+    "pack_out": (C.c_int, [C.POINTER(BatchOut), C.c_void_p, C.c_int64, i64p, i64p]),
     "batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_fallback_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),

@@ -1145,15 +1145,41 @@ extern "C" void ihp_free_out(ihp_batch_out *o)
 	memset(o, 0, sizeof(*o));
 }
 
-extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
+// Carve the arrays of an ihp_batch_out out of a slab laid out by OutLayout and fill in the genotypes
+// (indelope.nim:379: genotype(ref_support, alt_support, 1e-3), fp64 on the host).
+static void carve_out(char *host, const OutLayout &L, long long R, long long C, long long B, long long W, long long E, long long Hn,
+                      double error, ihp_batch_out *out)
 {
-	if (!b || !out || !b->ran) return IHP_E_ARG;
-	memset(out, 0, sizeof(*out));
+	out->n_regions = (int32_t)R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B; out->n_hits = Hn;
+	out->hit_off = (int64_t *)(host + L.hit_off); out->ref_hit = (int32_t *)(host + L.ref_hit); out->alt_hit = (int32_t *)(host + L.alt_hit);
+	out->status = (int32_t *)(host + L.status); out->n_contigs_pre = (int32_t *)(host + L.n_pre);
+	out->contig_off = (int64_t *)(host + L.contig_off);
+	out->ctg_start = (int64_t *)(host + L.ctg_start); out->ctg_nreads = (int64_t *)(host + L.ctg_nreads);
+	out->ctg_seq_off = (int64_t *)(host + L.ctg_seq_off); out->ctg_seq = (uint8_t *)(host + L.ctg_seq);
+	out->ctg_support = (uint32_t *)(host + L.ctg_support);
+	out->aln_flags = (int32_t *)(host + L.aln_flags); out->aln_ref_start = (int64_t *)(host + L.aln_ref_start);
+	out->aln_ref_len = (int32_t *)(host + L.aln_ref_len); out->aln_ez = (ihp_ez *)(host + L.aln_ez);
+	out->cigar_off = (int64_t *)(host + L.cigar_off); out->cigar = (uint32_t *)(host + L.cigar);
+	out->event_off = (int64_t *)(host + L.event_off); out->events = (ihp_event *)(host + L.events);
+	for (long long e = 0; e < E; ++e) {
+		ihp_event &x = out->events[e];
+		if (x.status != IHP_EV_TALLIED) continue;
+		ihp_genotype_t gt;
+		ihp_genotype(x.ref_support, x.alt_support, error, &gt);
+		x.gt = gt.gt; x.gl[0] = gt.gl[0]; x.gl[1] = gt.gl[1]; x.gl[2] = gt.gl[2];
+		x.qual = ihp_genotype_qual(&gt);
+	}
+}
+
+// Results compacted on the device into one slab (k_pack_count -> k_pack_scan -> k_pack); nothing is copied to the host
+// except the six counts that define the layout.  The slab stays valid until the batch runs, packs or is freed again.
+extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6])
+{
+	if (!b || !b->ran || !dev_ptr || !bytes || !counts) return IHP_E_ARG;
 	const int R = b->R;
 	hipStream_t s = b->stream;
 	int misc[M_WORDS];
 	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, s));
-	// per-region counts and their prefix sums (k_pack_count, k_pack_scan)
 	const size_t S = (size_t)R + 1;
 	if (!b->pack_cnt.p) { int rc = b->pack_cnt.alloc(sizeof(long long) * 5 * S); if (rc) return rc; }
 	long long *cnt = b->pack_cnt.as<long long>();
@@ -1182,54 +1208,87 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 		if (rc) return rc;
 	}
 	char *dev = b->pack_slab.as<char>();
-	void *slab = g_slabs.get(L.bytes);
-	if (!slab) { snprintf(g.err, sizeof(g.err), "hipHostMalloc of %zu bytes failed", L.bytes); return IHP_E_NOMEM; }
+	PackArgs a;
+	a.R = R; a.region_read_off = b->region_read_off.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
+	a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
+	a.ctg_len = b->ctg_len.as<int>(); a.aln_flags = b->aln_flags.as<int>(); a.aln_ref_len = b->aln_ref_len.as<int>();
+	a.n_ev = b->n_ev.as<int>();
+	a.ctg_start = b->ctg_start.as<long long>(); a.ctg_nreads = b->ctg_nreads.as<long long>();
+	a.ctg_seq_off = b->ctg_seq_off.as<long long>(); a.aln_ref_start = b->aln_ref_start.as<long long>();
+	a.cig_off = b->cig_off.as<long long>(); a.ev_off = b->ev_off.as<long long>();
+	a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>(); a.ez = b->ez.as<KswOut>();
+	a.cig_pool = b->cig_pool.as<uint32_t>(); a.ev_pool = b->ev_pool.as<DevEvent>(); a.cnt = cnt;
+	a.hit_pool = b->hit_pool.as<int>();
+	a.o_hit_off = (int64_t *)(dev + L.hit_off); a.o_ref_hit = (int32_t *)(dev + L.ref_hit); a.o_alt_hit = (int32_t *)(dev + L.alt_hit);
+	a.o_status = (int32_t *)(dev + L.status); a.o_n_pre = (int32_t *)(dev + L.n_pre); a.o_contig_off = (int64_t *)(dev + L.contig_off);
+	a.o_ctg_start = (int64_t *)(dev + L.ctg_start); a.o_ctg_nreads = (int64_t *)(dev + L.ctg_nreads);
+	a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off); a.o_seq = (uint8_t *)(dev + L.ctg_seq); a.o_sup = (uint32_t *)(dev + L.ctg_support);
+	a.o_aln_flags = (int32_t *)(dev + L.aln_flags); a.o_aln_ref_start = (int64_t *)(dev + L.aln_ref_start);
+	a.o_aln_ref_len = (int32_t *)(dev + L.aln_ref_len); a.o_ez = (ihp_ez *)(dev + L.aln_ez);
+	a.o_cigar_off = (int64_t *)(dev + L.cigar_off); a.o_cigar = (uint32_t *)(dev + L.cigar);
+	a.o_event_off = (int64_t *)(dev + L.event_off); a.o_events = (ihp_event *)(dev + L.events);
+	hipLaunchKernelGGL(k_pack, dim3(grid_for(R + 1, 16)), dim3(64), 0, s, a);
+	HIPC(hipGetLastError());
+	HIPC(hipStreamSynchronize(s));
+	*dev_ptr = dev; *bytes = (int64_t)L.bytes;
+	counts[0] = R; counts[1] = C; counts[2] = B; counts[3] = W; counts[4] = E; counts[5] = Hn;
+	return 0;
+}
+
+// An ihp_batch_out over a host copy of a packed slab (from ihp_batch_pack_dev on any rank, or ihp_pack_out): the arrays
+// point into `slab`, which the caller owns -- do not hand the result to ihp_free_out.
+extern "C" int ihp_unpack_slab(void *slab, int64_t bytes, const int64_t counts[6], double error, ihp_batch_out *out)
+{
+	if (!slab || !counts || !out) return IHP_E_ARG;
+	for (int k = 0; k < 6; ++k) if (counts[k] < 0) return IHP_E_ARG;
+	const OutLayout L(counts[0], counts[1], counts[2], counts[3], counts[4], counts[5]);
+	if ((int64_t)L.bytes > bytes) return IHP_E_CAPACITY;
+	memset(out, 0, sizeof(*out));
+	carve_out((char *)slab, L, counts[0], counts[1], counts[2], counts[3], counts[4], counts[5], error, out);
+	return 0;
+}
+
+// Host-side counterpart of the device pack: the arrays of `src` copied into one slab of the same layout (buf may be
+// null to ask for the size).  Genotype fields travel as they are.
+extern "C" int ihp_pack_out(const ihp_batch_out *src, void *buf, int64_t cap, int64_t *bytes, int64_t counts[6])
+{
+	if (!src || !bytes || !counts) return IHP_E_ARG;
+	const long long R = src->n_regions, C = src->n_contigs, B = src->n_bases, W = src->n_cigar_words, E = src->n_events, Hn = src->n_hits;
+	const OutLayout L(R, C, B, W, E, Hn);
+	*bytes = (int64_t)L.bytes;
+	counts[0] = R; counts[1] = C; counts[2] = B; counts[3] = W; counts[4] = E; counts[5] = Hn;
+	if (!buf) return 0;
+	if (cap < (int64_t)L.bytes) return IHP_E_CAPACITY;
+	char *d = (char *)buf;
+	memset(d, 0, L.bytes);
+#define CP(off, ptr, n, T) do { if ((n) > 0 && (ptr)) memcpy(d + L.off, (ptr), sizeof(T) * (size_t)(n)); } while (0)
+	CP(status, src->status, R, int32_t); CP(n_pre, src->n_contigs_pre, R, int32_t); CP(contig_off, src->contig_off, R + 1, int64_t);
+	CP(ctg_start, src->ctg_start, C, int64_t); CP(ctg_nreads, src->ctg_nreads, C, int64_t); CP(ctg_seq_off, src->ctg_seq_off, C + 1, int64_t);
+	CP(ctg_seq, src->ctg_seq, B, uint8_t); CP(ctg_support, src->ctg_support, B, uint32_t);
+	CP(aln_flags, src->aln_flags, C, int32_t); CP(aln_ref_start, src->aln_ref_start, C, int64_t); CP(aln_ref_len, src->aln_ref_len, C, int32_t);
+	CP(aln_ez, src->aln_ez, C, ihp_ez); CP(cigar_off, src->cigar_off, C + 1, int64_t); CP(cigar, src->cigar, W, uint32_t);
+	CP(event_off, src->event_off, C + 1, int64_t); CP(events, src->events, E, ihp_event);
+	CP(hit_off, src->hit_off, E + 1, int64_t); CP(ref_hit, src->ref_hit, Hn, int32_t); CP(alt_hit, src->alt_hit, Hn, int32_t);
+#undef CP
+	return 0;
+}
+
+extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
+{
+	if (!b || !out || !b->ran) return IHP_E_ARG;
+	memset(out, 0, sizeof(*out));
+	void *dev = nullptr; int64_t bytes = 0, cnt6[6];
+	int rc = ihp_batch_pack_dev(b, &dev, &bytes, cnt6);
+	if (rc) return rc;
+	hipStream_t s = b->stream;
+	void *slab = g_slabs.get((size_t)bytes);
+	if (!slab) { snprintf(g.err, sizeof(g.err), "hipHostMalloc of %lld bytes failed", (long long)bytes); return IHP_E_NOMEM; }
 	char *host = (char *)slab + sizeof(SlabHdr);
-	{
-		PackArgs a;
-		a.R = R; a.region_read_off = b->region_read_off.as<long long>(); a.ref_origin = b->ref_origin.as<long long>();
-		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
-		a.ctg_len = b->ctg_len.as<int>(); a.aln_flags = b->aln_flags.as<int>(); a.aln_ref_len = b->aln_ref_len.as<int>();
-		a.n_ev = b->n_ev.as<int>();
-		a.ctg_start = b->ctg_start.as<long long>(); a.ctg_nreads = b->ctg_nreads.as<long long>();
-		a.ctg_seq_off = b->ctg_seq_off.as<long long>(); a.aln_ref_start = b->aln_ref_start.as<long long>();
-		a.cig_off = b->cig_off.as<long long>(); a.ev_off = b->ev_off.as<long long>();
-		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>(); a.ez = b->ez.as<KswOut>();
-		a.cig_pool = b->cig_pool.as<uint32_t>(); a.ev_pool = b->ev_pool.as<DevEvent>(); a.cnt = cnt;
-		a.hit_pool = b->hit_pool.as<int>();
-		a.o_hit_off = (int64_t *)(dev + L.hit_off); a.o_ref_hit = (int32_t *)(dev + L.ref_hit); a.o_alt_hit = (int32_t *)(dev + L.alt_hit);
-		a.o_status = (int32_t *)(dev + L.status); a.o_n_pre = (int32_t *)(dev + L.n_pre); a.o_contig_off = (int64_t *)(dev + L.contig_off);
-		a.o_ctg_start = (int64_t *)(dev + L.ctg_start); a.o_ctg_nreads = (int64_t *)(dev + L.ctg_nreads);
-		a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off); a.o_seq = (uint8_t *)(dev + L.ctg_seq); a.o_sup = (uint32_t *)(dev + L.ctg_support);
-		a.o_aln_flags = (int32_t *)(dev + L.aln_flags); a.o_aln_ref_start = (int64_t *)(dev + L.aln_ref_start);
-		a.o_aln_ref_len = (int32_t *)(dev + L.aln_ref_len); a.o_ez = (ihp_ez *)(dev + L.aln_ez);
-		a.o_cigar_off = (int64_t *)(dev + L.cigar_off); a.o_cigar = (uint32_t *)(dev + L.cigar);
-		a.o_event_off = (int64_t *)(dev + L.event_off); a.o_events = (ihp_event *)(dev + L.events);
-		hipLaunchKernelGGL(k_pack, dim3(grid_for(R + 1, 16)), dim3(64), 0, s, a);
-		hipError_t e = hipGetLastError();
-		if (e == hipSuccess) e = hipMemcpyAsync(host, dev, L.bytes, hipMemcpyDeviceToHost, s);
-		if (e == hipSuccess) e = hipStreamSynchronize(s);
-		if (e != hipSuccess) { g_slabs.put(slab); return hip_fail(e, "pack / copy of the results", __LINE__); }
-	}
-	out->n_regions = R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B; out->n_hits = Hn;
-	out->hit_off = (int64_t *)(host + L.hit_off); out->ref_hit = (int32_t *)(host + L.ref_hit); out->alt_hit = (int32_t *)(host + L.alt_hit);
-	out->status = (int32_t *)(host + L.status); out->n_contigs_pre = (int32_t *)(host + L.n_pre);
-	out->contig_off = (int64_t *)(host + L.contig_off);
-	out->ctg_start = (int64_t *)(host + L.ctg_start); out->ctg_nreads = (int64_t *)(host + L.ctg_nreads);
-	out->ctg_seq_off = (int64_t *)(host + L.ctg_seq_off); out->ctg_seq = (uint8_t *)(host + L.ctg_seq);
-	out->ctg_support = (uint32_t *)(host + L.ctg_support);
-	out->aln_flags = (int32_t *)(host + L.aln_flags); out->aln_ref_start = (int64_t *)(host + L.aln_ref_start);
-	out->aln_ref_len = (int32_t *)(host + L.aln_ref_len); out->aln_ez = (ihp_ez *)(host + L.aln_ez);
-	out->cigar_off = (int64_t *)(host + L.cigar_off); out->cigar = (uint32_t *)(host + L.cigar);
-	out->event_off = (int64_t *)(host + L.event_off); out->events = (ihp_event *)(host + L.events);
-	for (long long e = 0; e < E; ++e) {                        // indelope.nim:379: genotype(ref_support, alt_support, 1e-3), fp64 on the host
-		ihp_event &x = out->events[e];
-		if (x.status != IHP_EV_TALLIED) continue;
-		ihp_genotype_t gt;
-		ihp_genotype(x.ref_support, x.alt_support, b->P.error, &gt);
-		x.gt = gt.gt; x.gl[0] = gt.gl[0]; x.gl[1] = gt.gl[1]; x.gl[2] = gt.gl[2];
-		x.qual = ihp_genotype_qual(&gt);
-	}
+	hipError_t e = hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	if (e != hipSuccess) { g_slabs.put(slab); return hip_fail(e, "copy of the packed results", __LINE__); }
+	const OutLayout L(cnt6[0], cnt6[1], cnt6[2], cnt6[3], cnt6[4], cnt6[5]);
+	carve_out(host, L, cnt6[0], cnt6[1], cnt6[2], cnt6[3], cnt6[4], cnt6[5], b->P.error, out);
 	return 0;
 }
 

@@ -54,6 +54,37 @@ def summaries_from_result(res):
     return out
 
 
+def gather_payload(slab, counts, rank, world, dst=0):
+    """The variable-length half of the end-of-job gather: every rank's packed result slab (a uint8
+    tensor on the process group's device: the device slab of ihp_batch_pack_dev under "nccl", host bytes under "gloo")
+    travels to `dst` point to point -- each peer over its own xGMI link to the root, no ring -- after one all_gather of
+    the seven int64 that size it.  Returns [(slab tensor, counts)] in rank order on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    meta = torch.tensor([slab.numel()] + [int(c) for c in counts], dtype=torch.int64, device=slab.device)
+    if world == 1:
+        return [(slab, meta[1:].cpu().numpy())]
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    if rank != dst:
+        if slab.numel():
+            dist.send(slab, dst=dst)
+        return None
+    out, pending = [], []
+    for r in range(world):                                 # all receives are posted before any is waited for: the
+        n = int(metas[r][0].item())                        # peers transmit at the same time, each on its own link
+        if r == dst:
+            buf = slab
+        else:
+            buf = torch.empty(n, dtype=torch.uint8, device=slab.device)
+            if n:
+                pending.append(dist.irecv(buf, src=r))
+        out.append((buf, metas[r][1:].cpu().numpy()))
+    for q in pending:
+        q.wait()
+    return out
+
+
 def gather_summaries(local, rank, world, dst=0):
     """One gather of the per-region records to `dst`.  `local`: int32 tensor [n_local, SUMMARY_WORDS] on the
     device the process group uses.  Shards may differ in size: they are padded to the longest and trimmed

@@ -494,3 +494,59 @@ def _gen_roi(self, read_start, read_stop, cigars, read_skip=None, origin=0, span
 
 
 Api.gen_roi = _gen_roi
+
+
+def _pack_out(self, result):
+    """(slab bytes as a uint8 array, counts[6]) of a BatchResult: the layout ihp_batch_pack_dev produces on the device."""
+    o = result.as_c()
+    nbytes, counts = C.c_int64(), np.zeros(6, np.int64)
+    self._chk(self.b.pack_out(C.byref(o), None, 0, C.byref(nbytes), A.ptr(counts, A.i64p)), "pack_out")
+    slab = np.zeros(max(1, nbytes.value), np.uint8)
+    self._chk(self.b.pack_out(C.byref(o), slab.ctypes.data_as(C.c_void_p), len(slab), C.byref(nbytes), A.ptr(counts, A.i64p)),
+              "pack_out")
+    return slab[:nbytes.value], counts
+
+
+def _unpack_slab(self, slab, counts, error=1e-3):
+    """BatchResult from a packed slab (uint8 array; e.g. another rank's device slab copied to the host)."""
+    slab = np.ascontiguousarray(slab, np.uint8)
+    counts = np.ascontiguousarray(counts, np.int64)
+    out = A.BatchOut()
+    buf = slab if len(slab) else np.zeros(1, np.uint8)
+    self._chk(self.b.unpack_slab(buf.ctypes.data_as(C.c_void_p), len(slab), A.ptr(counts, A.i64p), error, C.byref(out)),
+              "unpack_slab")
+    return BatchResult(out)             # numpy copies; `slab` stays the owner of the memory the views pointed into
+
+
+Api.pack_out = _pack_out
+Api.unpack_slab = _unpack_slab
+
+
+def concat_results(parts):
+    """BatchResults of consecutive region ranges (the ranks' shards, in rank order) as one."""
+    import copy
+    if len(parts) == 1:
+        return parts[0]
+    r = copy.copy(parts[0])
+    cat = np.concatenate
+    for f in ("status", "n_contigs_pre", "ctg_start", "ctg_nreads", "ctg_seq", "ctg_support", "aln_flags", "aln_ref_start",
+              "aln_ref_len", "aln_ez", "cigar", "events", "ref_hit", "alt_hit"):
+        setattr(r, f, cat([getattr(p, f) for p in parts]))
+
+    def offs(name, base_len):
+        out, base = [], 0
+        for i, p in enumerate(parts):
+            a = getattr(p, name)
+            out.append(a[:-1] + base)
+            base += int(a[-1])
+        return cat(out + [np.array([base], np.int64)])
+    r.contig_off = offs("contig_off", None)
+    r.ctg_seq_off = offs("ctg_seq_off", None)
+    r.cigar_off = offs("cigar_off", None)
+    r.event_off = offs("event_off", None)
+    r.hit_off = offs("hit_off", None)
+    r.n_regions = sum(p.n_regions for p in parts)
+    r.n_contigs = sum(p.n_contigs for p in parts)
+    r.n_events = sum(p.n_events for p in parts)
+    r.n_hits = sum(p.n_hits for p in parts)
+    return r

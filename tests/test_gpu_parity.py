@@ -449,3 +449,28 @@ def test_runtime_overflow_goes_to_the_catch_all_pass(hip, oracle):
             hip.batch_free(h)
         assert forwarded > 0
         assert_same(got, oracle.run_regions(b))
+
+
+def test_device_pack_is_what_fetch_returns(hip):
+    """ihp_batch_pack_dev: the slab left on the device (the multi-GPU payload) unpacks to the same results as
+    ihp_batch_fetch; the host-side pack of those results is byte-identical in layout."""
+    import torch
+    b, _ = synth.generate(150, n_reads=(8, 64), err_rate=1e-3, config_id=36, dup_frac=0.2)
+    h = hip.batch_upload(b)
+    try:
+        hip.batch_run(h)
+        hip.batch_sync(h)
+        ptr, nbytes, counts = hip.batch_pack_dev(h)
+
+        class Dev:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        slab = torch.as_tensor(Dev(), device="cuda").cpu().numpy()
+        res = hip.batch_fetch(h)
+    finally:
+        hip.batch_free(h)
+    back = hip.unpack_slab(slab, counts)
+    assert BatchResult.first_difference(back, res) is None
+    slab2, counts2 = hip.pack_out(res)
+    assert counts2.tolist() == counts.tolist() and len(slab2) == nbytes
+    again = hip.unpack_slab(slab2, counts2)
+    assert BatchResult.first_difference(again, res) is None
