@@ -122,6 +122,15 @@ def test_device_scan_edges(hip, oracle):
     en = st + 42
     kw = dict(min_event_support=255, min_read_coverage=1, max_read_coverage=600)
     assert hip.gen_roi(st, en, cg, **kw) == oracle.gen_roi(st, en, cg, **kw) == [(30, 31, list(range(300)))]
+    # a span shorter than the reads reach, all reads skippable, a single read: handled alike on both sides
+    rng = np.random.default_rng(8)
+    st2, en2, cg2, skip2 = random_reads(rng, 400, 6000, gap_every=25, hot=[900, 2500, 4100])
+    for kw2 in (dict(span=3000), dict(span=int(en2.max()) - 7), dict(read_skip=np.ones(400, np.uint8)), dict(span=1)):
+        kw2 = dict(dict(read_skip=skip2, min_event_support=3, min_read_coverage=2), **kw2)
+        assert hip.gen_roi(st2, en2, cg2, **kw2) == oracle.gen_roi(st2, en2, cg2, **kw2), kw2
+    one = (np.array([50], np.int64), np.array([150], np.int64), [cig("40M3D57M")])
+    kw1 = dict(min_event_support=1, min_read_coverage=1)
+    assert hip.gen_roi(*one, **kw1) == oracle.gen_roi(*one, **kw1) == [(90, 92, [0])]
     # more reads than max_read_coverage: the region is dropped (:483-485)
     kw["max_read_coverage"] = 299
     assert hip.gen_roi(st, en, cg, **kw) == oracle.gen_roi(st, en, cg, **kw) == []
