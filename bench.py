@@ -77,6 +77,10 @@ def main():
     ap.add_argument("--quals", action="store_true",
                     help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
                          "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
+    ap.add_argument("--sub-batches", type=int, default=2,
+                    help="the step submits the batch as this many sub-batches of consecutive regions, each on its own "
+                         "stream (ihp_batch_*): while one sub-batch's last regions drain a kernel, the other's next "
+                         "kernel fills the chip.  1 = one launch chain for the whole batch")
     ap.add_argument("--payload", action="store_true",
                     help="with --gpus N > 1: every step also packs the results on the device and sends each rank's slab "
                          "to rank 0 (the variable-length half of the SURVEY 8e gather); off by default, the per-step "
@@ -108,22 +112,31 @@ def main():
     if not args.quals:
         batch = batch.with_trim_bounds()                     # A0 on the host (SURVEY 8a row A0, 8b "trim bounds (a,b)")
     params = api.params(K=K)
-    h = api.batch_upload(batch, params)
-    sptr, sn = api.batch_summary_dev(h)
-    nint = sn * 8
-    summary = torch.as_tensor(_DevArray(sptr, nint), device="cuda") if nint else torch.zeros(0, dtype=torch.int32, device="cuda")
+    S = max(1, min(args.sub_batches, R))
+    subs = [batch.slice(R * i // S, R * (i + 1) // S) for i in range(S)]
+    hs = [api.batch_upload(sb, params) for sb in subs]
+    views = []
+    for h in hs:
+        sptr, sn = api.batch_summary_dev(h)
+        views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda") if sn else torch.zeros(0, dtype=torch.int32, device="cuda"))
+    summary = views[0] if S == 1 else torch.cat(views)       # per-region records of the whole batch, region order
     gather_list = [torch.empty_like(summary) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
-        api.batch_run(h)
-        api.batch_sync(h)
+        for h in hs:
+            api.batch_run(h)                                 # asynchronous: the sub-batches' launch chains overlap
+        for h in hs:
+            api.batch_sync(h)
         if world > 1:
+            if S > 1:
+                torch.cat(views, out=summary)
             dist.gather(summary, gather_list, dst=0)
             if args.payload:
                 from indelope_amd import dist as idist
-                ptr, nbytes, counts = api.batch_pack_dev(h)
-                slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
-                idist.gather_payload(slab, counts, rank, world, dst=0)
+                for h in hs:
+                    ptr, nbytes, counts = api.batch_pack_dev(h)
+                    slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
+                    idist.gather_payload(slab, counts, rank, world, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -135,8 +148,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        stage += api.batch_stage_ms(h)
-        fb_ms += api.batch_fallback_ms(h)
+        for h in hs:                                         # per launch: the mean over the sub-batches' launches
+            stage += np.array(api.batch_stage_ms(h)) / S
+            fb_ms += api.batch_fallback_ms(h) / S
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -149,16 +163,23 @@ def main():
     fb_ms /= max(args.steps, 1)
 
     if rank == 0:
-        res = api.batch_fetch(h)
+        from indelope_amd.host import concat_results
+        parts = [api.batch_fetch(h) for h in hs]
+        res = concat_results(parts)
         assert (res.status == 0).all(), "regions failed on the device"
         # B = sum_reads(len+9) + len_refwindow + sum_contigs(5 len+16) + sum_aln(44+4 n_cigar) + sum_events(2K+12)
         alg_bytes = batch.algorithmic_input_bytes() + res.algorithmic_output_bytes(K)
-        by_kernel = res.algorithmic_bytes_by_kernel(batch, K)     # the same terms, split by the kernel that moves them
+        # the same terms split by the kernel that moves them, per LAUNCH: a launch processes one sub-batch
+        by_kernel = {k: 0 for k in KERNELS}
+        for sb, pr in zip(subs, parts):
+            for k, v in pr.algorithmic_bytes_by_kernel(sb, K).items():
+                by_kernel[k] += v / S
+        by_kernel = {k: int(v) for k, v in by_kernel.items()}
         dom = int(np.argmax(stage[:3]))
         achieved = by_kernel[KERNELS[dom]] / (stage[dom] * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-        if args.config == "C2" and R == 10_000 and os.path.exists(pmc):
+        if args.config == "C2" and R == 10_000 and S == 2 and os.path.exists(pmc):
             k = json.load(open(pmc))["kernels"]
             # the stage is one launch of each of these (the later assembly passes are empty on this workload)
             names = {"k_assemble": ("k_assemble<64, true, 4>",), "k_ksw": ("k_ksw<3>", "k_ksw<4>"), "k_tally": ("k_tally",)}[KERNELS[dom]]
@@ -175,28 +196,31 @@ def main():
                                       else str(cfg["n_reads"][0]), cfg["read_len"], K, cfg["err_rate"], cfg["config_id"])
                                    + (", %g of events tandem duplications" % args.dup_frac if args.dup_frac else ""),
                        "read_trim": "device, from base qualities" if args.quals else "stager (trim bounds in the batch)",
+                       "submission": "%d sub-batch%s of consecutive regions per step, each on its own stream" % (S, "es" if S > 1 else ""),
                        "regions_per_gpu": R, "sharding": "contiguous region ranges per rank, one RCCL gather of "
                        "per-region result records per step" if world > 1 else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(by_kernel[KERNELS[dom]]),
-                         "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] / R, 1),
+                         "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] * S / R, 1),
+                         "launches_per_step": S,
                          "algorithmic_bytes_by_kernel": by_kernel,
                          "whole_path": {"algorithmic_bytes_per_step": int(alg_bytes),
-                                        "achieved": round(alg_bytes / (stage[3] * 1e-3) / 1e9, 2),
-                                        "frac": round(alg_bytes / (stage[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
+                                        "achieved": round(alg_bytes / (dt / args.steps) / 1e9, 2),
+                                        "frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}},
             "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),
                         "tallied": int((res.events["status"] == 0).sum()),
                         "fallback_events": int((res.events["aligned"] == 1).sum())},
         }
         if os.environ.get("IHP_PROFILE"):
-            out["profile_cycles"] = [int(x) for x in api.batch_profile(h)]
+            out["profile_cycles"] = [int(x) for x in sum(np.array(api.batch_profile(h)) for h in hs)]
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, K)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    api.batch_free(h)
+    for h in hs:
+        api.batch_free(h)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
