@@ -77,10 +77,12 @@ def main():
     ap.add_argument("--quals", action="store_true",
                     help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
                          "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
-    ap.add_argument("--sub-batches", type=int, default=2,
-                    help="the step submits the batch as this many sub-batches of consecutive regions, each on its own "
-                         "stream (ihp_batch_*): while one sub-batch's last regions drain a kernel, the other's next "
-                         "kernel fills the chip.  1 = one launch chain for the whole batch")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="submit the batch as this many sub-batches of consecutive regions, each on its own stream "
+                         "(ihp_batch_*): while one sub-batch's last regions drain a kernel, the other's next kernel fills "
+                         "the chip (+11%% regions/s with 2 on C2).  Default 1 = one launch chain for the whole batch, for "
+                         "which the HIP-event stage times ARE the kernel durations rocprofv3 reports; with more chains a "
+                         "later chain's kernel waits for wave slots, and its event interval includes that wait")
     ap.add_argument("--payload", action="store_true",
                     help="with --gpus N > 1: every step also packs the results on the device and sends each rank's slab "
                          "to rank 0 (the variable-length half of the SURVEY 8e gather); off by default, the per-step "
@@ -179,7 +181,7 @@ def main():
         achieved = by_kernel[KERNELS[dom]] / (stage[dom] * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-        if args.config == "C2" and R == 10_000 and S == 2 and os.path.exists(pmc):
+        if args.config == "C2" and R == 10_000 and S == 1 and os.path.exists(pmc):
             k = json.load(open(pmc))["kernels"]
             # the stage is one launch of each of these (the later assembly passes are empty on this workload)
             names = {"k_assemble": ("k_assemble<64, true, 4>",), "k_ksw": ("k_ksw<3>", "k_ksw<4>"), "k_tally": ("k_tally",)}[KERNELS[dom]]
