@@ -2,7 +2,7 @@
 //
 // Execution model used by every kernel in this library: ONE 64-lane wavefront per
 // workgroup, one unit of work (region / alignment / contig) per wavefront at a
-// time, persistent grid pulling work items from an atomic counter.  All control
+// time, persistent grid pulling work items from sharded counters (wq_next) or dealt round robin.  All control
 // flow around WSYNC() is wave-uniform.  gfx950 only: wave size is hard-coded 64.
 #pragma once
 #include <hip/hip_runtime.h>

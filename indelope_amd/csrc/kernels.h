@@ -1,5 +1,5 @@
 // kernels.h -- the __global__ entry points (gfx950).  Every kernel is a persistent
-// grid of single-wavefront workgroups pulling work items off an atomic counter.
+// grid of single-wavefront workgroups pulling work items off sharded counters (wq_next) or taking them round robin.
 #pragma once
 #include "contig_dev.h"
 #include "ksw_dev.h"
