@@ -77,12 +77,13 @@ def main():
     ap.add_argument("--quals", action="store_true",
                     help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
                          "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
-    ap.add_argument("--sub-batches", type=int, default=1,
-                    help="submit the batch as this many sub-batches of consecutive regions, each on its own stream "
-                         "(ihp_batch_*): while one sub-batch's last regions drain a kernel, the other's next kernel fills "
-                         "the chip (+11%% regions/s with 2 on C2).  Default 1 = one launch chain for the whole batch, for "
-                         "which the HIP-event stage times ARE the kernel durations rocprofv3 reports; with more chains a "
-                         "later chain's kernel waits for wave slots, and its event interval includes that wait")
+    ap.add_argument("--sub-batches", type=int, default=2,
+                    help="the step submits the batch as this many sub-batches of consecutive regions, each an ihp_batch on "
+                         "its own stream: while one sub-batch's last regions drain a kernel, the other's next kernel fills "
+                         "the chip (+10%% regions/s on C2).  With more than one chain a kernel can wait for wave slots the "
+                         "other chain holds, so the per-launch kernel_ms come from device wall-clock stamps "
+                         "(ihp_batch_kernel_ms: first workgroup's start -> marker behind the kernel), not from event "
+                         "intervals.  1 = one launch chain for the whole batch, timed with HIP events")
     ap.add_argument("--payload", action="store_true",
                     help="with --gpus N > 1: every step also packs the results on the device and sends each rank's slab "
                          "to rank 0 (the variable-length half of the SURVEY 8e gather); off by default, the per-step "
@@ -117,6 +118,9 @@ def main():
     S = max(1, min(args.sub_batches, R))
     subs = [batch.slice(R * i // S, R * (i + 1) // S) for i in range(S)]
     hs = [api.batch_upload(sb, params) for sb in subs]
+    if S > 1:
+        for h in hs:                                         # with several chains in flight a kernel can wait for wave slots:
+            api.batch_set_timing(h, True)                    # stage times from device wall-clock stamps, not event intervals
     views = []
     for h in hs:
         sptr, sn = api.batch_summary_dev(h)
@@ -151,8 +155,14 @@ def main():
     for _ in range(args.steps):
         step()
         for h in hs:                                         # per launch: the mean over the sub-batches' launches
-            stage += np.array(api.batch_stage_ms(h)) / S
-            fb_ms += api.batch_fallback_ms(h) / S
+            ev = np.array(api.batch_stage_ms(h))
+            if S > 1:
+                km = api.batch_kernel_ms(h)
+                ev[:3] = km[:3]
+                fb_ms += km[3] / S
+            else:
+                fb_ms += api.batch_fallback_ms(h) / S
+            stage += ev / S
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,7 +191,7 @@ def main():
         achieved = by_kernel[KERNELS[dom]] / (stage[dom] * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-        if args.config == "C2" and R == 10_000 and S == 1 and os.path.exists(pmc):
+        if args.config == "C2" and R == 10_000 and S == 2 and os.path.exists(pmc):
             k = json.load(open(pmc))["kernels"]
             # the stage is one launch of each of these (the later assembly passes are empty on this workload)
             names = {"k_assemble": ("k_assemble<64, true, 4>",), "k_ksw": ("k_ksw<3>", "k_ksw<4>"), "k_tally": ("k_tally",)}[KERNELS[dom]]

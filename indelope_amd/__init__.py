@@ -77,6 +77,15 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_pack_dev(h, C.byref(p), C.byref(n), _abi.ptr(counts, _abi.i64p)), "batch_pack_dev")
         return p.value, n.value, counts
 
+    def batch_set_timing(self, h, on=True):
+        self._chk_hip(self.b.batch_set_timing(h, 1 if on else 0), "batch_set_timing")
+
+    def batch_kernel_ms(self, h):
+        """[assemble, ksw2, tally, fallback] execution times (device wall clock) of the last run; needs batch_set_timing."""
+        ms = (C.c_float * 4)()
+        self._chk_hip(self.b.batch_kernel_ms(h, ms), "batch_kernel_ms")
+        return [float(x) for x in ms]
+
     def batch_fallback_ms(self, h):
         ms = C.c_float()
         self._chk_hip(self.b.batch_fallback_ms(h, C.byref(ms)), "batch_fallback_ms")

@@ -212,6 +212,8 @@ _PRODUCT_ONLY = {
     "pack_out": (C.c_int, [C.POINTER(BatchOut), C.c_void_p, C.c_int64, i64p, i64p]),
     "batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_fallback_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
     "debug_last_ksw_mode": (C.c_int, []),

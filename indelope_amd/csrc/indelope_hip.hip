@@ -376,7 +376,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.ez = d_ez.as<KswOut>(); a.cig_off = d_coff.as<long long>();
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
 	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
-	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr;
+	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr; a.t_start = nullptr;
 	g_last_ksw_mode = ksw_mode(P);
 	launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
@@ -607,6 +607,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
+enum { WQ_SETS = 10 };      // work-queue counter sets: 7 assembly launches, ksw2, tally, fallback
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_HIT = 20, M_WORDS = 24 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -626,11 +628,19 @@ struct ihp_batch {
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
 	long long cig_pool_cap = 0, cig_bump_cap = 0, ev_pool_cap = 0, njobs_cap = 0;
-	DBuf queues;
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
-	DBuf hit_pool, hit_region_cnt; long long hit_cap = 0;  // first-hit k-mer positions per (tallied event, read)
+	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
+	bool timing = false;                                   // device wall-clock stamps: start / end of the four stages
+	// everything a run clears lives in ONE buffer (`misc`) so that one memset does it: [counters | stamps | work queues |
+	// per-region hit counts]
+	static constexpr size_t Z_TIMES = 128, Z_QUEUES = 256;
+	size_t z_hitcnt() const { return Z_QUEUES + sizeof(int) * WQ_WORDS * WQ_SETS; }
+	size_t z_bytes() const { return z_hitcnt() + sizeof(int) * (size_t)std::max(R, 1); }
+	unsigned long long *times_dev() const { return (unsigned long long *)((char *)misc.p + Z_TIMES); }
+	int *queues_dev() const { return (int *)((char *)misc.p + Z_QUEUES); }
+	int *hitcnt_dev() const { return (int *)((char *)misc.p + z_hitcnt()); }
 	int grid_fb = 0, lds_fb = 0, fb_cig_cap = 0, max_region_reads = 0;
 	size_t fb_p_cap = 0;
 	// outputs
@@ -651,8 +661,6 @@ struct ihp_batch {
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
-enum { WQ_SETS = 10 };      // work-queue counter sets: 7 assembly launches, ksw2, tally, fallback
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_HIT = 20, M_WORDS = 24 };
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
@@ -828,8 +836,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm, b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
-	AL(misc, sizeof(int) * M_WORDS);
-	AL(queues, sizeof(int) * WQ_WORDS * WQ_SETS);
+	static_assert(sizeof(int) * M_WORDS <= ihp_batch::Z_TIMES, "misc counters overlap the stamps");
+	AL(misc, b->z_bytes());
 	if (p->fallback) {
 		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
@@ -844,11 +852,11 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	AL(cig_pool, 4 * (size_t)b->cig_pool_cap);
 	AL(ev_off, 8 * slots); AL(n_ev, 4 * slots); AL(ev_pool, sizeof(DevEvent) * (size_t)b->ev_pool_cap);
 	AL(summary, sizeof(ihp_region_summary) * R);
+
 	// HIT_SLOTS events per region at fixed places (2 x nreads ints each, region r at 8 x its first read index), then
 	// a bump region of the same size for regions with more tallied events
 	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
 	AL(hit_pool, sizeof(int) * (size_t)b->hit_cap);
-	AL(hit_region_cnt, sizeof(int) * (size_t)std::max(R, 1));
 #undef AL
 	for (auto &e : b->ev) HIPC(hipEventCreate(&e));
 	HIPC(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -863,12 +871,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	if (!b) return IHP_E_ARG;
 	hipStream_t s = b->stream;
 	const ihp_params &p = b->P;
-	HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_WORDS, s));
-	HIPC(hipMemsetAsync(b->queues.p, 0, sizeof(int) * WQ_WORDS * WQ_SETS, s));
-	int *wq = b->queues.as<int>();
+	HIPC(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // counters, stamps, work queues, per-region hit counts
+	int *wq = b->queues_dev();
 	const bool profiling = getenv("IHP_PROFILE") != nullptr;
 	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
 	int *misc = b->misc.as<int>();
+	unsigned long long *tm = b->timing ? b->times_dev() : nullptr;
 	HIPC(hipEventRecord(b->ev[0], s));
 	if (b->R > 0) {
 		AsmArgs a;
@@ -893,6 +901,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.out_sup = b->out_sup.as<uint32_t>();
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
+		a.t_start = nullptr;
 		// Passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  Every region
 		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
 		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
@@ -931,9 +940,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		if (n1) {
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = cl; a.n_in = cn; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
+			a.t_start = tm;                                        // the first launch of the stage
 			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
 			HIPC(hipGetLastError());
+			if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 1);   // the class-1 kernel itself; the (normally empty) overflow passes follow
 		}
+		a.t_start = nullptr;
 		if (side) HIPC(hipStreamWaitEvent(s, b->ev_join, 0));
 		pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>());
 		pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>());
@@ -945,6 +957,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		int8_t mat[25];
 		ihp_matrix(p.match, p.mismatch, mat);
 		KswArgs a;
+		a.t_start = tm ? tm + 2 : nullptr;
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.n_jobs_host = 0;
 		a.qbase = b->out_seq.as<uint8_t>(); a.tbase = b->ref_bases.as<uint8_t>();
 		a.P = make_ksw_params(5, mat, p.gap_open, p.gap_ext, p.bw, p.zdrop, p.ksw_flag, 1);   // ksw2.nim:154-157
@@ -959,9 +972,11 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 	}
+	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 3);
 	HIPC(hipEventRecord(b->ev[2], s));
 	if (b->R > 0 && b->n_reads > 0) {
 		TallyArgs a;
+		a.t_start = tm ? tm + 4 : nullptr;
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS;
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>();
 		a.bases = b->bases.as<uint8_t>(); a.mapq = b->mapq.as<uint8_t>();
@@ -971,8 +986,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.P.K = p.K; a.P.min_event_len = p.min_event_len; a.P.max_events = p.max_events; a.P.min_mapq_tally = p.min_mapq_tally;
 		a.P.fallback = p.fallback; a.fb_items = p.fallback ? b->fb_items.as<FbItem>() : nullptr; a.fb_count = misc + M_NFB;
 		a.hit_pool = b->hit_pool.as<int>(); a.hit_cursor = (unsigned long long *)(misc + M_HIT); a.hit_cap = b->hit_cap;
-		a.hit_overflow = misc + M_OVF_HIT; a.hit_region_cnt = b->hit_region_cnt.as<int>();
-		HIPC(hipMemsetAsync(b->hit_region_cnt.p, 0, sizeof(int) * (size_t)std::max(b->R, 1), s));
+		a.hit_overflow = misc + M_OVF_HIT; a.hit_region_cnt = b->hitcnt_dev();
 		a.hit_bump0 = 2ll * HIT_SLOTS * b->n_reads;
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.ev_cursor = (unsigned long long *)(misc + M_EV);
 		a.ev_pool_cap = b->ev_pool_cap; a.ev_off = b->ev_off.as<long long>(); a.n_ev = b->n_ev.as<int>();
@@ -982,11 +996,13 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		HIPC(hipGetLastError());
 	}
+	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 5);
 	HIPC(hipEventRecord(b->ev[3], s));
 	if (b->R > 0 && b->n_reads > 0 && p.fallback) {
 		int8_t mat[25];
 		ihp_matrix(p.fb_match, p.fb_mismatch, mat);                  // new_ez(mismatch=-2, gap_open=5, gap_ext=1), indelope.nim:318-319
 		FbArgs a;
+		a.t_start = tm ? tm + 6 : nullptr;
 		a.items = b->fb_items.as<FbItem>(); a.n_items = misc + M_NFB; a.max_region_reads = std::max(1, b->max_region_reads);
 		a.jobs = b->jobs.as<AlnJob>();
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>(); a.bases = b->bases.as<uint8_t>();
@@ -1005,6 +1021,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
 		HIPC(hipGetLastError());
 	}
+	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 7);
 	HIPC(hipEventRecord(b->ev[5], s));
 	if (b->R > 0) {
 		SummaryArgs a;
@@ -1050,6 +1067,28 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY3, sizeof(int), hipMemcpyDeviceToHost));
 	out[11] = nretry;                                 // ... and to the catch-all (HBM-arena) pass
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
+	return 0;
+}
+
+extern "C" int ihp_batch_set_timing(ihp_batch *b, int on)
+{
+	if (!b) return IHP_E_ARG;
+	b->timing = on != 0;
+	return 0;
+}
+
+// Execution time of the stages of the most recent run from device wall-clock stamps: from the moment the stage's first
+// workgroup started to a marker behind its last kernel.  ms[0] assemble, [1] ksw2, [2] tally, [3] fallback.
+extern "C" int ihp_batch_kernel_ms(ihp_batch *b, float ms[4])
+{
+	if (!b || !b->ran || !b->timing || !ms) return IHP_E_ARG;
+	unsigned long long t[8];
+	HIPC(hipStreamSynchronize(b->stream));
+	HIPC(hipMemcpy(t, b->times_dev(), sizeof(t), hipMemcpyDeviceToHost));
+	int khz = 0;
+	HIPC(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g.device));
+	for (int k = 0; k < 4; ++k)
+		ms[k] = (t[2 * k] && t[2 * k + 1] > t[2 * k] && khz > 0) ? (float)((double)(t[2 * k + 1] - t[2 * k]) / (double)khz) : 0.0f;
 	return 0;
 }
 

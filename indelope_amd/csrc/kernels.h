@@ -37,7 +37,17 @@ struct AsmArgs {
 	int *out_list, *n_out;                             // regions handed to the next, roomier pass (null: none)
 	int lds_arena;                                     // bytes of the dynamic LDS arena (LDS passes)
 	long long *prof;                                   // optional cycle counters (diagnostics)
+	unsigned long long *t_start;                       // optional: wall clock at which the launch's first workgroup starts
 };
+
+// Kernel execution time without a profiler: workgroup 0 is dispatched first, so its entry time is when the launch starts
+// to execute (an event recorded before the launch fires when the stream is ready, which is earlier when another stream's
+// kernels still hold the wave slots); a one-thread marker kernel behind the launch reads the clock when it has finished.
+__device__ __forceinline__ void mark_start(unsigned long long *t)
+{
+	if (t && blockIdx.x == 0 && threadIdx.x == 0) *t = (unsigned long long)wall_clock64();
+}
+__global__ void k_mark(unsigned long long *t) { *t = (unsigned long long)wall_clock64(); }
 
 // indelope.nim:23-38 on one read, lanes over bases.  Returns a; kept range [lo,hi).
 __device__ inline int read_trim_dev(const uint8_t *q, int n, int min_quality, int &lo, int &hi)
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 	if (LDSA) { A.seq = lds_arena; A.cap = a.lds_arena - 16; A.stage_off = a.lds_arena - 16 - a.stage_cap; }
 	else { A.seq = a.arena_seq + (size_t)blockIdx.x * a.arena_cap; A.cap = a.arena_cap - 16; A.stage_off = a.arena_cap - 16 - a.stage_cap; }
 	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof ? S.prof : nullptr;
+	mark_start(a.t_start);
 	if (lane < 16) S.prof[lane] = 0;
 	WSYNC();
 	const int n_items = a.in_list ? *a.n_in : a.n_regions;
@@ -387,6 +398,7 @@ struct KswArgs {
 	int *overflow;                             // [0] cigar pool, [1] LDS/p budget
 	int *work_counter;
 	long long *prof;                           // optional cycle counters (diagnostics)
+	unsigned long long *t_start;               // optional: see mark_start()
 };
 
 // MODE 3: top-byte register-resident sweep (ksw_narrow.h), left-aligned gaps; 4: same, KSW_EZ_RIGHT -- the
@@ -409,6 +421,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 	const KswArgsK a0 = (KswArgsK)__builtin_amdgcn_kernarg_segment_ptr();
 	{
 		const KswArgsK a = a0;
+		mark_start(a->t_start);
 		if (a->prof && lane < 4) ((long long *)(lds + a->lds_budget + 16))[lane] = 0;   // per-wave cycle counters live past the sweep's LDS
 	}
 	WSYNC();
@@ -512,12 +525,14 @@ struct TallyArgs {
 	int *hit_pool; unsigned long long *hit_cursor; long long hit_cap; int *hit_overflow;   // first-hit positions per (tallied event, read)
 	int *hit_region_cnt;                       // [R] events of the region that took one of its own hit slots
 	long long hit_bump0;                       // start of the shared bump region
+	unsigned long long *t_start;               // optional: see mark_start()
 };
 
 __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t tally_lds[];
 	const int lane = lane_id();
+	mark_start(a.t_start);
 	const int njobs = uni(*a.n_jobs);
 	// Items are dealt round robin (wave w takes w, w + grid, ...): they are short and alike, and a shared queue costs
 	// every wave a sweep over its eight counters at the end -- 65 000 same-address requests per launch, which at the
@@ -585,6 +600,7 @@ struct FbArgs {
 	uint32_t *cig_tmp; int cig_cap;            // per workgroup
 	int *overflow;                             // [1] LDS / traceback scratch budget
 	int *work_counter;
+	unsigned long long *t_start;               // optional: see mark_start()
 };
 
 // count_flanked_cigar (indelope.nim:185-199) over Ez.cigar (ksw2.nim:22-33); wave-uniform
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_item;
 	const int lane = lane_id();
+	mark_start(a.t_start);
 	const int n_items = *a.n_items;
 	const long long total = (long long)n_items * a.max_region_reads;
 	const int n = total > 0x7fffffff ? 0x7fffffff : (int)total;
