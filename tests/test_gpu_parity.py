@@ -474,3 +474,25 @@ def test_device_pack_is_what_fetch_returns(hip):
     assert counts2.tolist() == counts.tolist() and len(slab2) == nbytes
     again = hip.unpack_slab(slab2, counts2)
     assert BatchResult.first_difference(again, res) is None
+
+
+def test_device_clock_stage_times(hip):
+    """ihp_batch_kernel_ms (device wall-clock stamps) against ihp_batch_stage_ms (HIP events) on a single chain, where
+    nothing makes a kernel wait: the stamped execution times are positive and no longer than the event intervals."""
+    b, _ = synth.generate(2000, n_reads=(48, 64), err_rate=1e-3, config_id=37, dup_frac=0.05)
+    h = hip.batch_upload(b)
+    try:
+        hip.batch_set_timing(h, True)
+        for _ in range(2):
+            hip.batch_run(h)
+            hip.batch_sync(h)
+        km, ev = hip.batch_kernel_ms(h), hip.batch_stage_ms(h)
+        fb = hip.batch_fallback_ms(h)
+        res = hip.batch_fetch(h)
+    finally:
+        hip.batch_free(h)
+    assert (res.status == 0).all()
+    for k in range(3):
+        assert 0 < km[k] <= ev[k] * 1.05 + 0.02, (k, km, ev)
+        assert km[k] >= ev[k] * 0.5, (k, km, ev)
+    assert 0 < km[3] <= fb * 1.05 + 0.02
