@@ -58,8 +58,13 @@ def cpu_baseline(batch, K, want_seconds=12.0):
     dt = time.perf_counter() - t0
     n = n * reps
     o.use_reference_ksw(False)
+    # deterministic work counters of the restatement (secondary rate): per region on the probe sample
+    o.run_regions(probe, p)
+    cnt = o.counters()
+    work = {"char_compares": round(cnt["compares"] / probe.n_regions, 1), "ksw2_dp_cells": round(cnt["dp_cells"] / probe.n_regions, 1),
+            "kmer_steps": round(cnt["kmer_steps"] / probe.n_regions, 1)}
     return {"value": round(n / dt, 1), "unit": "regions/s", "cores": cores, "kind": "port",
-            "value_1thread": round(rate1, 1),
+            "value_1thread": round(rate1, 1), "work_per_region": work,
             "sample": "%d region passes (first regions of the workload, repeated), %d threads over independent regions; C restatement of "
                       "contig.nim/indelope.nim (oracle/), ksw2 = %s; Nim reference not buildable here"
                       % (n, cores, "reference ksw2_extz2_sse.c compiled (oracle/_ref)" if used_ref
@@ -230,6 +235,11 @@ def main():
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, K)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            # the work-based rate beside the HBM roofline: what the reference algorithm would have executed per second
+            w = out["cpu_baseline"]["work_per_region"]
+            out["work_rate"] = {"char_compares_per_s": round(w["char_compares"] * out["value"], -6),
+                                "ksw2_dp_cells_per_s": round(w["ksw2_dp_cells"] * out["value"], -6),
+                                "kmer_steps_per_s": round(w["kmer_steps"] * out["value"], -6)}
         print(json.dumps(out))
     for h in hs:
         api.batch_free(h)
