@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- candidate regions/sec through assemble + ksw2 + k-mer tally on MI355X.
 
-One "step" = one pass of the whole hot path (three HIP kernels + the per-region summary kernel) over one
-batch of synthetic candidate regions that is already resident in HBM.  Default workload = BASELINE.json
-configs[1] ("C2": 10k regions x 64 x 150 bp reads, SURVEY.md §8d generator).  With --gpus N each rank
-holds its own shard of regions (weak scaling: N x the same per-GPU batch) and every step ends with one
-RCCL gather of the fixed-size per-region result records to rank 0.
+One "step" = one pass of the whole hot path (the HIP kernels + the per-region summary kernel) over one batch of
+synthetic candidate regions that is already resident in HBM.  Default workload = BASELINE.json configs[1] ("C2":
+10k regions x 64 x 150 bp reads, SURVEY.md 8d generator).
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP events on the library's
-stream); `cpu_baseline` times the CPU oracle on this host's cores (checker used as a reported baseline
-only -- the Nim reference cannot be built in this image).
+  python bench.py                       one GPU, C2
+  python bench.py --gpus N              starts N ranks itself (one process per GPU over RCCL; the parent never touches
+                                        the GPU) -- or run it under `python -m torch.distributed.run --nproc-per-node N`
+  --scaling weak   (default)            every rank holds its own C2-sized shard (N x the same per-GPU batch); each step
+                                        ends with ONE RCCL gather of the fixed-size per-region records to rank 0
+  --scaling strong --config C4          the 5 M regions of BASELINE configs[3] split over the ranks by
+                                        indelope_amd.dist.shard_bounds, each rank generating its shard from the seed
+                                        (first_region), walked in resident chunks; one gather per step; `--payload`
+                                        adds the variable-length result slabs
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel; `cpu_baseline` times the CPU oracle on
+this host's cores (the checker, used as a reported baseline only -- the Nim reference cannot be built in this image);
+`e2e` is the PCIe-inclusive rate (host buffers in -> host buffers out), never `value`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,7 +32,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+ISSUE_PEAK = 3.65              # wave-instructions per cycle per CU, VALU+SALU interleaved at 8 waves/SIMD (tools/ubench_issue.hip)
 KERNELS = ["k_assemble", "k_ksw", "k_tally"]
+PMC_FILE = os.path.join("profiles", "r02_c2_pmc.json")
+MIX_FILE = os.path.join("profiles", "r02_c2_pmc_mix.json")
 
 
 class _DevArray:
@@ -38,37 +50,165 @@ class _DevBytes:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(batch, K, want_seconds=12.0):
-    """Oracle on the host cores over a bounded sample of the same workload."""
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def _host_cpus():
+    """CPUs this process may actually use: affinity mask, capped by a cgroup CPU quota if there is one."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    info = {"os_cpu_count": os.cpu_count(), "affinity": aff, "cgroup_quota_cpus": quota}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=5).stdout
+        for key, name in (("Model name", "model"), ("Socket(s)", "sockets"), ("Core(s) per socket", "cores_per_socket"),
+                          ("Thread(s) per core", "threads_per_core")):
+            for ln in txt.splitlines():
+                if ln.strip().startswith(key + ":"):
+                    v = ln.split(":", 1)[1].strip()
+                    info[name] = int(v) if v.isdigit() else v
+                    break
+    except Exception:
+        pass
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return usable, info
+
+
+def cpu_baseline(batch, K, want_seconds=16.0):
+    """Oracle on the host cores over a bounded sample of the same workload: a thread sweep 1, 2, 4, ... up to the CPUs
+    this process owns (affinity / cgroup quota, not os.cpu_count()); `value` is the best point of the curve."""
     import oracle
     o = oracle.get()
     used_ref = o.use_reference_ksw(True)
-    cores = os.cpu_count() or 1
+    usable, info = _host_cpus()
     p = o.params(K=K)
     probe = batch.slice(0, min(batch.n_regions, 512))
     t0 = time.perf_counter()
     o.bench_regions(probe, p, nthreads=1, reps=1)
     rate1 = probe.n_regions / (time.perf_counter() - t0)
-    # all cores: every thread owns a contiguous share of the regions and repeats it `reps` times
-    sample = batch.slice(0, min(batch.n_regions, max(cores * 8, 2048)))
-    n = sample.n_regions
-    reps = max(1, int(rate1 * cores * want_seconds / n / 2))
-    t0 = time.perf_counter()
-    o.bench_regions(sample, p, nthreads=cores, reps=reps)
-    dt = time.perf_counter() - t0
-    n = n * reps
+    counts = sorted({1, usable} | {c for c in (2, 4, 8, 16, 32, 64, 128, 256) if c < usable}
+                    | ({info.get("cores_per_socket")} if isinstance(info.get("cores_per_socket"), int)
+                       and info["cores_per_socket"] <= usable else set()))
+    per_point = want_seconds / len(counts)
+    curve = []
+    for c in counts:
+        # every thread owns a contiguous share of the sample and repeats it `reps` times
+        n = min(batch.n_regions, max(c * 16, 1024))
+        sample = batch.slice(0, n)
+        reps = max(1, int(rate1 * c * 0.8 * per_point / n))
+        t0 = time.perf_counter()
+        o.bench_regions(sample, p, nthreads=c, reps=reps)
+        dt = time.perf_counter() - t0
+        curve.append({"threads": c, "regions_per_s": round(n * reps / dt, 1), "region_passes": n * reps})
     o.use_reference_ksw(False)
+    best = max(curve, key=lambda x: x["regions_per_s"])
     # deterministic work counters of the restatement (SURVEY 8d, secondary rate): per region on the probe sample
     o.run_regions(probe, p)
     cnt = o.counters()
     work = {"char_compares": round(cnt["compares"] / probe.n_regions, 1), "ksw2_dp_cells": round(cnt["dp_cells"] / probe.n_regions, 1),
             "kmer_steps": round(cnt["kmer_steps"] / probe.n_regions, 1)}
-    return {"value": round(n / dt, 1), "unit": "regions/s", "cores": cores, "kind": "port",
-            "value_1thread": round(rate1, 1), "work_per_region": work,
-            "sample": "%d region passes (first regions of the workload, repeated), %d threads over independent regions; C restatement of "
-                      "contig.nim/indelope.nim (oracle/), ksw2 = %s; Nim reference not buildable here"
-                      % (n, cores, "reference ksw2_extz2_sse.c compiled (oracle/_ref)" if used_ref
-                         else "scalar restatement (oracle/_ref absent)")}
+    one = curve[0]["regions_per_s"]
+    out = {"value": best["regions_per_s"], "unit": "regions/s", "cores": best["threads"], "kind": "port",
+           "value_1thread": one, "curve": curve, "host": info, "cpus_usable": usable,
+           "scaling_vs_1thread": round(best["regions_per_s"] / one, 2),
+           "work_per_region": work,
+           "sample": "first regions of the workload, %d region passes at the best point (%d threads over independent regions, each "
+                     "repeating its share); C restatement of contig.nim/indelope.nim (oracle/), ksw2 = %s; Nim reference not "
+                     "buildable here" % (best["region_passes"], best["threads"],
+                                         "reference ksw2_extz2_sse.c compiled (oracle/_ref)" if used_ref
+                                         else "scalar restatement (oracle/_ref absent)")}
+    cps = info.get("cores_per_socket")
+    if isinstance(cps, int):
+        # the north-star's "single-socket CPU": the curve point at one socket's cores if this process owns that many,
+        # else the linear extrapolation from the per-thread rate at the best point (stated as such)
+        pt = [c for c in curve if c["threads"] == cps]
+        out["single_socket"] = ({"cores": cps, "regions_per_s": pt[0]["regions_per_s"], "how": "measured"} if pt else
+                                {"cores": cps, "regions_per_s": round(best["regions_per_s"] / best["threads"] * cps, 1),
+                                 "how": "extrapolated linearly from %d threads (this process owns %d CPUs)" % (best["threads"], usable)})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------ e2e
+def e2e_rates(api, batch, params, threads=3, reps=4):
+    """Host buffers in -> host buffers out (upload + run + device pack + fetch + host genotype): one batch at a time and
+    sustained with `threads` host threads, each driving batches of its own (every batch has its own stream)."""
+    import ctypes as C
+    import threading
+    from indelope_amd import _abi as A
+    t = {"upload": [], "run": [], "fetch": [], "total": []}
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        h = api.batch_upload(batch, params)
+        t1 = time.perf_counter()
+        api.batch_run(h)
+        api.batch_sync(h)
+        t2 = time.perf_counter()
+        out = A.BatchOut()
+        rc = api.b.batch_fetch(h, C.byref(out))              # device pack + one copy + genotype(): the C call alone
+        assert rc == 0, rc
+        t3 = time.perf_counter()
+        api.b.free_out(C.byref(out))
+        api.batch_free(h)
+        for k, v in zip(("upload", "run", "fetch", "total"), (t1 - t0, t2 - t1, t3 - t2, t3 - t0)):
+            t[k].append(v * 1e3)
+    med = {k: sorted(v[1:])[len(v[1:]) // 2] for k, v in t.items()}
+    n_each = max(4, reps * 2)
+
+    def worker():
+        for _ in range(n_each):
+            out = A.BatchOut()
+            cin = batch.as_c()
+            assert api.b.run_regions(C.byref(params), C.byref(cin), C.byref(out)) == 0
+            api.b.free_out(C.byref(out))
+    th = [threading.Thread(target=worker) for _ in range(threads)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return {"one_batch_ms": {k: round(v, 3) for k, v in med.items()},
+            "one_batch_regions_per_s": round(batch.n_regions / (med["total"] * 1e-3), 1),
+            "sustained": {"threads": threads, "batches": n_each * threads, "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
+                          "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)},
+            "inputs": "pageable host arrays, trim bounds" if batch.trim_lo is not None else "pageable host arrays, qualities",
+            "note": "upload + run + pack + fetch + genotype through the C ABI (ihp_batch_upload/run/fetch, ihp_run_regions); "
+                    "PCIe-inclusive, never `value`"}
+
+
+# ----------------------------------------------------------------------------------------------- launching
+def spawn_ranks(n, argv):
+    """`--gpus N` without a launcher: start N fresh ranks (one per GPU) from a parent that has not touched the GPU and
+    relay rank 0's JSON line.  torch.distributed.run gives every child RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["IHP_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in pr.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line:
+        print(line)
+    return pr.returncode if line or pr.returncode else 1
 
 
 def main():
@@ -76,74 +216,145 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2", help="BASELINE config id (C2, C3, C5) for the per-GPU batch")
-    ap.add_argument("--regions", type=int, default=0, help="override regions per GPU")
+    ap.add_argument("--config", default="C2", help="BASELINE config id (C2, C3, C4, C5)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank holds --regions regions of the config (default: the config's own count, at most "
+                         "200 000); strong: --regions is the TOTAL (default: the config's own count, e.g. 5 000 000 for C4), split "
+                         "over the ranks by dist.shard_bounds")
+    ap.add_argument("--regions", type=int, default=0, help="regions per GPU (weak) or in total (strong)")
+    ap.add_argument("--chunk", type=int, default=156_250,
+                    help="strong scaling: a rank walks its shard in resident chunks of this many regions (inputs of every chunk "
+                         "stay in HBM; when the shard's results would not fit beside them only one chunk's results are kept)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-check", action="store_true", help="skip the full-batch oracle comparison after the timed loop")
     ap.add_argument("--quals", action="store_true",
                     help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
                          "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
     ap.add_argument("--sub-batches", type=int, default=2,
-                    help="the step submits the batch as this many sub-batches of consecutive regions, each an ihp_batch on "
-                         "its own stream: while one sub-batch's last regions drain a kernel, the other's next kernel fills "
-                         "the chip (+10%% regions/s on C2).  With more than one chain a kernel can wait for wave slots the "
-                         "other chain holds, so the per-launch kernel_ms come from device wall-clock stamps "
-                         "(ihp_batch_kernel_ms: first workgroup's start -> marker behind the kernel), not from event "
-                         "intervals.  1 = one launch chain for the whole batch, timed with HIP events")
+                    help="weak scaling: the step submits the batch as this many sub-batches of consecutive regions, each an "
+                         "ihp_batch on its own stream: while one sub-batch's last regions drain a kernel, the other's next kernel "
+                         "fills the chip.  With more than one chain the per-launch kernel_ms come from device wall-clock stamps "
+                         "(ihp_batch_kernel_ms), not from event intervals.  1 = one launch chain, timed with HIP events")
     ap.add_argument("--payload", action="store_true",
-                    help="with --gpus N > 1: every step also packs the results on the device and sends each rank's slab "
-                         "to rank 0 (the variable-length half of the SURVEY 8e gather); off by default, the per-step "
-                         "collective is the gather of the fixed-size per-region records")
+                    help="with N > 1 ranks: every step also packs the results on the device and sends each rank's slab to rank 0 "
+                         "(the variable-length half of the SURVEY 8e gather)")
     ap.add_argument("--dup-frac", type=float, default=0.0,
                     help="fraction of planted events that are tandem duplications (these send the k-mer tally to the "
                          "alignment fallback, indelope.nim:312-372); 0 = the BASELINE workload")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU: the ranks form a gloo group, do the per-step gather on host tensors and rank "
+                         "0 prints a line with n_gpus = the number of ranks (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the parent starts the ranks and exits with their code: nothing below (torch, HIP) runs in it
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    if args.dry_run:
+        import torch.distributed as dist
+        from indelope_amd import dist as idist
+        if world > 1:
+            dist.init_process_group("gloo")
+        strong = args.scaling == "strong"
+        total = args.regions or 1000
+        bounds = idist.shard_bounds(np.ones(total), world) if strong else np.arange(world + 1) * total
+        n = int(bounds[rank + 1] - bounds[rank])
+        local = torch.full((n, idist.SUMMARY_WORDS), rank, dtype=torch.int32)
+        got = idist.gather_summaries(local, rank, world, dst=0)
+        if rank == 0:
+            assert got.shape[0] == int(bounds[-1]) and [int(got[int(bounds[r])][0]) for r in range(world)] == list(range(world))
+            print(json.dumps({"metric": "dry run (launcher check, no GPU work)", "value": 0.0, "n_gpus": world, "dry_run": True,
+                              "scaling": args.scaling, "regions_total": int(bounds[-1]), "launched_by": "bench.py --gpus" if
+                              os.environ.get("IHP_BENCH_SPAWNED") else "external launcher"}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import indelope_amd
     from indelope_amd import synth
+    from indelope_amd import dist as idist
     api = indelope_amd.api()
     api.init(local_rank)
 
     cfg = dict(synth.CONFIGS[args.config])
-    R = args.regions or min(cfg["n_regions"], 200_000)
-    cfg["n_regions"] = R
     K = cfg["K"]
-    batch, _ = synth.generate(first_region=rank * R, dup_frac=args.dup_frac, **cfg)
-    if not args.quals:
-        batch = batch.with_trim_bounds()                     # A0 on the host (SURVEY 8a row A0, 8b "trim bounds (a,b)")
+    strong = args.scaling == "strong"
     params = api.params(K=K)
-    S = max(1, min(args.sub_batches, R))
-    subs = [batch.slice(R * i // S, R * (i + 1) // S) for i in range(S)]
-    hs = [api.batch_upload(sb, params) for sb in subs]
-    if S > 1:
+    if strong:
+        total = args.regions or cfg["n_regions"]
+        bounds = idist.shard_bounds(np.ones(total), world)            # uniform reads per region in C2/C4/C5
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        R = hi - lo
+        cuts = list(range(lo, hi, max(1, args.chunk))) + [hi]
+        S = len(cuts) - 1
+    else:
+        R = args.regions or min(cfg["n_regions"], 200_000)
+        total = R * world
+        lo = rank * R
+        S = max(1, min(args.sub_batches, R))
+        cuts = [lo + R * i // S for i in range(S + 1)]
+    gen = dict(cfg)
+    subs, hs = [], []
+    for i in range(S):
+        gen["n_regions"] = cuts[i + 1] - cuts[i]
+        sb, _ = synth.generate(first_region=cuts[i], dup_frac=args.dup_frac, **gen)
+        if not args.quals:
+            sb = sb.with_trim_bounds()                       # A0 on the host (SURVEY 8a row A0, 8b "trim bounds (a,b)")
+        hs.append(api.batch_upload(sb, params))
+        subs.append(sb if (not strong or (rank == 0 and i == 0)) else None)     # strong: keep one chunk for the host-side legs
+    # strong scaling on few GPUs: the results of a whole shard may not fit beside its inputs -> one chunk's results at a time
+    import ctypes
+    cu_, ws_, hbm_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    api.b.device_info(ctypes.byref(cu_), ctypes.byref(ws_), ctypes.byref(hbm_))
+    hbm = hbm_.value
+    stream_outputs = strong and R * 64 * cfg["read_len"] * 9.0 > 0.7 * hbm
+    if stream_outputs:
+        for h in hs:
+            api.batch_release_outputs(h)
+    timing = (not strong) and S > 1
+    if timing:
         for h in hs:                                         # with several chains in flight a kernel can wait for wave slots:
             api.batch_set_timing(h, True)                    # stage times from device wall-clock stamps, not event intervals
     views = []
     for h in hs:
         sptr, sn = api.batch_summary_dev(h)
         views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda") if sn else torch.zeros(0, dtype=torch.int32, device="cuda"))
-    summary = views[0] if S == 1 else torch.cat(views)       # per-region records of the whole batch, region order
-    gather_list = [torch.empty_like(summary) for _ in range(world)] if (world > 1 and rank == 0) else None
+    summary = views[0] if S == 1 else torch.cat(views)       # per-region records of the rank's regions, region order
+    # shard sizes are known to every rank (bounds / equal shares): shards are padded to the longest, ONE gather per step
+    shard_sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)] if strong else [R] * world
+    m_pad = max(shard_sizes)
+    send = summary if R == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
+    gather_list = [torch.empty_like(send) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
-        for h in hs:
-            api.batch_run(h)                                 # asynchronous: the sub-batches' launch chains overlap
-        for h in hs:
-            api.batch_sync(h)
+        if strong:
+            for h in hs:                                     # chunk after chunk; the per-region records stay on the device
+                api.batch_run(h)
+                api.batch_sync(h)
+                if stream_outputs:
+                    api.batch_release_outputs(h)
+        else:
+            for h in hs:
+                api.batch_run(h)                             # asynchronous: the sub-batches' launch chains overlap
+            for h in hs:
+                api.batch_sync(h)
         if world > 1:
             if S > 1:
                 torch.cat(views, out=summary)
-            dist.gather(summary, gather_list, dst=0)
-            if args.payload:
-                from indelope_amd import dist as idist
+            if send is not summary:
+                send[:summary.numel()] = summary
+            dist.gather(send, gather_list, dst=0)            # THE per-step collective: fixed-size per-region records to rank 0
+            if args.payload and not stream_outputs:
                 for h in hs:
                     ptr, nbytes, counts = api.batch_pack_dev(h)
                     slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
@@ -159,15 +370,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for h in hs:                                         # per launch: the mean over the sub-batches' launches
-            ev = np.array(api.batch_stage_ms(h))
-            if S > 1:
-                km = api.batch_kernel_ms(h)
-                ev[:3] = km[:3]
-                fb_ms += km[3] / S
-            else:
-                fb_ms += api.batch_fallback_ms(h) / S
-            stage += ev / S
+        if not stream_outputs:
+            for h in hs:                                     # per launch: the mean over the step's launches
+                ev = np.array(api.batch_stage_ms(h))
+                if timing:
+                    km = api.batch_kernel_ms(h)
+                    ev[:3] = km[:3]
+                    fb_ms += km[3] / S
+                else:
+                    fb_ms += api.batch_fallback_ms(h) / S
+                stage += ev / S
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,66 +393,128 @@ def main():
 
     if rank == 0:
         from indelope_amd.host import concat_results
-        parts = [api.batch_fetch(h) for h in hs]
+        if stream_outputs:                                   # results were released chunk by chunk: rerun the first chunk for the report
+            api.batch_run(hs[0])
+            api.batch_sync(hs[0])
+            stage = np.array(api.batch_stage_ms(hs[0]))
+        keep = [i for i in range(S) if subs[i] is not None]
+        parts = [api.batch_fetch(hs[i]) for i in keep]
         res = concat_results(parts)
         assert (res.status == 0).all(), "regions failed on the device"
-        # SURVEY.md §8d: B = sum_reads(len+9) + len_refwindow + sum_contigs(5 len+16) + sum_aln(44+4 n_cigar) + sum_events(2K+12)
-        alg_bytes = batch.algorithmic_input_bytes() + res.algorithmic_output_bytes(K)
-        # the same terms split by the kernel that moves them, per LAUNCH: a launch processes one sub-batch
-        by_kernel = {k: 0 for k in KERNELS}
-        for sb, pr in zip(subs, parts):
-            for k, v in pr.algorithmic_bytes_by_kernel(sb, K).items():
-                by_kernel[k] += v / S
+        # SURVEY.md 8d: B = sum_reads(len+9) + len_refwindow + sum_contigs(5 len+16) + sum_aln(44+4 n_cigar) + sum_events(2K+12)
+        n_kept = sum(subs[i].n_regions for i in keep)
+        alg_bytes_kept = sum(subs[i].algorithmic_input_bytes() for i in keep) + res.algorithmic_output_bytes(K)
+        alg_per_region = alg_bytes_kept / max(n_kept, 1)
+        alg_bytes = alg_per_region * R                       # this rank's share per step (exact when every chunk is kept)
+        # the same terms split by the kernel that moves them, per LAUNCH: a launch processes one sub-batch / chunk
+        by_kernel = {k: 0.0 for k in KERNELS}
+        for i, pr in zip(keep, parts):
+            for k, v in pr.algorithmic_bytes_by_kernel(subs[i], K).items():
+                by_kernel[k] += v / len(keep)
         by_kernel = {k: int(v) for k, v in by_kernel.items()}
         dom = int(np.argmax(stage[:3]))
         achieved = by_kernel[KERNELS[dom]] / (stage[dom] * 1e-3) / 1e9
-        traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
-        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-        if args.config == "C2" and R == 10_000 and S == 2 and os.path.exists(pmc):
+        # HBM bytes per launch of the dominant kernel: NOT measured in this process (PMC counters need rocprofv3 passes of their
+        # own, tools/profile_round.sh); the figure of the committed passes over the same workload is quoted with its source
+        traffic, traffic_source, issue = None, None, None
+        pmc, mix = os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, MIX_FILE)
+        same = args.config == "C2" and R == 10_000 and S == 2 and not strong
+        if same and os.path.exists(pmc):
             k = json.load(open(pmc))["kernels"]
-            # the stage is one launch of each of these (the later assembly passes are empty on this workload)
-            names = {"k_assemble": ("k_assemble<64, true, 4>",), "k_ksw": ("k_ksw<3>", "k_ksw<4>"), "k_tally": ("k_tally",)}[KERNELS[dom]]
-            t = [k[n]["traffic"] for n in names if n in k]
-            traffic = int(sum(t)) if t else None
+            t = [v["traffic"] for n, v in k.items() if n.split("<")[0].split("::")[-1] == KERNELS[dom] and v.get("traffic")]
+            if t:
+                traffic, traffic_source = int(max(t)), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+        if same and os.path.exists(mix):
+            try:
+                k = json.load(open(mix))
+                for n, v in k.items():
+                    if n.split("<")[0].split("::")[-1] == KERNELS[dom] and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                        cyc = float(v["GRBM_GUI_ACTIVE"]) * 256
+                        va, sa = float(v["SQ_INSTS_VALU"]) / cyc, float(v.get("SQ_INSTS_SALU", 0)) / cyc
+                        issue = {"valu_per_cycle_per_cu": round(va, 3), "salu_per_cycle_per_cu": round(sa, 3),
+                                 "issue_frac": round((va + sa) / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
+                                 "source": MIX_FILE + "; peak = VALU+SALU interleaved at 8 waves/SIMD, tools/ubench_issue.hip"}
+                        break
+            except Exception:
+                pass
         out = {
             "metric": "candidate regions/sec (assemble+ksw2+kmer-genotype), 150bp x 64-read batches",
-            "value": round(world * R * args.steps / dt, 1), "unit": "regions/s",
+            "value": round(total * args.steps / dt, 1), "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d regions/GPU x %s reads x %d bp, K=%d, err %g (SURVEY 8d generator, seed 0x1DE10BE^%d)"
-                                   % (args.config, R, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
-                                      else str(cfg["n_reads"][0]), cfg["read_len"], K, cfg["err_rate"], cfg["config_id"])
+            "config": {"workload": "%s: %s x %s reads x %d bp, K=%d, err %g (SURVEY 8d generator, seed 0x1DE10BE^%d)"
+                                   % (args.config, ("%d regions in total" % total) if strong else ("%d regions/GPU" % R),
+                                      "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1] else str(cfg["n_reads"][0]),
+                                      cfg["read_len"], K, cfg["err_rate"], cfg["config_id"])
                                    + (", %g of events tandem duplications" % args.dup_frac if args.dup_frac else ""),
                        "read_trim": "device, from base qualities" if args.quals else "stager (trim bounds in the batch)",
-                       "submission": "%d sub-batch%s of consecutive regions per step, each on its own stream" % (S, "es" if S > 1 else ""),
-                       "regions_per_gpu": R, "sharding": "contiguous region ranges per rank, one RCCL gather of "
-                       "per-region result records per step" if world > 1 else "single GPU"},
+                       "submission": ("%d resident chunk%s of <= %d regions per rank, one after the other%s"
+                                      % (S, "s" if S > 1 else "", args.chunk, "; one chunk's results kept at a time" if stream_outputs else ""))
+                       if strong else "%d sub-batch%s of consecutive regions per step, each on its own stream" % (S, "es" if S > 1 else ""),
+                       "regions_per_gpu": R, "regions_total": total,
+                       "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
+                                    "records per step" + (" + result slabs to rank 0" if args.payload else "")) if world > 1 else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(by_kernel[KERNELS[dom]]),
-                         "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] * S / R, 1),
+                         "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] * len(keep) / max(n_kept, 1), 1),
                          "launches_per_step": S,
                          "algorithmic_bytes_by_kernel": by_kernel,
-                         "whole_path": {"algorithmic_bytes_per_step": int(alg_bytes),
-                                        "achieved": round(alg_bytes / (dt / args.steps) / 1e9, 2),
-                                        "frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}},
+                         "issue": issue,
+                         "whole_path": {"algorithmic_bytes_per_step": int(alg_bytes * world),
+                                        "achieved": round(alg_bytes * world / (dt / args.steps) / 1e9, 2),
+                                        "frac": round(alg_bytes * world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}},
             "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),
                         "tallied": int((res.events["status"] == 0).sum()),
-                        "fallback_events": int((res.events["aligned"] == 1).sum())},
+                        "fallback_events": int((res.events["aligned"] == 1).sum()), "regions_inspected": n_kept},
         }
         if os.environ.get("IHP_PROFILE"):
             out["profile_cycles"] = [int(x) for x in sum(np.array(api.batch_profile(h)) for h in hs)]
+        batch0 = subs[keep[0]]
+        if not args.no_check:
+            # outside the timed loop: every region the rank kept on the host goes through the oracle (all host threads) and must
+            # be bit-identical -- the whole 10 000-region batch at the default workload
+            import oracle
+            from indelope_amd.host import BatchResult
+            o = oracle.get()
+            usable, _ = _host_cpus()
+            t1 = time.perf_counter()
+            nchk, bad = 0, None
+            for i, pr in zip(keep, parts):
+                lim = min(subs[i].n_regions, max(0, 20_000 - nchk))
+                if lim == 0:
+                    break
+                sub = subs[i] if lim == subs[i].n_regions else subs[i].slice(0, lim)
+                exp = o.run_regions_mt(sub, o.params(K=K), usable)
+                got = pr if lim == subs[i].n_regions else api.run_regions(sub, params)
+                d = BatchResult.first_difference(got, exp)
+                nchk += lim
+                if d is not None:
+                    bad = d
+                    break
+            out["oracle_check"] = {"regions": nchk, "identical": bad is None, "first_difference": bad,
+                                   "seconds": round(time.perf_counter() - t1, 2), "threads": usable,
+                                   "what": "contigs, supports, ksw2 records + CIGARs, events, k-mer counts and hit positions against "
+                                           "the CPU oracle, after the timed loop"}
+            assert bad is None, "device results differ from the oracle: " + str(bad)
+        if not args.no_e2e and world == 1:
+            out["e2e"] = e2e_rates(api, batch0, params)
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(batch, K)
+            full = batch0
+            out["cpu_baseline"] = cpu_baseline(full, K)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            ss = out["cpu_baseline"].get("single_socket")
+            if ss:
+                out["gpu_over_single_socket_cpu"] = round(out["value"] / ss["regions_per_s"], 1)
             # the work-based rate beside the HBM roofline: what the reference algorithm would have executed per second
             w = out["cpu_baseline"]["work_per_region"]
             out["work_rate"] = {"char_compares_per_s": round(w["char_compares"] * out["value"], -6),
                                 "ksw2_dp_cells_per_s": round(w["ksw2_dp_cells"] * out["value"], -6),
                                 "kmer_steps_per_s": round(w["kmer_steps"] * out["value"], -6)}
         print(json.dumps(out))
+        sys.stdout.flush()
     for h in hs:
         api.batch_free(h)
     if world > 1:

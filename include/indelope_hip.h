@@ -65,13 +65,20 @@ typedef struct {
  * (ksw2.h:54, bound by ksw2_c.nim:53-55, sole caller ksw2.nim:154-157).
  * One alignment, computed by the HIP kernel.  `km` is ignored (always nil in
  * the reference).  ez->cigar is (re)allocated with realloc and retained by the
- * caller exactly as ksw2_extz2_sse.c:31-41 does.  On a HIP failure the call
- * leaves ez reset (n_cigar 0, score KSW_NEG_INF) and records the error for
- * ihp_last_hip_error().
+ * caller exactly as ksw2_extz2_sse.c:31-41 does.  The reference signature has
+ * no return code, so a failure (HIP error, unsupported flag, out of memory or
+ * capacity) is made loud instead of looking like "no alignment": ez is left
+ * reset (n_cigar 0, score KSW_NEG_INF), the reason is printed on stderr and
+ * kept for ihp_last_hip_error(), ihp_ksw_last_status() returns the IHP_E_* code
+ * of the most recent call (0 = ok), and with IHP_KSW_STRICT=1 in the
+ * environment the call abort()s the way the reference's own assert
+ * (ksw2_extz2_sse.c:237) would.
  */
 void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                    int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag,
                    ksw_extz_t *ez);
+
+int ihp_ksw_last_status(void);
 
 /* Scalar result fields of one alignment (ksw_extz_t minus the pointer).       */
 typedef struct {
@@ -384,9 +391,14 @@ void ihp_free_out(ihp_batch_out *out);
 typedef struct ihp_batch ihp_batch;     /* opaque device-resident batch        */
 int  ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **b);
 int  ihp_batch_run(ihp_batch *b);                     /* async on the batch stream */
-int  ihp_batch_sync(ihp_batch *b);
+int  ihp_batch_sync(ihp_batch *b);                    /* waits; IHP_E_CAPACITY if a device pool overflowed in the run */
 int  ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out);
 void ihp_batch_free(ihp_batch *b);
+/* Hand the batch's scratch and result buffers back to the device pool; its inputs and the per-region summary
+ * records (ihp_batch_summary_dev) stay.  For callers that walk through more regions than one GPU holds results for
+ * (C4 on fewer than 8 GPUs): every chunk's inputs stay resident, one chunk's results at a time.  The next
+ * ihp_batch_run takes buffers again; fetch / pack need that run first.                                           */
+int  ihp_batch_release_outputs(ihp_batch *b);
 /* The results of a batch compacted ON THE DEVICE into one slab that holds every array of ihp_batch_out (what
  * ihp_batch_fetch copies to the host in one piece): device pointer, size, and the six counts {regions, contigs,
  * bases, CIGAR words, events, hit entries} that define its layout.  Valid until the batch runs, packs or is freed
@@ -419,6 +431,10 @@ int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
  * not cover), 5 = ring sweep for bands > 62 or unbanded (ksw_wide.h; per job the LDS sweep
  * where the ring does not fit), 2 = LDS sweep.  Results are identical in every mode.       */
 int  ihp_debug_last_ksw_mode(void);
+/* Test hook: upper limits for the device pools of batches uploaded from now on -- {CIGAR bump-pool words,
+ * event-pool entries, hit-pool ints, ksw2 traceback bytes per wave}; 0 = the library's own sizing.  NULL resets.
+ * Lets the overflow paths (IHP_E_CAPACITY from ihp_batch_sync / fetch) be driven by small inputs.               */
+int  ihp_debug_limits(const int64_t limits[4]);
 /* Fixed-size per-region summary record left on the device for the multi-GPU
  * gather (one RCCL gather of these at the end).     */
 typedef struct {

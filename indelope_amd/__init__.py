@@ -102,6 +102,16 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_profile(h, _abi.ptr(out, _abi.i64p)), "batch_profile")
         return out
 
+    def batch_release_outputs(self, h):
+        """Scratch and result buffers back to the device pool (inputs and summary records stay); the next run takes them again."""
+        self._chk_hip(self.b.batch_release_outputs(h), "batch_release_outputs")
+
+    def debug_limits(self, cigar_words=0, events=0, hits=0, ksw_bytes=0):
+        """Test hook: cap the device pools of batches uploaded from now on (0 = library sizing)."""
+        import numpy as np
+        lim = np.array([cigar_words, events, hits, ksw_bytes], np.int64)
+        self._chk_hip(self.b.debug_limits(_abi.ptr(lim, _abi.i64p)), "debug_limits")
+
     def batch_free(self, h):
         self.b.batch_free(h)
 

@@ -207,6 +207,7 @@ _PRODUCT_ONLY = {
     "batch_sync": (C.c_int, [C.c_void_p]),
     "batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(BatchOut)]),
     "batch_free": (None, [C.c_void_p]),
+    "batch_release_outputs": (C.c_int, [C.c_void_p]),
     "batch_pack_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p, i64p]),
     "unpack_slab": (C.c_int, [C.c_void_p, C.c_int64, i64p, C.c_double, C.POINTER(BatchOut)]),
     "pack_out": (C.c_int, [C.POINTER(BatchOut), C.c_void_p, C.c_int64, i64p, i64p]),
@@ -217,6 +218,8 @@ _PRODUCT_ONLY = {
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
     "debug_last_ksw_mode": (C.c_int, []),
+    "debug_limits": (C.c_int, [i64p]),
+    "ksw_last_status": (C.c_int, []),
 }
 
 KSW_ARGTYPES = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,

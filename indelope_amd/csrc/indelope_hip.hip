@@ -40,11 +40,23 @@ int hip_fail(hipError_t e, const char *what, int line)
 }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x, __LINE__); } while (0)
 
+// HIP's current device is a per-thread setting: ihp_init binds the calling thread, every other host thread that
+// drives batches (header: "batches may be driven from several host threads at once") is bound on its first call.
+thread_local int tl_device = -1;
 int ensure_init()
 {
-	if (g.ready) return 0;
-	return ihp_init(0);
+	if (!g.ready) { int rc = ihp_init(0); if (rc) return rc; }
+	if (tl_device != g.device) {
+		hipError_t e = hipSetDevice(g.device);
+		if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __LINE__);
+		tl_device = g.device;
+	}
+	return 0;
 }
+
+// test hook (ihp_debug_limits): caps on the device pools so that the overflow paths can be driven by small inputs
+long long g_limits[4] = {0, 0, 0, 0};      // CIGAR bump words, event pool entries, hit pool ints, ksw traceback bytes
+int g_ksw_status = 0;                      // result of the most recent ksw_extz2_sse call (ihp_ksw_last_status)
 
 // Device memory comes from a caching pool: a BAM sweep uploads batch after batch of similar shape, and hipMalloc /
 // hipFree (which synchronises the device) of ~50 buffers per batch would cost more than the kernels.  Freed blocks are
@@ -112,6 +124,33 @@ struct StreamCache {
 	}
 };
 StreamCache g_streams;
+
+// A run's counters, overflow flags and stamps are left by its last kernel in a 256-byte block of page-locked host
+// memory (k_summary writes it over PCIe), so that ihp_batch_sync / fetch / profile read them without a device copy.
+constexpr int REPORT_INTS = 64;
+struct ReportPool {
+	std::mutex mu;
+	std::vector<int *> free_list, pages;
+	int *get() {
+		std::lock_guard<std::mutex> l(mu);
+		if (free_list.empty()) {
+			void *pg = nullptr;
+			if (hipHostMalloc(&pg, 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
+			pages.push_back((int *)pg);
+			for (int k = 0; k < 4096 / (int)(sizeof(int) * REPORT_INTS); ++k) free_list.push_back((int *)pg + k * REPORT_INTS);
+		}
+		int *r = free_list.back(); free_list.pop_back();
+		memset(r, 0, sizeof(int) * REPORT_INTS);
+		return r;
+	}
+	void put(int *r) { std::lock_guard<std::mutex> l(mu); free_list.push_back(r); }
+	void clear() {
+		std::lock_guard<std::mutex> l(mu);
+		for (auto pg : pages) (void)hipHostFree(pg);
+		pages.clear(); free_list.clear();
+	}
+};
+ReportPool g_reports;
 
 // device buffer; returned to the pool on scope exit / batch free
 struct DBuf {
@@ -204,9 +243,11 @@ extern "C" const char *ihp_strerror(int code)
 extern "C" const char *ihp_last_hip_error(void) { return g.err; }
 extern "C" const char *ihp_version(void) { return "indelope_hip 0.1 (gfx950)"; }
 
+static void slab_cache_clear();
+static void report_pool_clear();
 extern "C" int ihp_init(int device)
 {
-	if (g.ready && g.device == device) return 0;
+	if (g.ready && g.device == device) { tl_device = -1; return ensure_init(); }
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g.err, sizeof(g.err), "no HIP device"); return IHP_E_NODEVICE; }
 	if (device < 0 || device >= n) return IHP_E_ARG;
@@ -217,8 +258,17 @@ extern "C" int ihp_init(int device)
 		snprintf(g.err, sizeof(g.err), "device %d is %s; this library is built for gfx950 only", device, pr.gcnArchName);
 		return IHP_E_NODEVICE;
 	}
+	if (g.ready && g.device != device) {
+		// pooled blocks, streams and pinned slabs belong to the old device
+		(void)hipSetDevice(g.device);
+		if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
+		slab_cache_clear(); g_pool.clear(); g_streams.clear(); report_pool_clear();
+		g.ready = false;
+		HIPC(hipSetDevice(device));
+	}
 	if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
 	HIPC(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+	tl_device = device;
 	g.device = device; g.cus = pr.multiProcessorCount; g.hbm = (int64_t)pr.totalGlobalMem;
 	g.max_lds = (int)pr.sharedMemPerBlock;
 	if (g.max_lds > 65536) {
@@ -247,14 +297,20 @@ extern "C" int ihp_device_info(int *cu_count, int *wave_size, int64_t *hbm_bytes
 	return 0;
 }
 
-static void slab_cache_clear();
 extern "C" void ihp_shutdown(void)
 {
 	if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
 	slab_cache_clear();
+	report_pool_clear();
 	g_pool.clear();
 	g_streams.clear();
-	g.ready = false; g.device = -1;
+	g.ready = false; g.device = -1; tl_device = -1;
+}
+
+extern "C" int ihp_debug_limits(const int64_t limits[4])
+{
+	for (int k = 0; k < 4; ++k) g_limits[k] = limits ? (long long)limits[k] : 0;
+	return 0;
 }
 
 extern "C" void ihp_encode(const uint8_t *dna, int64_t n, uint8_t *out)
@@ -445,12 +501,23 @@ extern "C" void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen
 	ez->max_q = ez->max_t = ez->mqe_t = ez->mte_q = -1;          // ksw_reset_extz, ksw2_extz2_sse.c:81-86
 	ez->max = 0; ez->score = ez->mqe = ez->mte = KSW_NEG_INF;
 	ez->n_cigar = 0; ez->zdropped = 0;
+	g_ksw_status = 0;
 	if (m <= 0 || qlen <= 0 || tlen <= 0) return;
 	int64_t qo[2] = {0, qlen}, to[2] = {0, tlen}, co[2];
 	ihp_ez r;
 	std::vector<uint32_t> cig((size_t)qlen + tlen + 4);
 	const int rc = ihp_ksw_extz2_batch(1, query, qo, target, to, m, mat, q, e, w, zdrop, flag, &r, cig.data(), (int64_t)cig.size(), co);
-	if (rc) { if (rc != IHP_E_HIP) snprintf(g.err, sizeof(g.err), "ksw_extz2_sse: %s", ihp_strerror(rc)); return; }
+	if (rc) {
+		// The reference's signature has no return code and a reset ez reads as "no alignment": make the failure loud.
+		// The code stays in ihp_ksw_last_status(), the text goes to stderr; IHP_KSW_STRICT=1 aborts like the reference's
+		// own assert (ksw2_extz2_sse.c:237) would.
+		g_ksw_status = rc;
+		if (rc != IHP_E_HIP) snprintf(g.err, sizeof(g.err), "ksw_extz2_sse: %s (qlen %d, tlen %d, w %d, flag 0x%x)", ihp_strerror(rc), qlen, tlen, w, flag);
+		fprintf(stderr, "indelope_hip: ksw_extz2_sse FAILED, ez left reset: %s\n", g.err);
+		const char *strict = getenv("IHP_KSW_STRICT");
+		if (strict && strict[0] == '1') abort();
+		return;
+	}
 	ez->max = (uint32_t)r.max; ez->zdropped = (uint32_t)r.zdropped; ez->max_q = r.max_q; ez->max_t = r.max_t;
 	ez->mqe = r.mqe; ez->mqe_t = r.mqe_t; ez->mte = r.mte; ez->mte_q = r.mte_q; ez->score = r.score;
 	if (r.n_cigar > ez->m_cigar) {                               // grow like ksw_push_cigar (:34-37): powers of two from 4
@@ -462,6 +529,8 @@ extern "C" void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen
 	if (r.n_cigar > 0) memcpy(ez->cigar, cig.data(), sizeof(uint32_t) * (size_t)r.n_cigar);
 	ez->n_cigar = r.n_cigar;
 }
+
+extern "C" int ihp_ksw_last_status(void) { return g_ksw_status; }
 
 // ------------------------------------------------------------ Contig API ops
 static int contig_op(int op, ihp_contig *t, ihp_contig *q, int64_t min_overlap, int64_t max_mismatch, int rule,
@@ -633,8 +702,9 @@ struct ihp_batch {
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
 	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
 	bool timing = false;                                   // device wall-clock stamps: start / end of the four stages
-	// everything a run clears lives in ONE buffer (`misc`) so that one memset does it: [counters | stamps | work queues |
-	// per-region hit counts]
+	// everything a run expects to be zero lives in ONE buffer (`misc`): [counters | stamps | work queues | per-region hit
+	// counts].  It is cleared once at upload; after that the last kernel of every run (k_summary) copies the first
+	// REPORT_INTS ints to `report` and clears the buffer for the next run -- a run has no memset.
 	static constexpr size_t Z_TIMES = 128, Z_QUEUES = 256;
 	size_t z_hitcnt() const { return Z_QUEUES + sizeof(int) * WQ_WORDS * WQ_SETS; }
 	size_t z_bytes() const { return z_hitcnt() + sizeof(int) * (size_t)std::max(R, 1); }
@@ -648,8 +718,11 @@ struct ihp_batch {
 	DBuf out_seq, out_sup, jobs, ez, cig_off, cig_pool, ev_off, n_ev, ev_pool, summary;
 	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	hipStream_t stream = nullptr;
-	bool ran = false;
+	bool ran = false, work_live = false;
+	int *report = nullptr;                                 // page-locked host block: the last run's counters, flags and stamps
+	int grid_ovf2 = 0, grid_ovf3 = 0, grid_ovf4 = 0;       // grids of the run-time overflow launches
 	~ihp_batch() {
+		if (report) g_reports.put(report);
 		// the buffers go back to the pool (the members are released after this body): nothing of this batch may still be running
 		if (stream2) { (void)hipStreamSynchronize(stream2); g_streams.put(stream2); }
 		if (stream) { (void)hipStreamSynchronize(stream); g_streams.put(stream); }
@@ -661,6 +734,62 @@ struct ihp_batch {
 
 // misc layout (ints): [0..1] cigar cursor (u64), [2..3] event cursor (u64), [4] n_jobs,
 // [5] asm counter, [6] ksw counter, [7] tally counter, [8..10] overflow flags
+
+// Scratch and result buffers of a batch (everything but its inputs and the small per-run state): taken from the
+// caching pool at upload, handed back by ihp_batch_release_outputs and taken again by the next ihp_batch_run.
+static int alloc_work(ihp_batch *b)
+{
+	if (b->work_live) return 0;
+	int rc;
+	const ihp_params *p = &b->P;
+	const int R = b->R;
+	const long long slots = b->n_reads, NR = b->n_reads;
+#define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) return rc; } while (0)
+	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);
+	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_retry);
+	AL(lds_sup, sizeof(uint32_t) * (size_t)b->lds_arena1 * b->grid_asm);
+	AL(lds_sup2, sizeof(uint32_t) * (size_t)b->lds_arena2 * b->grid_asm2);
+	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
+	AL(retry_list, sizeof(int) * (size_t)R);
+	AL(retry_list2, sizeof(int) * (size_t)R);
+	AL(retry_list3, sizeof(int) * (size_t)R);
+	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm, b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
+	AL(p_scratch, b->p_cap * b->grid_ksw);
+	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
+	if (p->fallback) {
+		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
+		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
+		AL(fb_cig_tmp, sizeof(uint32_t) * (size_t)b->fb_cig_cap * b->grid_fb);
+	}
+	AL(prof, sizeof(long long) * 32);
+	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
+	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
+	AL(ctg_len, 4 * slots); AL(aln_flags, 4 * slots); AL(aln_ref_len, 4 * slots); AL(aln_ref_start, 8 * slots);
+	AL(out_seq, b->n_bases); AL(out_sup, 4 * (size_t)b->n_bases);
+	AL(jobs, sizeof(AlnJob) * slots); AL(ez, sizeof(KswOut) * slots); AL(cig_off, 8 * slots);
+	AL(cig_pool, 4 * (size_t)b->cig_pool_cap);
+	AL(ev_off, 8 * slots); AL(n_ev, 4 * slots); AL(ev_pool, sizeof(DevEvent) * (size_t)b->ev_pool_cap);
+
+	// HIT_SLOTS events per region at fixed places (2 x nreads ints each, region r at 8 x its first read index), then
+	// a bump region of the same size for regions with more tallied events (hit_cap, set at upload)
+	AL(hit_pool, sizeof(int) * (size_t)b->hit_cap);
+#undef AL
+	(void)NR; (void)slots;
+	b->work_live = true;
+	return 0;
+}
+
+static void release_work(ihp_batch *b)
+{
+	DBuf *bufs[] = {&b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
+	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
+	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
+	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
+	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab};
+	for (DBuf *d : bufs) d->release();
+	b->work_live = false;
+}
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
@@ -674,11 +803,12 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	if (rc) return rc;
 	ihp_batch *b = new (std::nothrow) ihp_batch();
 	if (!b) return IHP_E_NOMEM;
+#define HIPB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { delete b; return hip_fail(e_, #x, __LINE__); } } while (0)
 	b->P = *p; b->R = in->n_regions; b->n_reads = in->n_reads;
 	const int R = b->R; const long long NR = b->n_reads;
 	static const int64_t zero2[2] = {0, 0};
 	const int64_t *rro = R ? in->region_read_off : zero2, *ro = NR ? in->read_off : zero2, *fo = R ? in->ref_off : zero2;
-	if (rro[R] != NR) { delete b; return IHP_E_ARG; }
+	if (rro[0] != 0 || rro[R] != NR) { delete b; return IHP_E_ARG; }
 	b->n_bases = ro[NR]; b->n_ref = fo[R];
 	for (int r = 0; r < R; ++r) {
 		if (rro[r + 1] < rro[r] || fo[r + 1] < fo[r]) { delete b; return IHP_E_ARG; }
@@ -725,7 +855,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		// arena that minimises  sum(cost / occupancy)  over the two passes.
 		std::vector<std::pair<long long, long long>> need((size_t)R);          // (bytes needed, cost)
 		for (long long r = 0; r < R; ++r) {
-			const long long nb = in->read_off[in->region_read_off[r + 1]] - in->read_off[in->region_read_off[r]];
+			const long long nb = ro[rro[r + 1]] - ro[rro[r]];
 			need[(size_t)r] = {nb / 2 + 2 * b->stage_cap, nb + 1};
 		}
 		std::sort(need.begin(), need.end());
@@ -742,6 +872,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		}
 		b->lds_arena1 = (int)a1;
 		b->grid_asm = grid_for(R, std::max(1, std::min(16, g.max_lds / (b->lds_arena1 + 3840))));
+		if (getenv("IHP_ASM_WAVES")) b->grid_asm = grid_for(R, std::max(1, std::min(16, atoi(getenv("IHP_ASM_WAVES")))));   // diagnostics
 	}
 	b->lds_arena2 = std::max(12288, std::min(2 * b->lds_arena1, g.max_lds - 24576));   // + 7.5 KB (RegionStateT<128>)
 	{
@@ -772,11 +903,22 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		}
 		if ((rc = b->cls_list.upload(order.data(), sizeof(int) * (size_t)R, s))) { delete b; return rc; }
 		if ((rc = b->cls_n.upload(b->n_cls, sizeof(b->n_cls), s))) { delete b; return rc; }
-		HIPC(hipStreamSynchronize(s));                         // `order` goes out of scope
+		HIPB(hipStreamSynchronize(s));                         // `order` goes out of scope
 	}
 	b->grid_asm = std::min(b->grid_asm, std::max(1, b->n_cls[0]));
 	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
 	b->grid_asm3 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena3 + 14336)));
+	{
+		// Run-time overflow launches (a region that ran out of arena / contig slots in the pass its read bases
+		// predicted).  When every region of the batch was predicted to fit pass 1 these lists are almost always
+		// empty, and a full persistent grid of large-LDS workgroups costs 20-30 us per empty launch: two workgroups
+		// per CU then.  Batches with read-rich classes get the full grids (their lists are well used).
+		const bool side = b->n_cls[1] + b->n_cls[2] + b->n_cls[3] > 0;
+		const int small = 2 * g.cus;
+		b->grid_ovf2 = side ? b->grid_asm2 : std::min(b->grid_asm2, small);
+		b->grid_ovf3 = side ? b->grid_asm3 : std::min(b->grid_asm3, small);
+		b->grid_ovf4 = side ? b->grid_retry : std::min(b->grid_retry, small);
+	}
 	b->arena_cap = (3 * b->max_region_bases + 4 * b->stage_cap + 2048 + 15) / 16 * 16;
 	b->corr_cap = std::min(MAXLEN, b->max_region_bases) + 16;
 	const long long slots = NR;
@@ -804,6 +946,9 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	b->cig_bump_cap = 8 * njobs_cap + 4096;                      // CIGARs longer than CIG_SLOT words
 	b->cig_pool_cap = b->cig_bump_cap + (long long)CIG_SLOT * njobs_cap;
 	b->ev_pool_cap = (long long)std::max(1, p->max_events) * njobs_cap + 16;
+	if (g_limits[0] > 0) { b->cig_bump_cap = std::min(b->cig_bump_cap, g_limits[0]); b->cig_pool_cap = b->cig_bump_cap + (long long)CIG_SLOT * njobs_cap; }
+	if (g_limits[1] > 0) b->ev_pool_cap = std::min(b->ev_pool_cap, g_limits[1]);
+	if (g_limits[3] > 0) b->p_cap = std::min(b->p_cap, (size_t)g_limits[3]);
 	if (p->fallback) {
 		// a read against the rest of the reference window / of the contig from the read's start.  Contigs are rarely
 		// longer than the window; the scratch is sized for that and the kernel flags anything larger (IHP_E_CAPACITY).
@@ -823,45 +968,19 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
 		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(12, g.max_lds / (b->lds_fb + 256))));
 	}
-#define AL(buf, bytes) do { if ((rc = b->buf.alloc((size_t)(bytes)))) { delete b; return rc; } } while (0)
-	AL(arena_seq, (size_t)b->arena_cap * b->grid_retry);
-	AL(arena_sup, sizeof(uint32_t) * (size_t)b->arena_cap * b->grid_retry);
-	AL(lds_sup, sizeof(uint32_t) * (size_t)b->lds_arena1 * b->grid_asm);
-	AL(lds_sup2, sizeof(uint32_t) * (size_t)b->lds_arena2 * b->grid_asm2);
-	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
-	AL(retry_list, sizeof(int) * (size_t)R);
-	AL(retry_list2, sizeof(int) * (size_t)R);
-	AL(retry_list3, sizeof(int) * (size_t)R);
-	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
-	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm, b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
-	AL(p_scratch, b->p_cap * b->grid_ksw);
-	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	static_assert(sizeof(int) * M_WORDS <= ihp_batch::Z_TIMES, "misc counters overlap the stamps");
-	AL(misc, b->z_bytes());
-	if (p->fallback) {
-		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
-		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
-		AL(fb_cig_tmp, sizeof(uint32_t) * (size_t)b->fb_cig_cap * b->grid_fb);
-	}
-	AL(prof, sizeof(long long) * 32);
-	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
-	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
-	AL(ctg_len, 4 * slots); AL(aln_flags, 4 * slots); AL(aln_ref_len, 4 * slots); AL(aln_ref_start, 8 * slots);
-	AL(out_seq, b->n_bases); AL(out_sup, 4 * (size_t)b->n_bases);
-	AL(jobs, sizeof(AlnJob) * slots); AL(ez, sizeof(KswOut) * slots); AL(cig_off, 8 * slots);
-	AL(cig_pool, 4 * (size_t)b->cig_pool_cap);
-	AL(ev_off, 8 * slots); AL(n_ev, 4 * slots); AL(ev_pool, sizeof(DevEvent) * (size_t)b->ev_pool_cap);
-	AL(summary, sizeof(ihp_region_summary) * R);
-
-	// HIT_SLOTS events per region at fixed places (2 x nreads ints each, region r at 8 x its first read index), then
-	// a bump region of the same size for regions with more tallied events
+	if ((rc = b->misc.alloc(b->z_bytes())) || (rc = b->summary.alloc(sizeof(ihp_region_summary) * (size_t)R))) { delete b; return rc; }
 	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
-	AL(hit_pool, sizeof(int) * (size_t)b->hit_cap);
-#undef AL
-	for (auto &e : b->ev) HIPC(hipEventCreate(&e));
-	HIPC(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-	HIPC(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-	HIPC(hipStreamSynchronize(s));
+	if (g_limits[2] > 0) b->hit_cap = std::min(b->hit_cap, std::max(g_limits[2], 2 * HIT_SLOTS * NR));   // the fixed slots stay; the bump region shrinks
+	if ((rc = alloc_work(b))) { delete b; return rc; }
+	for (auto &e : b->ev) HIPB(hipEventCreate(&e));
+	HIPB(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+	b->report = g_reports.get();
+	if (!b->report) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of the report page failed"); return IHP_E_NOMEM; }
+	HIPB(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // the only memset of the batch's life (see ihp_batch::misc)
+	HIPB(hipStreamSynchronize(s));
+#undef HIPB
 	*bout = b;
 	return 0;
 }
@@ -869,9 +988,11 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 extern "C" int ihp_batch_run(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	hipStream_t s = b->stream;
 	const ihp_params &p = b->P;
-	HIPC(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // counters, stamps, work queues, per-region hit counts
+	{ int rc1 = alloc_work(b); if (rc1) return rc1; }
+	// counters, stamps, work queues and per-region hit counts are zero: cleared at upload and by the previous run's k_summary
 	int *wq = b->queues_dev();
 	const bool profiling = getenv("IHP_PROFILE") != nullptr;
 	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
@@ -913,27 +1034,27 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		const int n1 = b->n_cls[0], n2 = b->n_cls[1], n3 = b->n_cls[2], n4 = b->n_cls[3];
 		hipStream_t s2 = b->stream2;
 		const bool side = n2 + n3 + n4 > 0;
-		auto pass2 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
+		auto pass2 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr, int grid) {
 			x.arena_seq = nullptr; x.arena_sup = b->lds_sup2.as<uint32_t>(); x.arena_cap = b->lds_arena2; x.lds_arena = b->lds_arena2;
 			x.in_list = in; x.n_in = n_in; x.out_list = o3; x.n_out = misc + M_NRETRY2; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
-			hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(b->grid_asm2), dim3(64), b->lds_arena2, st, x);
+			hipLaunchKernelGGL((k_assemble<128, true, 1>), dim3(grid), dim3(64), b->lds_arena2, st, x);
 		};
-		auto pass3 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
+		auto pass3 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr, int grid) {
 			x.arena_seq = nullptr; x.arena_sup = b->lds_sup3.as<uint32_t>(); x.arena_cap = b->lds_arena3; x.lds_arena = b->lds_arena3;
 			x.in_list = in; x.n_in = n_in; x.out_list = o4; x.n_out = misc + M_NRETRY3; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
-			hipLaunchKernelGGL((k_assemble<256, true, 1>), dim3(b->grid_asm3), dim3(64), b->lds_arena3, st, x);
+			hipLaunchKernelGGL((k_assemble<256, true, 1>), dim3(grid), dim3(64), b->lds_arena3, st, x);
 		};
-		auto pass4 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr) {
+		auto pass4 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr, int grid) {
 			x.arena_seq = b->arena_seq.as<uint8_t>(); x.arena_sup = b->arena_sup.as<uint32_t>(); x.arena_cap = b->arena_cap; x.lds_arena = 0;
 			x.in_list = in; x.n_in = n_in; x.out_list = nullptr; x.n_out = nullptr; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
-			hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(b->grid_retry), dim3(64), 0, st, x);
+			hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(grid), dim3(64), 0, st, x);
 		};
 		if (side) {
 			HIPC(hipEventRecord(b->ev_fork, s));                   // the counters are cleared
 			HIPC(hipStreamWaitEvent(s2, b->ev_fork, 0));
-			if (n2) pass2(a, s2, cl + n1, cn + 1, 1, b->corr2.as<Corr>());
-			if (n3) pass3(a, s2, cl + n1 + n2, cn + 2, 2, b->corr2.as<Corr>());
-			if (n4) pass4(a, s2, cl + n1 + n2 + n3, cn + 3, 3, b->corr2.as<Corr>());
+			if (n2) pass2(a, s2, cl + n1, cn + 1, 1, b->corr2.as<Corr>(), b->grid_asm2);
+			if (n3) pass3(a, s2, cl + n1 + n2, cn + 2, 2, b->corr2.as<Corr>(), b->grid_asm3);
+			if (n4) pass4(a, s2, cl + n1 + n2 + n3, cn + 3, 3, b->corr2.as<Corr>(), b->grid_retry);
 			HIPC(hipGetLastError());
 			HIPC(hipEventRecord(b->ev_join, s2));
 		}
@@ -947,9 +1068,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		}
 		a.t_start = nullptr;
 		if (side) HIPC(hipStreamWaitEvent(s, b->ev_join, 0));
-		pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>());
-		pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>());
-		pass4(a, s, o4, misc + M_NRETRY3, 6, b->corr.as<Corr>());
+		pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>(), b->grid_ovf2);
+		pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>(), b->grid_ovf3);
+		pass4(a, s, o4, misc + M_NRETRY3, 6, b->corr.as<Corr>(), b->grid_ovf4);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[1], s));
@@ -1029,6 +1150,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
 		a.aln_flags = b->aln_flags.as<int>(); a.n_ev = b->n_ev.as<int>(); a.ev_off = b->ev_off.as<long long>();
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.out = b->summary.as<ihp_region_summary>();
+		a.zero = misc; a.n_zero = (int)(b->z_bytes() / sizeof(int)); a.n_report = REPORT_INTS;
+		HIPC(hipHostGetDevicePointer((void **)&a.report, b->report, 0));
 		hipLaunchKernelGGL(k_summary, dim3((b->R + 255) / 256), dim3(256), 0, s, a);
 		HIPC(hipGetLastError());
 	}
@@ -1037,10 +1160,25 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	return 0;
 }
 
+static int report_overflow(const ihp_batch *b)
+{
+	const int *m = b->report;
+	if (m[M_OVF] || m[M_OVF + 1] || m[M_OVF + 2] || m[M_OVF_HIT]) {
+		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d hits=%d", m[M_OVF], m[M_OVF + 1],
+		         m[M_OVF + 2], m[M_OVF_HIT]);
+		return IHP_E_CAPACITY;
+	}
+	return 0;
+}
+
+// Waits for the batch's run; a pool that overflowed during it (CIGAR / event / hit pools, ksw2 scratch) is reported
+// here as IHP_E_CAPACITY, not only when the results are fetched.
 extern "C" int ihp_batch_sync(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
+	if (b->ran && b->R > 0) return report_overflow(b);
 	return 0;
 }
 
@@ -1058,14 +1196,12 @@ extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
 extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 {
 	if (!b || !out) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
+	HIPC(hipStreamSynchronize(b->stream));
 	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
-	int nretry = 0;
-	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY, sizeof(int), hipMemcpyDeviceToHost));
-	out[15] = nretry;                                 // regions forwarded at run time to the second pass's overflow list
-	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY2, sizeof(int), hipMemcpyDeviceToHost));
-	out[7] = nretry;                                  // ... to the third pass's
-	HIPC(hipMemcpy(&nretry, b->misc.as<int>() + M_NRETRY3, sizeof(int), hipMemcpyDeviceToHost));
-	out[11] = nretry;                                 // ... and to the catch-all (HBM-arena) pass
+	out[15] = b->report[M_NRETRY];                    // regions forwarded at run time to the second pass's overflow list
+	out[7] = b->report[M_NRETRY2];                    // ... to the third pass's
+	out[11] = b->report[M_NRETRY3];                   // ... and to the catch-all (HBM-arena) pass
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
 	return 0;
 }
@@ -1083,8 +1219,9 @@ extern "C" int ihp_batch_kernel_ms(ihp_batch *b, float ms[4])
 {
 	if (!b || !b->ran || !b->timing || !ms) return IHP_E_ARG;
 	unsigned long long t[8];
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
-	HIPC(hipMemcpy(t, b->times_dev(), sizeof(t), hipMemcpyDeviceToHost));
+	memcpy(t, (const char *)b->report + ihp_batch::Z_TIMES, sizeof(t));
 	int khz = 0;
 	HIPC(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g.device));
 	for (int k = 0; k < 4; ++k)
@@ -1108,6 +1245,20 @@ extern "C" int ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n)
 }
 
 extern "C" void ihp_batch_free(ihp_batch *b) { delete b; }
+
+// Hands the batch's scratch and result buffers back to the device pool (its inputs and per-region summary records stay):
+// a caller that walks through more regions than one GPU holds results for keeps every chunk's inputs resident and only
+// one chunk's results at a time.  The results are gone (fetch / pack need another run); the next run takes buffers again.
+extern "C" int ihp_batch_release_outputs(ihp_batch *b)
+{
+	if (!b) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
+	HIPC(hipStreamSynchronize(b->stream));
+	if (b->stream2) HIPC(hipStreamSynchronize(b->stream2));
+	release_work(b);
+	b->ran = false;
+	return 0;
+}
 
 // ---- host result slabs ---------------------------------------------------------------
 // Every array of an ihp_batch_out lives in ONE pinned host allocation (64-byte header + sections), so that
@@ -1215,10 +1366,9 @@ static void carve_out(char *host, const OutLayout &L, long long R, long long C, 
 extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6])
 {
 	if (!b || !b->ran || !dev_ptr || !bytes || !counts) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	const int R = b->R;
 	hipStream_t s = b->stream;
-	int misc[M_WORDS];
-	HIPC(hipMemcpyAsync(misc, b->misc.p, sizeof(misc), hipMemcpyDeviceToHost, s));
 	const size_t S = (size_t)R + 1;
 	if (!b->pack_cnt.p) { int rc = b->pack_cnt.alloc(sizeof(long long) * 5 * S); if (rc) return rc; }
 	long long *cnt = b->pack_cnt.as<long long>();
@@ -1235,11 +1385,7 @@ extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, 
 	long long tot[5];
 	for (int k = 0; k < 5; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
 	HIPC(hipStreamSynchronize(s));
-	if (misc[M_OVF] || misc[M_OVF + 1] || misc[M_OVF + 2] || misc[M_OVF_HIT]) {
-		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d hits=%d", misc[M_OVF], misc[M_OVF + 1],
-		         misc[M_OVF + 2], misc[M_OVF_HIT]);
-		return IHP_E_CAPACITY;
-	}
+	if (R > 0) { const int rc = report_overflow(b); if (rc) return rc; }
 	const long long C = tot[0], B = tot[1], W = tot[2], E = tot[3], Hn = tot[4];
 	const OutLayout L(R, C, B, W, E, Hn);
 	if (b->pack_slab.n < L.bytes) {
@@ -1332,6 +1478,7 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 }
 
 static void slab_cache_clear() { g_slabs.clear(); }
+static void report_pool_clear() { g_reports.clear(); }
 
 extern "C" void *ihp_host_alloc(size_t bytes)
 {

@@ -204,6 +204,7 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 			if (a.trim_lo) { lo = bcast(mtlo, k); hi = bcast(mthi, k); o = lo; }   // :168 done by the stager
 			else if (len <= 512) {
 				if (a.quals) o = read_trim_regs(cur, a.trim_min_qual, lo, hi);    // :168
+				else if (len == 1) hi = 0;                 // no qualities = all 255: trim() still empties a 1-base read (:28-30)
 			} else if (a.quals) o = read_trim_dev(a.quals + b0, len, a.trim_min_qual, lo, hi);
 			const int tl = hi - lo;
 			if (tl > a.stage_cap || tl > MAXLEN) return IHP_E_CAPACITY;
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
 			lo = lo < 0 ? 0 : lo > len ? len : lo; hi = hi > len ? len : hi; hi = hi < lo ? lo : hi;
 			ta = lo;
 		} else if (a.quals) ta = read_trim_dev(a.quals + off, len, a.trim_min_qual, lo, hi);   // :328
+		else if (len == 1) hi = 0;                                     // no qualities = all 255 (:28-30)
 		const long long origin = uni(a.ref_origin[r]);
 		DevEvent *E = a.ev_pool + it.ev;
 		const int tstart = uni(E->tstart_rel), tstop = uni(E->tstop_rel);
@@ -721,11 +723,23 @@ struct SummaryArgs {
 	const long long *ev_off;
 	const DevEvent *ev_pool;
 	ihp_region_summary *out;
+	// end-of-run housekeeping (this is the last kernel of a run's launch chain): the run's counters, overflow flags
+	// and stamps are copied to `report` (page-locked host memory: ihp_batch_sync reads them without a copy) and
+	// everything the next run expects to be zero is cleared here, so a run needs no memset
+	int *zero; int n_zero;           // counters | stamps | work queues | per-region hit counts, in ints
+	int *report; int n_report;       // the first n_report ints of `zero`
 };
 
 __global__ void k_summary(const SummaryArgs a)
 {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a.zero) {
+		const int nt = (int)(gridDim.x * blockDim.x);
+		for (int i = r; i < a.n_zero; i += nt) {
+			if (i < a.n_report) a.report[i] = a.zero[i];
+			a.zero[i] = 0;
+		}
+	}
 	if (r >= a.n_regions) return;
 	ihp_region_summary s;
 	s.status = a.status[r]; s.n_contigs_pre = a.n_pre[r]; s.n_contigs = a.n_final[r];

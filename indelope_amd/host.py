@@ -137,6 +137,7 @@ class RegionBatch:
         n = self.n_reads
         ln = np.diff(self.read_off).astype(np.int64)
         lo, hi = np.zeros(n, np.int32), ln.astype(np.int32)
+        hi[ln == 1] = 0                        # a == high == 0: trim() empties a 1-base read whatever its quality (:28-30)
         if self.quals is not None and n and len(self.quals):
             good = np.asarray(self.quals) >= min_quality
             if not good.all():

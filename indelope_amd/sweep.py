@@ -48,6 +48,8 @@ class Roi:
 
 def trim_bounds(qualities, n, min_quality=15):
     """trim(sequence, base_qualities, min_quality) of indelope.nim:23-38 -> (lo, hi): kept [lo, hi), start += lo."""
+    if n == 1:
+        return 0, 0                            # a == high == 0: the read is emptied whatever its quality (:28-30)
     if qualities is None or n == 0:
         return 0, n
     high = n - 1

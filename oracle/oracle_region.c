@@ -198,6 +198,7 @@ static void fallback_align(const ihp_params *p, const ihp_batch_in *in, int64_t 
 		int64_t lo = 0, hi = n, a = 0;
 		if (in->trim_lo) { trim_given(in, ri, n, &lo, &hi); a = lo; }
 		else if (in->quals) a = orc_read_trim(in->quals + in->read_off[ri], n, p->trim_min_qual, &lo, &hi);
+		else if (n == 1) hi = 0;                                    /* quals NULL = all 255: trim() empties a 1-base read (:28-30) */
 		const int64_t rs = in->read_start[ri] + a, rl = hi - lo;    /* :328 */
 		if (rs > ev->tstop) continue;                               /* :329 */
 		const int64_t L = ev->type == 0 ? (int64_t)ev->len : 0;     /* :330-332 */
@@ -233,6 +234,7 @@ static orc_list assemble(const ihp_params *p, const ihp_batch_in *in, int64_t r0
 		int64_t n = in->read_off[i + 1] - in->read_off[i], lo = 0, hi = n, o = 0;
 		if (in->trim_lo) { trim_given(in, i, n, &lo, &hi); o = lo; }
 		else if (in->quals) o = orc_read_trim(in->quals + in->read_off[i], n, p->trim_min_qual, &lo, &hi);  /* :168 */
+		else if (n == 1) hi = 0;                                   /* quals NULL = all 255: a == high == 0 empties the read (:28-30) */
 		int64_t tl = hi - lo;
 		int64_t min_overlap = (int64_t)(p->min_overlap_pct * (double)tl);   /* :169 */
 		ihp_contig *qc = orc_make_contig(seq + lo, tl, in->read_start[i] + o, 1);
