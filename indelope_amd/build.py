@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     synth = os.path.join(LIBDIR, "libihp_synth.so")
     src = os.path.join(CSRC, "synth.cpp")
     if force or _stale(synth, [src]):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", synth, src]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", synth, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

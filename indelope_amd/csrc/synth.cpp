@@ -14,8 +14,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
+#include <sched.h>
 
 extern "C" {
 
@@ -82,19 +85,17 @@ int ihp_synth_sizes(const ihp_synth_cfg *c, int64_t *n_reads, int64_t *n_bases, 
 	return 0;
 }
 
-int ihp_synth_fill(const ihp_synth_cfg *c, int64_t *region_read_off, int64_t *read_off, uint8_t *bases,
-                   uint8_t *quals, int64_t *read_start, int64_t *read_stop, uint8_t *mapq, uint8_t *read_skip,
-                   int64_t *ref_off, uint8_t *ref_bases, int64_t *ref_origin,
-                   int32_t *truth /* [n_regions*4]: type0,len0,type1,len1 (type 0 ins, 1 del; -1 none) */)
+// regions [r_lo, r_hi); ri = index of region r_lo's first read (regions are independent PRNG streams)
+static void fill_range(const ihp_synth_cfg *c, int r_lo, int r_hi, int64_t ri, int64_t *region_read_off, int64_t *read_off, uint8_t *bases,
+                       uint8_t *quals, int64_t *read_start, int64_t *read_stop, uint8_t *mapq, uint8_t *read_skip,
+                       int64_t *ref_off, uint8_t *ref_bases, int64_t *ref_origin, int32_t *truth)
 {
 	static const char ACGT[] = "ACGT";
 	const int L = window_len(c), RL = c->read_len;
-	int64_t ri = 0;
-	region_read_off[0] = 0; read_off[0] = 0; ref_off[0] = 0;
 	std::vector<uint8_t> alt; std::vector<int32_t> amap;
 	struct Rd { int hap; int s; int order; };
 	std::vector<Rd> rds; std::vector<uint8_t> tmp;
-	for (int r = 0; r < c->n_regions; ++r) {
+	for (int r = r_lo; r < r_hi; ++r) {
 		Rng g(region_seed(c, r));
 		const int n = region_nreads(c, g);
 		uint8_t *W = ref_bases + (int64_t)r * L;
@@ -161,6 +162,34 @@ int ihp_synth_fill(const ihp_synth_cfg *c, int64_t *region_read_off, int64_t *re
 		}
 		region_read_off[r + 1] = ri;
 	}
+}
+
+int ihp_synth_fill(const ihp_synth_cfg *c, int64_t *region_read_off, int64_t *read_off, uint8_t *bases,
+                   uint8_t *quals, int64_t *read_start, int64_t *read_stop, uint8_t *mapq, uint8_t *read_skip,
+                   int64_t *ref_off, uint8_t *ref_bases, int64_t *ref_origin,
+                   int32_t *truth /* [n_regions*4]: type0,len0,type1,len1 (type 0 ins, 1 del; -1 none) */)
+{
+	region_read_off[0] = 0; read_off[0] = 0; ref_off[0] = 0;
+	const int R = c->n_regions;
+	// threads over contiguous region ranges (the CPUs this process may use); the output does not depend on the count
+	int nt = 1;
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = CPU_COUNT(&set);
+	if (const char *e = getenv("IHP_SYNTH_THREADS")) nt = atoi(e);
+	if (nt > 64) nt = 64;
+	if (nt > R / 256) nt = R / 256;
+	if (nt < 1) nt = 1;
+	std::vector<int64_t> first((size_t)nt + 1, 0);
+	for (int t = 0; t < nt; ++t) {
+		int64_t n = 0;
+		for (int r = (int)((int64_t)R * t / nt); r < (int)((int64_t)R * (t + 1) / nt); ++r) { Rng g(region_seed(c, r)); n += region_nreads(c, g); }
+		first[(size_t)t + 1] = first[(size_t)t] + n;
+	}
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; ++t)
+		th.emplace_back(fill_range, c, (int)((int64_t)R * t / nt), (int)((int64_t)R * (t + 1) / nt), first[(size_t)t], region_read_off, read_off,
+		                bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin, truth);
+	for (auto &x : th) x.join();
 	return 0;
 }
 

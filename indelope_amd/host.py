@@ -139,8 +139,9 @@ class RegionBatch:
         lo, hi = np.zeros(n, np.int32), ln.astype(np.int32)
         hi[ln == 1] = 0                        # a == high == 0: trim() empties a 1-base read whatever its quality (:28-30)
         if self.quals is not None and n and len(self.quals):
-            good = np.asarray(self.quals) >= min_quality
-            if not good.all():
+            allgood = int(np.asarray(self.quals).min()) >= min_quality      # the usual case: nothing to trim, no temporaries
+            good = None if allgood else np.asarray(self.quals) >= min_quality
+            if not allgood:
                 idx = np.arange(len(good), dtype=np.int64)
                 off = np.asarray(self.read_off[:-1], np.int64)
                 nz = ln > 0

@@ -1,5 +1,8 @@
 ## indelope_hip.nim -- Nim binding of include/indelope_hip.h (SOURCE ONLY: no Nim toolchain in the build image,
-## so this file has never been compiled; it documents the binding a maintainer adds to brentp/indelope).
+## so this file has never been compiled; it is the binding a maintainer adds to brentp/indelope).
+## Companion files: nim/contig_hip.nim (the `Contig` procs of contig.nim with their signatures, over the ABI) and
+## nim/genotyper_hip.nim (`genotype` / `qual` / `$` of genotyper.nim).  `roi`, `Fai`, `Record`, `skippable` are the
+## reference's own (indelope.nim:21,:40; hts-nim): this file is meant to be `include`d into / imported by indelope.nim.
 ##
 ## 1. ksw2 seam: in src/ksw2/ksw2_c.nim replace
 ##        {.compile: "csrc/ksw2_extz2_sse.c".}
@@ -111,6 +114,62 @@ proc ihp_format_variant*(v: ptr IhpVariant, chars: cstring, chrom: cstring, buf:
 proc ihp_host_alloc*(bytes: csize_t): pointer {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
 
+# ---- Contig / genotyper / ksw2 single-step entries (wrapped with the reference's signatures in nim/contig_hip.nim and
+# nim/genotyper_hip.nim)
+type
+  IhpContig* {.importc: "ihp_contig", header: "indelope_hip.h", bycopy.} = object   # contig.nim:7-15 over caller-owned buffers
+    sequence*: ptr uint8
+    support*: ptr uint32
+    len*, cap*, nreads*, start*: int64
+  IhpCorrection* {.importc: "ihp_correction", header: "indelope_hip.h", bycopy.} = object   # contig.nim:17
+    qoff*, toff*: int64
+    qbest*, pad: int32
+  IhpMatch* {.importc: "ihp_match", header: "indelope_hip.h", bycopy.} = object          # contig.nim:21
+    matches*, offset*, mismatches*, n_corrections*, contig_i*: int64
+    corrections*: ptr IhpCorrection
+    corr_cap*: int64
+  IhpGenotype* {.importc: "ihp_genotype_t", header: "indelope_hip.h", bycopy.} = object   # genotyper.nim:14
+    gt*, pad: int32
+    gl*: array[3, float64]
+  IhpBatch* {.importc: "ihp_batch", header: "indelope_hip.h", incompleteStruct.} = object   # opaque device-resident batch
+  IhpRegionSummary* {.importc: "ihp_region_summary", header: "indelope_hip.h", bycopy.} = object
+    status*, n_contigs_pre*, n_contigs*, n_aligned*, n_events*, n_tallied*, ref_support*, alt_support*: int32
+
+const
+  IHP_UNALIGNED* = low(int64)             # contig.nim:27
+  IHP_ALLOW_DEFAULT* = 0.cint             # contig.nim:44-47
+  IHP_ALLOW_SUPPORT* = 1.cint             # contig.nim:287-290 (the reference's test rule)
+  IHP_E_CAPACITY* = -5.cint
+  IHP_ALN_DONE* = 1'i32
+  IHP_EV_TALLIED* = 0'u8
+  IHP_VF_EMITTED* = 0'i32
+
+proc ihp_slide_align*(q, t: ptr IhpContig, min_overlap, max_mismatch: int64, allow_rule: cint, m: ptr IhpMatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_contig_insert*(t, q: ptr IhpContig, m: ptr IhpMatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_contig_trim*(c: ptr IhpContig, min_support: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_kmer_tally*(n_reads: int32, bases: ptr uint8, read_off: ptr int64, mapq: ptr uint8, min_mapq, K: int32,
+                     ref_kmer, alt_kmer: cstring, counts: ptr int32): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_genotype*(r, a: int64, error: float64, g: ptr IhpGenotype): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_genotype_qual*(g: ptr IhpGenotype): float64 {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_ksw_extz2_batch*(n: int32, queries: ptr uint8, q_off: ptr int64, targets: ptr uint8, t_off: ptr int64, m: int8,
+                          mat: ptr int8, q, e: int8, w, zdrop, flag: cint, ez: ptr IhpEz, cigar: ptr uint32, cigar_cap: int64,
+                          cigar_off: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_ksw_last_status*(): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_encode*(dna: ptr uint8, n: int64, outp: ptr uint8) {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_matrix*(match, mismatch: int8, out25: ptr int8) {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_last_hip_error*(): cstring {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_shutdown*() {.importc, cdecl, header: "indelope_hip.h".}
+# a batch kept resident in HBM: upload once, run (asynchronous, its own stream), sync, fetch
+proc ihp_batch_upload*(p: ptr IhpParams, inp: ptr IhpBatchIn, b: ptr ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_run*(b: ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_sync*(b: ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_fetch*(b: ptr IhpBatch, outp: ptr IhpBatchOut): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_release_outputs*(b: ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_free*(b: ptr IhpBatch) {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_pack_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, bytes: ptr int64, counts: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_unpack_slab*(slab: pointer, bytes: int64, counts: ptr int64, error: float64, outp: ptr IhpBatchOut): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_summary_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+
 proc ihp_init*(device: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_strerror*(code: cint): cstring {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_params_default*(p: ptr IhpParams) {.importc, cdecl, header: "indelope_hip.h".}
@@ -127,33 +186,97 @@ type Stager* = object
 proc init*(s: var Stager) =
   s.region_read_off = @[0'i64]; s.read_off = @[0'i64]; s.ref_off = @[0'i64]
 
-# proc add*(s: var Stager, r: roi, fai: Fai) =
-#   var lo = high(int); var hi = 0
-#   var read_seq = ""; var base_q = new_seq[uint8](300)
-#   for read in r.reads:
-#     discard read.sequence(read_seq); discard read.base_qualities(base_q)
-#     for c in read_seq: s.bases.add(uint8(c))
-#     # either hand over the qualities ...   for q in base_q[0..<read_seq.len]: s.quals.add(q)
-#     # ... or trim here (half the bytes to upload): a = first i < high with q >= 15 else high; emptied read: lo = hi = a;
-#     # else b = last i > a with q >= 15 else a; lo = a, hi = b + 1      (indelope.nim:23-38)
-#     let (lo, hi) = trim_bounds(base_q, read_seq.len); s.trim_lo.add(lo); s.trim_hi.add(hi)
-#     s.read_off.add(int64(s.bases.len))
-#     s.read_start.add(read.start); s.read_stop.add(read.stop)
-#     s.mapq.add(read.qual); s.read_skip.add(uint8(read.skippable(allow_unmapped=false)))
-#     lo = min(lo, read.start); hi = max(hi, read.stop)
-#   s.region_read_off.add(int64(s.read_start.len))
-#   # one window per region covers every per-contig fai.get of indelope.nim:220 (width = 13 for K = 27)
-#   let w = fai.get(r.reads[0].chrom, lo, hi + 13 + 50)
-#   for c in w: s.ref_bases.add(uint8(c))
-#   s.ref_off.add(int64(s.ref_bases.len)); s.ref_origin.add(int64(lo))
+proc trim_bounds*(base_q: seq[uint8], n: int, min_quality: int = 15): tuple[lo: int32, hi: int32] =
+  ## trim(sequence, base_qualities, min_quality) of indelope.nim:23-38 as bounds: the read keeps [lo, hi) and its start
+  ## moves by lo; an emptied read (a == high, :28-30 -- every 1-base read among them) is lo == hi == a.
+  let high = n - 1
+  var a = 0
+  while a < high and base_q[a] < uint8(min_quality): a += 1
+  if a == high or n <= 0: return (int32(max(a, 0)), int32(max(a, 0)))
+  var b = high
+  while b > a and base_q[b] < uint8(min_quality): b -= 1
+  return (int32(a), int32(b + 1))
 
-proc run*(s: var Stager, p: var IhpParams, outp: var IhpBatchOut): cint =
-  var b: IhpBatchIn
+proc add*(s: var Stager, r: roi, fai: Fai, trim_on_host: bool = true, K: int = 27) =
+  ## One `roi` (indelope.nim:21) appended to the batch: every field assemble / callsemble read from a Record
+  ## (indelope.nim:163-169 sequence + qualities + start, :213-216 stop + mapq, :293-300 sequence + mapq) and one reference
+  ## slice that covers every per-contig fai.get of :220.
+  var lo = high(int)
+  var hi = 0
+  var read_seq = ""
+  var base_q = new_seq[uint8](300)
+  for read in r.reads:
+    discard read.sequence(read_seq)
+    discard read.base_qualities(base_q)
+    for c in read_seq: s.bases.add(uint8(c))
+    if trim_on_host:                      # half the bytes to upload: the bounds instead of the qualities
+      let (tlo, thi) = trim_bounds(base_q, read_seq.len)
+      s.trim_lo.add(tlo); s.trim_hi.add(thi)
+    else:
+      for i in 0..<read_seq.len: s.quals.add(base_q[i])
+    s.read_off.add(int64(s.bases.len))
+    s.read_start.add(int64(read.start)); s.read_stop.add(int64(read.stop))
+    s.mapq.add(read.qual)
+    s.read_skip.add(uint8(read.skippable(allow_unmapped=false)))
+    lo = min(lo, read.start); hi = max(hi, read.stop)
+  s.region_read_off.add(int64(s.read_start.len))
+  # contigs start at a read's (trimmed) start and windows end at max_stop + width + 50 (:218-220)
+  let width = int((K + 1) / 2 - 1)
+  let w = fai.get(r.reads[0].chrom, lo, hi + width + 50)
+  for c in w: s.ref_bases.add(uint8(c))
+  s.ref_off.add(int64(s.ref_bases.len)); s.ref_origin.add(int64(lo))
+
+proc clear*(s: var Stager) =
+  s.region_read_off.set_len(1); s.read_off.set_len(1); s.ref_off.set_len(1)
+  s.read_start.set_len(0); s.read_stop.set_len(0); s.ref_origin.set_len(0)
+  s.bases.set_len(0); s.quals.set_len(0); s.mapq.set_len(0); s.read_skip.set_len(0); s.ref_bases.set_len(0)
+  s.trim_lo.set_len(0); s.trim_hi.set_len(0)
+
+proc fill*(s: var Stager, b: var IhpBatchIn) =
   b.n_regions = int32(s.ref_origin.len); b.n_reads = int64(s.read_start.len)
   b.region_read_off = addr s.region_read_off[0]; b.read_off = addr s.read_off[0]
-  b.bases = addr s.bases[0]; b.quals = addr s.quals[0]
+  b.bases = addr s.bases[0]; b.quals = if s.quals.len > 0: addr s.quals[0] else: nil
   b.read_start = addr s.read_start[0]; b.read_stop = addr s.read_stop[0]
   b.mapq = addr s.mapq[0]; b.read_skip = addr s.read_skip[0]
   b.ref_off = addr s.ref_off[0]; b.ref_bases = addr s.ref_bases[0]; b.ref_origin = addr s.ref_origin[0]
   if s.trim_lo.len > 0: (b.trim_lo = addr s.trim_lo[0]; b.trim_hi = addr s.trim_hi[0]; b.quals = nil)
+
+proc run*(s: var Stager, p: var IhpParams, outp: var IhpBatchOut): cint =
+  var b: IhpBatchIn
+  s.fill(b)
   result = ihp_run_regions(addr p, addr b, addr outp)
+
+
+# ---- the main loop of indelope.nim:601-608 over batches ---------------------------------------------------------
+# `flush` runs one staged batch and prints what the reference's loop would have printed for those regions, in region
+# order, through the same last-two-variants window (:604-608), which has to survive from one flush to the next.
+type Printed* = tuple[chrom: string, start: int64, refa: string, alta: string]
+
+proc flush*(s: var Stager, pending: var seq[roi], p: var IhpParams, last_var, last_var2: var Printed): cint =
+  if pending.len == 0: return 0
+  var outp: IhpBatchOut
+  result = s.run(p, outp)
+  if result != 0:
+    stderr.write_line("indelope_hip: " & $ihp_strerror(result) & " / " & $ihp_last_hip_error())
+    return
+  # filters, qual scalings, INFO and REF/ALT of indelope.nim:375-428 for every tallied event of the batch
+  var b: IhpBatchIn
+  s.fill(b)
+  var vars: IhpVariants
+  result = ihp_call_variants(addr p, addr b, addr outp, addr vars)
+  if result == 0:
+    let vs = cast[ptr UncheckedArray[IhpVariant]](vars.v)
+    var buf = new_string(4096)
+    for i in 0..<int(vars.n):
+      if vs[i].filter != IHP_VF_EMITTED: continue        # ihp_call_variants dedupes inside a batch; across batches here
+      let chrom = pending[int(vs[i].region)].reads[0].chrom
+      let refa = ($vars.chars)[int(vs[i].ref_off)..<int(vs[i].ref_off + vs[i].ref_len)]
+      let alta = ($vars.chars)[int(vs[i].alt_off)..<int(vs[i].alt_off + vs[i].alt_len)]
+      let cur: Printed = (chrom, vs[i].start, refa, alta)
+      if cur == last_var or cur == last_var2: continue   # v.same(last_var) / v.same(last_var2), :604-605
+      let n = ihp_format_variant(addr vs[i], vars.chars, chrom.cstring, buf.cstring, int64(buf.len))
+      echo buf[0..<int(n)]                               # :606
+      last_var2 = last_var; last_var = cur               # :607-608
+    ihp_free_variants(addr vars)
+  ihp_free_out(addr outp)
+  s.clear(); pending.set_len(0)

@@ -386,12 +386,13 @@ def batch_with_long_cigars(n_regions=24):
 
 
 def batch_with_many_events(n_regions=8):
-    """Regions whose single contig carries three tallied events (>= 4 bases each): more than a region's fixed hit slots."""
+    """Regions with two contigs of three tallied events each (deletions of 8-12 bases): six tallied events, more than a
+    region's four fixed hit slots, so the last ones need the shared bump region of the hit pool."""
     rng = np.random.default_rng(78)
     regions = []
     for _ in range(n_regions):
         ref = _rand_seq(rng, 700)
-        ctg = ref[20:120] + ref[128:230] + ref[240:340] + ref[350:450]       # deletions of 8, 10 and 10 bases
-        reads = [(ctg, 1020)] * 6 + [(ref[20:450], 1020)] * 2
-        regions.append(dict(reads=reads, ref=ref, origin=1000))
+        a = ref[20:120] + ref[128:230] + ref[240:340] + ref[350:450]       # deletions of 8, 10 and 10 bases
+        b = ref[20:100] + ref[108:200] + ref[210:300] + ref[312:450]       # deletions of 8, 10 and 12 bases elsewhere
+        regions.append(dict(reads=[(a, 1020)] * 5 + [(b, 1020)] * 5, ref=ref, origin=1000))
     return make_batch(regions)

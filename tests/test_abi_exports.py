@@ -54,3 +54,43 @@ def test_host_helpers_need_no_gpu(oracle):
     for r, a, e in [(3, 9, 1e-3), (0, 5, 1e-3), (40, 2, 1e-2)]:
         g, o = api.genotype(r, a, e), oracle.genotype(r, a, e)
         assert g.gt == o.gt and list(g.gl) == list(o.gl) and api.qual(g) == oracle.qual(o)
+
+
+def _build_harness():
+    import subprocess
+    lib_dir = os.path.join(ROOT, "indelope_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "abi_harness.bin")
+    src = os.path.join(ROOT, "tests", "abi_harness.c")
+    hdr = os.path.join(ROOT, "include", "indelope_hip.h")
+    if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(exe):
+        indelope_amd.load_library()                      # the library must have been built
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", lib_dir,
+                               "-lindelope_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_c_harness_sees_the_same_layouts():
+    """tests/abi_harness.c compiled by gcc against include/indelope_hip.h and linked with the library: struct sizes and
+    field offsets as a C compiler lays them out equal the ctypes mirrors, and the host-only entry points answer."""
+    import json
+    import subprocess
+    out = json.loads(subprocess.run([_build_harness()], capture_output=True, text=True, check=True).stdout)
+    pairs = {"ksw_extz_t": A.KswExtz, "ihp_ez": A.Ez, "ihp_contig": A.Contig, "ihp_correction": A.Correction, "ihp_match": A.Match,
+             "ihp_genotype_t": A.Genotype, "ihp_params": A.Params, "ihp_batch_in": A.BatchIn, "ihp_event": A.Event,
+             "ihp_batch_out": A.BatchOut, "ihp_variant": A.Variant, "ihp_variants": A.Variants, "ihp_roi_in": A.RoiIn,
+             "ihp_roi_out": A.RoiOut, "ihp_region_summary": A.RegionSummary}
+    for cname, ct in pairs.items():
+        assert out["sizeof_" + cname] == C.sizeof(ct), cname
+    n = 0
+    for key, off in out.items():
+        if "." not in key or key.startswith("sizeof"):
+            continue
+        cname, field = key.split(".")
+        assert getattr(pairs[cname], field).offset == off, key
+        n += 1
+    assert n >= 40
+    assert out["params_default"] == [C.sizeof(A.Params), 27, 50, 400, 4, 74, 65, 5]
+    assert out["matrix"] == [1, -2, -2, -2, 0, -2, 1, -2, -2, 0, -2, -2, 1, -2, 0, -2, -2, -2, 1, 0, 0, 0, 0, 0, 0]
+    assert out["encode"] == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4]
+    assert (out["genotype_10_10"], out["genotype_0_0"]) == (A.IHP_GT_HET, A.IHP_GT_UNKNOWN)
+    assert out["strerror_capacity"] == "capacity exceeded"

@@ -292,3 +292,14 @@ def test_threads_that_never_called_init(hip, oracle):
     for r in out:
         assert not isinstance(r, Exception), r
         assert_same(r, exp)
+
+
+def test_c_harness_drives_the_device():
+    """The C harness (gcc, include/indelope_hip.h, no Python in between): the reference's ksw2 KAT through the drop-in
+    symbol incl. cigar-buffer reuse, a hand-derived region through ihp_run_regions, the error convention."""
+    import json
+    import subprocess
+    from test_abi_exports import _build_harness
+    pr = subprocess.run([_build_harness(), "--gpu"], capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr
+    assert json.loads(pr.stdout)["gpu_checks"] is True

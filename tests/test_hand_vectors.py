@@ -23,8 +23,9 @@ def test_helper_batches_are_what_they_claim(oracle):
     assert (res.aln_ez["n_cigar"][res.aln_flags & 1 != 0] > 32).all() and (res.aln_flags & 1).sum() == 4
     b = hand_vectors.batch_with_many_events(3)
     res = oracle.run_regions(b)
-    tallied = [(res.events[res.event_off[c]:res.event_off[c + 1]]["status"] == 0).sum() for c in range(res.n_contigs)]
-    assert max(tallied) >= 3
+    per_region = [(res.events[res.event_off[res.contig_off[r]]:res.event_off[res.contig_off[r + 1]]]["status"] == 0).sum()
+                  for r in range(res.n_regions)]
+    assert min(per_region) >= 5, per_region            # more than the four fixed hit slots of a region
     b = hand_vectors.batch_with_one_base_reads()
     assert (np.diff(b.read_off) == 1).sum() == 4
     oracle.run_regions(b)
