@@ -473,6 +473,12 @@ def main():
         if os.environ.get("IHP_PROFILE"):
             out["profile_cycles"] = [int(x) for x in sum(np.array(api.batch_profile(h)) for h in hs)]
         batch0 = subs[keep[0]]
+        if not strong and len(keep) > 1:                     # the host-side legs work on the rank's whole batch
+            g2 = dict(cfg)
+            g2["n_regions"] = R
+            batch0, _ = synth.generate(first_region=lo, dup_frac=args.dup_frac, **g2)
+            if not args.quals:
+                batch0 = batch0.with_trim_bounds()
         if not args.no_check:
             # outside the timed loop: every region the rank kept on the host goes through the oracle (all host threads) and must
             # be bit-identical -- the whole 10 000-region batch at the default workload

@@ -300,6 +300,9 @@ typedef struct {
  * through the runtime's staging copies.  NULL on failure.                                 */
 void *ihp_host_alloc(size_t bytes);
 void  ihp_host_free(void *p);
+/* Device -> host copy of memory this library handed out as a device pointer (ihp_batch_pack_dev, ihp_batch_summary_dev),
+ * for callers that do not link the HIP runtime themselves.                                                         */
+int   ihp_copy_to_host(const void *dev_ptr, int64_t bytes, void *out);
 
 /* ------------------------------------- post-tally filters and Variant records (row f2) */
 /* indelope.nim:375-428 (the filters and Variant fields that follow the tally inside
@@ -422,8 +425,10 @@ int  ihp_batch_kernel_ms(ihp_batch *b, float ms[4]);
 int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
 /* Diagnostics: with IHP_PROFILE=1 in the environment the kernels sum shader-clock cycles
  * per phase over all waves: [0] assemble, [1] combine, [2] assemble+output, [3] regions;
- * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments.  Always filled:
- * [15]/[7]/[11] regions forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [22] ksw2 kernel mode. */
+ * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments; packed read phase: [12] read preparation,
+ * [13] target-offset filter, [14] query-offset phase, [15] insert, [27] set-up.  Always filled: [24]/[25]/[26] regions
+ * forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [23] regions the packed pass handed
+ * back to the byte-based class-1 kernel, [22] ksw2 kernel mode. */
 int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
  * ihp_batch_run used: 3/4 = top-byte register sweep (left/right gaps; the production
@@ -443,6 +448,8 @@ typedef struct {
 } ihp_region_summary;
 /* Device pointer (valid until the next run/free) + count of the summaries.    */
 int  ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n);
+/* The same records copied to the host (cap >= n_regions entries).             */
+int  ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int64_t cap);
 
 #ifdef __cplusplus
 }

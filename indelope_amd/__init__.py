@@ -77,6 +77,13 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_pack_dev(h, C.byref(p), C.byref(n), _abi.ptr(counts, _abi.i64p)), "batch_pack_dev")
         return p.value, n.value, counts
 
+    def copy_to_host(self, dev_ptr, nbytes):
+        """uint8 array with a copy of device memory this library handed out (pack slab, summary records)."""
+        import numpy as np
+        out = np.zeros(max(1, nbytes), np.uint8)
+        self._chk_hip(self.b.copy_to_host(dev_ptr, nbytes, out.ctypes.data_as(C.c_void_p)), "copy_to_host")
+        return out[:nbytes]
+
     def batch_set_timing(self, h, on=True):
         self._chk_hip(self.b.batch_set_timing(h, 1 if on else 0), "batch_set_timing")
 
@@ -95,6 +102,13 @@ class HipApi(Api):
         p, n = C.c_void_p(), C.c_int64()
         self._chk_hip(self.b.batch_summary_dev(h, C.byref(p), C.byref(n)), "batch_summary_dev")
         return p.value, n.value
+
+    def batch_summary_host(self, h, n):
+        """The per-region summary records of the last run as a numpy array of SUMMARY_DTYPE."""
+        import numpy as np
+        out = np.zeros(max(n, 1), _abi.SUMMARY_DTYPE)
+        self._chk_hip(self.b.batch_summary_host(h, out.ctypes.data_as(C.c_void_p), n), "batch_summary_host")
+        return out[:n]
 
     def batch_profile(self, h):
         import numpy as np

@@ -202,6 +202,7 @@ _PRODUCT_ONLY = {
     "shutdown": (None, []),
     "host_alloc": (C.c_void_p, [C.c_size_t]),
     "host_free": (None, [C.c_void_p]),
+    "copy_to_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "batch_upload": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(C.c_void_p)]),
     "batch_run": (C.c_int, [C.c_void_p]),
     "batch_sync": (C.c_int, [C.c_void_p]),
@@ -217,6 +218,7 @@ _PRODUCT_ONLY = {
     "batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
+    "batch_summary_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "debug_last_ksw_mode": (C.c_int, []),
     "debug_limits": (C.c_int, [i64p]),
     "ksw_last_status": (C.c_int, []),

@@ -1,0 +1,606 @@
+// asm2_dev.h -- read phase of assemble (indelope.nim:163-169 over contig.nim:70-141, :156-252) on 2-bit packed bases.
+//
+// k_assemble's first pass spent 10 us per read in ONE dependent chain (22 000 cycles for a wave alone on its CU:
+// tools/r2_probe.sh) -- contig metadata gathered from LDS for every read, a scalar walk to map lanes to contigs, LDS
+// crossbar shuffles, HBM round trips for the support difference arrays.  This version keeps the whole contig
+// directory in registers (lane c = contig c), the bases 2 bits each in LDS (16 per dword), the lane -> (contig, dword)
+// work list in a register that only changes when a contig grows, and records per read where it went instead of
+// touching per-base supports at all (they are counted once at the end).  A fresh read (support 1, nreads 1) can only
+// match exactly (contig.nim:44-47 cannot fire: every contig base has support >= 1), so slide_align is "longest exactly
+// matching overlap, first in scan order" and a 16-base window (one dword) is an exact prefilter:
+//   target offsets (contig.nim:81-111): a lane takes one dword of one contig and tests its 16 windows against the read's
+//     first 16 bases (16 x v_alignbit + v_xor, folded with v_min3);
+//   query offsets (:114-135): lane o holds the read's window at offset o, the contigs' first dwords come from the
+//     directory one v_readlane each.
+// Survivors are verified on the whole overlap (16 bases per lane) and ranked under the reference's total order
+// (matches desc, contig index asc, target phase before query phase, offset asc).
+// Preconditions (anything else is forwarded to the byte-based passes, whose results are identical): every eligible read
+// is upper-case ACGT with 20 <= trimmed length <= 1008, max_mismatch == 0, 0 < min_overlap_pct <= 1, at most 64 contigs.
+#pragma once
+#include "contig_dev.h"
+
+namespace ihp {
+
+typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
+
+// ------------------------------------------------------------------------------------------------ packing
+// code = (c >> 1) & 3: A 0, C 1, T 2, G 3; "ACTG"[code] gives the base back
+constexpr unsigned PK_LUT = 0x47544341u;
+__device__ __forceinline__ unsigned pack4(unsigned w, unsigned &diff)
+{   // four ASCII bases -> 8 bits (base k at bits 2k); diff |= bytes that are not one of ACGT
+	const unsigned sel = (w >> 1) & 0x03030303u;
+	diff |= __builtin_amdgcn_perm(0u, PK_LUT, sel) ^ w;
+	const unsigned x = sel | (sel >> 6);
+	return (x | (x >> 12)) & 0xffu;
+}
+
+struct PrepackArgs {
+	long long n_reads;
+	const long long *read_off;
+	const uint8_t *bases, *quals;             // quals may be null
+	const int *trim_lo_in, *trim_hi_in;       // the stager's trim bounds, or null
+	int trim_min_qual;
+	uint32_t *pk;                             // read i at dword (read_off[i] >> 4) + i, ceil(len / 16) dwords, tail bits zero
+	int *trim_lo, *trim_hi;                   // [n_reads] out: kept range [lo, hi) of every read (indelope.nim:23-38)
+	uint8_t *read_bad;                        // [n_reads] out: 1 = a base that is not upper-case ACGT
+};
+
+// One 16-lane group per read (four reads per wave at a time), grid-stride over all reads of the batch.
+__global__ __launch_bounds__(64) void k_prepack(const PrepackArgs a)
+{
+	const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+	const long long stride = (long long)gridDim.x * 4;
+	for (long long i0 = (long long)blockIdx.x * 4; i0 < a.n_reads; i0 += stride) {
+		const long long ri = i0 + grp;
+		const bool live = ri < a.n_reads;
+		long long off = 0; int len = 0;
+		if (live) { off = a.read_off[ri]; len = (int)(a.read_off[ri + 1] - off); }
+		// ---- trim bounds
+		int lo = 0, hi = len;
+		if (a.trim_lo_in) {
+			if (live) {
+				lo = a.trim_lo_in[ri]; hi = a.trim_hi_in[ri];
+				lo = lo < 0 ? 0 : lo > len ? len : lo;
+				hi = hi > len ? len : hi; hi = hi < lo ? lo : hi;
+			}
+		} else if (a.quals) {
+			// indelope.nim:23-38 inside a 16-lane group: a = first i < high with q >= min, else high; b = last i > a with q >= min
+			const int high = len - 1;
+			const unsigned mq = (unsigned)a.trim_min_qual & 0xff;
+			int aa = high > 0 ? high : 0;
+			bool found = !(live && high > 0);
+			for (int b0 = 0; ; b0 += 16) {
+				const int i = b0 + sub;
+				const bool g = !found && i < high && a.quals[off + i] >= mq;
+				const unsigned long long m = ballot(g);
+				const unsigned gm = (unsigned)(m >> (16 * grp)) & 0xffffu;
+				if (!found && gm) { aa = b0 + __builtin_ctz(gm); found = true; }
+				if (!found && b0 + 16 >= high) found = true;
+				if (!ballot(!found)) break;
+			}
+			if (aa == high || len <= 0) { lo = 0; hi = 0; }
+			else {
+				int bb = aa;
+				bool done = !live;
+				for (int top = high; ; top -= 16) {
+					const int i = top - sub;
+					const bool g = !done && i > aa && a.quals[off + i] >= mq;
+					const unsigned long long m = ballot(g);
+					const unsigned gm = (unsigned)(m >> (16 * grp)) & 0xffffu;
+					if (!done && gm) { bb = top - __builtin_ctz(gm); done = true; }
+					if (!done && top - 16 <= aa) done = true;
+					if (!ballot(!done)) break;
+				}
+				lo = aa; hi = bb + 1;
+			}
+			// groups leave the loops together (wave-uniform exits); a dead or short group just idles
+		} else if (len == 1) hi = 0;                         // no qualities = all 255: trim() still empties a 1-base read (:28-30)
+		if (live && sub == 0) { a.trim_lo[ri] = lo; a.trim_hi[ri] = hi; }
+		// ---- pack
+		unsigned diff = 0;
+		const long long pkb = (off >> 4) + ri;
+		const int nd = (len + 15) >> 4;
+		for (int d = sub; d < nd; d += 16) {
+			const uint8_t *p = a.bases + off + 16 * d;
+			unsigned w[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) w[k] = *(const u32_unaligned_t *)(p + 4 * k);
+			const int rem = len - 16 * d;                        // valid bases in this dword (>= 1)
+			unsigned out = 0, df = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				unsigned dk = 0;
+				const unsigned y = pack4(w[k], dk);
+				const int v = rem - 4 * k;                       // valid bases of this group of four
+				if (v < 4) dk &= v <= 0 ? 0u : (1u << (8 * v)) - 1u;
+				df |= dk;
+				out |= y << (8 * k);
+			}
+			if (rem < 16) out &= (1u << (2 * rem)) - 1u;
+			a.pk[pkb + d] = out;
+			diff |= df;
+		}
+		const unsigned long long bm = ballot(diff != 0);
+		if (live && sub == 0) a.read_bad[ri] = (uint8_t)(((bm >> (16 * grp)) & 0xffffull) != 0);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ bit helpers
+// bits [sh, sh + 32) of the 64-bit value hi:lo (sh in 0..31)
+__device__ __forceinline__ unsigned fsh(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// Does any of the 16 windows [j, j + 16), j = 0..15, of the 32 bases w1:w0 equal qh?  (16 x v_alignbit + v_xor folded with
+// v_min3; which ones is worked out for the rare hit lanes only, by window_bits.)
+__device__ __forceinline__ bool window_any(unsigned w0, unsigned w1, unsigned qh)
+{
+	unsigned x[16];
+	x[0] = w0 ^ qh;
+#pragma unroll
+	for (int j = 1; j < 16; ++j) x[j] = fsh(w1, w0, 2u * j) ^ qh;
+	const unsigned m0 = min(min(x[0], x[1]), min(x[2], x[3])), m1 = min(min(x[4], x[5]), min(x[6], x[7]));
+	const unsigned m2 = min(min(x[8], x[9]), min(x[10], x[11])), m3 = min(min(x[12], x[13]), min(x[14], x[15]));
+	return min(min(m0, m1), min(m2, m3)) == 0;
+}
+// The same for ONE wave-uniform pair (w0, w1): lane j tests window j; bit j of the result <-> window j equals qh.
+__device__ __forceinline__ unsigned window_bits(unsigned w0, unsigned w1, unsigned qh)
+{
+	const int lane = lane_id();
+	return (unsigned)ballot(lane < 16 && fsh(w1, w0, 2u * (unsigned)(lane & 15)) == qh);
+}
+
+// Are the n bases at bit offset xb of LDS dword array P (dword index xd) equal to those at (yd, yb)?  Lane l compares
+// bases [16 l, 16 l + 16); n <= 1024.  Reads one dword past the last one needed on each side (slots are padded).
+__device__ __forceinline__ bool bits_equal(const uint32_t *P, int xd, unsigned xb, int yd, unsigned yb, int n)
+{
+	const int lane = lane_id();
+	unsigned x = 0;
+	if (16 * lane < n) {
+		const unsigned a0 = P[xd + lane], a1 = P[xd + lane + 1], b0 = P[yd + lane], b1 = P[yd + lane + 1];
+		x = fsh(a1, a0, xb) ^ fsh(b1, b0, yb);
+		const int rem = n - 16 * lane;
+		if (rem < 16) x &= (1u << (2 * rem)) - 1u;
+	}
+	return ballot(x != 0) == 0;
+}
+
+// Copy nbits bits from (sd, sbit) to (dd, dbit) inside P (bit offsets may exceed 31; they are relative to the dword
+// indices sd / dd).  Lanes take destination dwords; bits of a destination dword outside the range are kept.  Source
+// and destination must not overlap.  Reads P[sd - 1 ..] at most one dword outside the source range (padded).
+__device__ __forceinline__ void copy_bits(uint32_t *P, int dd, int dbit, int sd, int sbit, int nbits)
+{
+	if (nbits <= 0) return;
+	const int lane = lane_id();
+	const int s = sbit - dbit;                                  // source bit of destination bit b is b + s
+	const int d_first = dbit >> 5, d_last = (dbit + nbits - 1) >> 5;
+	for (int d = d_first + lane; d <= d_last; d += 64) {
+		const int sb = 32 * d + s;                              // source bit of this dword's bit 0 (may be negative by < 32)
+		const int si = sb >> 5;                                 // arithmetic shift: floor
+		const unsigned v = fsh(P[sd + si + 1], P[sd + si], (unsigned)sb & 31u);
+		const int blo = dbit - 32 * d, bhi = dbit + nbits - 32 * d;      // valid bits of this dword: [blo, bhi)
+		unsigned mask = 0xffffffffu;
+		if (blo > 0) mask &= 0xffffffffu << blo;
+		if (bhi < 32) mask &= (1u << bhi) - 1u;
+		P[dd + d] = (P[dd + d] & ~mask) | (v & mask);
+	}
+}
+
+
+// lanes [lo, hi] of the wave, 0 <= lo, hi <= 63; empty when hi < lo
+__device__ __forceinline__ unsigned long long lane_range64(int lo, int hi)
+{
+	return hi < lo ? 0ull : ((~0ull << lo) & (~0ull >> (63 - hi)));
+}
+
+// ------------------------------------------------------------------------------------------------ read phase
+constexpr int V2_MIN_READ = 20, V2_MAX_READ = 960;       // trimmed read lengths this path takes
+constexpr int V2_MAX_CONTIGS = 64;                       // one directory lane per contig
+constexpr int V2_WL = 128;                               // work-list entries (two registers)
+constexpr int V2_HDR = 8, V2_DIRW = 8;                   // hand-over record: header dwords, dwords per contig
+
+__device__ __forceinline__ int wl_make(int dword, int c, int k) { return (dword << 2) | (c << 16) | (k << 22); }
+__device__ __forceinline__ unsigned dpp_wave_shl1(unsigned v)
+{   // lane l gets v[l + 1]; lane 63 gets 0
+	return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+__device__ __forceinline__ long long bcast64(long long v, int src)
+{
+	return ((long long)bcast((int)(v >> 32), src) << 32) | (unsigned)bcast((int)v, src);
+}
+
+// Candidate ranking of best_match (contig.nim:32-36, :107, :239) for exact matches: more matches, then the earlier contig,
+// then the target-offset phase before the query-offset phase, then the smaller offset.
+struct Best2 { int found, ma, c, ph, o; };
+__device__ __forceinline__ bool beats(const Best2 &b, int cn, int c, int ph, int o)
+{
+	if (!b.found) return true;
+	if (cn != b.ma) return cn > b.ma;
+	if (c != b.c) return c < b.c;
+	if (ph != b.ph) return ph < b.ph;
+	return o < b.o;
+}
+
+// What the read kernel needs of a batch (a small struct: the ~70 fields of AsmArgs do not fit the scalar registers and
+// were reloaded from spill lanes all through the read loop).
+struct ReadArgs {
+	const long long *region_read_off, *read_off, *read_start;
+	const uint8_t *mapq, *read_skip, *v2_read_bad;
+	const int *v2_trim_lo, *v2_trim_hi;
+	const uint32_t *v2_pk;
+	uint32_t *v2_hand; const long long *v2_hoff;
+	double min_overlap_pct;
+	int min_mapq_assemble, v2_pdw, n_regions;
+	const int *in_list, *n_in; int *out_list, *n_out; int *work_counter;
+	long long *prof; unsigned long long *t_start;
+};
+
+// Hand-over record of one region in HBM (a.v2_hand + a.v2_hoff[r], dwords), written by k_asm_reads, read by k_asm_combine:
+//   [0] contigs n (-1: the region was not taken), [1] reads of the region, [2..7] unused
+//   n x V2_DIRW: { packed data offset (dwords from the record's start), length, nreads, start lo, start hi, anchor, 0, 0 }
+//   one record dword per read of the region (see below), then the contigs' packed bases (ceil(len / 16) dwords each)
+// Capacity (host, v2_hoff): 8 + 9 min(64, reads) + reads + bases / 16 + 8 dwords.
+//
+// Packed area P (LDS dwords) of one wave:
+//   [0]                   zero pad (copy_bits may read the dword before a source)
+//   [1, 1 + QW)           the read being inserted, from bit 0 (QW = dwords of the longest read + 2 of zero padding)
+//   [RECB, RECB + reads)  one record per read of the region: contig (6 bits) | start relative to the contig's anchor,
+//                         biased by 16384 (15 bits) | trimmed length (10 bits); 0xffffffff = read not inserted
+//   [SLOT0, p_dwords)     contig slots, bump allocated, every slot followed by a pad dword
+// The supports are not touched here: a read adds 1 to every base it covers (contig.nim:198-200, :216-219 with
+// q.support == 1 and no corrections), so the support of a base is the number of records that cover it; positions are
+// kept relative to an anchor that moves when bases are prepended (contig.nim:180-205).
+__device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords, int r, long long *prof)
+{
+	const int lane = lane_id();
+	const long long r0 = uni(a.region_read_off[r]), r1 = uni(a.region_read_off[r + 1]);
+	const int nrr = (int)(r1 - r0);
+	long long tp_ = prof ? (long long)clock64() : 0;             // diagnostics: cycles per stage into prof[12..15] (prep, target filter, query phase, insert); [7] set-up
+#define V2_LAP(k) do { if (prof) { const long long t_ = (long long)clock64(); if (lane == 0) prof[k] += t_ - tp_; tp_ = t_; } } while (0)
+	// ---- pass 0: which reads take part (indelope.nim:164-165), preconditions, shortest / longest trimmed read
+	int minlen = 0x7fffffff, maxlen = 0;
+	bool viol = false;
+	for (long long g0 = r0; g0 < r1; g0 += 64) {
+		const long long my = g0 + lane;
+		if (my < r1 && a.mapq[my] >= a.min_mapq_assemble && !(a.read_skip && a.read_skip[my])) {
+			const int tl = a.v2_trim_hi[my] - a.v2_trim_lo[my];
+			viol |= a.v2_read_bad[my] != 0 || tl < V2_MIN_READ || tl > V2_MAX_READ;
+			minlen = tl < minlen ? tl : minlen; maxlen = tl > maxlen ? tl : maxlen;
+		}
+	}
+	if (ballot(viol)) return IHP_E_CAPACITY;
+	minlen = wave_min_i32(minlen); maxlen = wave_max_i32s(maxlen);
+	const int mo_min = maxlen ? (int)(a.min_overlap_pct * (double)minlen) : 17;
+	if (mo_min < 17) return IHP_E_CAPACITY;                  // a 16-base window must lie inside every acceptable overlap
+	if (maxlen - (int)(a.min_overlap_pct * (double)maxlen) > 127) return IHP_E_CAPACITY;   // query offsets 1..127 (two registers)
+	const int QW = ((maxlen + 15) >> 4) + 2;
+	const int RECB = 1 + QW, SLOT0 = RECB + nrr;
+	if (SLOT0 + 8 > p_dwords) return IHP_E_CAPACITY;
+	int bump = SLOT0;
+	if (lane == 0) P[0] = 0;
+	const long long base_idx = nrr ? (uni(a.read_off[r0]) >> 4) + r0 : 0;   // the region's first packed dword
+	const uint32_t *pkp = a.v2_pk + base_idx;
+	// contig directory: lane c <-> contig c (creation order = list order of contig.nim:243-248)
+	int d_woff = 0, d_len = 0, d_capw = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
+	unsigned d_head = 0;
+	int wl0 = 0, wl1 = 0, wl_n = 0;                           // work list: lane e of wl0 / wl1 = entry e / 64 + e
+	int n = 0;
+	auto wl_append = [&](int dword, int c, int k) -> bool {
+		if (wl_n >= V2_WL) return false;
+		const int e = wl_make(dword, c, k);
+		if (wl_n < 64) wl0 = lane == wl_n ? e : wl0;
+		else wl1 = lane == wl_n - 64 ? e : wl1;
+		wl_n++;
+		return true;
+	};
+	auto n_entries = [&](int len) { return len >= mo_min ? (len - mo_min) / 16 + 1 : 0; };   // dwords that hold a valid target offset
+
+	for (long long g0 = r0; g0 < r1; g0 += 64) {
+		const long long my = g0 + lane;
+		long long mstart = 0; int midx = 0, mpack = 0; bool ok = false;
+		if (my < r1) {
+			const long long moff = a.read_off[my];
+			mstart = a.read_start[my];
+			const int tlo = a.v2_trim_lo[my], tl = a.v2_trim_hi[my] - tlo;
+			ok = a.mapq[my] >= a.min_mapq_assemble && !(a.read_skip && a.read_skip[my]);
+			mstart += tlo;                                       // read.start + o (indelope.nim:169)
+			midx = (int)((moff >> 4) + my + (tlo >> 4) - base_idx);
+			const int mo = ok ? (int)(a.min_overlap_pct * (double)tl) : 0;      // :169, for 64 reads at once
+			mpack = (tl & 1023) | ((tlo & 15) << 10) | (mo << 14);
+		}
+		unsigned long long elig = ballot(ok), topf = elig;       // topf: reads whose packed bases have not been requested yet
+		int rec = -1;
+		// the packed bases of the next reads are in flight while the current one is matched
+		unsigned raw0 = 0, raw1 = 0, raw2 = 0, raw3 = 0;
+		auto fetch = [&]() -> unsigned {
+			if (!topf) return 0u;
+			const int k = ctz64(topf);
+			topf &= topf - 1;
+			const int pk = bcast(mpack, k);
+			const int nq = (((pk >> 10) & 15) + (pk & 1023) + 15) >> 4;     // dwords that hold the trimmed read (before shifting)
+			return lane <= nq ? pkp[bcast(midx, k) + lane] : 0u;             // one more than needed: the funnel shift's upper half
+		};
+		raw0 = fetch(); raw1 = fetch(); raw2 = fetch(); raw3 = fetch();
+		V2_LAP(7);
+		while (elig) {
+			const int k = ctz64(elig);
+			elig &= elig - 1;
+			const int pk = bcast(mpack, k);
+			const int tl = pk & 1023, mo = (unsigned)pk >> 14;
+			const int omin = tl - mo;                            // contig.nim:78 (abs: tl >= mo because pct <= 1)
+			// ---- the read: bits from 0, zero beyond its end; lane l holds bases [16 l, 16 l + 16)
+			unsigned rq = fsh(dpp_wave_shl1(raw0), raw0, 2u * (unsigned)((pk >> 10) & 15));
+			{
+				const int rem = tl - 16 * lane;
+				rq = rem <= 0 ? 0u : rem < 16 ? rq & ((1u << (2 * rem)) - 1u) : rq;
+			}
+			raw0 = raw1; raw1 = raw2; raw2 = raw3; raw3 = fetch();
+			if (lane < QW) P[1 + lane] = rq;                     // QW <= 62
+			LDS_ORDER();
+			const unsigned qh = (unsigned)__builtin_amdgcn_readlane((int)rq, 0);
+			// windows of the read at offsets lane and 64 + lane (query-offset phase)
+			unsigned wq0, wq1 = 0;
+			{
+				const int dw = 1 + (lane >> 4);
+				wq0 = fsh(P[dw + 1], P[dw], 2u * (unsigned)(lane & 15));
+				if (omin > 63) { const int d2 = dw + 4; wq1 = fsh(d2 + 1 < RECB ? P[d2 + 1] : 0u, d2 < RECB ? P[d2] : 0u, 2u * (unsigned)(lane & 15)); }
+			}
+			Best2 best = {0, 0, 0, 0, 0};
+			V2_LAP(12);
+			// ---- target offsets (contig.nim:81-111): one dword of one contig per lane
+			for (int h = 0; h * 64 < wl_n; ++h) {
+				const int ent = h ? wl1 : wl0;
+				unsigned w0 = 0, w1 = 0;
+				bool any = false;
+				if (h * 64 + lane < wl_n) {
+					const int dw = (ent & 0xffff) >> 2;
+					w0 = P[dw]; w1 = P[dw + 1];
+					any = window_any(w0, w1, qh);
+				}
+				unsigned long long hm = ballot(any);
+				while (hm) {
+					const int e = ctz64(hm);
+					hm &= hm - 1;
+					unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
+					const int en = __builtin_amdgcn_readlane(ent, e);
+					const int c = (en >> 16) & 63, kk = (unsigned)en >> 22;
+					const int tlen = bcast(d_len, c), woff = bcast(d_woff, c);
+					while (bits) {
+						const int o = 16 * kk + __builtin_ctz(bits);
+						bits &= bits - 1;
+						if (o > tlen - mo) continue;                 // :79 offsets 0 .. len(t) - min_overlap
+						const int cn = tl < tlen - o ? tl : tlen - o;
+						if (!beats(best, cn, c, 0, o)) continue;
+						if (bits_equal(P, 1, 0u, woff + (o >> 4), 2u * (unsigned)(o & 15), cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 0; best.o = o; }
+					}
+				}
+			}
+			V2_LAP(13);
+			// ---- query offsets 1 .. omin (contig.nim:114-135): lane o holds the read's window, the contigs' heads come by.
+			// Hits are rare (the read would have to extend a contig to the left): first only whether there is one at all.
+			{
+				const unsigned long long v0 = lane_range64(1, omin < 63 ? omin : 63), v1 = omin > 63 ? lane_range64(0, omin - 64) : 0ull;
+				unsigned long long any0 = 0, any1 = 0;
+				for (int c = 0; c < n; c += 4) {                     // lanes >= n hold head 0: a false hit only costs the second look
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const unsigned hd = (unsigned)__builtin_amdgcn_readlane((int)d_head, c + u);
+						any0 |= ballot(wq0 == hd);
+						if (omin > 63) any1 |= ballot(wq1 == hd);
+					}
+				}
+				if ((any0 & v0) | (any1 & v1)) {
+					for (int c = 0; c < n; ++c) {
+						const unsigned hd = (unsigned)__builtin_amdgcn_readlane((int)d_head, c);
+						const unsigned long long m0 = ballot(wq0 == hd) & v0, m1 = omin > 63 ? ballot(wq1 == hd) & v1 : 0ull;
+						if (!(m0 | m1)) continue;
+						const int tlen = bcast(d_len, c), woff = bcast(d_woff, c);
+						for (int half = 0; half < 2; ++half) {
+							unsigned long long m = half ? m1 : m0;
+							while (m) {
+								const int o = 64 * half + ctz64(m);
+								m &= m - 1;
+								const int cn = tl - o < tlen ? tl - o : tlen;
+								if (cn < mo - 1 || !beats(best, cn, c, 1, o)) continue;      // best_ma starts at min_overlap - 1 (:81, :107)
+								if (bits_equal(P, 1 + (o >> 4), 2u * (unsigned)(o & 15), woff, 0u, cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 1; best.o = o; }
+							}
+						}
+					}
+				}
+			}
+			V2_LAP(14);
+			// ---- insert (contig.nim:243-248)
+			int rec_c, rec_s;
+			if (best.found) {
+				const int c = best.c, off = best.ph ? -best.o : best.o, aoff = best.o;
+				const int tlen = bcast(d_len, c), woff = bcast(d_woff, c), capw = bcast(d_capw, c), anchor = bcast(d_anchor, c);
+				int newlen;
+				if (off < 0) { newlen = aoff + tlen; if (tl > newlen) newlen = tl; }          // contig.nim:180-195
+				else { newlen = tlen; if (off + tl > newlen) newlen = off + tl; }               // :210-213
+				if (newlen > MAXLEN) return IHP_E_CAPACITY;
+				const bool sel = lane == c;
+				if (off >= 0 && newlen <= 16 * capw) {
+					copy_bits(P, woff, 2 * tlen, 1, 2 * (tlen - off), 2 * (newlen - tlen));      // :220-221 new bases
+					d_len = sel ? newlen : d_len;
+					rec_s = off - anchor;
+				} else {
+					const int ncapw = (newlen + headroom(newlen) + 15) >> 4;
+					if (bump + ncapw + 1 > p_dwords) return IHP_E_CAPACITY;
+					const int nw = bump;
+					for (int i = lane; i <= ncapw; i += 64) P[nw + i] = 0;
+					LDS_ORDER();
+					if (off < 0) {
+						copy_bits(P, nw, 0, 1, 0, 2 * aoff);                                       // :184-185
+						LDS_ORDER();
+						copy_bits(P, nw, 2 * aoff, woff, 0, 2 * tlen);                             // :187-188
+						LDS_ORDER();
+						copy_bits(P, nw, 2 * (aoff + tlen), 1, 2 * (aoff + tlen), 2 * (tl - aoff - tlen));   // :191-195
+					} else {
+						copy_bits(P, nw, 0, woff, 0, 2 * tlen);
+						LDS_ORDER();
+						copy_bits(P, nw, 2 * tlen, 1, 2 * (tlen - off), 2 * (newlen - tlen));
+					}
+					LDS_ORDER();
+					bump += ncapw + 1;
+					const unsigned nh = (unsigned)uni((int)P[nw]);
+					d_woff = sel ? nw : d_woff; d_capw = sel ? ncapw : d_capw; d_len = sel ? newlen : d_len;
+					d_head = sel ? nh : d_head;
+					if (off < 0) {
+						const long long qstart = bcast64(mstart, k);
+						d_slo = sel ? (int)qstart : d_slo; d_shi = sel ? (int)(qstart >> 32) : d_shi;   // t.start = q.start (:204)
+						d_anchor = sel ? anchor + aoff : d_anchor;
+					}
+					rec_s = off < 0 ? -(anchor + aoff) : off - anchor;
+					// the contig's work-list entries point into the new slot
+					{
+						const bool m0 = ((wl0 >> 16) & 63) == c && lane < wl_n, m1 = ((wl1 >> 16) & 63) == c && 64 + lane < wl_n;
+						wl0 = m0 ? wl_make(nw + (int)((unsigned)wl0 >> 22), c, (int)((unsigned)wl0 >> 22)) : wl0;
+						wl1 = m1 ? wl_make(nw + (int)((unsigned)wl1 >> 22), c, (int)((unsigned)wl1 >> 22)) : wl1;
+					}
+				}
+				d_nreads = sel ? d_nreads + 1 : d_nreads;                                       // :203, :222
+				{
+					const int w2 = bcast(d_woff, c);
+					for (int kk = n_entries(tlen); kk < n_entries(newlen); ++kk) if (!wl_append(w2 + kk, c, kk)) return IHP_E_CAPACITY;
+				}
+				rec_c = c;
+			} else {                                                                            // contigs.add(q) (:248)
+				if (n >= V2_MAX_CONTIGS) return IHP_E_CAPACITY;
+				const int capw = (tl + 32 + 15) >> 4;
+				if (bump + capw + 1 > p_dwords) return IHP_E_CAPACITY;
+				const int nw = bump;
+				for (int i = lane; i <= capw; i += 64) P[nw + i] = i < QW ? rq : 0u;             // lane i holds dword i of the read (QW <= 62)
+				bump += capw + 1;
+				const bool sel = lane == n;
+				const long long qstart = bcast64(mstart, k);
+				d_woff = sel ? nw : d_woff; d_capw = sel ? capw : d_capw; d_len = sel ? tl : d_len; d_head = sel ? qh : d_head;
+				d_nreads = sel ? 1 : d_nreads; d_slo = sel ? (int)qstart : d_slo; d_shi = sel ? (int)(qstart >> 32) : d_shi;
+				d_anchor = sel ? 0 : d_anchor;
+				for (int kk = 0; kk < n_entries(tl); ++kk) if (!wl_append(nw + kk, n, kk)) return IHP_E_CAPACITY;
+				rec_c = n; rec_s = 0;
+				n++;
+			}
+			LDS_ORDER();
+			rec = lane == k ? (rec_c | ((rec_s + 16384) << 6) | (tl << 21)) : rec;
+			V2_LAP(15);
+		}
+		if (my < r1) P[RECB + (int)(my - r0)] = (uint32_t)rec;
+	}
+	LDS_ORDER();
+	// ---- hand-over record in HBM: header, directory, records, packed bases
+	uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
+	const int nd = lane < n ? (d_len + 15) >> 4 : 0;
+	const unsigned pincl = wave_scan_add((unsigned)nd);
+	const int pbase = V2_HDR + V2_DIRW * n + nrr;
+	const int poff = pbase + (int)pincl - nd;
+	if (lane == 0) { H[0] = (uint32_t)n; H[1] = (uint32_t)nrr; }
+	if (lane < n) {
+		uint4 a0, a1;
+		a0.x = (uint32_t)poff; a0.y = (uint32_t)d_len; a0.z = (uint32_t)d_nreads; a0.w = (uint32_t)d_slo;
+		a1.x = (uint32_t)d_shi; a1.y = (uint32_t)d_anchor; a1.z = 0; a1.w = 0;
+		*(uint4 *)(H + V2_HDR + V2_DIRW * lane) = a0;
+		*(uint4 *)(H + V2_HDR + V2_DIRW * lane + 4) = a1;
+	}
+	for (int i = lane; i < nrr; i += 64) H[V2_HDR + V2_DIRW * n + i] = P[RECB + i];
+	for (int c = 0; c < n; ++c) {
+		const int w = bcast(d_woff, c), cnt = bcast(nd, c), po = bcast(poff, c);
+		for (int i = lane; i < cnt; i += 64) H[po + i] = P[w + i];
+	}
+	V2_LAP(7);
+#undef V2_LAP
+	return 0;
+}
+
+// Build what the combine phase works on from a hand-over record: slot metadata in S (as materialize_supports() leaves it),
+// bases unpacked into the byte arena A.seq, supports counted from the read records into A.sup.  Returns 1 if the region
+// was not taken by the read phase (another pass has it), 0 when ready, IHP_E_CAPACITY when it does not fit this arena.
+template <class ST>
+__device__ inline int v2_take_over(const AsmArgs &a, ST &S, Arena &A, int r, int &n_pre)
+{
+	const int lane = lane_id();
+	const uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
+	const int n = uni((int)H[0]), nrr = uni((int)H[1]);
+	n_pre = 0;
+	if (n < 0) return 1;
+	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
+	if (lane < n) {
+		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
+		d_poff = (int)a0.x; d_len = (int)a0.y; d_nreads = (int)a0.z; d_slo = (int)a0.w; d_shi = (int)a1.x; d_anchor = (int)a1.y;
+	}
+	const uint32_t *REC = H + V2_HDR + V2_DIRW * n;
+	n_pre = n;
+	const int blen = lane < n ? align4(d_len) + SLOT_PAD : 0;
+	const unsigned bincl = wave_scan_add((unsigned)blen);
+	const int boff = (int)bincl - blen, btotal = __builtin_amdgcn_readlane((int)bincl, 63);
+	const int maxl = wave_max_i32s(lane < n ? d_len : 0);
+	if (btotal > A.cap || 4 * (maxl + 2) > A.cap) return IHP_E_CAPACITY;
+	for (int i = lane; i <= ST::MAXC; i += 64) S.alive[i] = 0;
+	WSYNC();
+	if (lane < n) {
+		S.off[lane] = boff; S.len[lane] = d_len; S.cap[lane] = align4(d_len); S.nreads[lane] = d_nreads;
+		S.start[lane] = ((long long)d_shi << 32) | (unsigned)d_slo; S.alive[lane] = 1; S.listA[lane] = (short)lane;
+	}
+	if (lane == 0) { S.bump = btotal; S.err = 0; }
+	// the records of up to 256 reads stay in registers for all contigs
+	unsigned rc0 = 0xffffffffu, rc1 = 0xffffffffu, rc2 = 0xffffffffu, rc3 = 0xffffffffu;
+	if (lane < nrr) rc0 = REC[lane];
+	if (64 + lane < nrr) rc1 = REC[64 + lane];
+	if (128 + lane < nrr) rc2 = REC[128 + lane];
+	if (192 + lane < nrr) rc3 = REC[192 + lane];
+	uint32_t *scratch = (uint32_t *)A.seq;                       // the byte arena is still empty: difference array of one contig
+	for (int c = 0; c < n; ++c) {
+		const int len = bcast(d_len, c), bo = bcast(boff, c), nr = bcast(d_nreads, c), anchor = bcast(d_anchor, c);
+		uint32_t *sup = A.sup + bo;
+		if (nr == 1) {                                           // a single read: support 1 everywhere
+			for (int i = lane; i < len; i += 64) sup[i] = 1u;
+			if (lane == 0) { S.smin[c] = 1; S.smax[c] = 1; S.lo3[c] = 0x3fffffff; S.hi3[c] = 0; }
+			continue;
+		}
+		for (int i = lane; i <= len; i += 64) scratch[i] = 0;
+		LDS_ORDER();
+		auto scatter = [&](unsigned rc) {
+			if (rc != 0xffffffffu && (int)(rc & 63u) == c) {
+				const int s = (int)((rc >> 6) & 0x7fffu) - 16384 + anchor, e = s + (int)(rc >> 21);
+				atomicAdd(&scratch[s], 1u);
+				atomicAdd(&scratch[e], 0xffffffffu);
+			}
+		};
+		scatter(rc0); scatter(rc1); scatter(rc2); scatter(rc3);
+		for (int i0 = 256; i0 < nrr; i0 += 64) { const int i = i0 + lane; scatter(i < nrr ? REC[i] : 0xffffffffu); }
+		LDS_ORDER();
+		unsigned carry = 0, mn = 0xffffffffu, mx = 0;
+		int first = 0x7fffffff, last = -1, cnt = 0;
+		for (int i0 = 0; i0 < len; i0 += 64) {
+			const int i = i0 + lane;
+			unsigned v = i < len ? scratch[i] : 0u;
+			v = wave_scan_add(v) + carry;
+			if (i < len) {
+				sup[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+				if (v >= 3u) { first = i < first ? i : first; last = i; cnt++; }
+			}
+			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+		}
+		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+		first = wave_min_i32(first); last = wave_max_i32s(last); cnt = wave_sum_i(cnt);
+		if (lane == 0) {
+			S.smin[c] = mn; S.smax[c] = mx;
+			const bool clean = last >= first && cnt == last - first + 1;
+			S.lo3[c] = clean ? first : 0x3fffffff; S.hi3[c] = clean ? last + 1 : 0;
+		}
+		LDS_ORDER();
+	}
+	LDS_ORDER();
+	for (int c = 0; c < n; ++c) {                                // bases: four per lane, one dword store
+		const int len = bcast(d_len, c), bo = bcast(boff, c);
+		const uint32_t *src = H + bcast(d_poff, c);
+		uint32_t *dst = (uint32_t *)(A.seq + bo);
+		for (int i4 = lane; 4 * i4 < len; i4 += 64) {
+			const int i = 4 * i4;
+			const unsigned c8 = (src[i >> 4] >> (2 * (i & 15))) & 0xffu;
+			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
+			dst[i4] = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
+		}
+	}
+	WSYNC();
+	return 0;
+}
+
+}  // namespace ihp

@@ -23,7 +23,7 @@ constexpr int FILTER_CH = 8;     // bases examined by the per-offset prefilter
 #define LDS_ORDER() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p ? 1 : 0); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int clz64(unsigned long long m) { return __clzll((long long)m); }

@@ -275,6 +275,10 @@ extern "C" int ihp_init(int device)
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
 		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
+		(void)hipFuncSetAttribute((const void *)k_asm_reads<6>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
+		(void)hipFuncSetAttribute((const void *)k_asm_reads<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -676,8 +680,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 10 };      // work-queue counter sets: 7 assembly launches, ksw2, tally, fallback
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_HIT = 20, M_WORDS = 24 };
+enum { WQ_SETS = 12 };      // work-queue counter sets: 9 assembly launches, ksw2, tally, fallback
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_WORDS = 24 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -691,6 +695,10 @@ struct ihp_batch {
 	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
 	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
+	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
+	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_sup, v2_hoff, v2_hand;
+	bool v2 = false; int v2_arena = 0, v2_pdw = 0, grid_v2 = 0, grid_v2r = 0, grid_pack = 0, grid_ovf1 = 0;
+	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
 	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
@@ -751,10 +759,11 @@ static int alloc_work(ihp_batch *b)
 	AL(lds_sup2, sizeof(uint32_t) * (size_t)b->lds_arena2 * b->grid_asm2);
 	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
+	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_sup, sizeof(uint32_t) * (size_t)b->v2_arena * b->grid_v2); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords); }
 	AL(retry_list2, sizeof(int) * (size_t)R);
 	AL(retry_list3, sizeof(int) * (size_t)R);
 	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
-	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm, b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, b->grid_v2), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	if (p->fallback) {
@@ -782,7 +791,7 @@ static int alloc_work(ihp_batch *b)
 
 static void release_work(ihp_batch *b)
 {
-	DBuf *bufs[] = {&b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
+	DBuf *bufs[] = {&b->retry_list0, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
 	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
@@ -909,12 +918,57 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
 	b->grid_asm3 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena3 + 14336)));
 	{
+		// Packed read phase for class 1 (asm2_dev.h, k_assemble2) when the parameters allow it: exact matching only
+		// (max_mismatch 0) and 0 < min_overlap_pct <= 1.  Its byte arena holds the contigs that reach combine (no read
+		// staging); the packed area holds the longest read, one record per read and the 2-bit contig slots.
+		const char *v1 = getenv("IHP_ASM_V1");
+		b->v2 = !(v1 && v1[0] == '1') && p->max_mismatch == 0 && p->min_overlap_pct > 0 && p->min_overlap_pct <= 1.0 && b->n_cls[0] > 0;
+		if (b->v2) {
+			long long nb1 = 0, nr1 = 0;
+			for (int r = 0; r < R; ++r) {
+				const long long nb = ro[rro[r + 1]] - ro[rro[r]];
+				if (nb * 3 / 10 + 2 * b->stage_cap <= b->lds_arena1) { nb1 = std::max(nb1, nb); nr1 = std::max<long long>(nr1, rro[r + 1] - rro[r]); }
+			}
+			const char *e1 = getenv("IHP_V2_ARENA"), *e2 = getenv("IHP_V2_PDW");
+			// what a region needs at least ...
+			long long need_arena = (nb1 * 36 / 100 + 512 + 15) / 16 * 16;
+			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * 6 / 10 + 64;
+			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
+			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave
+			const int occ_c = (int)std::max<long long>(1, std::min<long long>(20, g.max_lds / (need_arena + 3840)));
+			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
+			need_arena = std::max<long long>(need_arena, (g.max_lds / occ_c - 3840) / 16 * 16);
+			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
+			b->v2_arena = e1 ? atoi(e1) : (int)need_arena;
+			b->v2_pdw = e2 ? atoi(e2) : (int)need_pdw;
+			b->v2_pdw = b->v2_pdw / 4 * 4;
+			const int per_wave = b->v2_arena + 3840, per_wave_r = 4 * b->v2_pdw + 256;
+			if (per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
+			else {
+				const char *ew = getenv("IHP_ASM_WAVES"), *er = getenv("IHP_ASMR_WAVES");
+				b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(ew ? atoi(ew) : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
+				b->grid_v2r = std::min(grid_for(R, std::max(1, std::min(er ? atoi(er) : 32, g.max_lds / per_wave_r))), std::max(1, b->n_cls[0]));
+				b->grid_pack = grid_for((int)std::min<long long>((NR + 3) / 4, 1 << 30), 32);
+				// hand-over records between the two kernels: 8 + 9 min(64, reads) + reads + bases / 16 + 8 dwords per region
+				std::vector<long long> hoff((size_t)R + 1, 0);
+				for (int r = 0; r < R; ++r) {
+					const long long nr = rro[r + 1] - rro[r], nb = ro[rro[r + 1]] - ro[rro[r]];
+					hoff[(size_t)r + 1] = hoff[(size_t)r] + ((16 + 9 * std::min<long long>(64, nr) + nr + nb / 16 + 3) / 4 * 4);
+				}
+				b->v2_hand_dwords = hoff[(size_t)R];
+				if ((rc = b->v2_hoff.upload(hoff.data(), sizeof(long long) * ((size_t)R + 1), s))) { delete b; return rc; }
+				HIPB(hipStreamSynchronize(s));
+			}
+		}
+	}
+	{
 		// Run-time overflow launches (a region that ran out of arena / contig slots in the pass its read bases
 		// predicted).  When every region of the batch was predicted to fit pass 1 these lists are almost always
 		// empty, and a full persistent grid of large-LDS workgroups costs 20-30 us per empty launch: two workgroups
 		// per CU then.  Batches with read-rich classes get the full grids (their lists are well used).
 		const bool side = b->n_cls[1] + b->n_cls[2] + b->n_cls[3] > 0;
 		const int small = 2 * g.cus;
+		b->grid_ovf1 = std::min(b->grid_asm, small);           // regions the packed pass hands back to the byte-based class-1 kernel
 		b->grid_ovf2 = side ? b->grid_asm2 : std::min(b->grid_asm2, small);
 		b->grid_ovf3 = side ? b->grid_asm3 : std::min(b->grid_asm3, small);
 		b->grid_ovf4 = side ? b->grid_retry : std::min(b->grid_retry, small);
@@ -972,6 +1026,10 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	if ((rc = b->misc.alloc(b->z_bytes())) || (rc = b->summary.alloc(sizeof(ihp_region_summary) * (size_t)R))) { delete b; return rc; }
 	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
 	if (g_limits[2] > 0) b->hit_cap = std::min(b->hit_cap, std::max(g_limits[2], 2 * HIT_SLOTS * NR));   // the fixed slots stay; the bump region shrinks
+	if (b->v2) {
+		if ((rc = b->v2_pk.alloc(sizeof(uint32_t) * (size_t)((b->n_bases >> 4) + NR + 4))) || (rc = b->v2_trim_lo.alloc(sizeof(int) * (size_t)NR)) ||
+		    (rc = b->v2_trim_hi.alloc(sizeof(int) * (size_t)NR)) || (rc = b->v2_read_bad.alloc((size_t)NR))) { delete b; return rc; }
+	}
 	if ((rc = alloc_work(b))) { delete b; return rc; }
 	for (auto &e : b->ev) HIPB(hipEventCreate(&e));
 	HIPB(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1023,6 +1081,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.t_start = nullptr;
+		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr;
 		// Passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  Every region
 		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
 		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
@@ -1058,7 +1117,42 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			HIPC(hipGetLastError());
 			HIPC(hipEventRecord(b->ev_join, s2));
 		}
-		if (n1) {
+		if (n1 && b->v2) {
+			// class 1 through the packed read phase; what it cannot take goes to the byte-based class-1 kernel behind it
+			PrepackArgs pa;
+			pa.n_reads = b->n_reads; pa.read_off = b->read_off.as<long long>(); pa.bases = b->bases.as<uint8_t>();
+			pa.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr;
+			pa.trim_lo_in = b->has_trim ? b->trim_lo.as<int>() : nullptr; pa.trim_hi_in = b->has_trim ? b->trim_hi.as<int>() : nullptr;
+			pa.trim_min_qual = p.trim_min_qual; pa.pk = b->v2_pk.as<uint32_t>(); pa.trim_lo = b->v2_trim_lo.as<int>();
+			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
+			hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			AsmArgs x = a;
+			x.v2_pk = pa.pk; x.v2_trim_lo = pa.trim_lo; x.v2_trim_hi = pa.trim_hi; x.v2_read_bad = pa.read_bad; x.v2_pdw = b->v2_pdw;
+			x.v2_hand = b->v2_hand.as<uint32_t>(); x.v2_hoff = b->v2_hoff.as<long long>();
+			x.arena_seq = nullptr; x.arena_sup = b->v2_sup.as<uint32_t>(); x.arena_cap = b->v2_arena; x.lds_arena = b->v2_arena;
+			x.in_list = cl; x.n_in = cn; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0; x.work_counter = wq + 10 * WQ_WORDS;
+			x.t_start = tm;
+			ReadArgs ra;
+			ra.region_read_off = x.region_read_off; ra.read_off = x.read_off; ra.read_start = x.read_start; ra.mapq = x.mapq;
+			ra.read_skip = x.read_skip; ra.v2_read_bad = x.v2_read_bad; ra.v2_trim_lo = x.v2_trim_lo; ra.v2_trim_hi = x.v2_trim_hi;
+			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
+			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
+			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
+			{
+				static const int minw = getenv("IHP_ASMR_MINW") ? atoi(getenv("IHP_ASMR_MINW")) : 8;    // diagnostics: VGPR budget of the read kernel
+				if (minw >= 8) hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
+				else if (minw >= 6) hipLaunchKernelGGL((k_asm_reads<6>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
+				else hipLaunchKernelGGL((k_asm_reads<4>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
+			}
+			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS;
+			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2), dim3(64), b->v2_arena, s, x);
+			HIPC(hipGetLastError());
+			if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 1);
+			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
+			a.in_list = b->retry_list0.as<int>(); a.n_in = misc + M_NRETRY0; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
+			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_ovf1), dim3(64), b->lds_arena1, s, a);
+			HIPC(hipGetLastError());
+		} else if (n1) {
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = cl; a.n_in = cn; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
 			a.t_start = tm;                                        // the first launch of the stage
@@ -1199,10 +1293,11 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
 	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
-	out[15] = b->report[M_NRETRY];                    // regions forwarded at run time to the second pass's overflow list
-	out[7] = b->report[M_NRETRY2];                    // ... to the third pass's
-	out[11] = b->report[M_NRETRY3];                   // ... and to the catch-all (HBM-arena) pass
+	out[24] = b->report[M_NRETRY];                    // regions forwarded at run time to the second pass's overflow list
+	out[25] = b->report[M_NRETRY2];                   // ... to the third pass's
+	out[26] = b->report[M_NRETRY3];                   // ... and to the catch-all (HBM-arena) pass
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
+	out[23] = b->report[M_NRETRY0];                   // regions the packed read phase handed back to the byte-based class-1 kernel
 	return 0;
 }
 
@@ -1241,6 +1336,16 @@ extern "C" int ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n)
 {
 	if (!b || !dev_ptr || !n) return IHP_E_ARG;
 	*dev_ptr = b->summary.p; *n = b->R;
+	return 0;
+}
+
+// The per-region summary records of the last run copied to the host (the same records ihp_batch_summary_dev exposes).
+extern "C" int ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int64_t cap)
+{
+	if (!b || !b->ran || (!out && b->R) || cap < b->R) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
+	HIPC(hipStreamSynchronize(b->stream));
+	if (b->R) HIPC(hipMemcpy(out, b->summary.p, sizeof(ihp_region_summary) * (size_t)b->R, hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -1489,6 +1594,17 @@ extern "C" void *ihp_host_alloc(size_t bytes)
 }
 
 extern "C" void ihp_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// Device -> host copy for callers that hold a device pointer of this library (the slab of ihp_batch_pack_dev, the records
+// of ihp_batch_summary_dev) and do not link the HIP runtime themselves.
+extern "C" int ihp_copy_to_host(const void *dev_ptr, int64_t bytes, void *out)
+{
+	if (bytes < 0 || (bytes && (!dev_ptr || !out))) return IHP_E_ARG;
+	int rc = ensure_init();
+	if (rc) return rc;
+	if (bytes) HIPC(hipMemcpy(out, dev_ptr, (size_t)bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
 
 // ---- ROI evidence scan (roi_dev.h) ------------------------------------------------------------------
 extern "C" void ihp_free_roi(ihp_roi_out *out)

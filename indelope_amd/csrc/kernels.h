@@ -38,7 +38,15 @@ struct AsmArgs {
 	int lds_arena;                                     // bytes of the dynamic LDS arena (LDS passes)
 	long long *prof;                                   // optional cycle counters (diagnostics)
 	unsigned long long *t_start;                       // optional: wall clock at which the launch's first workgroup starts
+	// packed read phase (asm2_dev.h): what k_prepack left -- 2-bit bases, the kept range of every read, "not ACGT" flags
+	const uint32_t *v2_pk; const int *v2_trim_lo, *v2_trim_hi; const uint8_t *v2_read_bad;
+	int v2_pdw;                                        // dwords of the per-wave packed area in LDS (k_asm_reads)
+	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine: region r at v2_hand + v2_hoff[r]
 };
+
+}  // namespace ihp
+#include "asm2_dev.h"
+namespace ihp {
 
 // Kernel execution time without a profiler: workgroup 0 is dispatched first, so its entry time is when the launch starts
 // to execute (an event recorded before the launch fires when the stream is ready, which is earlier when another stream's
@@ -278,6 +286,60 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 	return 0;
 }
 
+// Final contigs of one region -> output slots, max_stop, the faidx-style window of every contig that passes
+// indelope.nim:209-211 and its alignment job (:213-220).
+template <class ST>
+__device__ inline void region_epilogue(const AsmArgs &a, ST &S, Arena &A, int r, int err, int n_pre, int &n_final)
+{
+	const int lane = lane_id();
+	if (err) n_final = 0;
+	const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
+	// max_stop over reads with mapq > 5 (indelope.nim:213-216)
+	long long mstop = -0x7fffffffffffffffll - 1;
+	for (long long ri = r0 + lane; ri < r1; ri += 64)
+		if (a.mapq[ri] > a.min_mapq_stop && a.read_stop[ri] > mstop) mstop = a.read_stop[ri];
+	mstop = -wave_min_ll(-mstop - 1) - 1;                  // wave max without negating LLONG_MIN
+	const long long seq_base = r0 < r1 ? a.read_off[r0] : 0;
+	const long long origin = a.ref_origin[r];
+	const long long L = a.ref_off[r + 1] - a.ref_off[r];
+	const int width = (int)((double)(a.K + 1) / 2.0 - 1.0);   // :218
+	long long cursor = 0;
+	for (int k = 0; k < n_final; ++k) {
+		const int c = S.listA[k];
+		const long long slot = r0 + k;
+		const int len = S.len[c];
+		const uint8_t *cs = A.seq + S.off[c]; const uint32_t *cp = A.sup + S.off[c];
+		for (int i = lane; i < len; i += 64) { a.out_seq[seq_base + cursor + i] = cs[i]; a.out_sup[seq_base + cursor + i] = cp[i]; }
+		if (lane == 0) {
+			const long long cstart = S.start[c], cn = S.nreads[c];
+			a.ctg_start[slot] = cstart; a.ctg_nreads[slot] = cn; a.ctg_len[slot] = len;
+			a.ctg_seq_off[slot] = seq_base + cursor;
+			int flags = 0; long long rs = 0; int rl = 0;
+			if (n_pre <= a.max_pre_contigs && cn >= a.min_reads && len >= a.min_ctg_len) {   // :209-211
+				const long long max_stop = cstart > mstop ? cstart : mstop;
+				// fai.get(chrom, ctg.start, max_stop+width+50) :220 -- faidx_fetch_seq clamping
+				long long beg = cstart - origin, end = max_stop + width + a.ref_pad - origin;
+				int clamped = 0;
+				if (end < beg) { beg = end; clamped = 1; }
+				if (beg < 0) { beg = 0; clamped = 1; } else if (L <= beg) { beg = L - 1; clamped = 1; }
+				if (end < 0) { end = 0; clamped = 1; } else if (L <= end) { end = L - 1; clamped = 1; }
+				long long reflen = L > 0 ? end - beg + 1 : 0;
+				if (L <= 0) { beg = 0; clamped = 1; }
+				flags = IHP_ALN_DONE | (clamped ? IHP_ALN_REF_CLAMPED : 0);
+				rs = origin + beg; rl = (int)reflen;
+				const int j = atomicAdd(a.n_jobs, 1);
+				AlnJob jb;
+				jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
+				jb.out = (int)slot; jb.region = r;
+				a.jobs[j] = jb;
+			}
+			a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
+		}
+		cursor += len;
+	}
+	if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
+}
+
 // MC contig slots; LDSA: contig bases in an LDS arena of a.lds_arena bytes (dynamic LDS).  Three passes
 // share this kernel: <64,true> with a small arena for typical regions at 16 waves/CU, <128,true> with a
 // large arena for regions whose reads cannot fit the small one, <1024,false> with an HBM arena as the
@@ -328,52 +390,99 @@ __global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 			WSYNC();
 			continue;
 		}
-		if (err) n_final = 0;
-		const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
-		// max_stop over reads with mapq > 5 (indelope.nim:213-216)
-		long long mstop = -0x7fffffffffffffffll - 1;
-		for (long long ri = r0 + lane; ri < r1; ri += 64)
-			if (a.mapq[ri] > a.min_mapq_stop && a.read_stop[ri] > mstop) mstop = a.read_stop[ri];
-		mstop = -wave_min_ll(-mstop - 1) - 1;                  // wave max without negating LLONG_MIN
-		const long long seq_base = r0 < r1 ? a.read_off[r0] : 0;
-		const long long origin = a.ref_origin[r];
-		const long long L = a.ref_off[r + 1] - a.ref_off[r];
-		const int width = (int)((double)(a.K + 1) / 2.0 - 1.0);   // :218
-		long long cursor = 0;
-		for (int k = 0; k < n_final; ++k) {
-			const int c = S.listA[k];
-			const long long slot = r0 + k;
-			const int len = S.len[c];
-			const uint8_t *cs = A.seq + S.off[c]; const uint32_t *cp = A.sup + S.off[c];
-			for (int i = lane; i < len; i += 64) { a.out_seq[seq_base + cursor + i] = cs[i]; a.out_sup[seq_base + cursor + i] = cp[i]; }
-			if (lane == 0) {
-				const long long cstart = S.start[c], cn = S.nreads[c];
-				a.ctg_start[slot] = cstart; a.ctg_nreads[slot] = cn; a.ctg_len[slot] = len;
-				a.ctg_seq_off[slot] = seq_base + cursor;
-				int flags = 0; long long rs = 0; int rl = 0;
-				if (n_pre <= a.max_pre_contigs && cn >= a.min_reads && len >= a.min_ctg_len) {   // :209-211
-					const long long max_stop = cstart > mstop ? cstart : mstop;
-					// fai.get(chrom, ctg.start, max_stop+width+50) :220 -- faidx_fetch_seq clamping
-					long long beg = cstart - origin, end = max_stop + width + a.ref_pad - origin;
-					int clamped = 0;
-					if (end < beg) { beg = end; clamped = 1; }
-					if (beg < 0) { beg = 0; clamped = 1; } else if (L <= beg) { beg = L - 1; clamped = 1; }
-					if (end < 0) { end = 0; clamped = 1; } else if (L <= end) { end = L - 1; clamped = 1; }
-					long long reflen = L > 0 ? end - beg + 1 : 0;
-					if (L <= 0) { beg = 0; clamped = 1; }
-					flags = IHP_ALN_DONE | (clamped ? IHP_ALN_REF_CLAMPED : 0);
-					rs = origin + beg; rl = (int)reflen;
-					const int j = atomicAdd(a.n_jobs, 1);
-					AlnJob jb;
-					jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
-					jb.out = (int)slot; jb.region = r;
-					a.jobs[j] = jb;
-				}
-				a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
-			}
-			cursor += len;
+		region_epilogue(a, S, A, r, err, n_pre, n_final);
+		if (a.prof && lane == 0) S.prof[2] += (long long)clock64() - tcR;
+		WSYNC();
+	}
+	WSYNC();
+	if (a.prof && lane < 16 && lane != 8 && lane != 9 && lane != 10 && lane != 11 && S.prof[lane])
+		atomicAdd((unsigned long long *)&a.prof[lane], (unsigned long long)S.prof[lane]);
+}
+
+
+// Class 1 with the packed read phase (asm2_dev.h), as two kernels so that each runs at the occupancy its own state allows:
+//   k_asm_reads    the read insertions on 2-bit bases: registers + a small packed area in LDS, 32 waves per CU; leaves one
+//                  hand-over record per region in HBM (contig directory, read records, packed bases);
+//   k_asm_combine  takes a record over into the byte representation (bases in the LDS arena, supports counted from the
+//                  records) and runs combine (contig.nim:254-281) and the epilogue on it.
+// A region that does not meet the packed path's preconditions, or runs out of room in either kernel, goes to out_list and
+// is assembled from scratch by the byte-based passes (k_assemble); results never depend on the pass.
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
+{
+	__shared__ int s_item;
+	__shared__ long long s_prof[16];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
+	uint32_t *P = (uint32_t *)lds_arena;
+	const int lane = lane_id();
+	mark_start(a.t_start);
+	if (lane < 16) s_prof[lane] = 0;
+	WSYNC();
+	const int n_items = a.in_list ? *a.n_in : a.n_regions;
+	unsigned wq_dead = 0;
+	for (;;) {
+		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
+		WSYNC();
+		int r = __builtin_amdgcn_readfirstlane(s_item);
+		WSYNC();
+		if (r < 0) break;
+		if (a.in_list) r = a.in_list[r];
+		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr);
+		if (err) {                                             // not for this path: the byte-based passes take it
+			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 		}
-		if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
+		WSYNC();
+	}
+	WSYNC();
+	if (a.prof && lane < 16 && s_prof[lane]) atomicAdd((unsigned long long *)&a.prof[lane == 7 ? 27 : lane], (unsigned long long)s_prof[lane]);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
+{
+	typedef RegionStateT<64> ST;
+	__shared__ ST S;
+	__shared__ int s_item;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
+	const int lane = lane_id();
+	Arena A;
+	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
+	A.seq = lds_arena; A.cap = a.lds_arena - 16; A.stage_off = a.lds_arena - 16;        // no staging area: reads never enter the byte arena
+	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof ? S.prof : nullptr;
+	mark_start(a.t_start);
+	if (lane < 16) S.prof[lane] = 0;
+	WSYNC();
+	const int n_items = a.in_list ? *a.n_in : a.n_regions;
+	unsigned wq_dead = 0;
+	for (;;) {
+		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
+		WSYNC();
+		int r = __builtin_amdgcn_readfirstlane(s_item);
+		WSYNC();
+		if (r < 0) break;
+		if (a.in_list) r = a.in_list[r];
+		int n_pre = 0, n_final = 0;
+		const long long tcR = a.prof ? (long long)clock64() : 0;
+		int err = v2_take_over(a, S, A, r, n_pre);
+		if (err == 1) continue;                                // the read phase did not take this region
+		const long long tcA = a.prof ? (long long)clock64() : 0;
+		if (!err) {
+			const int n2 = combine_pass(S, A, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
+			if (n2 < 0) err = n2;
+			else {
+				WSYNC();
+				const int n3 = combine_pass(S, A, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap, a.max_mismatch);
+				if (n3 < 0) err = n3; else n_final = n3;
+			}
+		}
+		WSYNC();
+		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[1] += (long long)clock64() - tcA; S.prof[3] += 1; }
+		if (err == IHP_E_CAPACITY && a.out_list) {             // no room here: the byte-based passes take it
+			if (lane == 0) a.out_list[atomicAdd(a.n_out, 1)] = r;
+			WSYNC();
+			continue;
+		}
+		region_epilogue(a, S, A, r, err, n_pre, n_final);
 		if (a.prof && lane == 0) S.prof[2] += (long long)clock64() - tcR;
 		WSYNC();
 	}

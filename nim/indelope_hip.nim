@@ -113,6 +113,7 @@ proc ihp_free_variants*(vars: ptr IhpVariants) {.importc, cdecl, header: "indelo
 proc ihp_format_variant*(v: ptr IhpVariant, chars: cstring, chrom: cstring, buf: cstring, cap: int64): int64 {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_host_alloc*(bytes: csize_t): pointer {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_copy_to_host*(dev_ptr: pointer, bytes: int64, outp: pointer): cint {.importc, cdecl, header: "indelope_hip.h".}
 
 # ---- Contig / genotyper / ksw2 single-step entries (wrapped with the reference's signatures in nim/contig_hip.nim and
 # nim/genotyper_hip.nim)
@@ -169,6 +170,7 @@ proc ihp_batch_free*(b: ptr IhpBatch) {.importc, cdecl, header: "indelope_hip.h"
 proc ihp_batch_pack_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, bytes: ptr int64, counts: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_unpack_slab*(slab: pointer, bytes: int64, counts: ptr int64, error: float64, outp: ptr IhpBatchOut): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_summary_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_summary_host*(b: ptr IhpBatch, outp: ptr IhpRegionSummary, cap: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 
 proc ihp_init*(device: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_strerror*(code: cint): cstring {.importc, cdecl, header: "indelope_hip.h".}

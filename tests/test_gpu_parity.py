@@ -347,7 +347,6 @@ def test_full_size_c2_properties(hip, oracle):
 
 def test_device_summary_records(hip):
     """The per-region records gathered across GPUs (k_summary) equal the same records built from the fetched results."""
-    import torch
     from indelope_amd import dist as idist
     b, _ = synth.generate(300, n_reads=(8, 64), err_rate=2e-3, config_id=33)
     h = hip.batch_upload(b)
@@ -355,11 +354,8 @@ def test_device_summary_records(hip):
         hip.batch_run(h)
         hip.batch_sync(h)
         ptr, n = hip.batch_summary_dev(h)
-        assert n == b.n_regions
-
-        class Dev:
-            __cuda_array_interface__ = {"shape": (n * idist.SUMMARY_WORDS,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-        got = torch.as_tensor(Dev(), device="cuda").cpu().numpy().reshape(-1, idist.SUMMARY_WORDS)
+        assert n == b.n_regions and ptr
+        got = hip.batch_summary_host(h, n).view(np.int32).reshape(-1, idist.SUMMARY_WORDS)
         res = hip.batch_fetch(h)
     finally:
         hip.batch_free(h)
@@ -443,7 +439,7 @@ def test_runtime_overflow_goes_to_the_catch_all_pass(hip, oracle):
             hip.batch_run(h)
             hip.batch_sync(h)
             prof = hip.batch_profile(h)
-            forwarded = int(prof[15] + prof[7] + prof[11])
+            forwarded = int(prof[24] + prof[25] + prof[26])
             got = hip.batch_fetch(h)
         finally:
             hip.batch_free(h)
@@ -454,17 +450,13 @@ def test_runtime_overflow_goes_to_the_catch_all_pass(hip, oracle):
 def test_device_pack_is_what_fetch_returns(hip):
     """ihp_batch_pack_dev: the slab left on the device (the multi-GPU payload) unpacks to the same results as
     ihp_batch_fetch; the host-side pack of those results is byte-identical in layout."""
-    import torch
     b, _ = synth.generate(150, n_reads=(8, 64), err_rate=1e-3, config_id=36, dup_frac=0.2)
     h = hip.batch_upload(b)
     try:
         hip.batch_run(h)
         hip.batch_sync(h)
         ptr, nbytes, counts = hip.batch_pack_dev(h)
-
-        class Dev:
-            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-        slab = torch.as_tensor(Dev(), device="cuda").cpu().numpy()
+        slab = hip.copy_to_host(ptr, nbytes)
         res = hip.batch_fetch(h)
     finally:
         hip.batch_free(h)

@@ -67,7 +67,6 @@ def test_c3_and_c5_shapes_at_size(hip, oracle):
 def test_c4_shard_full_size(hip, oracle):
     """BASELINE configs[3]: one rank's share of the 5 M regions (625 000 regions, 40 M reads) resident on one GPU --
     determinism, conservation, oracle parity on slices, and the per-region records the multi-GPU gather moves."""
-    import torch
     world, rank = 8, 5
     total = synth.CONFIGS["C4"]["n_regions"]
     bounds = idist.shard_bounds(np.ones(total), world)
@@ -79,16 +78,11 @@ def test_c4_shard_full_size(hip, oracle):
     try:
         hip.batch_run(h)
         hip.batch_sync(h)
-        ptr, n = hip.batch_summary_dev(h)
-        assert n == b.n_regions
-
-        class Dev:
-            __cuda_array_interface__ = {"shape": (n * idist.SUMMARY_WORDS,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-        s1 = torch.as_tensor(Dev(), device="cuda").cpu().numpy().reshape(-1, idist.SUMMARY_WORDS).copy()
+        s1 = hip.batch_summary_host(h, b.n_regions).view(np.int32).reshape(-1, idist.SUMMARY_WORDS).copy()
         res = hip.batch_fetch(h)
         hip.batch_run(h)                                   # determinism: the second run leaves the same records
         hip.batch_sync(h)
-        s2 = torch.as_tensor(Dev(), device="cuda").cpu().numpy().reshape(-1, idist.SUMMARY_WORDS)
+        s2 = hip.batch_summary_host(h, b.n_regions).view(np.int32).reshape(-1, idist.SUMMARY_WORDS)
         assert np.array_equal(s1, s2)
     finally:
         hip.batch_free(h)
