@@ -509,11 +509,17 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	return 0;
 }
 
+struct PackedMirror {
+	uint32_t *PM; int cap, bump;                               // dwords
+	unsigned short *pm_dw; unsigned char *pm_sh;               // per slot (LDS)
+	bool on;
+};
+
 // Build what the combine phase works on from a hand-over record: slot metadata in S (as materialize_supports() leaves it),
 // bases unpacked into the byte arena A.seq, supports counted from the read records into A.sup.  Returns 1 if the region
 // was not taken by the read phase (another pass has it), 0 when ready, IHP_E_CAPACITY when it does not fit this arena.
 template <class ST>
-__device__ inline int v2_take_over(const AsmArgs &a, ST &S, Arena &A, int r, int &n_pre)
+__device__ inline int v2_take_over(const AsmArgs &a, ST &S, Arena &A, PackedMirror &M, int r, int &n_pre)
 {
 	const int lane = lane_id();
 	const uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
@@ -588,8 +594,15 @@ __device__ inline int v2_take_over(const AsmArgs &a, ST &S, Arena &A, int r, int
 		LDS_ORDER();
 	}
 	LDS_ORDER();
+	// the packed bases go into the mirror as they are (one pad dword behind every contig), and as bytes into the arena
+	const int pnd = lane < n ? ((d_len + 15) >> 4) + 1 : 0;
+	const unsigned pincl = wave_scan_add((unsigned)pnd);
+	const int pmo = (int)pincl - pnd, ptotal = __builtin_amdgcn_readlane((int)pincl, 63);
+	M.on = ptotal + 2 <= M.cap;
+	M.bump = M.on ? ptotal : 0;
+	if (M.on && lane < n) { M.pm_dw[lane] = (unsigned short)pmo; M.pm_sh[lane] = 0; }
 	for (int c = 0; c < n; ++c) {                                // bases: four per lane, one dword store
-		const int len = bcast(d_len, c), bo = bcast(boff, c);
+		const int len = bcast(d_len, c), bo = bcast(boff, c), po = bcast(pmo, c);
 		const uint32_t *src = H + bcast(d_poff, c);
 		uint32_t *dst = (uint32_t *)(A.seq + bo);
 		for (int i4 = lane; 4 * i4 < len; i4 += 64) {
@@ -598,9 +611,219 @@ __device__ inline int v2_take_over(const AsmArgs &a, ST &S, Arena &A, int r, int
 			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
 			dst[i4] = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
 		}
+		if (M.on) for (int d = lane; d <= (len + 15) >> 4; d += 64) M.PM[po + d] = 16 * d < len ? src[d] : 0u;
 	}
 	WSYNC();
 	return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ combine phase
+// Packed mirror of the byte arena for the exact scans of combine (contig.nim:254-281): slot s has its bases 2 bits each
+// at dword pm_dw[s] of PM, starting pm_sh[s] bases into that dword (trim only moves the start).  The bytes stay the
+// authoritative copy: votes, corrections, inserts and trims work on them (contig_dev.h); a contig that an insert has
+// changed is packed again.  When the mirror runs out of room it is switched off and the byte scans take over.
+// Pack slot s again from its bytes (after an insert changed them).
+template <class ST>
+__device__ inline void pm_repack(const ST &S, const Arena &A, PackedMirror &M, int s)
+{
+	if (!M.on) return;
+	const int lane = lane_id();
+	const int len = uni(S.len[s]), off = uni(S.off[s]);
+	const int nd = (len + 15) >> 4;
+	if (M.bump + nd + 2 > M.cap) { M.on = false; return; }
+	const uint32_t *a32 = (const uint32_t *)A.seq;
+	for (int d = lane; d <= nd; d += 64) {
+		unsigned out = 0;
+		if (d < nd) {
+			unsigned junk = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) out |= pack4(ld32u(a32, off + 16 * d + 4 * k), junk) << (8 * k);
+			const int rem = len - 16 * d;
+			if (rem < 16) out &= (1u << (2 * rem)) - 1u;
+		}
+		M.PM[M.bump + d] = out;
+	}
+	if (lane == 0) { M.pm_dw[s] = (unsigned short)M.bump; M.pm_sh[s] = 0; }
+	M.bump += nd + 1;
+	LDS_ORDER();
+}
+
+// best_match (contig.nim:224-240) in the combine phase.  Pairs for which the vote rule can fire (may_allow) get the generic
+// byte scan one after the other, as in best_match_all<ST, true>; all others are exact matches and are found on the packed
+// mirror: target offsets with one dword of one contig per lane (16 windows against the query's first 16 bases), query
+// offsets with one offset per lane against the contigs' first 16 bases; survivors verified on the whole overlap and
+// ranked under the reference's total order.
+template <class ST>
+__device__ inline Best best_match_combine_packed(const ST &S, const Arena &A, const PackedMirror &M, int qs, const short *list, int n,
+                                                 int min_overlap, int max_mm)
+{
+	const int lane = lane_id();
+	n = uni(n); min_overlap = uni(min_overlap); qs = uni(qs);
+	const int qlen = uni(S.len[qs]);
+	const int omin = qlen - min_overlap;                         // contig.nim:78
+	if (!M.on || max_mm != 0 || min_overlap < 17 || omin < 0 || qlen < 16) return best_match_combine(S, A, qs, list, n, min_overlap, max_mm);
+	IHP_T0(A);
+	const uint32_t *PM = M.PM;
+	const int qd = uni((int)M.pm_dw[qs]), qsh = uni((int)M.pm_sh[qs]);
+	const unsigned qh = (unsigned)uni((int)fsh(PM[qd + 1], PM[qd], 2u * (unsigned)qsh));
+	const unsigned qmin = (unsigned)uni((int)S.smin[qs]), qmax = (unsigned)uni((int)S.smax[qs]);
+	const long long qreads = uni(S.nreads[qs]);
+	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
+	Best G = {0, 0, 0, -1, -1, 0};                               // best of the pairs that need the generic scan
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int m = n - c0 < 64 ? n - c0 : 64;
+		int m_ts = 0, m_len = 0, m_d = 0, m_sh = 0; unsigned m_head = 0;
+		bool use = lane < m, votes = false;
+		if (use) {
+			m_ts = list[c0 + lane]; m_len = S.len[m_ts]; m_d = M.pm_dw[m_ts]; m_sh = M.pm_sh[m_ts];
+			m_head = fsh(PM[m_d + 1], PM[m_d], 2u * (unsigned)m_sh);
+			if (m_ts == qs) use = false;                         // :227
+			else {
+				const unsigned tmin = S.smin[m_ts], tmax = S.smax[m_ts];
+				const long long treads = S.nreads[m_ts];
+				votes = (qmin < 3u && tmax > 3u * qmin && qreads > 3ll * (long long)qmin) ||
+				        (tmin < 3u && qmax > 3u * tmin && treads > 3ll * (long long)tmin);
+				if (votes) use = false;
+			}
+		}
+		if (ballot(lane < m && m_len < 16)) { IHP_T1(A, 5); return best_match_combine(S, A, qs, list, n, min_overlap, max_mm); }
+		unsigned long long gm = ballot(votes);
+		while (gm) {                                             // the vote rule may fire: generic scan on the bytes
+			const int i = ctz64(gm);
+			gm &= gm - 1;
+			IHP_T0(A);
+			slide_scan(S, A, qs, __builtin_amdgcn_readlane(m_ts, i), c0 + i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, G);
+			IHP_T1(A, 4);
+		}
+		// ---- offsets 0 .. len(t) - min_overlap on the contigs (:79-111): items = dwords that hold such an offset
+		const int nit = use && m_len >= min_overlap ? ((m_sh + m_len - min_overlap) >> 4) + 1 : 0;
+		const unsigned incl = wave_scan_add((unsigned)nit), excl = incl - (unsigned)nit;
+		const int Q = __builtin_amdgcn_readlane((int)incl, 63);
+		for (int g0 = 0; g0 < Q; g0 += 64) {
+			const int g = g0 + lane;
+			int own = 0;                                         // the last entry that starts at or before g owns it
+			for (int i = 0; i < m; ++i) own = g >= __builtin_amdgcn_readlane((int)excl, i) && __builtin_amdgcn_readlane(nit, i) ? i : own;
+			const int o_d = __builtin_amdgcn_ds_bpermute(own << 2, m_d), o_ex = __builtin_amdgcn_ds_bpermute(own << 2, (int)excl);
+			unsigned w0 = 0, w1 = 0;
+			bool any = false;
+			if (g < Q) {
+				const int dw = o_d + (g - o_ex);
+				w0 = PM[dw]; w1 = PM[dw + 1];
+				any = window_any(w0, w1, qh);
+			}
+			unsigned long long hm = ballot(any);
+			while (hm) {
+				const int e = ctz64(hm);
+				hm &= hm - 1;
+				unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
+				const int i = __builtin_amdgcn_readlane(own, e);
+				const int k = g0 + e - __builtin_amdgcn_readlane((int)excl, i);
+				const int tlen = __builtin_amdgcn_readlane(m_len, i), td = __builtin_amdgcn_readlane(m_d, i), tsh = __builtin_amdgcn_readlane(m_sh, i);
+				const int ts = __builtin_amdgcn_readlane(m_ts, i);
+				while (bits) {
+					const int o = 16 * k + __builtin_ctz(bits) - tsh;
+					bits &= bits - 1;
+					if (o < 0 || o > tlen - min_overlap) continue;
+					const int cn = qlen < tlen - o ? qlen : tlen - o;
+					const int pos = c0 + i;
+					if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (0 > B.ph || (0 == B.ph && o >= B.o))))))) continue;
+					if (bits_equal(PM, qd, 2u * (unsigned)qsh, td + ((tsh + o) >> 4), 2u * (unsigned)((tsh + o) & 15), cn)) {
+						B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = o; B.ph = 0; B.o = o;
+					}
+				}
+			}
+		}
+		// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
+		const unsigned long long usem = ballot(use);
+		for (int ob = 0; ob <= omin; ob += 64) {
+			const int o_l = ob + lane;
+			const bool valid = o_l >= 1 && o_l <= omin;
+			unsigned wq = 0;
+			if (valid) { const int b = qsh + o_l; wq = fsh(PM[qd + (b >> 4) + 1], PM[qd + (b >> 4)], 2u * (unsigned)(b & 15)); }
+			unsigned long long anym = 0;
+			for (int i = 0; i < m; ++i) anym |= ballot(wq == (unsigned)__builtin_amdgcn_readlane((int)m_head, i));
+			if (!(anym & ballot(valid))) continue;               // the usual case: no contig starts inside the query
+			for (int i = 0; i < m; ++i) {
+				if (!((usem >> i) & 1)) continue;
+				unsigned long long mask = ballot(valid && wq == (unsigned)__builtin_amdgcn_readlane((int)m_head, i));
+				if (!mask) continue;
+				const int tlen = __builtin_amdgcn_readlane(m_len, i), td = __builtin_amdgcn_readlane(m_d, i), tsh = __builtin_amdgcn_readlane(m_sh, i);
+				const int ts = __builtin_amdgcn_readlane(m_ts, i);
+				while (mask) {
+					const int o = ob + ctz64(mask);
+					mask &= mask - 1;
+					const int cn = qlen - o < tlen ? qlen - o : tlen;
+					const int pos = c0 + i;
+					if (cn < min_overlap - 1) continue;
+					if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (1 > B.ph || (1 == B.ph && o >= B.o))))))) continue;
+					const int b = qsh + o;
+					if (bits_equal(PM, qd + (b >> 4), 2u * (unsigned)(b & 15), td, 2u * (unsigned)tsh, cn)) {
+						B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = -o; B.ph = 1; B.o = o;
+					}
+				}
+			}
+		}
+	}
+	IHP_T1(A, 5);
+	// more matches, then fewer mismatches, then the earlier contig (contig.nim:32-36, :107, :239)
+	if (G.found && (!B.b.found || G.ma > B.b.ma || (G.ma == B.b.ma && (G.mm < B.b.mm || (G.mm == B.b.mm && G.pos < B.b.pos))))) return G;
+	return B.b;
+}
+
+// combine_pass (contig_dev.h; contig.nim:263-281) with the exact scans on the packed mirror.
+template <class ST>
+__device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, short *in, int n, short *out, long long min_support,
+                                          int combine_min_overlap, int max_mm)
+{
+	const int lane = lane_id();
+	int nout = 0, usedi = 0;
+	for (int i = 0; i < n; ++i) {                                  // :265-271
+		const int c = in[i];
+		if (min_support > 0) {
+			const long long ms = S.nreads[c] < min_support ? S.nreads[c] : min_support;
+			IHP_T0(A);
+			const int off0 = uni(S.off[c]);
+			trim_dev(S, A, c, ms);
+			const int moved = uni(S.off[c]) - off0;                // the trim only moves the slot's start (and length)
+			if (moved && M.on && lane == 0) { const int b = M.pm_sh[c] + moved; M.pm_dw[c] = (unsigned short)(M.pm_dw[c] + (b >> 4)); M.pm_sh[c] = (unsigned char)(b & 15); }
+			recompute_minmax(S, A, c);
+			IHP_T1(A, 7);
+		}
+		if (S.nreads[c] > 0 && nout == 0) {
+			if (lane == 0) out[0] = (short)c;
+			nout = 1; usedi = i;
+		}
+	}
+	WSYNC();
+	if (nout == 0) {                                               // :272
+		for (int i = lane; i < n; i += 64) S.alive[in[i]] = 0;
+		WSYNC();
+		return 0;
+	}
+	for (int i = 0; i < n; ++i) {                                  // :274-281
+		if (i == usedi) continue;
+		const int c = in[i];
+		Best b = best_match_combine_packed(S, A, M, c, out, nout, combine_min_overlap, max_mm);
+		if (b.found) {
+			IHP_T0(A);
+			const int nc = emit_corrections(S, A, c, b.slot, b.off, IHP_ALLOW_DEFAULT);
+			if (nc < 0) return IHP_E_CAPACITY;
+			const int rc = insert_dev(S, A, b.slot, c, b.off, nc);
+			if (rc) return rc;
+			if (lane == 0) S.alive[c] = 0;
+			recompute_minmax(S, A, b.slot);
+			pm_repack(S, A, M, b.slot);
+			IHP_T1(A, 6);
+		} else if (S.nreads[c] > 0) {
+			if (lane == 0) out[nout] = (short)c;
+			nout++;
+		} else {
+			if (lane == 0) S.alive[c] = 0;
+		}
+		WSYNC();
+	}
+	return nout;
 }
 
 }  // namespace ihp

@@ -680,8 +680,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 12 };      // work-queue counter sets: 9 assembly launches, ksw2, tally, fallback
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_WORDS = 24 };
+enum { WQ_SETS = 13 };      // work-queue counter sets: 10 assembly launches, ksw2, tally, fallback
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_WORDS = 24 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -697,7 +697,8 @@ struct ihp_batch {
 	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
 	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
 	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_sup, v2_hoff, v2_hand;
-	bool v2 = false; int v2_arena = 0, v2_pdw = 0, grid_v2 = 0, grid_v2r = 0, grid_pack = 0, grid_ovf1 = 0;
+	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, grid_v2 = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
+	DBuf retry_listc, v2_sup_big;
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
 	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -759,11 +760,12 @@ static int alloc_work(ihp_batch *b)
 	AL(lds_sup2, sizeof(uint32_t) * (size_t)b->lds_arena2 * b->grid_asm2);
 	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
-	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_sup, sizeof(uint32_t) * (size_t)b->v2_arena * b->grid_v2); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords); }
+	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_sup, sizeof(uint32_t) * (size_t)b->v2_arena * b->grid_v2); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords);
+		AL(retry_listc, sizeof(int) * (size_t)R); AL(v2_sup_big, sizeof(uint32_t) * (size_t)b->v2_arena_big * b->grid_v2big); }
 	AL(retry_list2, sizeof(int) * (size_t)R);
 	AL(retry_list3, sizeof(int) * (size_t)R);
 	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
-	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, b->grid_v2), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, std::max(b->grid_v2, b->grid_v2big)), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	if (p->fallback) {
@@ -791,7 +793,7 @@ static int alloc_work(ihp_batch *b)
 
 static void release_work(ihp_batch *b)
 {
-	DBuf *bufs[] = {&b->retry_list0, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
+	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->v2_sup_big, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
 	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
@@ -935,14 +937,26 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * 6 / 10 + 64;
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave
-			const int occ_c = (int)std::max<long long>(1, std::min<long long>(20, g.max_lds / (need_arena + 3840)));
+			// combine kernel: RegionStateT<64> + mirror arrays (4 KB static) + byte arena + packed mirror
+			const char *epm = getenv("IHP_V2_PM"), *eocc = getenv("IHP_V2_OCC");
+			const bool pm_on = !(epm && epm[0] == '0');                   // diagnostics: packed mirror for combine's exact scans
+			const int occ_max = eocc ? atoi(eocc) : 16;       // 16: the arena then holds every C2-like region (a region sent to the roomy launch costs a whole serial chain)
+			const long long need_pm = pm_on ? (nb1 / 16 * 4 / 10 + 96 + 3) / 4 * 4 : 0;
+			b->v2_pm = (int)need_pm;
+			need_arena = std::max<long long>(1024, need_arena - 768);       // the usual region needs ~0.25 of its read bases; the rest goes to the roomy launch
+			const int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / (need_arena + 4 * need_pm + 4096)));
 			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
-			need_arena = std::max<long long>(need_arena, (g.max_lds / occ_c - 3840) / 16 * 16);
+			need_arena = std::max<long long>(need_arena, (g.max_lds / occ_c - 4096 - 4 * need_pm) / 16 * 16);
+			// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
+			b->v2_arena_big = (int)std::min<long long>(g.max_lds - 32768, std::max<long long>(4 * need_arena, (nb1 + 1024 + 15) / 16 * 16));
+			b->v2_pm_big = (int)std::min<long long>(4096, 4 * need_pm);
+			(void)pm_on;
+			b->grid_v2big = grid_for(R, std::max(1, std::min(2, g.max_lds / (b->v2_arena_big + 4 * b->v2_pm_big + 4096))));
 			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
 			b->v2_arena = e1 ? atoi(e1) : (int)need_arena;
 			b->v2_pdw = e2 ? atoi(e2) : (int)need_pdw;
 			b->v2_pdw = b->v2_pdw / 4 * 4;
-			const int per_wave = b->v2_arena + 3840, per_wave_r = 4 * b->v2_pdw + 256;
+			const int per_wave = b->v2_arena + 4 * b->v2_pm + 4096, per_wave_r = 4 * b->v2_pdw + 256;
 			if (per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
 			else {
 				const char *ew = getenv("IHP_ASM_WAVES"), *er = getenv("IHP_ASMR_WAVES");
@@ -1081,7 +1095,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.t_start = nullptr;
-		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr;
+		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_pm_dw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr;
 		// Passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  Every region
 		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
 		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
@@ -1144,8 +1158,14 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				else if (minw >= 6) hipLaunchKernelGGL((k_asm_reads<6>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
 				else hipLaunchKernelGGL((k_asm_reads<4>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
 			}
-			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS;
-			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2), dim3(64), b->v2_arena, s, x);
+			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS; x.v2_pm_dw = b->v2_pm;
+			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
+			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			// regions whose contigs did not fit that arena: the same kernel with a roomy one (few workgroups per CU)
+			x.in_list = b->retry_listc.as<int>(); x.n_in = misc + M_NRETRYC; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0;
+			x.arena_sup = b->v2_sup_big.as<uint32_t>(); x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
+			x.work_counter = wq + 12 * WQ_WORDS;
+			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
 			HIPC(hipGetLastError());
 			if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 1);
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
@@ -1297,7 +1317,8 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	out[25] = b->report[M_NRETRY2];                   // ... to the third pass's
 	out[26] = b->report[M_NRETRY3];                   // ... and to the catch-all (HBM-arena) pass
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
-	out[23] = b->report[M_NRETRY0];                   // regions the packed read phase handed back to the byte-based class-1 kernel
+	out[23] = b->report[M_NRETRY0];                   // regions the packed path handed back to the byte-based class-1 kernel
+	out[28] = b->report[M_NRETRYC];                   // regions whose contigs needed the roomy combine launch
 	return 0;
 }
 

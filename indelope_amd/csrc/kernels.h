@@ -41,6 +41,7 @@ struct AsmArgs {
 	// packed read phase (asm2_dev.h): what k_prepack left -- 2-bit bases, the kept range of every read, "not ACGT" flags
 	const uint32_t *v2_pk; const int *v2_trim_lo, *v2_trim_hi; const uint8_t *v2_read_bad;
 	int v2_pdw;                                        // dwords of the per-wave packed area in LDS (k_asm_reads)
+	int v2_pm_dw;                                      // dwords of the packed mirror behind the byte arena (k_asm_combine)
 	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine: region r at v2_hand + v2_hoff[r]
 };
 
@@ -443,12 +444,16 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
 	typedef RegionStateT<64> ST;
 	__shared__ ST S;
 	__shared__ int s_item;
+	__shared__ unsigned short s_pm_dw[ST::MAXC + 1];
+	__shared__ unsigned char s_pm_sh[ST::MAXC + 1];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
 	const int lane = lane_id();
 	Arena A;
 	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
 	A.seq = lds_arena; A.cap = a.lds_arena - 16; A.stage_off = a.lds_arena - 16;        // no staging area: reads never enter the byte arena
 	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof ? S.prof : nullptr;
+	PackedMirror M;
+	M.PM = (uint32_t *)(lds_arena + a.lds_arena); M.cap = a.v2_pm_dw; M.bump = 0; M.pm_dw = s_pm_dw; M.pm_sh = s_pm_sh; M.on = false;
 	mark_start(a.t_start);
 	if (lane < 16) S.prof[lane] = 0;
 	WSYNC();
@@ -463,21 +468,21 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
 		if (a.in_list) r = a.in_list[r];
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
-		int err = v2_take_over(a, S, A, r, n_pre);
+		int err = v2_take_over(a, S, A, M, r, n_pre);
 		if (err == 1) continue;                                // the read phase did not take this region
 		const long long tcA = a.prof ? (long long)clock64() : 0;
 		if (!err) {
-			const int n2 = combine_pass(S, A, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
+			const int n2 = combine_pass_packed(S, A, M, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
 			if (n2 < 0) err = n2;
 			else {
 				WSYNC();
-				const int n3 = combine_pass(S, A, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap, a.max_mismatch);
+				const int n3 = combine_pass_packed(S, A, M, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap, a.max_mismatch);
 				if (n3 < 0) err = n3; else n_final = n3;
 			}
 		}
 		WSYNC();
 		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[1] += (long long)clock64() - tcA; S.prof[3] += 1; }
-		if (err == IHP_E_CAPACITY && a.out_list) {             // no room here: the byte-based passes take it
+		if (err == IHP_E_CAPACITY && a.out_list) {             // no room here: the next, roomier launch (or the byte-based passes) take it
 			if (lane == 0) a.out_list[atomicAdd(a.n_out, 1)] = r;
 			WSYNC();
 			continue;
