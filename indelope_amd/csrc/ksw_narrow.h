@@ -410,4 +410,120 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	return true;
 }
 
+// ---- the same sweep in pieces, for ksw_pair.h (two alignments side by side); ksw_wave_narrow above stays in one piece: split
+// like this it needed 12 more VGPRs at 8 waves per SIMD and spilled them ----
+// narrow_prepare: result reset, early outs, LDS tables, state.  Returns 0 to go on, 1 when `out` is already final
+// (:147, :171), 2 when the job is not for this sweep (a code outside the 5-letter alphabet).
+__device__ __forceinline__ int narrow_prepare(const uint8_t *query, int qlen, const uint8_t *target, int tlen, const KswParams &P, uint8_t *lds,
+                                     uint8_t *p, KswOut &out, NarrowState &F, NarrowEnv &E)
+{
+	const int lane = lane_id();
+	const int w = P.w;
+	const int q = P.q, e = P.e, qe = q + e;
+	out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;   // :81-86
+	out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = 0;
+	if (qlen <= 0 || tlen <= 0) return 1;                // :147
+	if (-P.min_sc > 2 * (q + e)) return 1;               // :171
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int ncol = n_col_ * 16;
+	const int TP = (tlen + 15) / 16 * 16 + 96, QR = (qlen + 15) / 16 * 16 + 96;
+	uint2 *tbl = (uint2 *)lds;                           // 5 entries, 64 bytes reserved
+	uint8_t *tg = lds + 64;                              // target codes, zero padded (sf of :175,:188)
+	unsigned *qs = (unsigned *)(tg + TP) + 16;           // selector words of the reversed query, padded with code 0 on
+	                                                     // both sides (:187): every index qlen-1-r+t a lane can form is in [-16, QR)
+	const unsigned ZW = (unsigned)(2 * qe) & 0xff, ZM = (unsigned)(2 * qe + P.sc_mch) & 0xff, ZX = (unsigned)(2 * qe + P.sc_mis) & 0xff;
+	if (lane < 5) {
+		uint2 t;
+		if (lane == 4) { t.x = ZW * 0x01010100u; t.y = ZW * 0x0101u; }     // :219-226 wildcard target
+		else {
+			t.x = (lane == 0 ? ZM : ZX) << 8 | (lane == 1 ? ZM : ZX) << 16 | (lane == 2 ? ZM : ZX) << 24;
+			t.y = (lane == 3 ? ZM : ZX) | ZW << 8;
+		}
+		tbl[lane] = t;
+	}
+	bool bad = false;                                    // a code outside the alphabet: not for this sweep
+	for (int i = lane; i < TP; i += 64) {
+		uint8_t b = 0;
+		if (i < tlen) { b = target[i]; if (P.encode_ascii) b = enc_base(b); }
+		bad |= b > 4;
+		tg[i] = b;
+	}
+	if (lane < 16) qs[lane - 16] = 1u << 24 | 0x000c0c0cu;
+	for (int i = lane; i < QR; i += 64) {
+		unsigned b = 0;
+		if (i < qlen) { b = query[qlen - 1 - i]; if (P.encode_ascii) b = enc_base((uint8_t)b); }
+		bad |= b > 4;
+		qs[i] = (b + 1) << 24 | 0x000c0c0cu;
+	}
+	if (ballot(bad)) return 2;
+	WSYNC();
+	F.XA = F.VA = F.UA = F.YA = 0; F.ZA = (int)(ZW << 24);
+	F.XB = F.VB = F.UB = F.YB = 0;
+	{
+		const uint2 ta = tbl[tg[lane]], tb = tbl[tg[64 + (lane & 15)]];
+		F.T1A = ta.x; F.T0A = ta.y; F.T1B = tb.x; F.T0B = tb.y;
+	}
+	F.rlB = -1; F.HA = F.HB = KSW_NEG_INF; F.st = 0; F.qptr = qs + (qlen - 1 + lane); F.qoffB = 64 + (lane & 15) - lane;
+	F.edge_h = KSW_NEG_INF; F.last_sc = -1;
+	F.ez_max = 0; F.ez_max_t = F.ez_max_q = -1; F.mqe = F.mte = F.score = KSW_NEG_INF; F.mqe_t = F.mte_q = -1;
+	E.tg = tg; E.qs = qs; E.tbl = tbl; E.p = p; E.qlen = qlen; E.tlen = tlen; E.w = w; E.ncol = ncol; E.qe = qe; E.e = e;
+	E.zdrop = P.zdrop; E.ZW24 = (int)(ZW << 24); E.M24 = ZM << 24; E.q24 = (int)(((unsigned)q & 0xff) << 24);
+	return 0;
+}
+
+// Where the steady diagonals of a job end: st0 = (r-w+1)>>1 > r-qlen+1, en0 = (r+w)>>1 < tlen-1, en < r
+__device__ __forceinline__ int narrow_r_hi(int qlen, int tlen, int w)
+{
+	int r_hi = 2 * tlen - 3 - w < 2 * qlen - w - 3 ? 2 * tlen - 3 - w : 2 * qlen - w - 3;
+	const int total = qlen + tlen - 1;
+	return r_hi + 1 < total ? r_hi + 1 : total;
+}
+__device__ __forceinline__ bool narrow_roomy(int qlen, int tlen, int w) { return qlen >= w + 32 && tlen >= w + 32; }   // the first w+31 diagonals stay clear of the sequence ends
+
+// diagonals 0 .. w+30 (w+31 when not roomy); r is the next diagonal on return
+template <bool RIGHT>
+__device__ __forceinline__ void narrow_head(NarrowState &F, const NarrowEnv &E, int &r, bool &stop, bool &tracked)
+{
+	const int w = E.w, total = E.qlen + E.tlen - 1;
+	stop = narrow_diag<RIGHT, ND_FIRST>(F, E, 0);
+	r = 1;
+	tracked = true;                                      // F.rlB is up to date
+	if (!stop && narrow_roomy(E.qlen, E.tlen, w)) {
+		do { if (narrow_diag<RIGHT, ND_EARLY>(F, E, r)) { stop = true; break; } } while (++r < w + 31);
+		tracked = false;
+	} else if (!stop) {
+		for (; r < total && r < w + 32; ++r) if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) { stop = true; break; }
+	}
+}
+
+// the steady diagonals from r on, then whatever is left
+template <bool RIGHT>
+__device__ __forceinline__ void narrow_rest(NarrowState &F, const NarrowEnv &E, int &r, bool &stop, bool &tracked)
+{
+	const int lane = lane_id();
+	const int w = E.w, total = E.qlen + E.tlen - 1, r_hi = narrow_r_hi(E.qlen, E.tlen, w);
+	if (w >= 49 && !stop && r < r_hi) {                  // w >= 49: a steady band spans blocks 0..3
+		int st0 = (r - w + 1) >> 1, en0 = (r + w) >> 1;
+		do {
+			if (narrow_diag<RIGHT, ND_STEADY>(F, E, r, st0, en0)) { stop = true; break; }
+			const int up = (r + w) & 1;                  // (r+w)>>1 grows on the step from an odd r+w, (r-w+1)>>1 otherwise
+			en0 += up; st0 += 1 - up;
+		} while (++r < r_hi);
+		F.last_sc = ((r - w) >> 1) - F.st + 63;          // of diagonal r-1 (st0 - st + 63)
+		tracked = false;
+	}
+	if (!stop) {
+		if (!tracked) F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;   // what the growing diagonals did not track (see narrow_diag)
+		for (; r < total; ++r) if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) { stop = true; break; }
+	}
+}
+
+__device__ __forceinline__ void narrow_finish(const NarrowState &F, const NarrowEnv &E, bool stop, int flag, uint8_t *p, uint32_t *cig_tmp, int cig_cap, KswOut &out)
+{
+	out.max = F.ez_max; out.zdropped = stop ? 1 : 0; out.max_q = F.ez_max_q; out.max_t = F.ez_max_t;   // every early exit is a z-drop (:98-101, :200-203)
+	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.score;
+	ksw_backtrack_wave(p, E.ncol, E.qlen, E.tlen, E.w, flag, stop ? 1 : 0, F.ez_max_t, F.ez_max_q, cig_tmp, cig_cap, out);
+}
+
 }  // namespace ihp
