@@ -419,22 +419,28 @@ def main():
         traffic, traffic_source, issue = None, None, None
         pmc, mix = os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, MIX_FILE)
         same = args.config == "C2" and R == 10_000 and S == 2 and not strong
+        # the launches a stage consists of (the assembly stage is the packed read phase, the combine phase and the byte-based
+        # passes behind them; the empty ones count too)
+        members = {"k_assemble": ("k_prepack", "k_asm_reads", "k_asm_combine", "k_assemble"), "k_ksw": ("k_ksw",), "k_tally": ("k_tally",)}[KERNELS[dom]]
+        base = lambda n: n.split("<")[0].split("::")[-1].strip()
         if same and os.path.exists(pmc):
             k = json.load(open(pmc))["kernels"]
-            t = [v["traffic"] for n, v in k.items() if n.split("<")[0].split("::")[-1] == KERNELS[dom] and v.get("traffic")]
+            t = [v["traffic"] * v.get("launches_per_stage", 1) for n, v in k.items() if base(n) in members and v.get("traffic")]
             if t:
-                traffic, traffic_source = int(max(t)), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+                traffic, traffic_source = int(sum(t)), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload; sum over the stage's launches)"
         if same and os.path.exists(mix):
             try:
                 k = json.load(open(mix))
+                va = sa = cyc = 0.0
                 for n, v in k.items():
-                    if n.split("<")[0].split("::")[-1] == KERNELS[dom] and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
-                        cyc = float(v["GRBM_GUI_ACTIVE"]) * 256
-                        va, sa = float(v["SQ_INSTS_VALU"]) / cyc, float(v.get("SQ_INSTS_SALU", 0)) / cyc
-                        issue = {"valu_per_cycle_per_cu": round(va, 3), "salu_per_cycle_per_cu": round(sa, 3),
-                                 "issue_frac": round((va + sa) / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
-                                 "source": MIX_FILE + "; peak = VALU+SALU interleaved at 8 waves/SIMD, tools/ubench_issue.hip"}
-                        break
+                    if base(n) in members and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: CU-cycles of a launch = (GUI / 8) x 256 CUs
+                        va += float(v["SQ_INSTS_VALU"]); sa += float(v.get("SQ_INSTS_SALU", 0)); cyc += float(v["GRBM_GUI_ACTIVE"]) * 32
+                if cyc:
+                    issue = {"valu_per_cycle_per_cu": round(va / cyc, 3), "salu_per_cycle_per_cu": round(sa / cyc, 3),
+                             "issue_frac": round((va + sa) / cyc / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
+                             "source": MIX_FILE + " (SQ_INSTS_VALU + SQ_INSTS_SALU over GRBM_GUI_ACTIVE/8 x 256 CU-cycles, summed over the stage's kernels); "
+                                       "peak = VALU+SALU interleaved at 8 waves/SIMD, tools/ubench_issue.hip"}
             except Exception:
                 pass
         out = {
@@ -456,7 +462,7 @@ def main():
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
                                     "records per step" + (" + result slabs to rank 0" if args.payload else "")) if world > 1 else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
-            "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(by_kernel[KERNELS[dom]]),
                          "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] * len(keep) / max(n_kept, 1), 1),

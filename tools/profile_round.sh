@@ -1,23 +1,45 @@
 #!/bin/bash
-# Round profile of the default bench workload (C2) on the GPU box:
-#   rocprofv3 --kernel-trace --stats  -> gpurun_out/prof/stats  (per-kernel time)
-#   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)   -> gpurun_out/prof/pmc_traffic.json
-#   instruction-mix passes (tools/pmc_mix.sh)                   -> gpurun_out/pmc_mix/mix.json
-#   bench.py (default flags, with cpu_baseline)                 -> gpurun_out/prof/bench.json
-# Copy what should be judged into profiles/ afterwards (see profiles/README.md).
+# Round profile on the GPU box (one gpurun call).  Everything lands in gpurun_out/prof; copy what should be judged into
+# profiles/ afterwards (tools/collect_profiles.py does, see profiles/README.md).
+#   default C2 bench under rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE / WRITE_SIZE (separate passes), the
+#   instruction-mix passes (tools/pmc_mix.sh), the plain bench line (with cpu_baseline, e2e, oracle check);
+#   steady state (100 000 regions, one chain): kernel stats + bench line + instruction mix;
+#   C3 / C5 kernel stats and bench lines, C2 variants (--quals, --dup-frac 0.1, --sub-batches 1), a C4 strong-scaling
+#   run on this one GPU (1.25 M regions in 8 resident chunks), the issue-rate microbenchmark.
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 5 --warmup 2 --no-cpu"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
+ARGS="--steps 5 --warmup 2 --no-cpu --no-e2e --no-check"
+stats() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py "$@" > $OUT/$name.log 2>&1; f=$(find $OUT/$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv; }
+stats c2 $ARGS
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1
 python3 tools/pmc_sum.py $OUT/fetch $OUT/write --json $OUT/pmc_raw.json > $OUT/pmc_raw.txt 2>&1
+bash tools/pmc_mix.sh > /dev/null 2>&1
+cp gpurun_out/pmc_mix/mix.json $OUT/c2_pmc_mix.json
+STEADY="--no-cpu --no-e2e --no-check --regions 100000 --steps 3 --warmup 1 --sub-batches 1"
+stats steady100k $STEADY
+bash tools/pmc_mix.sh --regions 100000 --sub-batches 1 > /dev/null 2>&1
+cp gpurun_out/pmc_mix/mix.json $OUT/steady100k_pmc_mix.json
+python3 bench.py $STEADY > $OUT/steady100k_bench.json 2>> $OUT/err
+stats c3 --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check
+stats c5 --config C5 --steps 5 --warmup 2 --no-cpu --no-e2e --no-check
+: > $OUT/other_workloads.jsonl
+python3 bench.py --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --config C5 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --quals >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --dup-frac 0.1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --sub-batches 1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
+IHP_ASM_V1=1 python3 bench.py --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
+IHP_KSW_PAIR=1 python3 bench.py --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --scaling strong --config C4 --regions 1250000 --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/c4_strong_1gpu.json 2>> $OUT/err
+timeout 120 tools/ubench_issue.bin > $OUT/ubench_issue.txt 2>&1
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<'PY'
 import json
 raw = json.load(open("gpurun_out/prof/pmc_raw.json"))
-out = {"workload": "C2 (10000 regions x 64 x 150bp), bench.py --steps 5 --warmup 2",
+out = {"workload": "C2 (10000 regions x 64 x 150bp), bench.py --steps 5 --warmup 2 (two sub-batches of 5000 regions per step)",
        "unit": "bytes per launch",
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = counter(KB) * 1024; "
                "FETCH_SIZE is uncalibrated for narrow accesses on gfx950 (MI355X_MICROARCH.md: reads exactly 1/2 for wide "
@@ -29,11 +51,12 @@ for k, v in raw.items():
         continue
     out["kernels"][k] = {"FETCH_SIZE": int(f * 1024), "WRITE_SIZE": int(w * 1024), "traffic": int((f + w) * 1024),
                          "launches_averaged": v.get("_launches")}
-json.dump(out, open("gpurun_out/prof/pmc_traffic.json", "w"), indent=1)
-print(json.dumps(out["kernels"], indent=1))
+    if k.startswith("k_asm_combine"):
+        out["kernels"][k]["launches_per_stage"] = 2      # the regular and the roomy launch (the average is over both)
+json.dump(out, open("gpurun_out/prof/c2_pmc.json", "w"), indent=1)
 PY
-bash tools/pmc_mix.sh > /dev/null 2>&1
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-cat $OUT/bench.json
-find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
-head -12 $OUT/kernel_stats.csv
+# the raw rocprofv3 output directories are large (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf $OUT/c2 $OUT/steady100k $OUT/c3 $OUT/c5 $OUT/fetch $OUT/write gpurun_out/pmc_mix/g1 gpurun_out/pmc_mix/g2 gpurun_out/pmc_mix/g3
+du -sh gpurun_out
+cat $OUT/bench.json | head -c 1500
+head -14 $OUT/c2_kernel_stats.csv | cut -c1-150
