@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-ISSUE_PEAK = 3.65              # wave-instructions per cycle per CU, VALU+SALU interleaved at 8 waves/SIMD (tools/ubench_issue.hip)
+ISSUE_PEAK = 1.0               # wave64 instructions per cycle per CU and per unit: a 16-lane SIMD takes 4 cycles per VALU instruction and
+                               # the scalar unit serves one SIMD per cycle, so a CU retires at most 1 VALU + 1 SALU per cycle (rocprofv3's
+                               # VALUBusy / SALUBusy definitions; tools/ubench_issue.hip reaches 0.93 / 0.96 by wall clock)
 KERNELS = ["k_assemble", "k_ksw", "k_tally"]
 PMC_FILE = os.path.join("profiles", "r02_c2_pmc.json")
 MIX_FILE = os.path.join("profiles", "r02_c2_pmc_mix.json")
@@ -431,16 +433,20 @@ def main():
         if same and os.path.exists(mix):
             try:
                 k = json.load(open(mix))
-                va = sa = cyc = 0.0
+                va = sa = vb = sb = cyc = 0.0
                 for n, v in k.items():
                     if base(n) in members and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
-                        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: CU-cycles of a launch = (GUI / 8) x 256 CUs
+                        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: CU-cycles of a launch = (GUI / 8) x 256 CUs.  The SQ_ACTIVE_INST_*
+                        # / SQ_INST_CYCLES_* counters are in quad-cycles per SIMD, i.e. in CU-cycles once summed over a CU's 4 SIMDs
                         va += float(v["SQ_INSTS_VALU"]); sa += float(v.get("SQ_INSTS_SALU", 0)); cyc += float(v["GRBM_GUI_ACTIVE"]) * 32
+                        vb += float(v.get("SQ_ACTIVE_INST_VALU", 0)); sb += float(v.get("SQ_INST_CYCLES_SALU", 0))
                 if cyc:
                     issue = {"valu_per_cycle_per_cu": round(va / cyc, 3), "salu_per_cycle_per_cu": round(sa / cyc, 3),
-                             "issue_frac": round((va + sa) / cyc / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
-                             "source": MIX_FILE + " (SQ_INSTS_VALU + SQ_INSTS_SALU over GRBM_GUI_ACTIVE/8 x 256 CU-cycles, summed over the stage's kernels); "
-                                       "peak = VALU+SALU interleaved at 8 waves/SIMD, tools/ubench_issue.hip"}
+                             "valu_busy": round(vb / cyc, 3), "salu_busy": round(sb / cyc, 3),
+                             "issue_frac": round(max(va, sa) / cyc / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
+                             "source": MIX_FILE + " (SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_ACTIVE_INST_VALU, SQ_INST_CYCLES_SALU over GRBM_GUI_ACTIVE/8 x 256 "
+                                       "CU-cycles, summed over the stage's kernels); peak = 1 VALU + 1 SALU wave-instruction per cycle per CU; "
+                                       "issue_frac is the busier of the two units"}
             except Exception:
                 pass
         out = {
