@@ -197,17 +197,6 @@ int ksw_mode(const KswParams &P)
 
 int g_last_ksw_mode = -1;
 
-// Two jobs per wavefront (ksw_pair.h) for the production kernel when both jobs' LDS still leaves 16 waves per CU.
-bool ksw_pair_on(int mode, size_t lds_per_job)
-{
-	// Off unless asked for: measured on MI355X the pair kernel issues a third fewer instructions per alignment but is not
-	// faster (100k regions: 13.4-14.2 ms against 13.0 ms): with 4-5 waves per SIMD instead of 8 the wave-level latency of a
-	// diagonal (DPP chains, LDS selector reads, scalar bookkeeping) is no longer covered.  DESIGN.md section 4.2.
-	const char *e = getenv("IHP_KSW_PAIR");
-	if (!(e && e[0] == '1')) return false;
-	return mode == 3 && 2 * lds_per_job * 4 * KSW_PAIR_WAVES <= (size_t)g.max_lds;
-}
-
 size_t ksw_mode_lds(int mode, int qlen, int tlen)
 {
 	if (mode == 5) return std::max(ksw_lds_bytes(qlen, tlen), std::max(ksw_wide_lds_bytes<3>(qlen, tlen), ksw_wide_lds_bytes<6>(qlen, tlen)));
@@ -221,7 +210,6 @@ template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStr
 	else if (mode == 3) hipLaunchKernelGGL(k_ksw<3>, grid, dim3(64), lds, s, a);
 	else if (mode == 4) hipLaunchKernelGGL(k_ksw<4>, grid, dim3(64), lds, s, a);
 	else if (mode == 5) hipLaunchKernelGGL(k_ksw<5>, grid, dim3(64), lds, s, a);
-	else if (mode == 6) hipLaunchKernelGGL(k_ksw<6>, grid, dim3(64), lds, s, a);
 	else hipLaunchKernelGGL(k_ksw<2>, grid, dim3(64), lds, s, a);
 }
 
@@ -424,19 +412,18 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 		                               : ksw_wide_ok<6>(P, j.qlen, j.tlen) ? ksw_wide_lds_bytes<6>(j.qlen, j.tlen) : (size_t)0));
 		int w = P.w < 0 ? std::max(j.qlen, j.tlen) : P.w;
 		int nc = (std::min(std::min(j.qlen, j.tlen), w + 1) + 15) / 16 + 1;
-		p_need = std::max(p_need, ((size_t)(j.qlen + j.tlen - 1) * nc + 1) * 16);
+		p_need = std::max(p_need, std::max(((size_t)(j.qlen + j.tlen - 1) * nc + 1) * 16, ksw_narrow_p_bytes(j.qlen, j.tlen)));
 		cig_bound += j.qlen + j.tlen;
 		cig_cap = std::max(cig_cap, j.qlen + j.tlen);
 	}
 	if ((long long)lds_need > g.max_lds - 2048) { snprintf(g.err, sizeof(g.err), "alignment needs %zu B of LDS", lds_need); return IHP_E_CAPACITY; }
 	const int mode = ksw_mode(P);
-	const int pair = ksw_pair_on(mode, lds_need + 64) ? 1 : 0;
-	const int grid = grid_for(pair ? (n + 1) / 2 : n, 32);
+	const int grid = grid_for(n, 32);
 	DBuf d_jobs, d_p, d_ct, d_ez, d_coff, d_pool, d_misc;
 	int rc;
 	if ((rc = d_jobs.upload(jobs.data(), sizeof(AlnJob) * n, g.stream))) return rc;
-	if ((rc = d_p.alloc((p_need + 64) * grid * (pair + 1)))) return rc;
-	if ((rc = d_ct.alloc(sizeof(uint32_t) * (size_t)(cig_cap + 4) * grid * (pair + 1)))) return rc;
+	if ((rc = d_p.alloc((p_need + 64) * grid))) return rc;
+	if ((rc = d_ct.alloc(sizeof(uint32_t) * (size_t)(cig_cap + 4) * grid))) return rc;
 	if ((rc = d_ez.alloc(sizeof(KswOut) * n))) return rc;
 	if ((rc = d_coff.alloc(sizeof(long long) * n))) return rc;
 	const long long fixed_words = (long long)n * CIG_SLOT;
@@ -452,9 +439,8 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
 	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
 	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr; a.t_start = nullptr;
-	a.pair = pair;
 	g_last_ksw_mode = mode;
-	launch_ksw(pair ? 6 : g_last_ksw_mode, dim3(grid), (lds_need + 64) * (pair + 1), g.stream, a);
+	launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
 	HIPC(hipMemcpyAsync(ez.data(), d_ez.p, sizeof(KswOut) * n, hipMemcpyDeviceToHost, g.stream));
@@ -727,7 +713,6 @@ struct ihp_batch {
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
 	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
 	bool timing = false;                                   // device wall-clock stamps: start / end of the four stages
-	int ksw_pair = 0;                                      // k_ksw<3> sweeps two jobs per wavefront
 	// everything a run expects to be zero lives in ONE buffer (`misc`): [counters | stamps | work queues | per-region hit
 	// counts].  It is cleared once at upload; after that the last kernel of every run (k_summary) copies the first
 	// REPORT_INTS ints to `report` and clears the buffer for the next run -- a run has no memset.
@@ -783,8 +768,8 @@ static int alloc_work(ihp_batch *b)
 	AL(retry_list3, sizeof(int) * (size_t)R);
 	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
 	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, std::max(b->grid_v2, b->grid_v2big)), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
-	AL(p_scratch, b->p_cap * b->grid_ksw * (b->ksw_pair + 1));
-	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw * (b->ksw_pair + 1));
+	AL(p_scratch, b->p_cap * b->grid_ksw);
+	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	if (p->fallback) {
 		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
@@ -1021,15 +1006,10 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		const int w = p->bw < 0 ? std::max(qmax, tmax) : p->bw;
 		const int nc = (std::min(std::min(qmax, tmax), w + 1) + 15) / 16 + 1;
 		const int qeff = std::min(qmax, tmax + 2 * std::max(w, 64));
-		b->p_cap = ((size_t)(qeff + tmax) * nc + 1) * 16 + 64;
+		b->p_cap = std::max(((size_t)(qeff + tmax) * nc + 1) * 16, ksw_narrow_p_bytes(qeff, tmax)) + 64;
 		b->cig_cap = qeff + tmax + 8;
 	}
 	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_KSW_WAVES") ? atoi(getenv("IHP_KSW_WAVES")) : 32);
-	{
-		int8_t mat[25];
-		ihp_matrix(p->match, p->mismatch, mat);
-		b->ksw_pair = ksw_pair_on(ksw_mode(make_ksw_params(5, mat, p->gap_open, p->gap_ext, p->bw, p->zdrop, p->ksw_flag, 1)), (size_t)b->lds_ksw) ? 1 : 0;
-	}
 	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_TALLY_WAVES") ? atoi(getenv("IHP_TALLY_WAVES")) : 32);
 	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
 	b->njobs_cap = njobs_cap;
@@ -1225,9 +1205,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
 		a.cig_pool_cap = b->cig_pool_cap; a.cig_bump_cap = b->cig_bump_cap; a.overflow = misc + M_OVF; a.work_counter = wq + 7 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
-		a.pair = b->ksw_pair;
 		g_last_ksw_mode = ksw_mode(a.P);
-		launch_ksw(b->ksw_pair ? 6 : g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw * (b->ksw_pair + 1), s, a);
+		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 	}
 	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 3);

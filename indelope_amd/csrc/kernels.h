@@ -4,7 +4,6 @@
 #include "contig_dev.h"
 #include "ksw_dev.h"
 #include "ksw_narrow.h"
-#include "ksw_pair.h"
 #include "ksw_wide.h"
 #include "tally_dev.h"
 #include "roi_dev.h"
@@ -515,8 +514,6 @@ struct KswArgs {
 	int *work_counter;
 	long long *prof;                           // optional cycle counters (diagnostics)
 	unsigned long long *t_start;               // optional: see mark_start()
-	int pair;                                  // MODE 3: a work item is a PAIR of jobs (2j, 2j+1) swept side by side (ksw_pair.h);
-	                                           // LDS, traceback scratch and CIGAR staging hold two jobs per workgroup
 };
 
 // MODE 3: top-byte register-resident sweep (ksw_narrow.h), left-aligned gaps; 4: same, KSW_EZ_RIGHT -- the
@@ -529,10 +526,8 @@ struct KswArgs {
 typedef const __attribute__((address_space(4))) KswArgs *KswArgsK;
 __device__ __forceinline__ KswArgsK ksw_args_again(KswArgsK p) { asm volatile("" : "+s"(p)); return p; }
 
-// MODE 6: MODE 3 with two jobs per wavefront (ksw_pair.h); its registers allow KSW_PAIR_WAVES waves per SIMD.
-constexpr int KSW_PAIR_WAVES = 5;
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 || MODE == 4 ? 8 : MODE == 6 ? KSW_PAIR_WAVES : 1))) void k_ksw(const KswArgs)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 || MODE == 4 ? 8 : 1))) void k_ksw(const KswArgs)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_item;
@@ -542,10 +537,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 	{
 		const KswArgsK a = a0;
 		mark_start(a->t_start);
-		if (a->prof && lane < 4) ((long long *)(lds + (MODE == 6 ? 2 : 1) * (a->lds_budget + 64) - 48))[lane] = 0;   // per-wave cycle counters live past the sweep's LDS
+		if (a->prof && lane < 4) ((long long *)(lds + a->lds_budget + 16))[lane] = 0;   // per-wave cycle counters live past the sweep's LDS
 	}
 	WSYNC();
-	if constexpr (MODE != 6) {
+	{
 		unsigned wq_dead = 0;
 		for (;;) {
 			KswArgsK a = ksw_args_again(a0);
@@ -567,7 +562,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 				if (w < 0) w = jb.tlen > jb.qlen ? jb.tlen : jb.qlen;
 				int ncol_ = jb.qlen < jb.tlen ? jb.qlen : jb.tlen;
 				ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
-				const size_t pneed = ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
+				const size_t pneed = MODE == 3 || MODE == 4 ? ksw_narrow_p_bytes(jb.qlen, jb.tlen)
+				                                            : ((size_t)(jb.qlen + jb.tlen - 1 > 0 ? jb.qlen + jb.tlen - 1 : 0) * ncol_ + 1) * 16;
 				// MODE 5: bands wider than the register layouts of MODE 0-4 (w < 0 or w > 62): the ring sweep of ksw_wide.h when
 				// the job fits it (3 or 6 slots), the LDS sweep otherwise
 				const int wide = MODE != 5 ? 0 : ksw_wide_ok<3>(P, jb.qlen, jb.tlen) ? 3 : ksw_wide_ok<6>(P, jb.qlen, jb.tlen) ? 6 : 0;
@@ -621,126 +617,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 			if (lane == 0) { a->ez[jb.out] = out; a->cig_off[jb.out] = off; }
 			WSYNC();
 		}
-	} else {
-		unsigned wq_dead = 0;
-		// results of one job -> its slots (CIGAR words from the staging area `ct`)
-		auto emit = [&](const int j, const AlnJob &jb, KswOut &out, const uint32_t *ct) {
-			const KswArgsK a = ksw_args_again(a0);
-			long long off = -1;
-			if (out.n_cigar > 0) {
-				if (out.n_cigar <= CIG_SLOT) off = a->cig_bump_cap + (long long)j * CIG_SLOT;   // the job's own slot: no atomic
-				else {
-					if (lane == 0) s_off = (long long)atomicAdd(a->cig_cursor, (unsigned long long)out.n_cigar);
-					WSYNC();
-					off = s_off;
-					if (off + out.n_cigar > a->cig_bump_cap) off = a->cig_pool_cap;     // bump region exhausted
-				}
-				if (off + out.n_cigar <= a->cig_pool_cap) {
-					uint32_t *pool = a->cig_pool;
-					for (int i = lane; i < out.n_cigar; i += 64) pool[off + i] = ct[i];
-				} else {
-					if (lane == 0) atomicExch(&a->overflow[0], 1);
-					off = -1;
-				}
-			} else if (out.n_cigar < 0) {
-				if (lane == 0) atomicExch(&a->overflow[1], 1);             // LDS / traceback scratch budget
-			}
-			if (lane == 0) { a->ez[jb.out] = out; a->cig_off[jb.out] = off; }
-			WSYNC();
-		};
-		auto too_big = [](KswOut &out) {
-			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
-			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
-		};
-		for (;;) {
-			KswArgsK a = ksw_args_again(a0);
-			const int njobs = a->n_jobs ? *a->n_jobs : a->n_jobs_host;
-			constexpr bool pairs = MODE == 6;
-			const int nitems = pairs ? (njobs + 1) >> 1 : njobs;
-			if (lane == 0) s_item = wq_next(a->work_counter, nitems, (int)blockIdx.x, wq_dead);
-			WSYNC();
-			const int item = __builtin_amdgcn_readfirstlane(s_item);   // wave-uniform by construction; tells the compiler so
-			WSYNC();
-			if (item < 0) break;
-			const int j = pairs ? 2 * item : item;
-			const AlnJob jb = a->jobs[j];
-			const size_t pstride = pairs ? 2 * a->p_cap : a->p_cap;
-			const int cstride = pairs ? 2 * a->cig_cap : a->cig_cap;
-			uint8_t *p = a->p_scratch + (size_t)blockIdx.x * pstride;
-			uint32_t *ct = a->cig_tmp + (size_t)blockIdx.x * cstride;
-			const KswParams P = {a->P.m, a->P.sc_mch, a->P.sc_mis, a->P.min_sc, a->P.q, a->P.e, a->P.w, a->P.zdrop, a->P.flag,
-			                     a->P.encode_ascii, a->P.codes_ok};
-			auto needs = [&](const AlnJob &x, size_t &lneed, size_t &pneed, int &wide) {
-				int w = P.w;
-				if (w < 0) w = x.tlen > x.qlen ? x.tlen : x.qlen;
-				int ncol_ = x.qlen < x.tlen ? x.qlen : x.tlen;
-				ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
-				pneed = ((size_t)(x.qlen + x.tlen - 1 > 0 ? x.qlen + x.tlen - 1 : 0) * ncol_ + 1) * 16;
-				// MODE 5: bands wider than the register layouts of MODE 0-4 (w < 0 or w > 62): the ring sweep of ksw_wide.h when
-				// the job fits it (3 or 6 slots), the LDS sweep otherwise
-				wide = MODE != 5 ? 0 : ksw_wide_ok<3>(P, x.qlen, x.tlen) ? 3 : ksw_wide_ok<6>(P, x.qlen, x.tlen) ? 6 : 0;
-				lneed = MODE == 5 ? (wide == 3 ? ksw_wide_lds_bytes<3>(x.qlen, x.tlen) : wide == 6 ? ksw_wide_lds_bytes<6>(x.qlen, x.tlen) : ksw_lds_bytes(x.qlen, x.tlen))
-				                  : (MODE >= 3) ? ksw_narrow_lds_bytes(x.qlen, x.tlen) : MODE != 2 ? ksw_fast_lds_bytes(x.qlen, x.tlen) : ksw_lds_bytes(x.qlen, x.tlen);
-			};
-			long long *pacc = a->prof ? (long long *)(lds + (pairs ? 2 : 1) * (a->lds_budget + 64) - 48) : nullptr;
-			const int cig_cap = a->cig_cap;
-			const size_t p_cap = a->p_cap;
-			const int lds_budget = a->lds_budget;
-			const uint8_t *qbase = a->qbase, *tbase = a->tbase;
-			// one job with this workgroup's first set of buffers
-			auto single = [&](const AlnJob &x, KswOut &out, uint8_t *ldsx, uint8_t *px, uint32_t *ctx) {
-				size_t lneed, pneed; int wide;
-				needs(x, lneed, pneed, wide);
-				const uint8_t *qy = qbase + x.q_off, *tg = tbase + x.t_off;
-				if (x.qlen > 0 && x.tlen > 0 && (lneed > (size_t)lds_budget || pneed > p_cap)) too_big(out);
-				else if (MODE == 3 || MODE == 4 || MODE == 6) {
-					if (!ksw_wave_narrow<MODE == 4>(qy, x.qlen, tg, x.tlen, P, ldsx, px, ctx, cig_cap, out, pacc))
-						out.n_cigar = -1;                                  // a code outside the alphabet: the host never sends those here
-				} else if (MODE == 0 || MODE == 1) {
-					ksw_wave_fast<MODE == 1>(qy, x.qlen, tg, x.tlen, P, ldsx, px, ctx, cig_cap, out, pacc);
-				} else if (MODE == 5) {
-					bool done = false;
-					if (wide == 3) done = ksw_wave_wide<3, false>(qy, x.qlen, tg, x.tlen, P, ldsx, px, ctx, cig_cap, out);
-					else if (wide == 6) done = ksw_wave_wide<6, false>(qy, x.qlen, tg, x.tlen, P, ldsx, px, ctx, cig_cap, out);
-					if (!done) {                                           // too wide for the ring, or a code outside the alphabet
-						if (ksw_lds_bytes(x.qlen, x.tlen) > (size_t)lds_budget) too_big(out);
-						else ksw_wave(qy, x.qlen, tg, x.tlen, P, ldsx, px, ctx, cig_cap, out, pacc);
-					}
-				} else {
-					ksw_wave(qy, x.qlen, tg, x.tlen, P, ldsx, px, ctx, cig_cap, out, pacc);
-				}
-			};
-			KswOut out;
-			if (MODE == 6 && j + 1 < njobs) {
-				const AlnJob jb2 = a->jobs[j + 1];
-				KswOut out2;
-				uint8_t *lds2 = lds + lds_budget + 64, *p2 = p + p_cap;
-				uint32_t *ct2 = ct + cig_cap;
-				size_t l1, p1n, l2, p2n; int wd;
-				needs(jb, l1, p1n, wd); needs(jb2, l2, p2n, wd);
-				const bool fit = jb.qlen > 0 && jb.tlen > 0 && jb2.qlen > 0 && jb2.tlen > 0 && l1 <= (size_t)lds_budget && l2 <= (size_t)lds_budget &&
-				                 p1n <= p_cap && p2n <= p_cap;
-				bool done = false;
-				if (fit) {
-					const long long tc0 = pacc ? (long long)clock64() : 0;
-					done = ksw_wave_narrow_pair(qbase + jb.q_off, jb.qlen, tbase + jb.t_off, jb.tlen, qbase + jb2.q_off, jb2.qlen, tbase + jb2.t_off, jb2.tlen,
-					                            P, lds, lds2, p, p2, ct, ct2, cig_cap, out, out2);
-					if (pacc && lane == 0) { pacc[1] += (long long)clock64() - tc0; pacc[3] += 2; }
-				}
-				if (!done) { single(jb, out, lds, p, ct); WSYNC(); single(jb2, out2, lds2, p2, ct2); }
-				emit(j, jb, out, ct);
-				emit(j + 1, jb2, out2, ct2);
-			} else {
-				single(jb, out, lds, p, ct);
-				emit(j, jb, out, ct);
-			}
-		}
 	}
 	WSYNC();
 	{
 		const KswArgsK a = ksw_args_again(a0);
 		if (a->prof && lane < 4)
-			atomicAdd((unsigned long long *)&a->prof[8 + lane], (unsigned long long)((long long *)(lds + (MODE == 6 ? 2 : 1) * (a->lds_budget + 64) - 48))[lane]);
+			atomicAdd((unsigned long long *)&a->prof[8 + lane], (unsigned long long)((long long *)(lds + a->lds_budget + 16))[lane]);
 	}
 }
 

@@ -86,6 +86,9 @@ __device__ __forceinline__ int sext8(unsigned v) { return (int)(signed char)(v &
 // Wave-parallel walk back through p (:47-79, :380-385).  off[r]/off_end[r] are recomputed from r.
 // Lane k speculates on the cell reached after k moves in the direction of the current state; a
 // ballot gives the length of the run, so a CIGAR of n ops costs O(n + len/64) round trips to HBM.
+// PACKED: p is ksw_narrow.h's slot matrix (80 dwords per slot, a nibble of four compare bits per cell) instead of the
+// reference's n_col*16 bytes per diagonal.
+template <bool PACKED = false>
 __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, int tlen, int w, int flag,
                                           int zdropped, int ez_max_t, int ez_max_q,
                                           uint32_t *cig_tmp, int cig_cap, KswOut &out)
@@ -113,7 +116,14 @@ __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, 
 			ksw_band(rr, qlen, tlen, w, st0, en0, st, en);
 			if (ik < st) force_state = 2;                // :56
 			if (ik > en) force_state = 1;                // :57
-			const unsigned tmp = force_state < 0 ? p[(size_t)rr * ncol + ik - st] : 0;
+			unsigned tmp = 0;
+			if (force_state < 0) {
+				if (!PACKED) tmp = p[(size_t)rr * ncol + ik - st];
+				else {
+					const unsigned nib = ((const unsigned *)p)[(size_t)((rr >> 3) + (st >> 4)) * 80 + (ik - st)] >> (4 * (7 - (rr & 7))) & 15u;
+					tmp = ((nib & 4) ? 2u : (nib >> 3)) | ((nib & 2) << 2) | ((nib & 1) << 4);
+				}
+			}
 			int s = state;
 			if (s == 0) s = tmp & 7;                     // :64
 			else if (!((tmp >> (s + 2)) & 1)) s = 0;     // :65

@@ -130,7 +130,7 @@ __device__ __forceinline__ bool wide_diag(WideState<NS> &F, const NarrowEnv &E, 
 	const int st = nst;
 	const int sc = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;       // last refreshed score position (:215)
 	const int top = sc > en ? sc : en;
-	uint8_t *pr = E.p + (size_t)r * E.ncol - st;
+	uint8_t *pr = E.pb + (size_t)r * E.ncol - st;
 	const unsigned *qrow = E.qs + (E.qlen - 1 - r);             // qrr of :193 (selector words)
 	const int ur = r ? E.q24 : 0;
 	int hk[NS];
@@ -144,8 +144,9 @@ __device__ __forceinline__ bool wide_diag(WideState<NS> &F, const NarrowEnv &E, 
 		F.Z[k] = (ge0 && t <= sc) ? znew : F.Z[k];              // :214-228
 		int ut = F.U[k], yt = F.Y[k];
 		if (r <= en) { const bool tr = t == r; yt = tr ? 0 : yt; ut = tr ? ur : ut; }   // :212
-		int xn, vn, un, yn; unsigned d;
-		narrow_cell<RIGHT>(F.Z[k], xp[k], vp[k], ut, yt, E.M24, E.q24, xn, vn, un, yn, d);
+		int xn, vn, un, yn; unsigned nib = 0;
+		narrow_cell<RIGHT>(F.Z[k], xp[k], vp[k], ut, yt, E.M24, E.q24, xn, vn, un, yn, nib);
+		const unsigned d = narrow_p_byte(nib);
 		const bool act = t <= en;                                // t >= st always
 		F.X[k] = act ? xn : F.X[k]; F.V[k] = act ? vn : F.V[k]; F.U[k] = act ? un : F.U[k]; F.Y[k] = act ? yn : F.Y[k];
 		if (act) pr[t] = (uint8_t)d;                             // :283
@@ -267,7 +268,7 @@ __device__ inline bool ksw_wave_wide(const uint8_t *query, int qlen, const uint8
 	F.st = 0; F.edge_h = KSW_NEG_INF;
 	F.ez_max = 0; F.ez_max_t = F.ez_max_q = -1; F.mqe = F.mte = F.score = KSW_NEG_INF; F.mqe_t = F.mte_q = -1;
 	NarrowEnv E;
-	E.tg = tg; E.qs = qs; E.tbl = tbl; E.p = p; E.qlen = qlen; E.tlen = tlen; E.w = w; E.ncol = ncol; E.qe = qe; E.e = e;
+	E.tg = tg; E.qs = qs; E.tbl = tbl; E.p = nullptr; E.pb = p; E.qlen = qlen; E.tlen = tlen; E.w = w; E.ncol = ncol; E.qe = qe; E.e = e;
 	E.zdrop = P.zdrop; E.ZW24 = (int)(ZW << 24); E.M24 = ZM << 24; E.q24 = (int)(((unsigned)q & 0xff) << 24);
 	const int total = qlen + tlen - 1;
 	bool stop = false;

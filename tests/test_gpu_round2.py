@@ -297,28 +297,3 @@ def test_c_harness_drives_the_device():
     pr = subprocess.run([_build_harness(), "--gpu"], capture_output=True, text=True)
     assert pr.returncode == 0, pr.stderr
     assert json.loads(pr.stdout)["gpu_checks"] is True
-
-
-def test_ksw_pair_kernel(hip, oracle, monkeypatch):
-    """k_ksw<6> (two alignments per wavefront over the steady diagonals, ksw_pair.h; opt-in with IHP_KSW_PAIR=1) gives the
-    results of the single sweep: the compiled reference's golden vectors, random pairs, whole regions."""
-    import golden_util
-    monkeypatch.setenv("IHP_KSW_PAIR", "1")
-    assert golden_util.check_ksw2(hip) >= 200
-    rng = np.random.default_rng(11)
-    qs, ts = [], []
-    for _ in range(101):                                   # an odd count: the last job has no partner
-        n = int(rng.integers(120, 420))
-        t = rng.integers(0, 4, n + int(rng.integers(40, 160))).astype(np.uint8)
-        q = t[:n].copy()
-        k = int(rng.integers(30, n - 30))
-        q = np.concatenate([q[:k], q[k + int(rng.integers(1, 30)):]]) if rng.random() < 0.5 else np.concatenate([q[:k], rng.integers(0, 4, int(rng.integers(1, 30))).astype(np.uint8), q[k:]])
-        qs.append(q); ts.append(t)
-    for w, z in ((50, 400), (62, 100), (49, -1)):
-        got_ez, got_c = hip.align_batch(qs, ts, bw=w, z=z, encoded=True)
-        assert hip.b.debug_last_ksw_mode() == 3
-        exp_ez, exp_c = oracle.align_batch(qs, ts, bw=w, z=z, encoded=True)
-        assert np.array_equal(got_ez, exp_ez)
-        assert all(np.array_equal(a, b) for a, b in zip(got_c, exp_c))
-    b, _ = synth.generate(400, n_reads=(16, 64), err_rate=1e-3, config_id=91)
-    assert_same(hip.run_regions(b), oracle.run_regions(b))
