@@ -286,7 +286,6 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_ksw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
-		(void)hipFuncSetAttribute((const void *)k_ksw<6>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 	}
 	g.ready = true;
 	return 0;

@@ -354,10 +354,13 @@ struct SteadyCtl {
 };
 
 // One steady diagonal (see narrow_steady_loop) and the step to the next.  HASB = block 4 is computed (hiT >= 64);
-// EDGE = the band origin moved on this diagonal and lane 0 takes the block edge ex, ev (:207-208; without a move the
-// edge is 0, :210); PAR = parity of r + w when the caller knows it (0: st0 grows on the step to r+1, 1: en0 does; the
-// lane masks then move by one shift), -1 to work both out here.
-template <bool RIGHT, bool HASB, bool EDGE, int PAR>
+// EDGE = 1: the band origin moved on this diagonal and lane 0 takes the block edge ex, ev (:207-208; without a move the
+// edge is 0, :210).  EDGE = 2: a diagonal 1 <= r <= w+30 of a job with qlen, tlen >= w+32 -- the band still starts in
+// block 0 (lane 0 takes x1 = 0, v1 = q, :211), grows from the single cell t = r (st0 = max(0,(r-w+1)>>1),
+// en0 = min(r,(r+w)>>1)), computes blocks 0 .. en0/16 only (the execution mask keeps the cells above untouched) and,
+// while r <= en, holds the boundary cell t = r (:212).  PAR = parity of r + w when the caller knows it (0: st0 grows
+// on the step to r+1, 1: en0 does; the lane masks then move by one shift), -1 to work both out here.
+template <bool RIGHT, bool HASB, int EDGE, int PAR>
 __device__ __forceinline__ void narrow_steady_step(NarrowState &F, const NarrowEnv &E, SteadyCtl &C, const int ex = 0, const int ev = 0)
 {
 	const int lane = lane_id();
@@ -365,7 +368,9 @@ __device__ __forceinline__ void narrow_steady_step(NarrowState &F, const NarrowE
 	const int st = F.st, r = C.r;
 	if (PAR < 0) { C.geLoM = ~0ull << (C.st0 - st); C.spM = HASB ? 0ull : 1ull << (C.en0 - st); }
 	int xpA = dppz_shr1(F.XA), vpA = dppz_shr1(F.VA);    // neighbours of r-1
-	if (EDGE) { xpA = set_lane0(ex, 0, xpA); vpA = set_lane0(ev, 0, vpA); }
+	if (EDGE == 1) { xpA = set_lane0(ex, 0, xpA); vpA = set_lane0(ev, 0, vpA); }
+	if (EDGE == 2) vpA = set_lane0(E.q24, 0, vpA);
+	const int en = C.en0 | 15;                           // EDGE == 2: last computed cell; t = r is computed while r <= en
 	const int HpA = dppz_shr1(F.HA);
 	const unsigned long long geLoM = C.geLoM;
 	unsigned long long mIB = 0;
@@ -379,8 +384,10 @@ __device__ __forceinline__ void narrow_steady_step(NarrowState &F, const NarrowE
 		const int zf = narrow_z(F.T0B, F.T1B, F.qptr[F.qoffB]);            // qs[qlen-1-r+st+64+lane]
 		const int zB = lane_in(~geLoM) ? zf : E.ZW24;                      // refreshed up to lane loA + 63: lanes 0..loA-1 here
 		if (lane < 16) {
+			int ut = F.UB, yt = F.YB;
+			if (EDGE == 2 && 64 + lane == r) { yt = 0; ut = E.q24; }       // :212
 			int xn, vn, un, yn;
-			narrow_cell<RIGHT>(zB, xpB, vpB, F.UB, F.YB, E.M24, E.q24, xn, vn, un, yn, F.accB);   // :283
+			narrow_cell<RIGHT>(zB, xpB, vpB, ut, yt, E.M24, E.q24, xn, vn, un, yn, F.accB);   // :283
 			F.XB = xn; F.VB = vn; F.UB = un; F.YB = yn;
 			const bool sp = 64 + lane == C.en0 - st;
 			F.HB = (sp ? HpB : F.HB) + (int)((unsigned)(sp ? un : vn) >> 24);   // :318, :323-329 in H' form
@@ -388,11 +395,15 @@ __device__ __forceinline__ void narrow_steady_step(NarrowState &F, const NarrowE
 		mIB = ballot(F.HB > C.thrI) & 0xffffull;
 	}
 	// ---- slot A (blocks 0..3) --------------------------------------------------------
-	{
+	F.qptr -= 1;
+	if (EDGE != 2 || lane_in(~0ull >> (63 - (en < 63 ? en : 63)))) {
 		const bool geLo = lane_in(geLoM);
-		const int znew = narrow_z(F.T0A, F.T1A, *F.qptr);            // qs[qlen-1-r+st+lane]
-		F.qptr -= 1;
-		F.ZA = geLo ? znew : F.ZA;                                      // :214-228: refreshed from st0 to st0 + 63
+		const int znew = narrow_z(F.T0A, F.T1A, F.qptr[1]);          // qs[qlen-1-r+st+lane]
+		F.ZA = geLo ? znew : F.ZA;                                      // :214-228: refreshed from st0 to st0 + 63 (or to en)
+		if (EDGE == 2 && r <= en && r < 64) {                           // :212
+			const bool tr = lane_in(1ull << r);
+			F.YA = tr ? 0 : F.YA; F.UA = tr ? E.q24 : F.UA;
+		}
 		int xn, vn, un, yn;
 		narrow_cell<RIGHT>(F.ZA, xpA, vpA, F.UA, F.YA, E.M24, E.q24, xn, vn, un, yn, F.accA);   // :283
 		F.XA = xn; F.VA = vn; F.UA = un; F.YA = yn;
@@ -449,7 +460,10 @@ __device__ __forceinline__ void narrow_steady_step(NarrowState &F, const NarrowE
 		}
 	}
 	// ---- the step to r + 1: (r+w)>>1 grows from an odd r+w, (r-w+1)>>1 otherwise ----
-	if (PAR == 0) { C.st0 += 1; C.geLoM <<= 1; }
+	if (EDGE == 2) {
+		const int s1 = (r + 2 - E.w) >> 1, e1 = (r + 1 + E.w) >> 1;
+		C.st0 = s1 > 0 ? s1 : 0; C.en0 = e1 < r + 1 ? e1 : r + 1;
+	} else if (PAR == 0) { C.st0 += 1; C.geLoM <<= 1; }
 	else if (PAR == 1) { C.en0 += 1; C.spM <<= 1; }
 	else { const int up = (r + E.w) & 1; C.en0 += up; C.st0 += 1 - up; }
 	C.thrI += E.qe; C.r = r + 1;
@@ -460,13 +474,13 @@ template <bool RIGHT, bool HASB>
 __device__ __forceinline__ void narrow_steady_run(NarrowState &F, const NarrowEnv &E, SteadyCtl &C, const int bound)
 {
 	C.lim = C.stop_r < 0 ? bound : -0x7fffffff - 1;
-	if (C.r < C.lim && ((C.r + E.w) & 1)) narrow_steady_step<RIGHT, HASB, false, -1>(F, E, C);
+	if (C.r < C.lim && ((C.r + E.w) & 1)) narrow_steady_step<RIGHT, HASB, 0, -1>(F, E, C);
 	C.geLoM = ~0ull << (C.st0 - F.st); C.spM = HASB ? 0ull : 1ull << ((C.en0 - F.st) & 63);
 	while (C.r + 1 < C.lim) {
-		narrow_steady_step<RIGHT, HASB, false, 0>(F, E, C);
-		narrow_steady_step<RIGHT, HASB, false, 1>(F, E, C);
+		narrow_steady_step<RIGHT, HASB, 0, 0>(F, E, C);
+		narrow_steady_step<RIGHT, HASB, 0, 1>(F, E, C);
 	}
-	if (C.r < C.lim) narrow_steady_step<RIGHT, HASB, false, -1>(F, E, C);
+	if (C.r < C.lim) narrow_steady_step<RIGHT, HASB, 0, -1>(F, E, C);
 }
 
 // The steady diagonals r .. r_hi-1: w in [49, 62], the band limited by w on both sides (st0 = (r-w+1)>>1,
@@ -494,6 +508,14 @@ __device__ __forceinline__ bool narrow_steady_loop(NarrowState &F, const NarrowE
 	C.geLoM = C.spM = 0;
 	F.HA += (r - 1) * qe; F.HB += (r - 1) * qe;
 	if (r & 7) F.accB >>= 4 * (8 - (r & 7));            // placed -> shifted form (nibble of r-1 lowest)
+	if (r < w + 31) {                                    // the caller starts this early only when the job has room (EDGE = 2)
+		C.st0 = C.st0 > 0 ? C.st0 : 0; C.en0 = C.en0 < r ? C.en0 : r;
+		C.lim = r_hi < w + 31 ? r_hi : w + 31;
+		while (C.r < C.lim) {
+			if (C.en0 < 64) narrow_steady_step<RIGHT, false, 2, -1>(F, E, C);
+			else narrow_steady_step<RIGHT, true, 2, -1>(F, E, C);
+		}
+	}
 	while (C.r < r_hi && C.stop_r < 0) {
 		C.lim = r_hi;
 		const bool moved = (C.st0 & ~15) != F.st;
@@ -525,8 +547,8 @@ __device__ __forceinline__ bool narrow_steady_loop(NarrowState &F, const NarrowE
 		int r_b = 2 * (F.st + 64) - w;                   // block 4 from here on
 		r_b = r_b > C.r ? r_b : C.r; r_b = r_b < r_end ? r_b : r_end;
 		if (moved) {                                     // the diagonal of the move: lane 0 takes the block edge
-			if (C.r < r_b) narrow_steady_step<RIGHT, false, true, -1>(F, E, C, ex, ev);
-			else narrow_steady_step<RIGHT, true, true, -1>(F, E, C, ex, ev);
+			if (C.r < r_b) narrow_steady_step<RIGHT, false, 1, -1>(F, E, C, ex, ev);
+			else narrow_steady_step<RIGHT, true, 1, -1>(F, E, C, ex, ev);
 		}
 		narrow_steady_run<RIGHT, false>(F, E, C, r_b);
 		narrow_steady_run<RIGHT, true>(F, E, C, r_end);
@@ -617,7 +639,9 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	bool stop = narrow_diag<RIGHT, ND_FIRST>(F, E, 0);
 	int r = 1;
 	bool tracked = true;                                 // F.rlB is up to date
-	if (!stop && roomy) {
+	if (!stop && roomy && w >= 49 && r < r_hi) {
+		// the steady loop takes the early diagonals too
+	} else if (!stop && roomy) {
 		do { if (narrow_diag<RIGHT, ND_EARLY>(F, E, r)) { stop = true; break; } } while (++r < w + 31);
 		tracked = false;
 	} else if (!stop) {
