@@ -570,6 +570,145 @@ __device__ __forceinline__ bool narrow_steady_loop(NarrowState &F, const NarrowE
 	return stop;
 }
 
+// lanes lo .. hi of the wave, 0 <= lo <= hi <= 63 (one s_bfm_b64 unless the range is the whole wave)
+__device__ __forceinline__ unsigned long long lane_span(int lo, int hi)
+{
+	unsigned long long m;
+	const int n = hi - lo + 1;
+	asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(n), "s"(lo));
+	return n >= 64 ? ~0ull : m;
+}
+
+struct TailCtl {
+	int r, st0, en0;                                     // the coming diagonal and its true band
+	int lim;                                             // end of the run (the next move, or the last diagonal + 1)
+	int stopped;                                         // 1: z-drop on diagonal r; 2: the band left the matrix before r
+};
+
+// One diagonal behind the steady ones, once the band is narrower than 48 cells (see narrow_tail_loop): the band is cut
+// by the end of the query and / or the target (st0 = max(r-qlen+1, (r-w+1)>>1), en0 = min(tlen-1, (r+w)>>1)), shrinks,
+// never reaches block 4 (hiT <= 62) and refreshes no score past lane 62, so slot B only waits for the next move; the
+// computed lanes (blocks 0 .. (en0|15)-st) run under the execution mask.  Plain H here: a one-cell band reads the H a
+// cell kept when it left the band (:318).  The end-of-sequence results (:351-357) are taken on every diagonal.
+template <bool RIGHT, bool EDGE>
+__device__ __forceinline__ void narrow_tail_step(NarrowState &F, const NarrowEnv &E, TailCtl &C, const int zd, const int ex = 0, const int ev = 0)
+{
+	const int INTMIN = -0x7fffffff - 1;
+	const int st = F.st, r = C.r, st0 = C.st0, en0 = C.en0;
+	const int loA = st0 - st, hiT = en0 - st;
+	const int sc = loA + (((en0 - st0) >> 4) + 1) * 16 - 1;      // last refreshed score lane (:215): <= 62
+	const int nTop = (en0 | 15) - st;                    // last computed lane: 15, 31, 47 or 63
+	int xpA = dppz_shr1(F.XA), vpA = dppz_shr1(F.VA), HpA = dppz_shr1(F.HA);   // neighbours of r-1
+	if (EDGE) { xpA = set_lane0(ex, 0, xpA); vpA = set_lane0(ev, 0, vpA); }
+	if (hiT == 0) HpA = set_lane0(F.edge_h, 0, HpA);     // en0 on lane 0: H[en0-1] is the block edge
+	const unsigned long long inTM = lane_span(loA, hiT);
+	F.qptr -= 1;
+	{
+		const int znew = narrow_z(F.T0A, F.T1A, F.qptr[1]);          // qs[qlen-1-r+st+lane]
+		F.ZA = lane_in(lane_span(loA, sc)) ? znew : F.ZA;               // :214-228 (the 16-byte stores run past en)
+	}
+	if (lane_in(lane_span(0, nTop))) {
+		int xn, vn, un, yn;
+		narrow_cell<RIGHT>(F.ZA, xpA, vpA, F.UA, F.YA, E.M24, E.q24, xn, vn, un, yn, F.accA);   // :283
+		F.XA = xn; F.VA = vn; F.UA = un; F.YA = yn;
+		const bool sp = lane_in(1ull << hiT);
+		const int h = (sp ? HpA : F.HA) + (int)((unsigned)(sp ? un : vn) >> 24) - E.qe;   // :318, :323-329
+		F.HA = lane_in(inTM) ? h : F.HA;
+	}
+	if ((r & 7) == 7) narrow_flush(F, E, r, st);
+	// ---- ez updates (:351-357) -----------------------------------------------------------
+	{
+		const int Hen0 = __builtin_amdgcn_readlane(F.HA, hiT), Hst0 = __builtin_amdgcn_readlane(F.HA, loA);
+		const bool c1 = en0 == E.tlen - 1, c2 = r - st0 == E.qlen - 1;
+		if (c1 && Hen0 > F.mte) { F.mte = Hen0; F.mte_q = r - (en0 | 15); }               // rounded en (:352)
+		if (c2 && Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st0; }
+		if (c1 && r == E.qlen + E.tlen - 2) F.score = Hen0;                                 // :356-357
+	}
+	// ---- exact max (:312-349) and ksw_apply_zdrop (:88-104) ----------------------------
+	const unsigned long long mI = ballot(F.HA > F.ez_max) & inTM;
+	if (mI) {
+		int max_H, max_t;
+		if (!(mI & (mI - 1))) {
+			const int i = ctz64(mI);
+			max_H = __builtin_amdgcn_readlane(F.HA, i); max_t = st + i;
+		} else {
+			const int hAm = lane_in(inTM) ? F.HA : INTMIN;
+			max_H = wave_max_i32_keep(hAm);
+			max_t = narrow_max_t(hAm, INTMIN, max_H, false, 0ull, loA, st, st0, en0);
+		}
+		F.ez_max = max_H; F.ez_max_t = max_t; F.ez_max_q = r - max_t;
+	} else if (!(ballot(F.HA >= F.ez_max - zd) & inTM)) {
+		// ez.max - max_H > zdrop: the full test of :98-101
+		const int hAm = lane_in(inTM) ? F.HA : INTMIN;
+		const int max_H = wave_max_i32_keep(hAm);
+		const int t = narrow_max_t(hAm, INTMIN, max_H, false, 0ull, loA, st, st0, en0), dq = r - t;
+		if (t >= F.ez_max_t && dq >= F.ez_max_q) {
+			const int tl = t - F.ez_max_t, ql = dq - F.ez_max_q;
+			const int l = tl > ql ? tl - ql : ql - tl;
+			if (F.ez_max - max_H > zd + l * E.e) { C.stopped = 1; C.lim = INTMIN; return; }
+		}
+	}
+	// ---- the band of r + 1 (:196-205) ----
+	{
+		const int a = r + 2 - E.qlen, b = (r + 2 - E.w) >> 1, c = (r + 1 + E.w) >> 1;
+		C.st0 = a > b ? a : b; C.en0 = c < E.tlen - 1 ? c : E.tlen - 1; C.r = r + 1;
+		if (C.st0 > C.en0 && r + 1 < E.qlen + E.tlen - 1) { C.stopped = 2; C.lim = INTMIN; }   // :200-203
+	}
+}
+
+// The diagonals behind the steady ones, r .. total-1.  While the band is still 48 or more cells wide (a handful of
+// diagonals) the general narrow_diag<ND_ANY> does them; from then on narrow_tail_step, run by run between two moves of
+// the band origin.  Returns true when the sweep stops early (z-drop, or the band leaves the matrix: F.band_exit);
+// r is then the diagonal it stopped on.
+template <bool RIGHT>
+__device__ __forceinline__ bool narrow_tail_loop(NarrowState &F, const NarrowEnv &E, int &r, const int total)
+{
+	const int lane = lane_id();
+	for (; r < total; ++r) {
+		int st0, en0, nst, en;
+		if (ksw_band(r, E.qlen, E.tlen, E.w, st0, en0, nst, en) && en0 - st0 < 48 && r > E.w + 32 && nst > 0) break;
+		if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) return true;
+	}
+	if (r >= total) return false;
+	TailCtl C;
+	C.r = r; C.stopped = 0;
+	{
+		const int a = r + 1 - E.qlen, b = (r + 1 - E.w) >> 1, c = (r + E.w) >> 1;
+		C.st0 = a > b ? a : b; C.en0 = c < E.tlen - 1 ? c : E.tlen - 1;
+	}
+	const int zd = E.zdrop < 0 ? 0x3fffffff : E.zdrop;
+	while (C.r < total && !C.stopped) {
+		const bool moved = (C.st0 & ~15) != F.st;
+		int ex = 0, ev = 0;
+		if (moved) {
+			// the band origin moved one block right: close the traceback slot, rotate the registers 16 lanes, re-seed slot B
+			if (C.r & 7) narrow_flush(F, E, C.r - 1, F.st);
+			ex = __builtin_amdgcn_readlane(F.XA, 15); ev = __builtin_amdgcn_readlane(F.VA, 15);
+			F.edge_h = __builtin_amdgcn_readlane(F.HA, 15);
+			const int zB = F.rlB < 0 ? E.ZW24 : narrow_z(F.T0B, F.T1B, E.qs[E.qlen - 1 - F.rlB + F.st + 64 + (lane & 15)]);
+			F.XA = (int)rot16((unsigned)F.XA, (unsigned)F.XB, lane); F.VA = (int)rot16((unsigned)F.VA, (unsigned)F.VB, lane);
+			F.UA = (int)rot16((unsigned)F.UA, (unsigned)F.UB, lane); F.YA = (int)rot16((unsigned)F.YA, (unsigned)F.YB, lane);
+			F.ZA = (int)rot16((unsigned)F.ZA, (unsigned)zB, lane);
+			F.HA = (int)rot16((unsigned)F.HA, (unsigned)F.HB, lane);
+			F.st = C.st0 & ~15;
+			F.qptr += 16;
+			F.XB = F.VB = F.UB = F.YB = 0; F.HB = KSW_NEG_INF;
+			F.rlB = -1;
+			const uint2 ta = E.tbl[E.tg[F.st + lane]], tb = E.tbl[E.tg[F.st + 64 + (lane & 15)]];
+			F.T1A = ta.x; F.T0A = ta.y; F.T1B = tb.x; F.T0B = tb.y;
+		}
+		// the next move: st0 = max(r-qlen+1, (r-w+1)>>1) reaches st + 16
+		const int m1 = F.st + 15 + E.qlen, m2 = 2 * (F.st + 16) + E.w - 1;
+		int r_end = m1 < m2 ? m1 : m2;
+		C.lim = r_end < total ? r_end : total;
+		if (moved) narrow_tail_step<RIGHT, true>(F, E, C, zd, ex, ev);
+		while (C.r < C.lim) narrow_tail_step<RIGHT, false>(F, E, C, zd);
+	}
+	r = C.r;
+	if (C.stopped == 2) F.band_exit = 1;
+	return C.stopped != 0;
+}
+
 // Returns false when the job is not for this sweep (a code outside the 5-letter alphabet; nothing useful in
 // `out`): the caller runs ksw_wave_fast() instead.  Precondition: ksw_narrow_ok(P).
 template <bool RIGHT>
@@ -653,7 +792,7 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	}
 	if (!stop) {
 		if (!tracked) F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;   // what the growing diagonals did not track (see narrow_diag)
-		for (; r < total; ++r) if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) { stop = true; break; }
+		stop = narrow_tail_loop<RIGHT>(F, E, r, total);
 	}
 	{
 		const int r_last = stop ? (F.band_exit ? r - 1 : r) : total - 1;     // the last diagonal whose cells were computed
