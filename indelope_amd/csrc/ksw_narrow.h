@@ -656,6 +656,80 @@ __device__ __forceinline__ void narrow_tail_step(NarrowState &F, const NarrowEnv
 	}
 }
 
+__device__ __forceinline__ unsigned long long bit_clear(unsigned long long m, int i) { asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i)); return m; }
+__device__ __forceinline__ unsigned long long bit_set(unsigned long long m, int i) { asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(i)); return m; }
+
+// A run of narrow_tail_step diagonals C.r .. lim-1 in the usual shape of the tail: the band is cut by the end of the
+// query only (st0 = r - qlen + 1 grows on every diagonal, en0 = (r+w)>>1 < tlen-1 on every other one), and within the
+// run the band origin, the number of computed blocks and the number of refreshed 16-byte score groups do not change.
+// Then every lane set moves by a bit or two per diagonal, H[st0] is the only end-of-sequence result (:353-354), and
+// nothing else has to be worked out.  The caller has done the diagonal of a move (lane-0 edge) with narrow_tail_step.
+template <bool RIGHT>
+__device__ __forceinline__ void narrow_tail_qrun(NarrowState &F, const NarrowEnv &E, TailCtl &C, const int zd)
+{
+	const int INTMIN = -0x7fffffff - 1;
+	const int st = F.st;
+	int r = C.r, loA = C.st0 - st, hiT = C.en0 - st;
+	int sc = loA + (((hiT - loA) >> 4) + 1) * 16 - 1;    // last refreshed score lane (:215): <= 62
+	const int nTop = (C.en0 | 15) - st;                  // last computed lane
+	unsigned long long inTM = lane_span(loA, hiT), refM = lane_span(loA, sc), spM = 1ull << hiT;
+	const unsigned long long actM = ~0ull >> (63 - nTop);
+	int lim = C.lim, stopped = 0;
+	do {
+		const int xpA = dppz_shr1(F.XA), vpA = dppz_shr1(F.VA), HpA = dppz_shr1(F.HA);   // neighbours of r-1 (no move: edge 0, :210)
+		F.qptr -= 1;
+		{
+			const int znew = narrow_z(F.T0A, F.T1A, F.qptr[1]);      // qs[qlen-1-r+st+lane]
+			F.ZA = lane_in(refM) ? znew : F.ZA;                         // :214-228
+		}
+		if (lane_in(actM)) {
+			int xn, vn, un, yn;
+			narrow_cell<RIGHT>(F.ZA, xpA, vpA, F.UA, F.YA, E.M24, E.q24, xn, vn, un, yn, F.accA);   // :283
+			F.XA = xn; F.VA = vn; F.UA = un; F.YA = yn;
+			const bool sp = lane_in(spM);
+			const int h = (sp ? HpA : F.HA) + (int)((unsigned)(sp ? un : vn) >> 24) - E.qe;   // :318, :323-329
+			F.HA = lane_in(inTM) ? h : F.HA;
+		}
+		if ((r & 7) == 7) narrow_flush(F, E, r, st);
+		{                                                            // :353-354 (r - st0 == qlen - 1 on every diagonal here)
+			const int Hst0 = __builtin_amdgcn_readlane(F.HA, loA);
+			if (Hst0 > F.mqe) { F.mqe = Hst0; F.mqe_t = st + loA; }
+		}
+		// ---- exact max (:312-349) and ksw_apply_zdrop (:88-104) ----------------------------
+		const unsigned long long mI = ballot(F.HA > F.ez_max) & inTM;
+		if (mI) {
+			int max_H, max_t;
+			if (!(mI & (mI - 1))) {
+				const int i = ctz64(mI);
+				max_H = __builtin_amdgcn_readlane(F.HA, i); max_t = st + i;
+			} else {
+				const int hAm = lane_in(inTM) ? F.HA : INTMIN;
+				max_H = wave_max_i32_keep(hAm);
+				max_t = narrow_max_t(hAm, INTMIN, max_H, false, 0ull, loA, st, st + loA, st + hiT);
+			}
+			F.ez_max = max_H; F.ez_max_t = max_t; F.ez_max_q = r - max_t;
+		} else if (!(ballot(F.HA >= F.ez_max - zd) & inTM)) {
+			// ez.max - max_H > zdrop: the full test of :98-101
+			const int hAm = lane_in(inTM) ? F.HA : INTMIN;
+			const int max_H = wave_max_i32_keep(hAm);
+			const int t = narrow_max_t(hAm, INTMIN, max_H, false, 0ull, loA, st, st + loA, st + hiT), dq = r - t;
+			if (t >= F.ez_max_t && dq >= F.ez_max_q) {
+				const int tl = t - F.ez_max_t, ql = dq - F.ez_max_q;
+				const int l = tl > ql ? tl - ql : ql - tl;
+				if (F.ez_max - max_H > zd + l * E.e) { stopped = 1; lim = INTMIN; }
+			}
+		}
+		// ---- the band of r + 1: st0 + 1, en0 + 1 from an odd r + w ----
+		const int p = (r + E.w) & 1;
+		inTM = bit_clear(inTM, loA); refM = bit_clear(refM, loA);
+		loA += 1; sc += 1; refM = bit_set(refM, sc);
+		hiT += p; spM <<= p; inTM |= spM;
+		r += 1;
+	} while (r < lim);
+	C.r = stopped ? r - 1 : r; C.st0 = st + loA; C.en0 = st + hiT;
+	if (stopped) { C.stopped = 1; C.lim = INTMIN; }
+}
+
 // The diagonals behind the steady ones, r .. total-1.  While the band is still 48 or more cells wide (a handful of
 // diagonals) the general narrow_diag<ND_ANY> does them; from then on narrow_tail_step, run by run between two moves of
 // the band origin.  Returns true when the sweep stops early (z-drop, or the band leaves the matrix: F.band_exit);
@@ -678,6 +752,7 @@ __device__ __forceinline__ bool narrow_tail_loop(NarrowState &F, const NarrowEnv
 	}
 	const int zd = E.zdrop < 0 ? 0x3fffffff : E.zdrop;
 	while (C.r < total && !C.stopped) {
+		if (C.st0 > C.en0) { C.stopped = 2; break; }     // :200-203 (behind a narrow_tail_qrun)
 		const bool moved = (C.st0 & ~15) != F.st;
 		int ex = 0, ev = 0;
 		if (moved) {
@@ -702,7 +777,28 @@ __device__ __forceinline__ bool narrow_tail_loop(NarrowState &F, const NarrowEnv
 		int r_end = m1 < m2 ? m1 : m2;
 		C.lim = r_end < total ? r_end : total;
 		if (moved) narrow_tail_step<RIGHT, true>(F, E, C, zd, ex, ev);
-		while (C.r < C.lim) narrow_tail_step<RIGHT, false>(F, E, C, zd);
+		while (C.r < C.lim) {
+			// the usual shape (cut by the end of the query only): a run up to the next diagonal on which the band origin,
+			// the computed blocks (en0 crosses a multiple of 16), the refreshed score groups ((en0-st0)>>4 drops), the cut
+			// (en0 reaches tlen-1) or the band itself (st0 > en0) changes
+			const int rr = C.r, wd = C.en0 - C.st0, p = (rr + E.w) & 1;
+			if (wd < 0) { C.stopped = 2; C.lim = -0x7fffffff - 1; break; }   // :200-203 (behind a narrow_tail_qrun)
+			const bool qcut = C.st0 == rr + 1 - E.qlen && C.st0 >= (rr + 1 - E.w) >> 1 && ((rr + E.w) >> 1) < E.tlen - 1 && wd >= 0;
+			if (qcut) {
+				const int r_k = rr + 2 * ((wd & 15) + 1) - 1 + p;            // width falls to 16k - 1
+				const int r_e = rr + 2 * (16 - (C.en0 & 15)) - p;             // en0 reaches the next multiple of 16
+				const int r_t = 2 * (E.tlen - 1) - E.w;                      // (r+w)>>1 reaches tlen-1
+				int e = r_k < r_e ? r_k : r_e; e = e < r_t ? e : r_t; e = e < C.lim ? e : C.lim;
+				if (e > rr) {
+					const int keep = C.lim;
+					C.lim = e;
+					narrow_tail_qrun<RIGHT>(F, E, C, zd);
+					if (!C.stopped) C.lim = keep;
+					continue;
+				}
+			}
+			narrow_tail_step<RIGHT, false>(F, E, C, zd);
+		}
 	}
 	r = C.r;
 	if (C.stopped == 2) F.band_exit = 1;
