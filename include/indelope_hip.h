@@ -414,10 +414,11 @@ int  ihp_pack_out(const ihp_batch_out *src, void *buf, int64_t cap, int64_t *byt
 /* Per-stage device time of the most recent ihp_batch_run+sync, from HIP events
  * on the batch stream: ms[0] assemble, ms[1] ksw2, ms[2] tally, ms[3] total.  */
 int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);
-/* The same per stage as EXECUTION time -- from the moment the stage's first workgroup starts on the device to a marker
- * behind it, read from the device's wall clock (ms[0] the class-1 assembly kernel, [1] ksw2, [2] tally, [3] fallback) --
- * for callers that keep several batches in flight: a kernel of one batch can wait for wave slots held by another's,
- * and an event interval includes that wait.  Costs four one-thread marker launches per run; off by default.          */
+/* The same per stage as EXECUTION time -- from the moment the stage's first workgroup starts on the device to the moment
+ * the next stage's does (the summary kernel's for the last one), read from the device's wall clock (ms[0] assembly incl.
+ * the 2-bit packing and the overflow passes, [1] ksw2, [2] tally, [3] fallback) -- for callers that keep several batches
+ * in flight: a kernel of one batch can wait for wave slots held by another's, and an event interval includes that
+ * wait.  One clock read per stage by the kernels themselves; off by default.                                          */
 int  ihp_batch_set_timing(ihp_batch *b, int on);
 int  ihp_batch_kernel_ms(ihp_batch *b, float ms[4]);
 /* Device time of the alignment-fallback kernel (indelope.nim:312-372) in the same run; it is

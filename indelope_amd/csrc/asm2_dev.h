@@ -43,12 +43,14 @@ struct PrepackArgs {
 	uint32_t *pk;                             // read i at dword (read_off[i] >> 4) + i, ceil(len / 16) dwords, tail bits zero
 	int *trim_lo, *trim_hi;                   // [n_reads] out: kept range [lo, hi) of every read (indelope.nim:23-38)
 	uint8_t *read_bad;                        // [n_reads] out: 1 = a base that is not upper-case ACGT
+	unsigned long long *t_start;              // optional: device wall clock when the launch starts to execute (see mark_start())
 };
 
 // One 16-lane group per read (four reads per wave at a time), grid-stride over all reads of the batch.
 __global__ __launch_bounds__(64) void k_prepack(const PrepackArgs a)
 {
 	const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+	if (a.t_start && blockIdx.x == 0 && threadIdx.x == 0) *a.t_start = (unsigned long long)wall_clock64();
 	const long long stride = (long long)gridDim.x * 4;
 	for (long long i0 = (long long)blockIdx.x * 4; i0 < a.n_reads; i0 += stride) {
 		const long long ri = i0 + grp;

@@ -1140,13 +1140,14 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			pa.trim_lo_in = b->has_trim ? b->trim_lo.as<int>() : nullptr; pa.trim_hi_in = b->has_trim ? b->trim_hi.as<int>() : nullptr;
 			pa.trim_min_qual = p.trim_min_qual; pa.pk = b->v2_pk.as<uint32_t>(); pa.trim_lo = b->v2_trim_lo.as<int>();
 			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
+			pa.t_start = tm;                                       // the first launch of the stage
 			hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			AsmArgs x = a;
 			x.v2_pk = pa.pk; x.v2_trim_lo = pa.trim_lo; x.v2_trim_hi = pa.trim_hi; x.v2_read_bad = pa.read_bad; x.v2_pdw = b->v2_pdw;
 			x.v2_hand = b->v2_hand.as<uint32_t>(); x.v2_hoff = b->v2_hoff.as<long long>();
 			x.arena_seq = nullptr; x.arena_sup = b->v2_sup.as<uint32_t>(); x.arena_cap = b->v2_arena; x.lds_arena = b->v2_arena;
 			x.in_list = cl; x.n_in = cn; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0; x.work_counter = wq + 10 * WQ_WORDS;
-			x.t_start = tm;
+			x.t_start = nullptr;
 			ReadArgs ra;
 			ra.region_read_off = x.region_read_off; ra.read_off = x.read_off; ra.read_start = x.read_start; ra.mapq = x.mapq;
 			ra.read_skip = x.read_skip; ra.v2_read_bad = x.v2_read_bad; ra.v2_trim_lo = x.v2_trim_lo; ra.v2_trim_hi = x.v2_trim_hi;
@@ -1168,7 +1169,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			x.work_counter = wq + 12 * WQ_WORDS;
 			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
 			HIPC(hipGetLastError());
-			if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 1);
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = b->retry_list0.as<int>(); a.n_in = misc + M_NRETRY0; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
 			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_ovf1), dim3(64), b->lds_arena1, s, a);
@@ -1179,7 +1179,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			a.t_start = tm;                                        // the first launch of the stage
 			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
 			HIPC(hipGetLastError());
-			if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 1);   // the class-1 kernel itself; the (normally empty) overflow passes follow
 		}
 		a.t_start = nullptr;
 		if (side) HIPC(hipStreamWaitEvent(s, b->ev_join, 0));
@@ -1208,7 +1207,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 	}
-	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 3);
 	HIPC(hipEventRecord(b->ev[2], s));
 	if (b->R > 0 && b->n_reads > 0) {
 		TallyArgs a;
@@ -1232,7 +1230,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		HIPC(hipGetLastError());
 	}
-	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 5);
 	HIPC(hipEventRecord(b->ev[3], s));
 	if (b->R > 0 && b->n_reads > 0 && p.fallback) {
 		int8_t mat[25];
@@ -1257,7 +1254,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
 		HIPC(hipGetLastError());
 	}
-	if (tm) hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, tm + 7);
 	HIPC(hipEventRecord(b->ev[5], s));
 	if (b->R > 0) {
 		SummaryArgs a;
@@ -1267,6 +1263,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.out = b->summary.as<ihp_region_summary>();
 		a.zero = misc; a.n_zero = (int)(b->z_bytes() / sizeof(int)); a.n_report = REPORT_INTS;
 		HIPC(hipHostGetDevicePointer((void **)&a.report, b->report, 0));
+		a.t_end = tm ? (int)(ihp_batch::Z_TIMES / sizeof(int)) + 14 : -1;    // stamp [7]
 		hipLaunchKernelGGL(k_summary, dim3((b->R + 255) / 256), dim3(256), 0, s, a);
 		HIPC(hipGetLastError());
 	}
@@ -1331,7 +1328,8 @@ extern "C" int ihp_batch_set_timing(ihp_batch *b, int on)
 }
 
 // Execution time of the stages of the most recent run from device wall-clock stamps: from the moment the stage's first
-// workgroup started to a marker behind its last kernel.  ms[0] assemble, [1] ksw2, [2] tally, [3] fallback.
+// workgroup started to the moment the next stage's did (in stream order nothing of a stage runs after that; the last stage
+// ends where the summary kernel starts).  ms[0] assemble, [1] ksw2, [2] tally, [3] fallback.
 extern "C" int ihp_batch_kernel_ms(ihp_batch *b, float ms[4])
 {
 	if (!b || !b->ran || !b->timing || !ms) return IHP_E_ARG;
@@ -1341,8 +1339,13 @@ extern "C" int ihp_batch_kernel_ms(ihp_batch *b, float ms[4])
 	memcpy(t, (const char *)b->report + ihp_batch::Z_TIMES, sizeof(t));
 	int khz = 0;
 	HIPC(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g.device));
-	for (int k = 0; k < 4; ++k)
-		ms[k] = (t[2 * k] && t[2 * k + 1] > t[2 * k] && khz > 0) ? (float)((double)(t[2 * k + 1] - t[2 * k]) / (double)khz) : 0.0f;
+	// stamps: [0] assembly, [2] ksw2, [4] tally, [6] fallback (0 when that stage was not launched), [7] summary
+	for (int k = 0; k < 4; ++k) {
+		unsigned long long end = 0;
+		for (int j = 2 * k + 2; j <= 6 && !end; j += 2) end = t[j];
+		if (!end) end = t[7];
+		ms[k] = (t[2 * k] && end > t[2 * k] && khz > 0) ? (float)((double)(end - t[2 * k]) / (double)khz) : 0.0f;
+	}
 	return 0;
 }
 
