@@ -209,6 +209,13 @@ __device__ __forceinline__ long long bcast64(long long v, int src)
 	return ((long long)bcast((int)(v >> 32), src) << 32) | (unsigned)bcast((int)v, src);
 }
 
+// Cost class of a region for the combine kernel (0 = most work): combine compares every contig with a growing list
+// (contig.nim:254-281), so its time grows with the square of the contigs the read phase leaves.  k_asm_reads files every
+// region under its class and k_asm_combine takes the classes in order -- the longest chains start first and the short ones
+// fill the end of the launch instead of the other way round.
+constexpr int LPT_CLASSES = 8;
+__device__ __forceinline__ int lpt_class(int n) { return n >= 19 ? 0 : n >= 17 ? 1 : n >= 15 ? 2 : n >= 13 ? 3 : n >= 11 ? 4 : n >= 9 ? 5 : n >= 7 ? 6 : 7; }
+
 // Candidate ranking of best_match (contig.nim:32-36, :107, :239) for exact matches: more matches, then the earlier contig,
 // then the target-offset phase before the query-offset phase, then the smaller offset.
 struct Best2 { int found, ma, c, ph, o; };
@@ -229,6 +236,7 @@ struct ReadArgs {
 	const int *v2_trim_lo, *v2_trim_hi;
 	const uint32_t *v2_pk;
 	uint32_t *v2_hand; const long long *v2_hoff;
+	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by cost class, longest first (see lpt_class)
 	double min_overlap_pct;
 	int min_mapq_assemble, v2_pdw, n_regions;
 	const int *in_list, *n_in; int *out_list, *n_out; int *work_counter;
@@ -250,7 +258,7 @@ struct ReadArgs {
 // The supports are not touched here: a read adds 1 to every base it covers (contig.nim:198-200, :216-219 with
 // q.support == 1 and no corrections), so the support of a base is the number of records that cover it; positions are
 // kept relative to an anchor that moves when bases are prepended (contig.nim:180-205).
-__device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords, int r, long long *prof)
+__device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords, int r, long long *prof, int &n_contigs)
 {
 	const int lane = lane_id();
 	const long long r0 = uni(a.region_read_off[r]), r1 = uni(a.region_read_off[r + 1]);
@@ -508,6 +516,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	}
 	V2_LAP(7);
 #undef V2_LAP
+	n_contigs = n;
 	return 0;
 }
 

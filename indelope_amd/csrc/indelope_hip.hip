@@ -682,7 +682,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 
 // ------------------------------------------------------- the batched region path
 enum { WQ_SETS = 13 };      // work-queue counter sets: 10 assembly launches, ksw2, tally, fallback
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_WORDS = 24 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_LPT = 24, M_WORDS = 32 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -697,7 +697,7 @@ struct ihp_batch {
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
 	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
 	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
-	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_sup, v2_hoff, v2_hand;
+	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_sup, v2_hoff, v2_hand, lpt_seg;
 	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, grid_v2 = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
 	DBuf retry_listc, v2_sup_big;
 	long long v2_hand_dwords = 0;
@@ -762,7 +762,7 @@ static int alloc_work(ihp_batch *b)
 	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
 	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_sup, sizeof(uint32_t) * (size_t)b->v2_arena * b->grid_v2); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords);
-		AL(retry_listc, sizeof(int) * (size_t)R); AL(v2_sup_big, sizeof(uint32_t) * (size_t)b->v2_arena_big * b->grid_v2big); }
+		AL(retry_listc, sizeof(int) * (size_t)R); AL(lpt_seg, sizeof(int) * (size_t)R * LPT_CLASSES); AL(v2_sup_big, sizeof(uint32_t) * (size_t)b->v2_arena_big * b->grid_v2big); }
 	AL(retry_list2, sizeof(int) * (size_t)R);
 	AL(retry_list3, sizeof(int) * (size_t)R);
 	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
@@ -794,7 +794,7 @@ static int alloc_work(ihp_batch *b)
 
 static void release_work(ihp_batch *b)
 {
-	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->v2_sup_big, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
+	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_sup_big, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
 	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
@@ -1096,7 +1096,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.t_start = nullptr;
-		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_pm_dw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr;
+		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_pm_dw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr; a.lpt_cnt = nullptr; a.lpt_seg = nullptr; a.lpt_stride = 0;
 		// Passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  Every region
 		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
 		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
@@ -1152,6 +1152,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ra.region_read_off = x.region_read_off; ra.read_off = x.read_off; ra.read_start = x.read_start; ra.mapq = x.mapq;
 			ra.read_skip = x.read_skip; ra.v2_read_bad = x.v2_read_bad; ra.v2_trim_lo = x.v2_trim_lo; ra.v2_trim_hi = x.v2_trim_hi;
 			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
+			static const bool lpt_on = !(getenv("IHP_V2_LPT") && atoi(getenv("IHP_V2_LPT")) == 0);   // diagnostics: region order of the combine launch
+			ra.lpt_cnt = lpt_on ? misc + M_LPT : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
 			{
@@ -1161,10 +1163,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				else hipLaunchKernelGGL((k_asm_reads<4>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
 			}
 			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS; x.v2_pm_dw = b->v2_pm;
+			x.lpt_cnt = ra.lpt_cnt; x.lpt_seg = ra.lpt_seg; x.lpt_stride = ra.lpt_stride;
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
 			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
 			// regions whose contigs did not fit that arena: the same kernel with a roomy one (few workgroups per CU)
 			x.in_list = b->retry_listc.as<int>(); x.n_in = misc + M_NRETRYC; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0;
+			x.lpt_cnt = nullptr;
 			x.arena_sup = b->v2_sup_big.as<uint32_t>(); x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
 			x.work_counter = wq + 12 * WQ_WORDS;
 			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);

@@ -43,6 +43,7 @@ struct AsmArgs {
 	int v2_pdw;                                        // dwords of the per-wave packed area in LDS (k_asm_reads)
 	int v2_pm_dw;                                      // dwords of the packed mirror behind the byte arena (k_asm_combine)
 	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine: region r at v2_hand + v2_hoff[r]
+	const int *lpt_cnt, *lpt_seg; int lpt_stride;      // k_asm_combine: its regions by cost class (asm2_dev.h lpt_class), or null
 };
 
 }  // namespace ihp
@@ -428,9 +429,13 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		WSYNC();
 		if (r < 0) break;
 		if (a.in_list) r = a.in_list[r];
-		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr);
+		int nc = 0;
+		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr, nc);
 		if (err) {                                             // not for this path: the byte-based passes take it
 			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.out_list[atomicAdd(a.n_out, 1)] = r; }
+		} else if (a.lpt_cnt && lane == 0) {
+			const int c = lpt_class(nc);
+			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
 		}
 		WSYNC();
 	}
@@ -457,7 +462,13 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
 	mark_start(a.t_start);
 	if (lane < 16) S.prof[lane] = 0;
 	WSYNC();
-	const int n_items = a.in_list ? *a.n_in : a.n_regions;
+	int lpt[LPT_CLASSES];
+	int n_items = a.in_list ? *a.n_in : a.n_regions;
+	if (a.lpt_cnt) {
+		n_items = 0;
+#pragma unroll
+		for (int c = 0; c < LPT_CLASSES; ++c) { lpt[c] = uni(a.lpt_cnt[c]); n_items += lpt[c]; }
+	}
 	unsigned wq_dead = 0;
 	for (;;) {
 		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
@@ -465,7 +476,12 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
 		int r = __builtin_amdgcn_readfirstlane(s_item);
 		WSYNC();
 		if (r < 0) break;
-		if (a.in_list) r = a.in_list[r];
+		if (a.lpt_cnt) {                                        // item -> (class, position): the classes laid end to end
+			int c = 0;
+#pragma unroll
+			for (int k = 0; k < LPT_CLASSES - 1; ++k) if (c == k && r >= lpt[k]) { r -= lpt[k]; c = k + 1; }
+			r = uni(a.lpt_seg[(size_t)c * a.lpt_stride + r]);
+		} else if (a.in_list) r = a.in_list[r];
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
 		int err = v2_take_over(a, S, A, M, r, n_pre);
