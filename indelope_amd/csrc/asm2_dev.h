@@ -794,11 +794,15 @@ __device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, shor
 		if (min_support > 0) {
 			const long long ms = S.nreads[c] < min_support ? S.nreads[c] : min_support;
 			IHP_T0(A);
-			const int off0 = uni(S.off[c]);
-			trim_dev(S, A, c, ms);
-			const int moved = uni(S.off[c]) - off0;                // the trim only moves the slot's start (and length)
-			if (moved && M.on && lane == 0) { const int b = M.pm_sh[c] + moved; M.pm_dw[c] = (unsigned short)(M.pm_dw[c] + (b >> 4)); M.pm_sh[c] = (unsigned char)(b & 15); }
-			recompute_minmax(S, A, c);
+			// every support >= ms on two or more bases: trim (contig.nim:49-68) keeps the contig as it is -- the usual case of
+			// a single-read contig (support 1 everywhere, ms = 1) -- and the supports in HBM need not be looked at
+			if (!((long long)uni((int)S.smin[c]) >= ms && uni(S.len[c]) >= 2)) {
+				const int off0 = uni(S.off[c]);
+				trim_dev(S, A, c, ms);
+				const int moved = uni(S.off[c]) - off0;            // the trim only moves the slot's start (and length)
+				if (moved && M.on && lane == 0) { const int b = M.pm_sh[c] + moved; M.pm_dw[c] = (unsigned short)(M.pm_dw[c] + (b >> 4)); M.pm_sh[c] = (unsigned char)(b & 15); }
+				recompute_minmax(S, A, c);
+			}
 			IHP_T1(A, 7);
 		}
 		if (S.nreads[c] > 0 && nout == 0) {
