@@ -796,7 +796,24 @@ __device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, shor
 			IHP_T0(A);
 			// every support >= ms on two or more bases: trim (contig.nim:49-68) keeps the contig as it is -- the usual case of
 			// a single-read contig (support 1 everywhere, ms = 1) -- and the supports in HBM need not be looked at
-			if (!((long long)uni((int)S.smin[c]) >= ms && uni(S.len[c]) >= 2)) {
+			const int len0 = uni(S.len[c]), lo3 = uni(S.lo3[c]), hi3 = uni(S.hi3[c]);
+			if ((long long)uni((int)S.smin[c]) >= ms && len0 >= 2) {
+			} else if (ms == 3 && hi3 > lo3 && len0 >= 2) {
+				// the supports >= 3 are one run [lo3, hi3) (recompute_minmax): the trim is known without reading them.
+				// a = first i < len-1 with support >= 3, b = last i > a with support >= 3 (contig.nim:52-64)
+				if (lo3 >= len0 - 1) {                              // :56-60: nothing qualifies below the last base
+					if (lane == 0) { S.start[c] += len0 - 1; S.len[c] = 0; S.nreads[c] = 0; }
+				} else {
+					const int a0 = lo3, b0 = hi3 - 1 > lo3 ? hi3 - 1 : lo3;
+					if (lane == 0) {
+						S.start[c] += a0; S.off[c] += a0; S.cap[c] -= a0; S.len[c] = b0 - a0 + 1;
+						// what is left has every support >= 3: the extrema only gate the vote rule (a bound will do), the zone is all of it
+						S.smin[c] = 3u; S.lo3[c] = 0; S.hi3[c] = b0 - a0 + 1;
+						if (a0 && M.on) { const int b = M.pm_sh[c] + a0; M.pm_dw[c] = (unsigned short)(M.pm_dw[c] + (b >> 4)); M.pm_sh[c] = (unsigned char)(b & 15); }
+					}
+				}
+				LDS_ORDER();
+			} else {
 				const int off0 = uni(S.off[c]);
 				trim_dev(S, A, c, ms);
 				const int moved = uni(S.off[c]) - off0;            // the trim only moves the slot's start (and length)
