@@ -429,7 +429,8 @@ int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
  * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments; packed read phase: [12] read preparation,
  * [13] target-offset filter, [14] query-offset phase, [15] insert, [27] set-up.  Always filled: [24]/[25]/[26] regions
  * forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [23] regions the packed pass handed
- * back to the byte-based class-1 kernel, [22] ksw2 kernel mode. */
+ * back to the byte-based class-1 kernel, [28] regions sent on to the roomy combine launch, [29] regions the read phase
+ * filed under the second (larger-arena) combine launch, [22] ksw2 kernel mode. */
 int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
  * ihp_batch_run used: 3/4 = top-byte register sweep (left/right gaps; the production

@@ -213,7 +213,7 @@ __device__ __forceinline__ long long bcast64(long long v, int src)
 // (contig.nim:254-281), so its time grows with the square of the contigs the read phase leaves.  k_asm_reads files every
 // region under its class and k_asm_combine takes the classes in order -- the longest chains start first and the short ones
 // fill the end of the launch instead of the other way round.
-constexpr int LPT_CLASSES = 8;
+constexpr int LPT_CLASSES = 8, LPT_TIERS = 2;      // two combine launches: the usual arena, and one ~2.5x as large at half the occupancy
 __device__ __forceinline__ int lpt_class(int n) { return n >= 19 ? 0 : n >= 17 ? 1 : n >= 15 ? 2 : n >= 13 ? 3 : n >= 11 ? 4 : n >= 9 ? 5 : n >= 7 ? 6 : 7; }
 
 // Candidate ranking of best_match (contig.nim:32-36, :107, :239) for exact matches: more matches, then the earlier contig,
@@ -236,7 +236,9 @@ struct ReadArgs {
 	const int *v2_trim_lo, *v2_trim_hi;
 	const uint32_t *v2_pk;
 	uint32_t *v2_hand; const long long *v2_hoff;
-	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by cost class, longest first (see lpt_class)
+	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by arena tier and cost class, longest first (see lpt_class)
+	int *n_tier_b;                                            // counts the regions filed under the second tier (diagnostics)
+	int tier_a_cap;                                           // bytes of the first combine launch's arena (a region that needs more is filed under the second tier)
 	double min_overlap_pct;
 	int min_mapq_assemble, v2_pdw, n_regions;
 	const int *in_list, *n_in; int *out_list, *n_out; int *work_counter;
@@ -258,7 +260,7 @@ struct ReadArgs {
 // The supports are not touched here: a read adds 1 to every base it covers (contig.nim:198-200, :216-219 with
 // q.support == 1 and no corrections), so the support of a base is the number of records that cover it; positions are
 // kept relative to an anchor that moves when bases are prepended (contig.nim:180-205).
-__device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords, int r, long long *prof, int &n_contigs)
+__device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords, int r, long long *prof, int &n_contigs, int &arena_need)
 {
 	const int lane = lane_id();
 	const long long r0 = uni(a.region_read_off[r]), r1 = uni(a.region_read_off[r + 1]);
@@ -517,6 +519,14 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	V2_LAP(7);
 #undef V2_LAP
 	n_contigs = n;
+	// what combine needs of its byte arena: every contig in a slot of its own and the longest one's difference array
+	// (v2_take_over), plus room for a merge or two of the longest contigs before the first compaction
+	{
+		const int bl = lane < n ? align4(d_len) + SLOT_PAD : 0;
+		const int mxl = wave_max_i32s(lane < n ? d_len : 0);
+		const int btotal = wave_sum_i(bl) + mxl + 64, mx4 = 4 * (mxl + 2);
+		arena_need = btotal > mx4 ? btotal : mx4;
+	}
 	return 0;
 }
 

@@ -681,8 +681,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 13 };      // work-queue counter sets: 10 assembly launches, ksw2, tally, fallback
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_LPT = 24, M_WORDS = 32 };
+enum { WQ_SETS = 15 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; the last one holds the combine cost-class counters
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_WORDS = 24 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -698,11 +698,11 @@ struct ihp_batch {
 	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
 	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
 	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_sup, v2_hoff, v2_hand, lpt_seg;
-	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, grid_v2 = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
-	DBuf retry_listc, v2_sup_big;
+	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, v2_arena_b = 0, v2_pm_b = 0, grid_v2 = 0, grid_v2b = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
+	DBuf retry_listc, v2_sup_big, v2_sup_b;
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
-	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bfork = nullptr, ev_bjoin = nullptr;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
@@ -738,6 +738,8 @@ struct ihp_batch {
 		if (stream) { (void)hipStreamSynchronize(stream); g_streams.put(stream); }
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		if (ev_join) (void)hipEventDestroy(ev_join);
+		if (ev_bfork) (void)hipEventDestroy(ev_bfork);
+		if (ev_bjoin) (void)hipEventDestroy(ev_bjoin);
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	}
 };
@@ -762,11 +764,11 @@ static int alloc_work(ihp_batch *b)
 	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
 	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_sup, sizeof(uint32_t) * (size_t)b->v2_arena * b->grid_v2); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords);
-		AL(retry_listc, sizeof(int) * (size_t)R); AL(lpt_seg, sizeof(int) * (size_t)R * LPT_CLASSES); AL(v2_sup_big, sizeof(uint32_t) * (size_t)b->v2_arena_big * b->grid_v2big); }
+		AL(retry_listc, sizeof(int) * (size_t)R); AL(lpt_seg, sizeof(int) * (size_t)R * LPT_CLASSES * LPT_TIERS); AL(v2_sup_b, sizeof(uint32_t) * (size_t)b->v2_arena_b * b->grid_v2b); AL(v2_sup_big, sizeof(uint32_t) * (size_t)b->v2_arena_big * b->grid_v2big); }
 	AL(retry_list2, sizeof(int) * (size_t)R);
 	AL(retry_list3, sizeof(int) * (size_t)R);
-	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), b->grid_retry));
-	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, std::max(b->grid_v2, b->grid_v2big)), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
+	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), std::max(b->grid_retry, b->grid_v2b)));
+	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, std::max(std::max(b->grid_v2, b->grid_v2b), b->grid_v2big)), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	if (p->fallback) {
@@ -794,7 +796,7 @@ static int alloc_work(ihp_batch *b)
 
 static void release_work(ihp_batch *b)
 {
-	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_sup_big, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
+	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_sup_b, &b->v2_sup_big, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
 	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
@@ -953,6 +955,14 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 			b->v2_pm_big = (int)std::min<long long>(4096, 4 * need_pm);
 			(void)pm_on;
 			b->grid_v2big = grid_for(R, std::max(1, std::min(2, g.max_lds / (b->v2_arena_big + 4 * b->v2_pm_big + 4096))));
+			// the second tier: regions whose contigs (known when the read phase ends) need more than the first arena -- many
+			// single-read contigs, long reads -- at half the occupancy
+			{
+				const int occ_b = std::max(1, occ_c / 2);
+				b->v2_pm_b = (int)std::min<long long>(4096, 2 * need_pm);
+				b->v2_arena_b = (int)std::max<long long>(need_arena, (g.max_lds / occ_b - 4096 - 4 * b->v2_pm_b) / 16 * 16);
+				b->grid_v2b = std::min(grid_for(R, occ_b), std::max(1, b->n_cls[0]));
+			}
 			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
 			b->v2_arena = e1 ? atoi(e1) : (int)need_arena;
 			b->v2_pdw = e2 ? atoi(e2) : (int)need_pdw;
@@ -1049,6 +1059,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	for (auto &e : b->ev) HIPB(hipEventCreate(&e));
 	HIPB(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_bfork, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_bjoin, hipEventDisableTiming));
 	b->report = g_reports.get();
 	if (!b->report) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of the report page failed"); return IHP_E_NOMEM; }
 	HIPB(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // the only memset of the batch's life (see ihp_batch::misc)
@@ -1153,7 +1165,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ra.read_skip = x.read_skip; ra.v2_read_bad = x.v2_read_bad; ra.v2_trim_lo = x.v2_trim_lo; ra.v2_trim_hi = x.v2_trim_hi;
 			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
 			static const bool lpt_on = !(getenv("IHP_V2_LPT") && atoi(getenv("IHP_V2_LPT")) == 0);   // diagnostics: region order of the combine launch
-			ra.lpt_cnt = lpt_on ? misc + M_LPT : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
+			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
+			ra.tier_a_cap = b->v2_arena - 16; ra.n_tier_b = misc + M_NTIERB;     // tier_a_cap = Arena::cap of the first launch
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
 			{
@@ -1165,7 +1178,21 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS; x.v2_pm_dw = b->v2_pm;
 			x.lpt_cnt = ra.lpt_cnt; x.lpt_seg = ra.lpt_seg; x.lpt_stride = ra.lpt_stride;
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
+			// the second tier's regions (those whose contigs need more than the first arena; the read phase knows): the same kernel
+			// with a larger arena at half the occupancy, on the second stream beside the first tier's launch
+			HIPC(hipEventRecord(b->ev_bfork, s));
+			if (ra.lpt_cnt) {
+				HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
+				AsmArgs y = x;
+				y.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
+				y.arena_sup = b->v2_sup_b.as<uint32_t>(); y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
+				y.work_counter = wq + 13 * WQ_WORDS; y.corr = b->corr2.as<Corr>();
+				hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
+				HIPC(hipEventRecord(b->ev_bjoin, s2));
+			} else HIPC(hipEventRecord(b->ev_bjoin, s));
+			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
 			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second tier)
 			// regions whose contigs did not fit that arena: the same kernel with a roomy one (few workgroups per CU)
 			x.in_list = b->retry_listc.as<int>(); x.n_in = misc + M_NRETRYC; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0;
 			x.lpt_cnt = nullptr;
@@ -1321,6 +1348,7 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 	out[22] = g_last_ksw_mode;                        // which k_ksw<MODE> ran
 	out[23] = b->report[M_NRETRY0];                   // regions the packed path handed back to the byte-based class-1 kernel
 	out[28] = b->report[M_NRETRYC];                   // regions whose contigs needed the roomy combine launch
+	out[29] = b->report[M_NTIERB];                    // regions the read phase filed under the second (larger-arena) combine launch
 	return 0;
 }
 

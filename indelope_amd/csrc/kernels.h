@@ -43,7 +43,8 @@ struct AsmArgs {
 	int v2_pdw;                                        // dwords of the per-wave packed area in LDS (k_asm_reads)
 	int v2_pm_dw;                                      // dwords of the packed mirror behind the byte arena (k_asm_combine)
 	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine: region r at v2_hand + v2_hoff[r]
-	const int *lpt_cnt, *lpt_seg; int lpt_stride;      // k_asm_combine: its regions by cost class (asm2_dev.h lpt_class), or null
+	const int *lpt_cnt, *lpt_seg; int lpt_stride;      // k_asm_combine: its regions by cost class (asm2_dev.h lpt_class; the LPT_CLASSES counters and
+	                                                   // list segments of this launch's tier), or null
 };
 
 }  // namespace ihp
@@ -429,13 +430,15 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		WSYNC();
 		if (r < 0) break;
 		if (a.in_list) r = a.in_list[r];
-		int nc = 0;
-		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr, nc);
+		int nc = 0, need = 0;
+		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr, nc, need);
 		if (err) {                                             // not for this path: the byte-based passes take it
 			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 		} else if (a.lpt_cnt && lane == 0) {
-			const int c = lpt_class(nc);
+			const bool tier_b = need > a.tier_a_cap;
+			const int c = lpt_class(nc) + (tier_b ? LPT_CLASSES : 0);
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
+			if (tier_b) atomicAdd(a.n_tier_b, 1);
 		}
 		WSYNC();
 	}

@@ -430,7 +430,8 @@ def test_ksw2_wide_ring_boundaries(hip, oracle):
 
 def test_runtime_overflow_goes_to_the_catch_all_pass(hip, oracle):
     """Regions whose contigs outgrow the arena their read bases predicted (here: 2% errors, so nearly every read stays
-    a contig of its own) are forwarded at run time to the next pass; the results do not depend on the pass."""
+    a contig of its own) go to a launch with a larger arena or are forwarded at run time to the next pass; the results do
+    not depend on the pass."""
     for cfg in (dict(n_regions=120, n_reads=(40, 64), err_rate=2e-2, config_id=81),
                 dict(n_regions=60, n_reads=(100, 256), err_rate=1e-2, config_id=82)):
         b, _ = synth.generate(**cfg)
@@ -439,7 +440,7 @@ def test_runtime_overflow_goes_to_the_catch_all_pass(hip, oracle):
             hip.batch_run(h)
             hip.batch_sync(h)
             prof = hip.batch_profile(h)
-            forwarded = int(prof[23] + prof[24] + prof[25] + prof[26] + prof[28])    # byte-based overflow passes + the packed path's own second chances
+            forwarded = int(prof[23] + prof[24] + prof[25] + prof[26] + prof[28] + prof[29])    # byte-based overflow passes + the packed path's larger arenas
             got = hip.batch_fetch(h)
         finally:
             hip.batch_free(h)
