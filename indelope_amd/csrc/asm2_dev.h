@@ -196,7 +196,8 @@ __device__ __forceinline__ unsigned long long lane_range64(int lo, int hi)
 // ------------------------------------------------------------------------------------------------ read phase
 constexpr int V2_MIN_READ = 20, V2_MAX_READ = 960;       // trimmed read lengths this path takes
 constexpr int V2_MAX_CONTIGS = 64;                       // one directory lane per contig
-constexpr int V2_WL = 128;                               // work-list entries (two registers)
+constexpr int V2_WL = 128;                               // work-list entries in registers (two of them)
+constexpr int V2_WLX = 192;                              // ... and in LDS behind them, for regions of long reads (contigs of many dwords)
 constexpr int V2_HDR = 8, V2_DIRW = 8;                   // hand-over record: header dwords, dwords per contig
 
 __device__ __forceinline__ int wl_make(int dword, int c, int k) { return (dword << 2) | (c << 16) | (k << 22); }
@@ -256,6 +257,7 @@ struct ReadArgs {
 //   [1, 1 + QW)           the read being inserted, from bit 0 (QW = dwords of the longest read + 2 of zero padding)
 //   [RECB, RECB + reads)  one record per read of the region: contig (6 bits) | start relative to the contig's anchor,
 //                         biased by 16384 (15 bits) | trimmed length (10 bits); 0xffffffff = read not inserted
+//   [WLXB, WLXB + V2_WLX) work-list entries beyond the 128 in registers (regions with reads longer than 200 bases only)
 //   [SLOT0, p_dwords)     contig slots, bump allocated, every slot followed by a pad dword
 // The supports are not touched here: a read adds 1 to every base it covers (contig.nim:198-200, :216-219 with
 // q.support == 1 and no corrections), so the support of a base is the number of records that cover it; positions are
@@ -284,7 +286,9 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	if (mo_min < 17) return IHP_E_CAPACITY;                  // a 16-base window must lie inside every acceptable overlap
 	if (maxlen - (int)(a.min_overlap_pct * (double)maxlen) > 127) return IHP_E_CAPACITY;   // query offsets 1..127 (two registers)
 	const int QW = ((maxlen + 15) >> 4) + 2;
-	const int RECB = 1 + QW, SLOT0 = RECB + nrr;
+	const int RECB = 1 + QW, WLXB = RECB + nrr;
+	const int wlx_n = maxlen > 200 ? V2_WLX : 0;              // work-list entries beyond the two registers
+	const int SLOT0 = WLXB + wlx_n;
 	if (SLOT0 + 8 > p_dwords) return IHP_E_CAPACITY;
 	int bump = SLOT0;
 	if (lane == 0) P[0] = 0;
@@ -296,10 +300,11 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	int wl0 = 0, wl1 = 0, wl_n = 0;                           // work list: lane e of wl0 / wl1 = entry e / 64 + e
 	int n = 0;
 	auto wl_append = [&](int dword, int c, int k) -> bool {
-		if (wl_n >= V2_WL) return false;
+		if (wl_n >= V2_WL + wlx_n) return false;
 		const int e = wl_make(dword, c, k);
 		if (wl_n < 64) wl0 = lane == wl_n ? e : wl0;
-		else wl1 = lane == wl_n - 64 ? e : wl1;
+		else if (wl_n < V2_WL) wl1 = lane == wl_n - 64 ? e : wl1;
+		else { if (lane == 0) P[WLXB + wl_n - V2_WL] = (uint32_t)e; LDS_ORDER(); }
 		wl_n++;
 		return true;
 	};
@@ -359,7 +364,8 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 			V2_LAP(12);
 			// ---- target offsets (contig.nim:81-111): one dword of one contig per lane
 			for (int h = 0; h * 64 < wl_n; ++h) {
-				const int ent = h ? wl1 : wl0;
+				int ent = h ? wl1 : wl0;
+				if (h >= 2) ent = h * 64 + lane < wl_n ? (int)P[WLXB + (h - 2) * 64 + lane] : 0;
 				unsigned w0 = 0, w1 = 0;
 				bool any = false;
 				if (h * 64 + lane < wl_n) {
@@ -466,6 +472,11 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 						const bool m0 = ((wl0 >> 16) & 63) == c && lane < wl_n, m1 = ((wl1 >> 16) & 63) == c && 64 + lane < wl_n;
 						wl0 = m0 ? wl_make(nw + (int)((unsigned)wl0 >> 22), c, (int)((unsigned)wl0 >> 22)) : wl0;
 						wl1 = m1 ? wl_make(nw + (int)((unsigned)wl1 >> 22), c, (int)((unsigned)wl1 >> 22)) : wl1;
+						for (int i = lane; i < wl_n - V2_WL; i += 64) {
+							const int e = (int)P[WLXB + i];
+							if (((e >> 16) & 63) == c) P[WLXB + i] = (uint32_t)wl_make(nw + (int)((unsigned)e >> 22), c, (int)((unsigned)e >> 22));
+						}
+						LDS_ORDER();
 					}
 				}
 				d_nreads = sel ? d_nreads + 1 : d_nreads;                                       // :203, :222

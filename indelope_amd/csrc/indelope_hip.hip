@@ -937,7 +937,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 			const char *e1 = getenv("IHP_V2_ARENA"), *e2 = getenv("IHP_V2_PDW");
 			// what a region needs at least ...
 			long long need_arena = (nb1 * 36 / 100 + 512 + 15) / 16 * 16;
-			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * 6 / 10 + 64;
+			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave
 			// combine kernel: RegionStateT<64> + mirror arrays (4 KB static) + byte arena + packed mirror
