@@ -27,7 +27,7 @@ extern "C" {
 #define IHP_E_ARG        (-3)  /* bad argument (null pointer, negative size...) */
 #define IHP_E_NOMEM      (-4)  /* host or device allocation failed              */
 #define IHP_E_CAPACITY   (-5)  /* caller-provided buffer too small              */
-#define IHP_E_UNSUPPORTED (-6) /* parameter combination not implemented on GPU  */
+#define IHP_E_UNSUPPORTED (-6) /* parameter combination the entry point does not take (e.g. KSW_EZ_SCORE_ONLY on the per-region path) */
 
 const char *ihp_strerror(int code);
 const char *ihp_last_hip_error(void);   /* text of the last failing HIP call    */
@@ -46,6 +46,8 @@ void ihp_shutdown(void);
 #define KSW_EZ_GENERIC_SC  0x04
 #define KSW_EZ_APPROX_MAX  0x08
 #define KSW_EZ_APPROX_DROP 0x10
+#define KSW_EZ_SPLICE_FOR  0x100   /* ignored, as by ksw2_extz2_sse.c */
+#define KSW_EZ_SPLICE_REV  0x200
 #define KSW_EZ_EXTZ_ONLY   0x40
 #define KSW_EZ_REV_CIGAR   0x80
 

@@ -188,6 +188,7 @@ int grid_for(int items, int waves_per_cu)
 int ksw_mode(const KswParams &P)
 {
 	const int right = (P.flag & KSW_EZ_RIGHT) ? 1 : 0;
+	if (P.flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP)) return 2;   // the LDS sweep does every flag
 	if (P.w < 0 || P.w > 62) {
 		KswParams Q = P; Q.w = 0;
 		return (!right && ksw_narrow_ok(Q)) ? 5 : 2;             // 5: ring sweep per job where it fits, LDS sweep otherwise
@@ -389,14 +390,22 @@ static int codes_below(const uint8_t *s, size_t n, int m)
 	return (int)mx < m;
 }
 
+// The per-region path needs the CIGAR and the exact maximum of every contig alignment (the event iterators and the
+// tally start from them): flags that drop either are refused there.  The stand-alone alignment entry points
+// (ksw_extz2_sse, ihp_ksw_extz2_batch) take every flag of ksw2.h:8-16 (the LDS sweep, MODE 2, does score-only, generic
+// scoring and the approximate maximum; the splice flags mean nothing to ksw_extz2_sse and are ignored as there).
 static int ksw_flags_supported(int flag)
 {
 	return !(flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP));
 }
+static int ksw_flags_supported_standalone(int flag, int m)
+{
+	return !(flag & KSW_EZ_GENERIC_SC) || m <= 8;             // the matrix travels in the launch arguments: 64 entries
+}
 
 // Run `n` jobs; qbase/tbase already on the device.  Results in host vectors.
 static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, const uint8_t *d_t, const KswParams &P,
-                        std::vector<KswOut> &ez, std::vector<long long> &coff, std::vector<uint32_t> &pool)
+                        std::vector<KswOut> &ez, std::vector<long long> &coff, std::vector<uint32_t> &pool, const int8_t *mat = nullptr)
 {
 	const int n = (int)jobs.size();
 	ez.assign(n, KswOut());
@@ -406,7 +415,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	size_t lds_need = 0, p_need = 0; long long cig_bound = 0; int cig_cap = 0;
 	for (const AlnJob &j : jobs) {
 		if (j.qlen <= 0 || j.tlen <= 0) continue;
-		lds_need = std::max(lds_need, (P.w >= 0 && P.w <= 62) ? ksw_narrow_lds_bytes(j.qlen, j.tlen)
+		lds_need = std::max(lds_need, ksw_mode(P) == 2 ? ksw_lds_bytes(j.qlen, j.tlen) : (P.w >= 0 && P.w <= 62) ? ksw_narrow_lds_bytes(j.qlen, j.tlen)
 		                    : std::max(ksw_lds_bytes(j.qlen, j.tlen), ksw_wide_ok<3>(P, j.qlen, j.tlen) ? ksw_wide_lds_bytes<3>(j.qlen, j.tlen)
 		                               : ksw_wide_ok<6>(P, j.qlen, j.tlen) ? ksw_wide_lds_bytes<6>(j.qlen, j.tlen) : (size_t)0));
 		int w = P.w < 0 ? std::max(j.qlen, j.tlen) : P.w;
@@ -438,6 +447,8 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
 	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
 	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr; a.t_start = nullptr;
+	a.gm = 0; memset(a.gmat, 0, sizeof(a.gmat));
+	if ((P.flag & KSW_EZ_GENERIC_SC) && mat && P.m <= 8) { a.gm = P.m; for (int i = 0; i < P.m * P.m; ++i) a.gmat[i] = mat[i]; }
 	g_last_ksw_mode = mode;
 	launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
@@ -462,7 +473,7 @@ extern "C" int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int6
                                    ihp_ez *ez, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_off)
 {
 	if (n < 0 || !q_off || !t_off || !mat || !ez || !cigar_off || (n && (!queries || !targets))) return IHP_E_ARG;
-	if (!ksw_flags_supported(flag)) return IHP_E_UNSUPPORTED;
+	if (!ksw_flags_supported_standalone(flag, m)) return IHP_E_UNSUPPORTED;
 	int rc = ensure_init();
 	if (rc) return rc;
 	cigar_off[0] = 0;
@@ -479,7 +490,7 @@ extern "C" int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int6
 	std::vector<KswOut> out; std::vector<long long> coff; std::vector<uint32_t> pool;
 	KswParams P = make_ksw_params(m, mat, q, e, w, zdrop, flag, 0);
 	P.codes_ok = codes_below(queries, (size_t)q_off[n], m) && codes_below(targets, (size_t)t_off[n], m);
-	rc = run_ksw_jobs(jobs, d_q.as<uint8_t>(), d_t.as<uint8_t>(), P, out, coff, pool);
+	rc = run_ksw_jobs(jobs, d_q.as<uint8_t>(), d_t.as<uint8_t>(), P, out, coff, pool, mat);
 	if (rc) return rc;
 	int64_t used = 0; int ret = 0;
 	for (int i = 0; i < n; ++i) {
@@ -1234,6 +1245,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_pool = b->cig_pool.as<uint32_t>(); a.cig_cursor = (unsigned long long *)(misc + M_CIG);
 		a.cig_pool_cap = b->cig_pool_cap; a.cig_bump_cap = b->cig_bump_cap; a.overflow = misc + M_OVF; a.work_counter = wq + 7 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
+		a.gm = 0; memset(a.gmat, 0, sizeof(a.gmat));
 		g_last_ksw_mode = ksw_mode(a.P);
 		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());

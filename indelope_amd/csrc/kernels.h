@@ -533,6 +533,7 @@ struct KswArgs {
 	int *work_counter;
 	long long *prof;                           // optional cycle counters (diagnostics)
 	unsigned long long *t_start;               // optional: see mark_start()
+	signed char gmat[64]; int gm;              // KSW_EZ_GENERIC_SC: the m x m score matrix (gm = m <= 8, else 0); MODE 2 only
 };
 
 // MODE 3: top-byte register-resident sweep (ksw_narrow.h), left-aligned gaps; 4: same, KSW_EZ_RIGHT -- the
@@ -609,7 +610,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 						} else ksw_wave(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
 					}
 				} else {
-					ksw_wave(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc);
+					signed char gmat[64];
+					const int gm = a->gm;
+					if (gm) for (int i = 0; i < 64; ++i) gmat[i] = a->gmat[i];
+					ksw_wave(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc, gm ? gmat : nullptr);
 				}
 			}
 			a = ksw_args_again(a0);

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint8_t enc_base(uint8_t c)
 __host__ __device__ __forceinline__ size_t ksw_lds_bytes(int qlen, int tlen)
 {
 	const size_t T = (size_t)((tlen + 15) / 16) * 16, Q = (size_t)((qlen + 15) / 16) * 16 + 16;
-	return 8 * T + Q + 4 * T;
+	return 8 * T + Q + 4 * T + 64;                       // records, reversed query, H[], generic score matrix (KSW_EZ_GENERIC_SC)
 }
 
 // Band of anti-diagonal r (:196-205).  Returns false when st > en (band exit).
@@ -157,9 +157,13 @@ __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, 
 }
 
 // cig_tmp: per-wave scratch for the CIGAR (capacity cig_cap words).  out.n_cigar = -1 if too small.
+// gmat (KSW_EZ_GENERIC_SC, m <= 8): the m x m score matrix; the scores of a diagonal are then mat[target][query] on the
+// true band [st0, en0] only (:229-232), not match / mismatch / wildcard on 16-byte groups.  KSW_EZ_APPROX_MAX (and
+// KSW_EZ_APPROX_DROP with it) replaces the exact maximum by the reference's H0 walk (:358-374); KSW_EZ_SCORE_ONLY skips
+// the traceback.  The reference never sets these flags on the path; they are here for the FFI seam.
 __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *target, int tlen,
                                 const KswParams P, uint8_t *lds, uint8_t *p, uint32_t *cig_tmp, int cig_cap,
-                                KswOut &out, long long *pacc = nullptr)
+                                KswOut &out, long long *pacc = nullptr, const signed char *gmat = nullptr)
 {
 	const long long tc0 = pacc ? (long long)clock64() : 0;
 	const int lane = lane_id();
@@ -178,6 +182,9 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 	uint2 *rec = (uint2 *)lds;                           // [T]
 	uint8_t *qr = lds + 8 * (size_t)T;                   // [QR]
 	int *H = (int *)(lds + 8 * (size_t)T + QR);          // [T]
+	uint8_t *gm = lds + 8 * (size_t)T + QR + 4 * (size_t)T;   // [64] generic score matrix
+	const bool generic = (flag & KSW_EZ_GENERIC_SC) != 0 && gmat != nullptr, approx = (flag & KSW_EZ_APPROX_MAX) != 0;
+	if (generic && lane < 64) gm[lane] = lane < P.m * P.m ? (uint8_t)gmat[lane] : 0;
 	const unsigned qe2 = (unsigned)(qe * 2) & 0xff, sc_mch = (unsigned)P.sc_mch & 0xff, sc_mis = (unsigned)P.sc_mis & 0xff;
 	const unsigned m1 = (unsigned)(P.m - 1) & 0xff, max_sc8 = (unsigned)(P.sc_mch + qe * 2) & 0xff, q8 = (unsigned)q & 0xff;
 	const bool with_cigar = !(flag & KSW_EZ_SCORE_ONLY), right = (flag & KSW_EZ_RIGHT) != 0;
@@ -198,6 +205,7 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 	int last_st = -1, last_en = -1;
 	int ez_max = 0, ez_max_t = -1, ez_max_q = -1, mqe = KSW_NEG_INF, mqe_t = -1, mte = KSW_NEG_INF, mte_q = -1;
 	int score = KSW_NEG_INF, zdropped = 0;
+	int H0 = 0, last_H0_t = 0;                           // KSW_EZ_APPROX_MAX
 	for (int r = 0; r < qlen + tlen - 1; ++r) {
 		int st0, en0, st, en;
 		if (!ksw_band(r, qlen, tlen, w, st0, en0, st, en)) { zdropped = 1; break; }   // :200-203
@@ -212,7 +220,7 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 		int bh = -0x7fffffff - 1, brk = 0x7fffffff, bt = 0, Hen0 = 0, Hst0 = 0;
 		// the 16-byte score stores run up to 15 bytes past en (:215-228); those bytes stay behind as the
 		// stale s[] of later diagonals, so lanes in (en, sc_hi] refresh their score byte and nothing else
-		const int hi = sc_hi < T ? (sc_hi > en ? sc_hi : en) : (T - 1 > en ? T - 1 : en);
+		const int hi = generic ? en : sc_hi < T ? (sc_hi > en ? sc_hi : en) : (T - 1 > en ? T - 1 : en);
 		const int nch = (hi - st + 64) / 64;
 		for (int c = nch - 1; c >= 0; --c) {             // top chunk first: t-1 of r-1 is still intact below
 			const int tb = st + c * 64, t = tb + lane;
@@ -231,7 +239,9 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 				else xv = rec[t - 1].x & 0xffffu;
 				unsigned sv = R.y & 0xff;
 				const unsigned sfb = (R.y >> 8) & 0xff;
-				if (t >= st0 && t <= sc_hi) {            // :214-228
+				if (generic) {                           // :229-232
+					if (t >= st0 && t <= en0) sv = gm[sfb * (unsigned)P.m + qr[qoff + t]];
+				} else if (t >= st0 && t <= sc_hi) {     // :214-228
 					const unsigned qb = qr[qoff + t];
 					sv = sfb == qb ? sc_mch : sc_mis;
 					if (sfb == m1 || qb == m1) sv = 0;
@@ -304,19 +314,37 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 			}
 		}
 		LDS_ORDER();                                     // p stores keep streaming; LDS is in order per wave
-		const int max_H = bh, max_t = bt;
-		if (en0 == tlen - 1 && Hen0 > mte) { mte = Hen0; mte_q = r - en; }            // :351-352 (rounded en)
-		if (r - st0 == qlen - 1 && Hst0 > mqe) { mqe = Hst0; mqe_t = st0; }           // :353-354
-		{                                                                             // ksw_apply_zdrop :88-104
-			const int t = max_t;
-			if (max_H > ez_max) { ez_max = max_H; ez_max_t = t; ez_max_q = r - t; }
+		// ksw_apply_zdrop :88-104
+		auto apply_zdrop = [&](int Hv, int t) -> bool {
+			if (Hv > ez_max) { ez_max = Hv; ez_max_t = t; ez_max_q = r - t; }
 			else if (t >= ez_max_t && r - t >= ez_max_q) {
 				const int tl = t - ez_max_t, ql = (r - t) - ez_max_q;
 				const int l = tl > ql ? tl - ql : ql - tl;
-				if (P.zdrop >= 0 && ez_max - max_H > P.zdrop + l * e) { zdropped = 1; break; }
+				if (P.zdrop >= 0 && ez_max - Hv > P.zdrop + l * e) { zdropped = 1; return true; }
 			}
+			return false;
+		};
+		if (!approx) {
+			const int max_H = bh, max_t = bt;
+			if (en0 == tlen - 1 && Hen0 > mte) { mte = Hen0; mte_q = r - en; }            // :351-352 (rounded en)
+			if (r - st0 == qlen - 1 && Hst0 > mqe) { mqe = Hst0; mqe_t = st0; }           // :353-354
+			if (apply_zdrop(max_H, max_t)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) score = Hen0;                    // :356-357 (en0 == tlen-1)
+		} else {                                                                          // approximate max (:358-374)
+			if (r > 0) {
+				const bool in0 = last_H0_t >= st0 && last_H0_t <= en0, in1 = last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0;
+				if (in0 && in1) {
+					const int d0 = (int)((rec[last_H0_t].x >> 8) & 0xffu) - qe;             // v8[last_H0_t]
+					const int d1 = (int)((rec[last_H0_t + 1].x >> 16) & 0xffu) - qe;        // u8[last_H0_t + 1]
+					if (d0 > d1) H0 += d0;
+					else { H0 += d1; ++last_H0_t; }
+				} else if (in0) H0 += (int)((rec[last_H0_t].x >> 8) & 0xffu) - qe;
+				else { ++last_H0_t; H0 += (int)((rec[last_H0_t].x >> 16) & 0xffu) - qe; }
+				H0 = uni(H0); last_H0_t = uni(last_H0_t);
+				if ((flag & KSW_EZ_APPROX_DROP) && apply_zdrop(H0, last_H0_t)) break;
+			} else { H0 = uni((int)((rec[0].x >> 8) & 0xffu)) - qe - qe; last_H0_t = 0; }
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) score = H0;
 		}
-		if (r == qlen + tlen - 2 && en0 == tlen - 1) score = Hen0;                    // :356-357 (en0 == tlen-1)
 		last_st = st; last_en = en;
 	}
 	out.max = ez_max; out.zdropped = zdropped; out.max_q = ez_max_q; out.max_t = ez_max_t;

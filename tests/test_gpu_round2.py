@@ -172,26 +172,50 @@ def test_bad_struct_size_and_arguments(hip):
     assert e.value.code == A.IHP_E_ARG
 
 
-def test_unsupported_ksw_flags(hip):
-    q, t = hip.encode("ACGTACGTAC"), hip.encode("ACGTACGGTAC")
+def _ksw_call(fn, q, t, m, mat, gapo, gape, w, z, flag):
+    ez = A.KswExtz()
+    fn(None, len(q), A.ptr(q, A.u8p), len(t), A.ptr(t, A.u8p), m, A.ptr(mat, A.i8p), gapo, gape, w, z, flag, C.byref(ez))
+    cig = [int(ez.cigar[i]) for i in range(ez.n_cigar)]
+    out = (ez.max, ez.zdropped, ez.max_q, ez.max_t, ez.mqe, ez.mqe_t, ez.mte, ez.mte_q, ez.score, ez.n_cigar)
+    if ez.cigar:
+        C.CDLL(None).free(ez.cigar)
+    return out, cig
+
+
+def test_ksw_flags_of_the_ffi_seam(hip, oracle):
+    """KSW_EZ_SCORE_ONLY / APPROX_MAX / APPROX_DROP / GENERIC_SC (ksw2.h:8-12; the reference path never sets them) through
+    the drop-in `ksw_extz2_sse` symbol: every ksw_extz_t field and the CIGAR against the reference's own C compiled by
+    oracle/Makefile (oracle/_ref).  The per-region path, which needs the CIGAR and the exact maximum, refuses them."""
+    import test_oracle_ksw2 as tk
     for flag in (A.KSW_EZ_SCORE_ONLY, A.KSW_EZ_APPROX_MAX, A.KSW_EZ_GENERIC_SC):
-        with pytest.raises(IhpError) as e:
-            hip.align_batch([q], [t], flag=flag, encoded=True)
-        assert e.value.code == A.IHP_E_UNSUPPORTED
         with pytest.raises(IhpError) as e:
             hip.run_regions(synth.generate(2, n_reads=(8, 8), config_id=71)[0], hip.params(ksw_flag=flag))
         assert e.value.code == A.IHP_E_UNSUPPORTED
-    # the reference-signature entry point cannot return a code: ez is left reset and the status says why
-    mat = hip.matrix()
-    ez = A.KswExtz()
-    hip.cdll.ksw_extz2_sse(None, len(q), A.ptr(q, A.u8p), len(t), A.ptr(t, A.u8p), 5, A.ptr(mat, A.i8p), 4, 1, -1, -1,
-                           A.KSW_EZ_SCORE_ONLY, C.byref(ez))
-    assert ez.n_cigar == 0 and ez.score == A.KSW_NEG_INF
-    assert hip.b.ksw_last_status() == A.IHP_E_UNSUPPORTED
-    hip.cdll.ksw_extz2_sse(None, len(q), A.ptr(q, A.u8p), len(t), A.ptr(t, A.u8p), 5, A.ptr(mat, A.i8p), 4, 1, -1, -1, 0, C.byref(ez))
-    assert hip.b.ksw_last_status() == 0 and ez.n_cigar > 0
-    if ez.cigar:
-        C.CDLL(None).free(ez.cigar)
+    ref = oracle.ref_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref (the compiled reference ksw2) is not built")
+    S, R, G, AM, AD, X, RV = (A.KSW_EZ_SCORE_ONLY, A.KSW_EZ_RIGHT, A.KSW_EZ_GENERIC_SC, A.KSW_EZ_APPROX_MAX, A.KSW_EZ_APPROX_DROP,
+                              A.KSW_EZ_EXTZ_ONLY, A.KSW_EZ_REV_CIGAR)
+    rng = np.random.default_rng(77)
+    gen = rng.integers(-6, 3, (5, 5)).astype(np.int8)          # a generic matrix: positive diagonal, no wildcard row
+    gen[np.arange(5), np.arange(5)] = [2, 3, 1, 2, 1]
+    gen = np.ascontiguousarray(gen.reshape(-1))
+    plain = hip.matrix()
+    sets = [(S, plain, 4, 1, 50, 400), (S | R, plain, 4, 2, -1, -1), (AM, plain, 4, 1, 50, 400), (AM | AD, plain, 4, 1, 50, 100),
+            (AM | AD | X, plain, 4, 1, 30, 60), (AM | R | RV, plain, 5, 1, -1, -1), (G, gen, 4, 1, 50, 400), (G | R, gen, 6, 2, -1, 200),
+            (G | AM | AD, gen, 4, 1, 40, 80), (G | S, gen, 4, 1, 50, 400), (0x100, plain, 4, 1, 50, 400)]
+    n = 0
+    for si, (flag, mat, go, ge, w, z) in enumerate(sets):
+        for q, t in tk.cases(900 + si, 12):
+            qe, te = hip.encode(q), hip.encode(t)
+            got = _ksw_call(hip.cdll.ksw_extz2_sse, qe, te, 5, mat, go, ge, w, z, flag)
+            assert hip.b.ksw_last_status() == 0
+            exp = _ksw_call(ref.ksw_extz2_sse, qe, te, 5, mat, go, ge, w, z, flag)
+            assert got == exp, (si, hex(flag), len(q), len(t), got, exp)
+            n += 1
+        if flag & (S | G | AM):
+            assert hip.b.debug_last_ksw_mode() == 2
+    assert n >= 120
 
 
 @pytest.mark.parametrize("which", ["cigar", "events", "hits", "ksw"])
