@@ -51,7 +51,7 @@ for k, v in raw.items():
     out["kernels"][k] = {"FETCH_SIZE": int(f * 1024), "WRITE_SIZE": int(w * 1024), "traffic": int((f + w) * 1024),
                          "launches_averaged": v.get("_launches")}
     if k.startswith("k_asm_combine"):
-        out["kernels"][k]["launches_per_stage"] = 2      # the regular and the roomy launch (the average is over both)
+        out["kernels"][k]["launches_per_stage"] = 3      # first tier, second tier and the roomy launch (the average is over all three)
 json.dump(out, open("gpurun_out/prof/c2_pmc.json", "w"), indent=1)
 PY
 # the raw rocprofv3 output directories are large (gpurun merges at most 64 MiB back): keep the summaries only
