@@ -321,3 +321,64 @@ def test_c_harness_drives_the_device():
     pr = subprocess.run([_build_harness(), "--gpu"], capture_output=True, text=True)
     assert pr.returncode == 0, pr.stderr
     assert json.loads(pr.stdout)["gpu_checks"] is True
+
+
+def _pair(rng, qlen, tlen, sub=0.01, indel=0.01, shift=None):
+    """A query of ~qlen bases derived from a window of a random target of tlen bases."""
+    t = rng.integers(0, 4, tlen)
+    lo = 0 if shift is None else shift
+    src = t[lo:lo + qlen].copy()
+    q = []
+    for b in src:
+        u = rng.random()
+        if u < indel / 2:
+            continue
+        if u < indel:
+            q += [b, int(rng.integers(0, 4))]
+            continue
+        q.append(int((b + rng.integers(1, 4)) % 4) if rng.random() < sub else int(b))
+    q = np.array(q if q else [0], np.uint8)
+    L = "ACGT"
+    return "".join(L[i] for i in q), "".join(L[i] for i in t)
+
+
+def test_ksw_sweep_phases(hip, oracle):
+    """The production sweep is laid out by phase (early / steady periods / tail runs cut by the query or the target);
+    shapes that put the ends of the phases everywhere -- query longer and shorter than the target, jobs too short for a
+    steady phase, z-drops in every phase, every band width the steady loop takes -- against the oracle, field by field."""
+    rng = np.random.default_rng(20261002)
+    R = A.KSW_EZ_RIGHT
+    n = 0
+    for w, z, flag, go, ge in ((50, 400, 0, 4, 1), (49, 40, 0, 4, 1), (62, 15, R, 4, 2), (55, 100, 0, 6, 1), (50, -1, 0, 4, 1),
+                               (57, 25, R, 4, 1), (50, 8, 0, 4, 1), (61, 60, 0, 5, 2)):
+        qs, ts = [], []
+        for _ in range(150):
+            shape = rng.integers(0, 6)
+            if shape == 0:
+                ql, tl = int(rng.integers(200, 420)), int(rng.integers(200, 420))             # either may be the longer one
+            elif shape == 1:
+                tl = int(rng.integers(120, 200)); ql = int(rng.integers(300, 500))          # cut by the target first
+            elif shape == 2:
+                ql = int(rng.integers(w + 20, w + 45)); tl = int(rng.integers(w + 20, 300))  # around the "room for the early phase" limit
+            elif shape == 3:
+                ql, tl = int(rng.integers(1, 90)), int(rng.integers(1, 90))                  # no steady phase at all
+            elif shape == 4:
+                ql = int(rng.integers(250, 400)); tl = ql + int(rng.integers(-3, 60))        # ends close together
+            else:
+                ql, tl = int(rng.integers(500, 700)), int(rng.integers(500, 700))            # many periods
+            sub = float(rng.choice([0.0, 0.01, 0.05, 0.3]))                                   # 0.3: scores fall, z-drops
+            q, t = _pair(rng, min(ql, tl) if rng.random() < 0.5 else ql, tl, sub=sub, indel=float(rng.choice([0.0, 0.01, 0.04])),
+                         shift=int(rng.integers(0, max(1, tl // 3))) if rng.random() < 0.4 else None)
+            if len(q) < ql:                                                                   # pad the query with unrelated bases
+                q += "".join("ACGT"[i] for i in rng.integers(0, 4, ql - len(q)))
+            qs.append(q); ts.append(t)
+        kw = dict(match=1, mismatch=-2, gap_open=go, gap_ext=ge, bw=w, z=z, flag=flag)
+        ez, cg = hip.align_batch(qs, ts, **kw)
+        assert hip.b.debug_last_ksw_mode() == (4 if flag & R else 3)
+        ez2, cg2 = oracle.align_batch(qs, ts, **kw)
+        for i in range(len(qs)):
+            assert ez[i].tolist() == ez2[i].tolist(), (w, z, flag, i, len(qs[i]), len(ts[i]), ez[i], ez2[i])
+            assert cg[i].tolist() == cg2[i].tolist(), (w, z, flag, i, len(qs[i]), len(ts[i]))
+        n += len(qs)
+    assert n == 1200
+
