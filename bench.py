@@ -307,22 +307,22 @@ def main():
         cuts = [lo + R * i // S for i in range(S + 1)]
     gen = dict(cfg)
     subs, hs = [], []
+    # strong scaling on few GPUs: the results of a whole shard may not fit beside its inputs -> one chunk's results at a time
+    # (decided before the uploads: a chunk hands its scratch and result buffers back as soon as it is resident)
+    import ctypes
+    cu_, ws_, hbm_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    api.b.device_info(ctypes.byref(cu_), ctypes.byref(ws_), ctypes.byref(hbm_))
+    hbm = hbm_.value
+    stream_outputs = strong and R * 64 * cfg["read_len"] * 9.0 > 0.7 * hbm
     for i in range(S):
         gen["n_regions"] = cuts[i + 1] - cuts[i]
         sb, _ = synth.generate(first_region=cuts[i], dup_frac=args.dup_frac, **gen)
         if not args.quals:
             sb = sb.with_trim_bounds()                       # A0 on the host (SURVEY 8a row A0, 8b "trim bounds (a,b)")
         hs.append(api.batch_upload(sb, params))
+        if stream_outputs:
+            api.batch_release_outputs(hs[-1])
         subs.append(sb if (not strong or (rank == 0 and i == 0)) else None)     # strong: keep one chunk for the host-side legs
-    # strong scaling on few GPUs: the results of a whole shard may not fit beside its inputs -> one chunk's results at a time
-    import ctypes
-    cu_, ws_, hbm_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
-    api.b.device_info(ctypes.byref(cu_), ctypes.byref(ws_), ctypes.byref(hbm_))
-    hbm = hbm_.value
-    stream_outputs = strong and R * 64 * cfg["read_len"] * 9.0 > 0.7 * hbm
-    if stream_outputs:
-        for h in hs:
-            api.batch_release_outputs(h)
     timing = (not strong) and S > 1
     if timing:
         for h in hs:                                         # with several chains in flight a kernel can wait for wave slots:
