@@ -1257,6 +1257,11 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS;
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>();
 		a.bases = b->bases.as<uint8_t>(); a.mapq = b->mapq.as<uint8_t>();
+		{
+			static const bool tally_pk = !(getenv("IHP_TALLY_PK") && atoi(getenv("IHP_TALLY_PK")) == 0);   // diagnostics
+			const bool have = b->v2 && b->n_cls[0] > 0 && tally_pk;    // k_prepack ran in this chain
+			a.pk = have ? b->v2_pk.as<uint32_t>() : nullptr; a.read_bad = have ? b->v2_read_bad.as<uint8_t>() : nullptr;
+		}
 		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();
 		a.ref_origin = b->ref_origin.as<long long>(); a.ctg_start = b->ctg_start.as<long long>();
 		a.ez = b->ez.as<KswOut>(); a.cig_off = b->cig_off.as<long long>(); a.cig_pool = b->cig_pool.as<uint32_t>();
@@ -1270,6 +1275,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.overflow = misc + M_OVF; a.work_counter = wq + 8 * WQ_WORDS;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.lds_bytes = std::min(g.max_lds - 4096, 64 * ((b->max_read_len + 3) / 4 * 4) + 64);
+		// with the 2-bit reads at hand a group of 64 reads is a quarter of that; the rare region with a base that is not
+		// upper-case ACGT then walks its reads in HBM (tally_reads) instead of staging them
+		if (a.pk) a.lds_bytes = std::min(a.lds_bytes, 64 * 4 * ((b->max_read_len + 15) / 16 + 1) + 64);
 		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		HIPC(hipGetLastError());
 	}

@@ -653,6 +653,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 struct TallyArgs {
 	const AlnJob *jobs; const int *n_jobs;
 	const uint8_t *out_seq, *ref_bases, *bases, *mapq;
+	const uint32_t *pk; const uint8_t *read_bad;   // k_prepack's 2-bit bases and per-read "not all upper-case ACGT" flags, or null
 	const long long *read_off, *region_read_off, *ref_origin, *ctg_start;
 	const KswOut *ez; const long long *cig_off; const uint32_t *cig_pool;
 	TallyParams P;
@@ -696,6 +697,13 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 		const long long base0 = a.read_off[rr0], end0 = a.read_off[ge0];
 		int nev = 0, ntrunc = 0;
 		if (ez.n_cigar > 0 && coff >= 0) nev = count_events(cig, ez.n_cigar, ez.max_q, &ntrunc);
+		// the 2-bit reads serve the tally when every read of the region is clean (the usual case)
+		bool packed = a.pk != nullptr && nev > 0;
+		if (packed) {
+			bool badr = false;
+			for (long long i = rr0 + lane; i < rr1; i += 64) badr |= a.read_bad[i] != 0;
+			packed = !ballot(badr);
+		}
 		long long eoff = -1;
 		const long long tj1 = a.prof ? (long long)clock64() : 0;
 		if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[20], (unsigned long long)(tj1 - tj0));
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
 				            a.bases, a.read_off, a.mapq, rr0, rr1,
 				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count,
 				            a.hit_pool, a.hit_cursor, a.hit_cap, a.hit_overflow, a.hit_region_cnt ? a.hit_region_cnt + r : nullptr,
-				            8 * rr0, a.hit_bump0, base0, end0);
+				            8 * rr0, a.hit_bump0, base0, end0, packed ? a.pk : nullptr);
 			} else {
 				if (lane == 0) atomicExch(&a.overflow[2], 1);
 				eoff = -1; nev = 0;

@@ -175,6 +175,73 @@ __device__ __forceinline__ bool tally_stage_first(const uint8_t *bases, long lon
 	return true;
 }
 
+// A k-mer code of the A C G T = 0 1 2 3 alphabet in k_prepack's A C T G = 0 1 2 3 (digit d -> d ^ (d >> 1): an involution)
+__device__ __forceinline__ unsigned long long to_packed_alphabet(unsigned long long code)
+{
+	return code ^ ((code >> 1) & 0x5555555555555555ull);
+}
+
+// The tally on the 2-bit bases k_prepack left in HBM (read i at dword (read_off[i] >> 4) + i, from bit 0): a quarter of the
+// staging of tally_reads_lds() and no per-base decoding or validation -- the caller has checked that no read of the region
+// has a base that is not upper-case ACGT (k_prepack's read_bad), so every window of a read is a valid k-mer (:300).
+// Lanes = reads as there; same counts, same first-hit positions.  Returns false (nothing done) when a group of 64 reads
+// does not fit the LDS area.
+__device__ inline bool tally_reads_packed(const uint32_t *pk, const long long *read_off, const uint8_t *mapq,
+                                          long long r0, long long r1, int min_mapq, int K,
+                                          unsigned long long refe, unsigned long long alte, int counts[3],
+                                          uint32_t *lds32, int lds_bytes, int *ref_hit, int *alt_hit)
+{
+	const int lane = lane_id();
+	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
+	const unsigned long long ref_f = to_packed_alphabet(refe), ref_r = to_packed_alphabet(revcomp_code(refe, K));
+	const unsigned long long alt_f = to_packed_alphabet(alte), alt_r = to_packed_alphabet(revcomp_code(alte, K));
+	for (long long b = r0; b < r1; b += 64) {                   // fits?  (decided before anything is counted)
+		const long long e = b + 64 < r1 ? b + 64 : r1;
+		const long long nd = ((read_off[e] >> 4) + e) - ((read_off[b] >> 4) + b);
+		if (4 * nd + 8 > lds_bytes) return false;
+	}
+	int nref = 0, nalt = 0, nboth = 0;
+	for (long long b = r0; b < r1; b += 64) {
+		const long long e = b + 64 < r1 ? b + 64 : r1;
+		const long long gb = (read_off[b] >> 4) + b;
+		const int nd = (int)(((read_off[e] >> 4) + e) - gb);
+		WSYNC();
+		for (int i = lane; i < nd; i += 64) lds32[i] = pk[gb + i];
+		WSYNC();
+		const long long ri = b + lane;
+		const bool use = ri < e && !(mapq && mapq[ri] < min_mapq);   // :294
+		int d0 = 0, n = 0;
+		if (use) { const long long o = read_off[ri]; d0 = (int)((o >> 4) + ri - gb); n = (int)(read_off[ri + 1] - o); }
+		const int nmax = wave_max_i32s(n);
+		unsigned long long f = 0, rfm = 0, afm = 0;
+		int rpos = -1, apos = -1;
+		for (int j0 = 0; j0 < nmax; j0 += 16) {
+			const unsigned dw = j0 < n ? lds32[d0 + (j0 >> 4)] : 0u;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				f = ((f << 2) | (unsigned long long)((dw >> (2 * k)) & 3u)) & mask;
+				const int j = j0 + k;
+				if (j < K - 1) continue;                                  // (wave-uniform) no full window yet
+				const unsigned long long full = ballot(j < n);
+				const unsigned long long hr = full & (ballot(f == ref_f) | ballot(f == ref_r));   // :301-309
+				const unsigned long long ha = full & (ballot(f == alt_f) | ballot(f == alt_r));
+				const int wpos = j - (K - 1);                             // start of this window: the first hit is kept
+				rpos = lane_in_mask(hr & ~rfm) ? wpos : rpos;
+				apos = lane_in_mask(ha & ~afm) ? wpos : apos;
+				rfm |= hr; afm |= ha;
+			}
+		}
+		const unsigned long long usem = ballot(use);
+		rfm &= usem; afm &= usem;
+		if (ref_hit && ri < e) { ref_hit[ri - r0] = use ? rpos : -1; alt_hit[ri - r0] = use ? apos : -1; }
+		nref += popc64(rfm);
+		nalt += popc64(afm);
+		nboth += popc64(rfm & afm);                               // :310-311
+	}
+	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
+	return true;
+}
+
 __device__ __forceinline__ int distinct_bytes(const char *s, int n)
 {
 	unsigned seen_lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -266,8 +333,8 @@ __device__ inline void fill_events(const CigSrc cigar, int ntrunc,
                                    int job, int ev_index0, FbItem *fb_items, int *fb_count,
                                    int *hit_pool, unsigned long long *hit_cursor, long long hit_cap, int *hit_overflow,
                                    int *region_cnt, long long region_base, long long bump0,
-                                   long long base0, long long end0)
-{   // base0 / end0: read_off of the region's first read and of the end of its first group of 64 (loaded by the caller)
+                                   long long base0, long long end0, const uint32_t *pk = nullptr)
+{   // pk: the region's reads as 2-bit bases (all of them upper-case ACGT), or null.  base0 / end0: read_off of the region's first read and of the end of its first group of 64 (loaded by the caller)
 	const int lane = lane_id();
 	const int K = P.K;
 	const int width = (int)((double)(K + 1) / 2.0 - 1.0);                // :218
@@ -303,7 +370,7 @@ __device__ inline void fill_events(const CigSrc cigar, int ntrunc,
 			if (qstart + K > ctg_len) qstart = ctg_len - K;
 			if (lane < K) ak = ctg[qstart + lane];                       // :248
 			// the reads travel to LDS while the k-mer bytes are still on their way
-			if (!staged && r1 > r0) staged = tally_stage_first(bases, base0, end0, lds32, lds_bytes);
+			if (!pk && !staged && r1 > r0) staged = tally_stage_first(bases, base0, end0, lds32, lds_bytes);
 			if (!ballot(lane < K && rk != ak)) {                         // :255-262
 				qstart = e_qs - 3;
 				if (qstart < 0) qstart = 0;
@@ -339,9 +406,12 @@ __device__ inline void fill_events(const CigSrc cigar, int ntrunc,
 					if (hoff + 2 * nr > hit_cap) { hoff = -1; if (lane == 0) atomicExch(hit_overflow, 1); }
 				}
 			}
-			tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
-			                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr, staged);
-			if (r1 - r0 > 64) staged = false;                            // later groups have overwritten the first one
+			if (!(pk && tally_reads_packed(pk, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
+			                               hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr))) {
+				tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
+				                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr, staged);
+				if (r1 - r0 > 64) staged = false;                        // later groups have overwritten the first one
+			} else staged = false;
 			status = IHP_EV_TALLIED;
 		}
 		DevEvent *o = ev + ii;
