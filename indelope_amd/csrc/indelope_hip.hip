@@ -1056,7 +1056,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<3>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<3>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
 		else if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<6>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<6>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
 		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
-		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(12, g.max_lds / (b->lds_fb + 256))));
+		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(16, g.max_lds / (b->lds_fb + 256))));
 	}
 	static_assert(sizeof(int) * M_WORDS <= ihp_batch::Z_TIMES, "misc counters overlap the stamps");
 	if ((rc = b->misc.alloc(b->z_bytes())) || (rc = b->summary.alloc(sizeof(ihp_region_summary) * (size_t)R))) { delete b; return rc; }

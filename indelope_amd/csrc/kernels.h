@@ -770,7 +770,7 @@ __device__ __forceinline__ int count_flanked_cigar_dev(const uint32_t *cigar, in
 	return n;
 }
 
-__global__ __launch_bounds__(64) void k_fallback(const FbArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_fallback(const FbArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_item;
