@@ -312,7 +312,10 @@ __device__ inline void region_epilogue(const AsmArgs &a, ST &S, Arena &A, int r,
 		const long long slot = r0 + k;
 		const int len = S.len[c];
 		const uint8_t *cs = A.seq + S.off[c]; const uint32_t *cp = A.sup + S.off[c];
-		for (int i = lane; i < len; i += 64) { a.out_seq[seq_base + cursor + i] = cs[i]; a.out_sup[seq_base + cursor + i] = cp[i]; }
+		// a contig of one read has support 1 on every base (contig.nim:143-150; nothing was ever merged into it): the
+		// supports in HBM need not be read back, which would be one more round trip in the region's chain
+		if (S.nreads[c] == 1) { for (int i = lane; i < len; i += 64) { a.out_seq[seq_base + cursor + i] = cs[i]; a.out_sup[seq_base + cursor + i] = 1u; } }
+		else for (int i = lane; i < len; i += 64) { a.out_seq[seq_base + cursor + i] = cs[i]; a.out_sup[seq_base + cursor + i] = cp[i]; }
 		if (lane == 0) {
 			const long long cstart = S.start[c], cn = S.nreads[c];
 			a.ctg_start[slot] = cstart; a.ctg_nreads[slot] = cn; a.ctg_len[slot] = len;
