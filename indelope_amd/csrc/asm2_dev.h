@@ -803,6 +803,152 @@ __device__ inline Best best_match_combine_packed(const ST &S, const Arena &A, co
 	return B.b;
 }
 
+// ---- the candidates of a combine pass kept in registers --------------------------------------------------------------------
+// best_match_combine_packed() gathers, for every call, the metadata of every candidate from LDS (slot, length, mirror
+// position, first 16 bases, support extrema, reads) and works out which lane gets which (contig, dword) of the target-offset
+// scan.  Within one pass that changes only when a contig is merged into another: lane j holds contig in[j] of the pass for
+// its whole length, the (contig, dword) map of up to 128 items is kept with it, and a call only masks them with the set of
+// contigs that are in `out` so far (list order = lane order, so the lane index is the position of contig.nim:239).
+struct CombDir {
+	int ts, len, d, sh, nr, nit; unsigned head, smin, smax, excl;   // lane j <-> in[j]
+	int own0, own1, dw0, dw1;                                       // lane g <-> item g (own0, dw0) and item 64 + g (own1, dw1)
+	int Q, n;                                                       // items, contigs
+	unsigned long long inout;                                       // lanes whose contig is in `out`
+	bool valid;
+};
+
+__device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+template <class ST>
+__device__ inline void comb_dir_build(const ST &S, const PackedMirror &M, const short *in, int n, int min_overlap, CombDir &D)
+{
+	const int lane = lane_id();
+	n = uni(n);
+	D.n = n; D.ts = 0; D.len = 0; D.d = 0; D.sh = 0; D.nr = 0; D.nit = 0; D.head = 0; D.smin = 0; D.smax = 0; D.excl = 0;
+	D.own0 = D.own1 = D.dw0 = D.dw1 = 0; D.Q = 0;
+	bool bad = false;
+	D.valid = M.on && n <= 64 && n > 0 && min_overlap >= 17;
+	if (!D.valid) return;
+	if (lane < n) {
+		D.ts = in[lane]; D.len = S.len[D.ts]; D.d = M.pm_dw[D.ts]; D.sh = M.pm_sh[D.ts];
+		D.head = fsh(M.PM[D.d + 1], M.PM[D.d], 2u * (unsigned)D.sh);
+		D.smin = S.smin[D.ts]; D.smax = S.smax[D.ts];
+		const long long nr = S.nreads[D.ts];
+		D.nr = (int)nr;
+		bad = D.len < 16 || nr <= 0 || nr > 0x3fffffffll;
+	}
+	if (ballot(bad)) { D.valid = false; return; }
+	D.nit = lane < n && D.len >= min_overlap ? ((D.sh + D.len - min_overlap) >> 4) + 1 : 0;
+	const unsigned incl = wave_scan_add((unsigned)D.nit);
+	D.excl = incl - (unsigned)D.nit;
+	D.Q = __builtin_amdgcn_readlane((int)incl, 63);
+	if (D.Q > 128) { D.valid = false; return; }
+	int own0 = 0, own1 = 0;                                        // the last entry that starts at or before the item owns it
+	for (int i = 0; i < n; ++i) {
+		const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
+		if (ni) { own0 = lane >= ex ? i : own0; own1 = 64 + lane >= ex ? i : own1; }
+	}
+	D.own0 = own0; D.own1 = own1;
+	D.dw0 = __builtin_amdgcn_ds_bpermute(own0 << 2, D.d) + (lane - __builtin_amdgcn_ds_bpermute(own0 << 2, (int)D.excl));
+	D.dw1 = __builtin_amdgcn_ds_bpermute(own1 << 2, D.d) + (64 + lane - __builtin_amdgcn_ds_bpermute(own1 << 2, (int)D.excl));
+}
+
+// best_match (contig.nim:224-240) of contig in[qi] against the contigs of D.inout; same result as
+// best_match_combine_packed(S, A, M, in[qi], out, nout, ...) with Best::pos counted in lanes.
+template <class ST>
+__device__ inline Best best_match_dir(const ST &S, const Arena &A, const PackedMirror &M, const CombDir &D, int qi, int min_overlap)
+{
+	const int lane = lane_id();
+	qi = uni(qi);
+	const int qs = __builtin_amdgcn_readlane(D.ts, qi), qlen = __builtin_amdgcn_readlane(D.len, qi);
+	const int omin = qlen - min_overlap;                         // contig.nim:78
+	IHP_T0(A);
+	const uint32_t *PM = M.PM;
+	const int qd = __builtin_amdgcn_readlane(D.d, qi), qsh = __builtin_amdgcn_readlane(D.sh, qi);
+	const unsigned qh = (unsigned)__builtin_amdgcn_readlane((int)D.head, qi);
+	const unsigned qmin = (unsigned)__builtin_amdgcn_readlane((int)D.smin, qi), qmax = (unsigned)__builtin_amdgcn_readlane((int)D.smax, qi);
+	const int qreads = __builtin_amdgcn_readlane(D.nr, qi);
+	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
+	Best G = {0, 0, 0, -1, -1, 0};                               // best of the pairs that need the generic scan
+	const bool in = lane_of(D.inout);
+	const bool votes = in && ((qmin < 3u && D.smax > 3u * qmin && (long long)qreads > 3ll * (long long)qmin) ||
+	                          (D.smin < 3u && qmax > 3u * D.smin && (long long)D.nr > 3ll * (long long)D.smin));
+	const unsigned long long vm = ballot(votes);
+	unsigned long long gm = vm;
+	while (gm) {                                                 // the vote rule may fire: generic scan on the bytes
+		const int i = ctz64(gm);
+		gm &= gm - 1;
+		IHP_T0(A);
+		slide_scan(S, A, qs, __builtin_amdgcn_readlane(D.ts, i), i, min_overlap, 0, IHP_ALLOW_DEFAULT, G);
+		IHP_T1(A, 4);
+	}
+	const unsigned long long usem = D.inout & ~vm;
+	// ---- offsets 0 .. len(t) - min_overlap on the contigs (:79-111): items = dwords that hold such an offset
+	for (int w = 0; w * 64 < D.Q; ++w) {
+		const int own = w ? D.own1 : D.own0, dw = w ? D.dw1 : D.dw0;
+		unsigned w0 = 0, w1 = 0;
+		bool any = false;
+		if (64 * w + lane < D.Q && ((usem >> own) & 1ull)) {
+			w0 = PM[dw]; w1 = PM[dw + 1];
+			any = window_any(w0, w1, qh);
+		}
+		unsigned long long hm = ballot(any);
+		while (hm) {
+			const int e = ctz64(hm);
+			hm &= hm - 1;
+			unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
+			const int i = __builtin_amdgcn_readlane(own, e);
+			const int k = 64 * w + e - __builtin_amdgcn_readlane((int)D.excl, i);
+			const int tlen = __builtin_amdgcn_readlane(D.len, i), td = __builtin_amdgcn_readlane(D.d, i), tsh = __builtin_amdgcn_readlane(D.sh, i);
+			const int ts = __builtin_amdgcn_readlane(D.ts, i);
+			while (bits) {
+				const int o = 16 * k + __builtin_ctz(bits) - tsh;
+				bits &= bits - 1;
+				if (o < 0 || o > tlen - min_overlap) continue;
+				const int cn = qlen < tlen - o ? qlen : tlen - o;
+				const int pos = i;
+				if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (0 > B.ph || (0 == B.ph && o >= B.o))))))) continue;
+				if (bits_equal(PM, qd, 2u * (unsigned)qsh, td + ((tsh + o) >> 4), 2u * (unsigned)((tsh + o) & 15), cn)) {
+					B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = o; B.ph = 0; B.o = o;
+				}
+			}
+		}
+	}
+	// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
+	for (int ob = 0; ob <= omin; ob += 64) {
+		const int o_l = ob + lane;
+		const bool valid = o_l >= 1 && o_l <= omin;
+		unsigned wq = 0;
+		if (valid) { const int b = qsh + o_l; wq = fsh(PM[qd + (b >> 4) + 1], PM[qd + (b >> 4)], 2u * (unsigned)(b & 15)); }
+		const unsigned long long okm = ballot(valid);
+		unsigned long long um = usem;
+		while (um) {
+			const int i = ctz64(um);
+			um &= um - 1;
+			unsigned long long mask = ballot(wq == (unsigned)__builtin_amdgcn_readlane((int)D.head, i)) & okm;
+			if (!mask) continue;                                 // the usual case: the contig does not start inside the query
+			const int tlen = __builtin_amdgcn_readlane(D.len, i), td = __builtin_amdgcn_readlane(D.d, i), tsh = __builtin_amdgcn_readlane(D.sh, i);
+			const int ts = __builtin_amdgcn_readlane(D.ts, i);
+			while (mask) {
+				const int o = ob + ctz64(mask);
+				mask &= mask - 1;
+				const int cn = qlen - o < tlen ? qlen - o : tlen;
+				const int pos = i;
+				if (cn < min_overlap - 1) continue;
+				if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (1 > B.ph || (1 == B.ph && o >= B.o))))))) continue;
+				const int b = qsh + o;
+				if (bits_equal(PM, qd + (b >> 4), 2u * (unsigned)(b & 15), td, 2u * (unsigned)tsh, cn)) {
+					B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = -o; B.ph = 1; B.o = o;
+				}
+			}
+		}
+	}
+	IHP_T1(A, 5);
+	// more matches, then fewer mismatches, then the earlier contig (contig.nim:32-36, :107, :239)
+	if (G.found && (!B.b.found || G.ma > B.b.ma || (G.ma == B.b.ma && (G.mm < B.b.mm || (G.mm == B.b.mm && G.pos < B.b.pos))))) return G;
+	return B.b;
+}
+
 // combine_pass (contig_dev.h; contig.nim:263-281) with the exact scans on the packed mirror.
 template <class ST>
 __device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, short *in, int n, short *out, long long min_support,
@@ -854,10 +1000,16 @@ __device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, shor
 		WSYNC();
 		return 0;
 	}
+	// the candidates in registers for the whole pass (see CombDir); anything outside its preconditions takes the per-call path
+	CombDir D;
+	D.valid = false;
+	if (max_mm == 0 && usedi == 0) comb_dir_build(S, M, in, n, combine_min_overlap, D);
+	D.inout = 1ull;
 	for (int i = 0; i < n; ++i) {                                  // :274-281
 		if (i == usedi) continue;
 		const int c = in[i];
-		Best b = best_match_combine_packed(S, A, M, c, out, nout, combine_min_overlap, max_mm);
+		const bool dir = D.valid && __builtin_amdgcn_readlane(D.len, i) >= combine_min_overlap;
+		Best b = dir ? best_match_dir(S, A, M, D, i, combine_min_overlap) : best_match_combine_packed(S, A, M, c, out, nout, combine_min_overlap, max_mm);
 		if (b.found) {
 			IHP_T0(A);
 			const int nc = emit_corrections(S, A, c, b.slot, b.off, IHP_ALLOW_DEFAULT);
@@ -867,10 +1019,16 @@ __device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, shor
 			if (lane == 0) S.alive[c] = 0;
 			recompute_minmax(S, A, b.slot);
 			pm_repack(S, A, M, b.slot);
+			if (D.valid) {                                         // the target changed: its lane and the item map again
+				const unsigned long long keep = D.inout;
+				comb_dir_build(S, M, in, n, combine_min_overlap, D);
+				D.inout = keep;
+			}
 			IHP_T1(A, 6);
 		} else if (S.nreads[c] > 0) {
 			if (lane == 0) out[nout] = (short)c;
 			nout++;
+			D.inout |= 1ull << i;
 		} else {
 			if (lane == 0) S.alive[c] = 0;
 		}
