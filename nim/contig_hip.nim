@@ -1,40 +1,16 @@
-## contig_hip.nim -- the `Contig` surface of src/contig.nim with the reference's proc signatures, delegating every
-## step that touches bases or supports to the HIP library through include/indelope_hip.h (SOURCE ONLY: there is no
-## Nim toolchain in the build image, so this file has never been compiled).
+## contig_hip.nim -- a PATCH for src/contig.nim, not a module: `include` it right after contig.nim's type section
+## (contig.nim:6-27); it adds three procs that hand the work of `trim` (contig.nim:49), `slide_align` (:70) and
+## `insert(t, q, m)` (:156) to the HIP library through include/indelope_hip.h.  Everything else of contig.nim -- the
+## types, `match_sort`, `make_contig`, `best_match`, the seq `insert`s, `combine` -- stays the reference's own code and
+## reaches the device through these three (INTEGRATION.md section 3 shows the diff).
+## SOURCE ONLY: there is no Nim toolchain in the build image, so this file has never been compiled.
 ##
-## These are the single-step entries the reference's own in-file tests exercise (contig.nim:292-430); one call is one
-## kernel launch and two copies, so they are the compatibility path.  The BAM sweep uses the batched path of
-## nim/indelope_hip.nim (Stager + flush), where assemble/combine run inside ihp_run_regions.
-import algorithm
+## One call is one kernel launch and two copies: the compatibility path the reference's in-file tests exercise
+## (contig.nim:292-430).  The BAM sweep uses the batched path of nim/indelope_hip.nim (Stager + flush).
 import indelope_hip
 
-type
-  Contig* = ref object of RootObj        # contig.nim:7-15
-    sequence*: string
-    support*: seq[uint32]
-    nreads*: int
-    start*: int
-
-  correction_site* = tuple[qoff: int, toff: int, qbest: bool]                                        # contig.nim:17
-  Match* = tuple[matches: int, offset: int, mismatches: int, corrections: seq[correction_site], contig_i: int]   # :21
-
-const unaligned* = low(int)              # contig.nim:27
-
-proc aligned*(ma: Match): bool {.inline.} = ma.offset != unaligned                                    # :29
-proc len*(c: Contig): int {.inline.} = c.sequence.len                                                 # :38
-proc `[]`*(c: Contig, i: int): char {.inline.} = c.sequence[i]                                        # :41
-
-proc match_sort(a, b: Match): int =      # contig.nim:32-36
-  if a.matches == b.matches: return a.mismatches - b.mismatches
-  return b.matches - a.matches
-
-proc make_contig*(dna: string, start: int, support: uint32 = 1): Contig =                             # :143-150
-  var bc = new_seq[uint32](dna.len)
-  for i in 0..bc.high: bc[i] = support
-  return Contig(sequence: dna, support: bc, nreads: int(support), start: start)
-
-# view of a Contig's buffers with `extra` elements of headroom for an insert that makes it longer
-proc view(c: Contig, extra: int = 0): IhpContig =
+proc hipView(c: Contig, extra: int = 0): IhpContig =
+  ## the contig's own buffers, grown by `extra` elements when the call may make it longer
   let n = c.sequence.len
   if extra > 0:
     c.sequence.set_len(n + extra); c.support.set_len(n + extra)
@@ -43,40 +19,40 @@ proc view(c: Contig, extra: int = 0): IhpContig =
   result.len = int64(n); result.cap = int64(c.sequence.len)
   result.nreads = int64(c.nreads); result.start = int64(c.start)
 
-proc take(c: Contig, v: IhpContig) =
+proc hipTake(c: Contig, v: IhpContig) =
   c.sequence.set_len(int(v.len)); c.support.set_len(int(v.len))
   c.nreads = int(v.nreads); c.start = int(v.start)
 
-proc check(rc: cint, what: string) =
+proc hipCheck(rc: cint, what: string) =
   if rc != 0: raise newException(IOError, what & ": " & $ihp_strerror(rc) & " / " & $ihp_last_hip_error())
 
-proc trim*(c: Contig, min_support: int = 2) =                                                         # contig.nim:49
-  var v = c.view()
-  check(ihp_contig_trim(addr v, int64(min_support)), "ihp_contig_trim")
-  c.take(v)
+proc hip_trim(c: Contig, min_support: int) =
+  var v = c.hipView()
+  hipCheck(ihp_contig_trim(addr v, int64(min_support)), "ihp_contig_trim")
+  c.hipTake(v)
 
-proc slide_align*(q: Contig, t: var Contig, min_overlap: int = 50, max_mismatch: int = 0,
-                  allow_rule: cint = IHP_ALLOW_DEFAULT): Match =                                       # contig.nim:70
-  ## `allowed: allowable_mismatch_fn` of the reference is a closure and cannot cross to the device; the two rules the
-  ## reference ever passes (contig.nim:44-47 and the test rule :287-290) are selected by `allow_rule`.
+proc hip_slide_align(q: Contig, t: Contig, min_overlap, max_mismatch: int, default_rule: bool): Match =
+  ## `allowed` of the reference is a Nim closure and cannot cross to the device; the two rules it is ever given
+  ## (contig.nim:44-47 and the tests' `allow_test`, :287-290) are IHP_ALLOW_DEFAULT / IHP_ALLOW_SUPPORT.
   var corr = new_seq[IhpCorrection](16)
   var m: IhpMatch
   while true:
     m.corrections = addr corr[0]; m.corr_cap = int64(corr.len)
-    var qv = q.view()
-    var tv = t.view()
-    let rc = ihp_slide_align(addr qv, addr tv, int64(min_overlap), int64(max_mismatch), allow_rule, addr m)
-    if rc == IHP_E_CAPACITY:              # n_corrections holds the count needed
+    var qv = q.hipView()
+    var tv = t.hipView()
+    let rc = ihp_slide_align(addr qv, addr tv, int64(min_overlap), int64(max_mismatch),
+                             (if default_rule: IHP_ALLOW_DEFAULT else: IHP_ALLOW_SUPPORT), addr m)
+    if rc == IHP_E_CAPACITY:               # m.n_corrections holds the count needed
       corr.set_len(int(m.n_corrections)); continue
-    check(rc, "ihp_slide_align")
+    hipCheck(rc, "ihp_slide_align")
     break
-  result = (matches: int(m.matches), offset: (if m.offset == IHP_UNALIGNED: unaligned else: int(m.offset)),
-            mismatches: int(m.mismatches), corrections: new_seq[correction_site](int(m.n_corrections)), contig_i: -1)
+  result.matches = int(m.matches); result.mismatches = int(m.mismatches); result.contig_i = -1
+  result.offset = if m.offset == IHP_UNALIGNED: unaligned else: int(m.offset)
+  result.corrections = new_seq[correction_site](int(m.n_corrections))
   for i in 0..<int(m.n_corrections):
     result.corrections[i] = (int(corr[i].qoff), int(corr[i].toff), corr[i].qbest != 0)
 
-proc insert*(t: var Contig, q: var Contig, m: var Match) =                                             # contig.nim:156
-  if not m.aligned: return
+proc hip_insert(t: Contig, q: Contig, m: Match) =
   var corr = new_seq[IhpCorrection](max(1, m.corrections.len))
   for i, c in m.corrections:
     corr[i].qoff = int64(c.qoff); corr[i].toff = int64(c.toff); corr[i].qbest = int32(c.qbest)
@@ -84,51 +60,7 @@ proc insert*(t: var Contig, q: var Contig, m: var Match) =                      
   cm.matches = int64(m.matches); cm.offset = int64(m.offset); cm.mismatches = int64(m.mismatches)
   cm.n_corrections = int64(m.corrections.len); cm.contig_i = int64(m.contig_i)
   cm.corrections = addr corr[0]; cm.corr_cap = int64(corr.len)
-  var tv = t.view(extra = abs(m.offset) + q.len)      # the merged contig is at most |offset| + len(t) + len(q) long
-  var qv = q.view()
-  check(ihp_contig_insert(addr tv, addr qv, addr cm), "ihp_contig_insert")
-  t.take(tv); q.take(qv)                              # insert mutates q too (corrections, :167-169)
-
-proc best_match(contigs: var seq[Contig], q: Contig, min_overlap: int = 65, max_mismatch: int = 0): Match =   # :224-240
-  var matches = new_seq_of_cap[Match](2)
-  for i, c in contigs:
-    if c == q: continue
-    var ma = slide_align(q, contigs[i], min_overlap = min_overlap, max_mismatch = max_mismatch)
-    if ma.aligned:
-      ma.contig_i = i
-      matches.add(ma)
-  if len(matches) == 0:
-    var ma: Match
-    ma.offset = unaligned
-    return ma
-  matches.sort(match_sort)               # stable merge sort: ties go to the lower contig index
-  return matches[0]
-
-proc insert*(contigs: var seq[Contig], q: var Contig, min_overlap: int = 50, max_mismatch: int = 0) =  # contig.nim:243
-  var ma = contigs.best_match(q, min_overlap = min_overlap, max_mismatch = max_mismatch)
-  if ma.aligned: contigs[ma.contig_i].insert(q, ma)
-  else: contigs.add(q)
-
-proc insert*(contigs: var seq[Contig], q: string, start: int, min_overlap: int = 50, max_mismatch: int = 0) =   # :250
-  var qc = make_contig(q, start)
-  contigs.insert(qc, min_overlap = min_overlap, max_mismatch = max_mismatch)
-
-proc combine*(contigs: var seq[Contig], max_mismatch: int = 0, min_support: int = 3, again: bool = true): seq[Contig] =   # :254
-  if again:
-    contigs = contigs.combine(max_mismatch, min_support = 0, again = false)
-  result = new_seq_of_cap[Contig](len(contigs))
-  var usedi = 0
-  for i, c in contigs:
-    if min_support > 0:
-      c.trim(min_support = min(c.nreads, min_support))
-    if c.nreads > 0 and result.len == 0:
-      result.add(c)
-      usedi = i
-  if result.len == 0: return
-  for i in 0..contigs.high:
-    if i == usedi: continue
-    var ma = result.best_match(contigs[i], max_mismatch = max_mismatch)
-    if ma.aligned:
-      result[ma.contig_i].insert(contigs[i], ma)
-    elif contigs[i].nreads > 0:
-      result.add(contigs[i])
+  var tv = t.hipView(extra = abs(m.offset) + q.sequence.len)   # the merged contig is at most |offset| + len(t) + len(q) long
+  var qv = q.hipView()
+  hipCheck(ihp_contig_insert(addr tv, addr qv, addr cm), "ihp_contig_insert")
+  t.hipTake(tv); q.hipTake(qv)              # the library mutates q as the reference does (corrections)

@@ -1,7 +1,7 @@
 ## indelope_hip.nim -- Nim binding of include/indelope_hip.h (SOURCE ONLY: no Nim toolchain in the build image,
 ## so this file has never been compiled; it is the binding a maintainer adds to brentp/indelope).
-## Companion files: nim/contig_hip.nim (the `Contig` procs of contig.nim with their signatures, over the ABI) and
-## nim/genotyper_hip.nim (`genotype` / `qual` / `$` of genotyper.nim).  `roi`, `Fai`, `Record`, `skippable` are the
+## Companion files: nim/contig_hip.nim (a patch for contig.nim: `trim`, `slide_align`, `insert(t, q, m)` over the ABI) and
+## nim/genotyper_hip.nim (a patch for genotyper.nim: `genotype`).  `roi`, `Fai`, `Record`, `skippable` are the
 ## reference's own (indelope.nim:21,:40; hts-nim): this file is meant to be `include`d into / imported by indelope.nim.
 ##
 ## 1. ksw2 seam: in src/ksw2/ksw2_c.nim replace
@@ -115,8 +115,8 @@ proc ihp_host_alloc*(bytes: csize_t): pointer {.importc, cdecl, header: "indelop
 proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_copy_to_host*(dev_ptr: pointer, bytes: int64, outp: pointer): cint {.importc, cdecl, header: "indelope_hip.h".}
 
-# ---- Contig / genotyper / ksw2 single-step entries (wrapped with the reference's signatures in nim/contig_hip.nim and
-# nim/genotyper_hip.nim)
+# ---- Contig / genotyper / ksw2 single-step entries (called from the reference's own procs through the patches
+# nim/contig_hip.nim and nim/genotyper_hip.nim)
 type
   IhpContig* {.importc: "ihp_contig", header: "indelope_hip.h", bycopy.} = object   # contig.nim:7-15 over caller-owned buffers
     sequence*: ptr uint8
