@@ -187,6 +187,78 @@ def e2e_rates(api, batch, params, threads=3, reps=4):
                     "PCIe-inclusive, never `value`"}
 
 
+# ------------------------------------------------------------------------------------------ other configs
+def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2):
+    """A short run of another BASELINE config on this GPU (the same step as the headline: `sub_batches` chains in flight,
+    resident inputs): value, per-launch stage times, the HBM-roofline fraction of its dominant stage, oracle check."""
+    from indelope_amd import synth
+    from indelope_amd.host import BatchResult, concat_results
+    cfg = dict(synth.CONFIGS[name])
+    K = cfg["K"]
+    params = api.params(K=K)
+    cfg["n_regions"] = regions
+    cuts = [regions * i // sub_batches for i in range(sub_batches + 1)]
+    subs, hs = [], []
+    for i in range(sub_batches):
+        g = dict(cfg)
+        g["n_regions"] = cuts[i + 1] - cuts[i]
+        sb, _ = synth.generate(first_region=cuts[i], **g)
+        sb = sb.with_trim_bounds()
+        subs.append(sb)
+        hs.append(api.batch_upload(sb, params))
+        api.batch_set_timing(hs[-1], True)
+
+    def step():
+        for h in hs:
+            api.batch_run(h)
+        for h in hs:
+            api.batch_sync(h)
+    try:
+        for _ in range(warmup):
+            step()
+        for h in hs:
+            api.batch_kernel_ms_mean(h, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dt = time.perf_counter() - t0
+        km = np.array([api.batch_kernel_ms_mean(h)[0] for h in hs]).mean(axis=0)
+        parts = [api.batch_fetch(h) for h in hs]
+    finally:
+        for h in hs:
+            api.batch_free(h)
+    res = concat_results(parts)
+    by_kernel = {k: 0.0 for k in KERNELS}
+    for sb, pr in zip(subs, parts):
+        for k, v in pr.algorithmic_bytes_by_kernel(sb, K).items():
+            by_kernel[k] += v / len(parts)
+    dom = int(np.argmax(km[:3]))
+    achieved = by_kernel[KERNELS[dom]] / (km[dom] * 1e-3) / 1e9
+    whole = (sum(sb.algorithmic_input_bytes() for sb in subs) + res.algorithmic_output_bytes(K)) / (dt / steps) / 1e9
+    out = {"workload": "%s: %d regions x %s reads x %d bp, K=%d" % (name, regions, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
+                                                                       else str(cfg["n_reads"][0]), cfg["read_len"], K),
+           "value": round(regions * steps / dt, 1), "unit": "regions/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+           "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS, km[:3])}, k_fallback=round(float(km[3]), 4)),
+           "roofline": {"kernel": KERNELS[dom], "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "whole_path_frac": round(whole / HBM_PEAK_GBS, 5)},
+           "failed_regions": int((res.status != 0).sum())}
+    if check:
+        import oracle
+        o = oracle.get()
+        usable, _ = _host_cpus()
+        t1 = time.perf_counter()
+        bad, n = None, 0
+        for sb, pr in zip(subs, parts):
+            lim = min(sb.n_regions, 10_000)
+            exp = o.run_regions_mt(sb.slice(0, lim), o.params(K=K), usable)
+            got = pr if lim == sb.n_regions else api.run_regions(sb.slice(0, lim), params)
+            bad = bad or BatchResult.first_difference(got, exp)
+            n += lim
+        out["oracle_check"] = {"regions": n, "identical": bad is None, "first_difference": bad, "seconds": round(time.perf_counter() - t1, 2)}
+        assert bad is None, "%s: device results differ from the oracle: %s" % (name, bad)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- launching
 def spawn_ranks(n, argv):
     """`--gpus N` without a launcher: start N fresh ranks (one per GPU) from a parent that has not touched the GPU and
@@ -247,6 +319,15 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks form a gloo group, do the per-step gather on host tensors and rank "
                          "0 prints a line with n_gpus = the number of ranks (tests/test_bench_launch.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="form the RCCL process group, run the per-step gather (and --payload) even with ONE rank: the multi-GPU code "
+                         "path on a single GPU (tests/test_gpu_round3.py)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="rank 0 checks the gathered per-region records (and payload slabs) against its own fetched results")
+    ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 legs (`other_configs`) of the default run")
+    ap.add_argument("--profile", action="store_true", help="per-phase cycle counters of the kernels (ihp_debug_set profile) in `profile_cycles`")
+    ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
+                    help="library path / occupancy switches (ihp_debug_set), e.g. --knob asm_v1=1; results do not depend on them")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -278,8 +359,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                    # --force-dist without a launcher: a group of one
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import indelope_amd
@@ -287,6 +371,11 @@ def main():
     from indelope_amd import dist as idist
     api = indelope_amd.api()
     api.init(local_rank)
+    if args.profile:
+        api.debug_set(profile=1)
+    for kv in args.knob:
+        k_, v_ = kv.split("=")
+        api.debug_set(**{k_: int(v_)})
 
     cfg = dict(synth.CONFIGS[args.config])
     K = cfg["K"]
@@ -323,10 +412,11 @@ def main():
         if stream_outputs:
             api.batch_release_outputs(hs[-1])
         subs.append(sb if (not strong or (rank == 0 and i == 0)) else None)     # strong: keep one chunk for the host-side legs
-    timing = (not strong) and S > 1
-    if timing:
-        for h in hs:                                         # with several chains in flight a kernel can wait for wave slots:
-            api.batch_set_timing(h, True)                    # stage times from device wall-clock stamps, not event intervals
+    # Stage times come from device wall-clock stamps (with several chains in flight a kernel can wait for wave slots, and an
+    # event interval would include that wait); the stamps land in page-locked host memory and ihp_batch_sync adds them up, so
+    # the timed loop below reads nothing
+    for h in hs:
+        api.batch_set_timing(h, True)
     views = []
     for h in hs:
         sptr, sn = api.batch_summary_dev(h)
@@ -336,21 +426,28 @@ def main():
     shard_sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)] if strong else [R] * world
     m_pad = max(shard_sizes)
     send = summary if R == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
-    gather_list = [torch.empty_like(send) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_list = [torch.empty_like(send) for _ in range(world)] if (use_dist and rank == 0) else None
+    last_payload = [None]
 
     def step():
         if strong:
-            for h in hs:                                     # chunk after chunk; the per-region records stay on the device
+            # chunk after chunk with TWO in flight: a chunk's launch chain ends in tails that the next chunk's first kernels
+            # fill; the per-region records stay on the device.  (A chunk's scratch can only go back to the pool once it is done.)
+            for i, h in enumerate(hs):
                 api.batch_run(h)
-                api.batch_sync(h)
-                if stream_outputs:
-                    api.batch_release_outputs(h)
+                if i >= 1:
+                    api.batch_sync(hs[i - 1])
+                    if stream_outputs:
+                        api.batch_release_outputs(hs[i - 1])
+            api.batch_sync(hs[-1])
+            if stream_outputs:
+                api.batch_release_outputs(hs[-1])
         else:
             for h in hs:
                 api.batch_run(h)                             # asynchronous: the sub-batches' launch chains overlap
             for h in hs:
                 api.batch_sync(h)
-        if world > 1:
+        if use_dist:
             if S > 1:
                 torch.cat(views, out=summary)
             if send is not summary:
@@ -360,45 +457,36 @@ def main():
                 for h in hs:
                     ptr, nbytes, counts = api.batch_pack_dev(h)
                     slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
-                    idist.gather_payload(slab, counts, rank, world, dst=0)
+                    last_payload[0] = idist.gather_payload(slab, counts, rank, world, dst=0, force=True)
 
     for _ in range(args.warmup):
         step()
-    stage = np.zeros(4)
-    fb_ms = 0.0
-    if world > 1:
+    for h in hs:
+        api.batch_kernel_ms_mean(h, reset=True)              # the warm-up runs do not count
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if not stream_outputs:
-            for h in hs:                                     # per launch: the mean over the step's launches
-                ev = np.array(api.batch_stage_ms(h))
-                if timing:
-                    km = api.batch_kernel_ms(h)
-                    ev[:3] = km[:3]
-                    fb_ms += km[3] / S
-                else:
-                    fb_ms += api.batch_fallback_ms(h) / S
-                stage += ev / S
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    stage /= max(args.steps, 1)
-    fb_ms /= max(args.steps, 1)
+    # per LAUNCH (a launch processes one sub-batch / chunk): the mean over the timed steps' launches
+    km = np.array([api.batch_kernel_ms_mean(h)[0] for h in hs]).mean(axis=0)
+    stage = np.array([km[0], km[1], km[2], km[:4].sum()])
+    fb_ms = float(km[3])
 
     if rank == 0:
         from indelope_amd.host import concat_results
         if stream_outputs:                                   # results were released chunk by chunk: rerun the first chunk for the report
             api.batch_run(hs[0])
             api.batch_sync(hs[0])
-            stage = np.array(api.batch_stage_ms(hs[0]))
         keep = [i for i in range(S) if subs[i] is not None]
         parts = [api.batch_fetch(hs[i]) for i in keep]
         res = concat_results(parts)
@@ -466,7 +554,7 @@ def main():
                        if strong else "%d sub-batch%s of consecutive regions per step, each on its own stream" % (S, "es" if S > 1 else ""),
                        "regions_per_gpu": R, "regions_total": total,
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
-                                    "records per step" + (" + result slabs to rank 0" if args.payload else "")) if world > 1 else "single GPU"},
+                                    "records per step" + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
@@ -482,7 +570,25 @@ def main():
                         "tallied": int((res.events["status"] == 0).sum()),
                         "fallback_events": int((res.events["aligned"] == 1).sum()), "regions_inspected": n_kept},
         }
-        if os.environ.get("IHP_PROFILE"):
+        if args.verify_gather and use_dist:
+            # what rank 0 received in the last step against its own results: the records of the RCCL gather are the per-region
+            # summaries of the fetched results, the payload slab unpacks to the same results
+            got = torch.cat([g[:n * idist.SUMMARY_WORDS] for g, n in zip(gather_list, shard_sizes)]).cpu().numpy()
+            mine = idist.summaries_from_result(res).view(np.int32).reshape(-1)
+            # (strong scaling keeps only the first chunk's results on the host: its records are the head of the gathered ones)
+            ok = bool(np.array_equal(got[:len(mine)], mine)) and (len(got) == len(mine) if (world == 1 and not strong) else len(got) >= len(mine))
+            chk = {"records": int(len(got) // idist.SUMMARY_WORDS), "records_identical_to_own_results": ok, "backend": dist.get_backend()}
+            if args.payload and last_payload[0] is not None and not strong:
+                from indelope_amd.host import BatchResult
+                slab, counts = last_payload[0][0]
+                back = api.unpack_slab(slab.cpu().numpy(), counts)
+                d = BatchResult.first_difference(back, parts[-1])
+                chk["payload_bytes"] = int(slab.numel())
+                chk["payload_identical_to_own_results"] = d is None
+                ok = ok and d is None
+            out["gather_check"] = chk
+            assert ok, "gathered records / payload differ from the rank's own results: %r" % chk
+        if args.profile and not stream_outputs:
             out["profile_cycles"] = [int(x) for x in sum(np.array(api.batch_profile(h)) for h in hs)]
         batch0 = subs[keep[0]]
         if not strong and len(keep) > 1:                     # the host-side legs work on the rank's whole batch
@@ -517,6 +623,10 @@ def main():
                                    "what": "contigs, supports, ksw2 records + CIGARs, events, k-mer counts and hit positions against "
                                            "the CPU oracle, after the timed loop"}
             assert bad is None, "device results differ from the oracle: " + str(bad)
+        if not args.no_other and args.config == "C2" and not strong and world == 1 and not args.dup_frac and R == 10_000:
+            # the other single-GPU configs of BASELINE.json, a few steps each, in the same record (never `value`)
+            out["other_configs"] = {"C3": quick_config(api, "C3", 50_000, steps=4, warmup=1, check=not args.no_check),
+                                    "C5": quick_config(api, "C5", 10_000, steps=6, warmup=2, check=not args.no_check)}
         if not args.no_e2e and world == 1:
             out["e2e"] = e2e_rates(api, batch0, params)
         if not args.no_cpu and world == 1:
@@ -535,7 +645,7 @@ def main():
         sys.stdout.flush()
     for h in hs:
         api.batch_free(h)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

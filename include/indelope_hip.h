@@ -423,10 +423,14 @@ int  ihp_batch_stage_ms(ihp_batch *b, float ms[4]);
  * wait.  One clock read per stage by the kernels themselves; off by default.                                          */
 int  ihp_batch_set_timing(ihp_batch *b, int on);
 int  ihp_batch_kernel_ms(ihp_batch *b, float ms[4]);
+/* The same four times as a mean over the runs waited for with ihp_batch_sync since timing was switched on (or since the
+ * last call with reset != 0): the stamps arrive in page-locked host memory, ihp_batch_sync adds them up without a HIP
+ * call, so a timed loop needs no read-out inside it.  n_runs (may be NULL) = runs in the mean.                       */
+int  ihp_batch_kernel_ms_mean(ihp_batch *b, float ms[4], int64_t *n_runs, int reset);
 /* Device time of the alignment-fallback kernel (indelope.nim:312-372) in the same run; it is
  * included in ms[3] and runs between the tally and the summary.                               */
 int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
-/* Diagnostics: with IHP_PROFILE=1 in the environment the kernels sum shader-clock cycles
+/* Diagnostics: after ihp_debug_set("profile", 1) the kernels sum shader-clock cycles
  * per phase over all waves: [0] assemble, [1] combine, [2] assemble+output, [3] regions;
  * [8] ksw2 init, [9] ksw2 DP, [10] ksw2 traceback, [11] alignments; packed read phase: [12] read preparation,
  * [13] target-offset filter, [14] query-offset phase, [15] insert, [27] set-up.  Always filled: [24]/[25]/[26] regions
@@ -444,6 +448,18 @@ int  ihp_debug_last_ksw_mode(void);
  * event-pool entries, hit-pool ints, ksw2 traceback bytes per wave}; 0 = the library's own sizing.  NULL resets.
  * Lets the overflow paths (IHP_E_CAPACITY from ihp_batch_sync / fetch) be driven by small inputs.               */
 int  ihp_debug_limits(const int64_t limits[4]);
+/* Test / diagnostics switches for batches uploaded (and runs started) from now on; results never depend on them.
+ *   "asm_v1" 1      class-1 regions through the byte-based k_assemble passes only (no packed assembly)
+ *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
+ *   "lpt" 0         k_asm_combine in input order: no cost classes, no second arena tier
+ *   "pm" 0          no packed mirror in k_asm_combine (its exact scans run on the byte arena)
+ *   "asm_waves", "asmr_waves", "comb_occ", "ksw_waves", "tally_waves"   waves per CU of a kernel (0 = library sizing)
+ *   "v2_arena", "v2_pdw"   LDS bytes / dwords per wave of the packed assembly (0 = library sizing)
+ *   "profile" 1     per-phase cycle counters (ihp_batch_profile)
+ *   "strict_ksw" 1  ksw_extz2_sse aborts when it fails (same as IHP_KSW_STRICT=1 in the environment)
+ * key == NULL resets everything.  Returns IHP_E_ARG for an unknown key.  These replace the IHP_* environment
+ * variables of earlier rounds; the library reads no environment variable besides IHP_KSW_STRICT.                  */
+int  ihp_debug_set(const char *key, int64_t value);
 /* Fixed-size per-region summary record left on the device for the multi-GPU
  * gather (one RCCL gather of these at the end).     */
 typedef struct {

@@ -93,6 +93,12 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_kernel_ms(h, ms), "batch_kernel_ms")
         return [float(x) for x in ms]
 
+    def batch_kernel_ms_mean(self, h, reset=False):
+        """([assemble, ksw2, tally, fallback] mean ms, runs) over the runs synced since timing was switched on / the last reset."""
+        ms, n = (C.c_float * 4)(), C.c_int64()
+        self._chk_hip(self.b.batch_kernel_ms_mean(h, ms, C.byref(n), 1 if reset else 0), "batch_kernel_ms_mean")
+        return [float(x) for x in ms], int(n.value)
+
     def batch_fallback_ms(self, h):
         ms = C.c_float()
         self._chk_hip(self.b.batch_fallback_ms(h, C.byref(ms)), "batch_fallback_ms")
@@ -125,6 +131,13 @@ class HipApi(Api):
         import numpy as np
         lim = np.array([cigar_words, events, hits, ksw_bytes], np.int64)
         self._chk_hip(self.b.debug_limits(_abi.ptr(lim, _abi.i64p)), "debug_limits")
+
+    def debug_set(self, **kw):
+        """Test / diagnostics switches of the library (ihp_debug_set); no arguments = reset all."""
+        if not kw:
+            self._chk_hip(self.b.debug_set(None, 0), "debug_set")
+        for k, v in kw.items():
+            self._chk_hip(self.b.debug_set(k.encode(), int(v)), "debug_set(%s)" % k)
 
     def batch_free(self, h):
         self.b.batch_free(h)

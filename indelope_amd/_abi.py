@@ -216,11 +216,13 @@ _PRODUCT_ONLY = {
     "batch_fallback_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "batch_kernel_ms_mean": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), i64p, C.c_int]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
     "batch_summary_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "debug_last_ksw_mode": (C.c_int, []),
     "debug_limits": (C.c_int, [i64p]),
+    "debug_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "ksw_last_status": (C.c_int, []),
 }
 

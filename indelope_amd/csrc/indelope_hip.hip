@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -26,6 +27,7 @@ struct Ctx {
 	bool ready = false;
 	int device = -1;
 	int cus = 0;
+	int wall_khz = 0;                                      // rate of the device wall clock (wall_clock64) in kHz
 	int64_t hbm = 0;
 	int max_lds = 65536;
 	hipStream_t stream = nullptr;
@@ -57,6 +59,21 @@ int ensure_init()
 // test hook (ihp_debug_limits): caps on the device pools so that the overflow paths can be driven by small inputs
 long long g_limits[4] = {0, 0, 0, 0};      // CIGAR bump words, event pool entries, hit pool ints, ksw traceback bytes
 int g_ksw_status = 0;                      // result of the most recent ksw_extz2_sse call (ihp_ksw_last_status)
+
+// test / diagnostics switches (ihp_debug_set): which of the equivalent paths a batch takes and at what occupancy.  Results
+// never depend on them (tests/test_gpu_round3.py runs the parity suite's workloads under every path switch).
+struct Knobs {
+	int asm_v1 = 0;        // 1: class 1 through the byte-based k_assemble passes only (no packed assembly)
+	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
+	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
+	int pm = 1;            // 0: no packed mirror in k_asm_combine (exact scans on the bytes)
+	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
+	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
+	int profile = 0;       // 1: kernels sum shader-clock cycles per phase (ihp_batch_profile)
+	int strict_ksw = 0;    // 1: ksw_extz2_sse aborts on failure (also IHP_KSW_STRICT=1 in the environment)
+};
+Knobs g_knob;
+std::atomic<int> g_live_batches{0};
 
 // Device memory comes from a caching pool: a BAM sweep uploads batch after batch of similar shape, and hipMalloc /
 // hipFree (which synchronises the device) of ~50 buffers per batch would cost more than the kernels.  Freed blocks are
@@ -146,6 +163,8 @@ struct ReportPool {
 	void put(int *r) { std::lock_guard<std::mutex> l(mu); free_list.push_back(r); }
 	void clear() {
 		std::lock_guard<std::mutex> l(mu);
+		// a live batch still points into its page (k_summary writes there, sync / fetch read it): the pages stay until no batch does
+		if (g_live_batches.load() > 0) return;
 		for (auto pg : pages) (void)hipHostFree(pg);
 		pages.clear(); free_list.clear();
 	}
@@ -272,14 +291,13 @@ extern "C" int ihp_init(int device)
 	tl_device = device;
 	g.device = device; g.cus = pr.multiProcessorCount; g.hbm = (int64_t)pr.totalGlobalMem;
 	g.max_lds = (int)pr.sharedMemPerBlock;
+	if (hipDeviceGetAttribute(&g.wall_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess) g.wall_khz = 0;
 	if (g.max_lds > 65536) {
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
 		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
-		(void)hipFuncSetAttribute((const void *)k_asm_reads<6>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
-		(void)hipFuncSetAttribute((const void *)k_asm_reads<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -316,6 +334,19 @@ extern "C" int ihp_debug_limits(const int64_t limits[4])
 {
 	for (int k = 0; k < 4; ++k) g_limits[k] = limits ? (long long)limits[k] : 0;
 	return 0;
+}
+
+extern "C" int ihp_debug_set(const char *key, int64_t value)
+{
+	if (!key) { g_knob = Knobs(); return 0; }
+	struct { const char *name; int *field; } tab[] = {
+		{"asm_v1", &g_knob.asm_v1}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"pm", &g_knob.pm},
+		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
+		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
+		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
+	};
+	for (auto &e : tab) if (!strcmp(e.name, key)) { *e.field = (int)value; return 0; }
+	return IHP_E_ARG;
 }
 
 extern "C" void ihp_encode(const uint8_t *dna, int64_t n, uint8_t *out)
@@ -531,7 +562,7 @@ extern "C" void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen
 		if (rc != IHP_E_HIP) snprintf(g.err, sizeof(g.err), "ksw_extz2_sse: %s (qlen %d, tlen %d, w %d, flag 0x%x)", ihp_strerror(rc), qlen, tlen, w, flag);
 		fprintf(stderr, "indelope_hip: ksw_extz2_sse FAILED, ez left reset: %s\n", g.err);
 		const char *strict = getenv("IHP_KSW_STRICT");
-		if (strict && strict[0] == '1') abort();
+		if (g_knob.strict_ksw || (strict && strict[0] == '1')) abort();
 		return;
 	}
 	ez->max = (uint32_t)r.max; ez->zdropped = (uint32_t)r.zdropped; ez->max_q = r.max_q; ez->max_t = r.max_t;
@@ -740,13 +771,19 @@ struct ihp_batch {
 	hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	hipStream_t stream = nullptr;
 	bool ran = false, work_live = false;
+	double acc_ms[4] = {0, 0, 0, 0}; long long acc_n = 0;  // stage times summed over the runs since the last reset (ihp_batch_kernel_ms_mean)
+	bool acc_pending = false;                              // the last run's stamps have not been added yet
+	bool dirty = false;                                    // a run was cut short after some launches: `misc` is not known to be clear
 	int *report = nullptr;                                 // page-locked host block: the last run's counters, flags and stamps
 	int grid_ovf2 = 0, grid_ovf3 = 0, grid_ovf4 = 0;       // grids of the run-time overflow launches
+	ihp_batch() { g_live_batches.fetch_add(1); }
 	~ihp_batch() {
-		if (report) g_reports.put(report);
 		// the buffers go back to the pool (the members are released after this body): nothing of this batch may still be running
 		if (stream2) { (void)hipStreamSynchronize(stream2); g_streams.put(stream2); }
 		if (stream) { (void)hipStreamSynchronize(stream); g_streams.put(stream); }
+		// only now can the report slot be handed to another batch: a run in flight would still write its counters there
+		if (report) g_reports.put(report);
+		g_live_batches.fetch_sub(1);
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		if (ev_join) (void)hipEventDestroy(ev_join);
 		if (ev_bfork) (void)hipEventDestroy(ev_bfork);
@@ -897,7 +934,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		}
 		b->lds_arena1 = (int)a1;
 		b->grid_asm = grid_for(R, std::max(1, std::min(16, g.max_lds / (b->lds_arena1 + 3840))));
-		if (getenv("IHP_ASM_WAVES")) b->grid_asm = grid_for(R, std::max(1, std::min(16, atoi(getenv("IHP_ASM_WAVES")))));   // diagnostics
+		if (g_knob.asm_waves) b->grid_asm = grid_for(R, std::max(1, std::min(16, g_knob.asm_waves)));
 	}
 	b->lds_arena2 = std::max(12288, std::min(2 * b->lds_arena1, g.max_lds - 24576));   // + 7.5 KB (RegionStateT<128>)
 	{
@@ -937,24 +974,21 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		// Packed read phase for class 1 (asm2_dev.h, k_assemble2) when the parameters allow it: exact matching only
 		// (max_mismatch 0) and 0 < min_overlap_pct <= 1.  Its byte arena holds the contigs that reach combine (no read
 		// staging); the packed area holds the longest read, one record per read and the 2-bit contig slots.
-		const char *v1 = getenv("IHP_ASM_V1");
-		b->v2 = !(v1 && v1[0] == '1') && p->max_mismatch == 0 && p->min_overlap_pct > 0 && p->min_overlap_pct <= 1.0 && b->n_cls[0] > 0;
+		b->v2 = !g_knob.asm_v1 && p->max_mismatch == 0 && p->min_overlap_pct > 0 && p->min_overlap_pct <= 1.0 && b->n_cls[0] > 0;
 		if (b->v2) {
 			long long nb1 = 0, nr1 = 0;
 			for (int r = 0; r < R; ++r) {
 				const long long nb = ro[rro[r + 1]] - ro[rro[r]];
 				if (nb * 3 / 10 + 2 * b->stage_cap <= b->lds_arena1) { nb1 = std::max(nb1, nb); nr1 = std::max<long long>(nr1, rro[r + 1] - rro[r]); }
 			}
-			const char *e1 = getenv("IHP_V2_ARENA"), *e2 = getenv("IHP_V2_PDW");
 			// what a region needs at least ...
 			long long need_arena = (nb1 * 36 / 100 + 512 + 15) / 16 * 16;
 			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave
 			// combine kernel: RegionStateT<64> + mirror arrays (4 KB static) + byte arena + packed mirror
-			const char *epm = getenv("IHP_V2_PM"), *eocc = getenv("IHP_V2_OCC");
-			const bool pm_on = !(epm && epm[0] == '0');                   // diagnostics: packed mirror for combine's exact scans
-			const int occ_max = eocc ? atoi(eocc) : 16;       // 16: the arena then holds every C2-like region (a region sent to the roomy launch costs a whole serial chain)
+			const bool pm_on = g_knob.pm != 0;                            // packed mirror for combine's exact scans
+			const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 16;       // 16: the arena then holds every C2-like region (a region sent to the roomy launch costs a whole serial chain)
 			const long long need_pm = pm_on ? (nb1 / 16 * 4 / 10 + 96 + 3) / 4 * 4 : 0;
 			b->v2_pm = (int)need_pm;
 			need_arena = std::max<long long>(1024, need_arena - 768);       // the usual region needs ~0.25 of its read bases; the rest goes to the roomy launch
@@ -975,15 +1009,20 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 				b->grid_v2b = std::min(grid_for(R, occ_b), std::max(1, b->n_cls[0]));
 			}
 			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
-			b->v2_arena = e1 ? atoi(e1) : (int)need_arena;
-			b->v2_pdw = e2 ? atoi(e2) : (int)need_pdw;
+			b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena : (int)need_arena;
+			b->v2_pdw = g_knob.v2_pdw ? g_knob.v2_pdw : (int)need_pdw;
 			b->v2_pdw = b->v2_pdw / 4 * 4;
 			const int per_wave = b->v2_arena + 4 * b->v2_pm + 4096, per_wave_r = 4 * b->v2_pdw + 256;
-			if (per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
+			// every combine launch must fit what hipFuncSetAttribute allows (max_lds - 8192 of dynamic LDS beside ~4 KB static):
+			// the second tier and the roomy launch give up arena first, the packed path is switched off only when the first tier does not fit
+			const int dyn_max = g.max_lds - 8192 - 1024;
+			b->v2_pm_b = std::min(b->v2_pm_b, dyn_max / 8 / 4 * 4); b->v2_pm_big = std::min(b->v2_pm_big, dyn_max / 8 / 4 * 4);
+			b->v2_arena_b = std::min(b->v2_arena_b, (dyn_max - 4 * b->v2_pm_b) / 16 * 16);
+			b->v2_arena_big = std::min(b->v2_arena_big, (dyn_max - 4 * b->v2_pm_big) / 16 * 16);
+			if (b->v2_arena + 4 * b->v2_pm > dyn_max || per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
 			else {
-				const char *ew = getenv("IHP_ASM_WAVES"), *er = getenv("IHP_ASMR_WAVES");
-				b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(ew ? atoi(ew) : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
-				b->grid_v2r = std::min(grid_for(R, std::max(1, std::min(er ? atoi(er) : 32, g.max_lds / per_wave_r))), std::max(1, b->n_cls[0]));
+				b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
+				b->grid_v2r = std::min(grid_for(R, std::max(1, std::min(g_knob.asmr_waves ? g_knob.asmr_waves : 32, g.max_lds / per_wave_r))), std::max(1, b->n_cls[0]));
 				b->grid_pack = grid_for((int)std::min<long long>((NR + 3) / 4, 1 << 30), 32);
 				// hand-over records between the two kernels: 8 + 9 min(64, reads) + reads + bases / 16 + 8 dwords per region
 				std::vector<long long> hoff((size_t)R + 1, 0);
@@ -1029,8 +1068,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		b->p_cap = std::max(((size_t)(qeff + tmax) * nc + 1) * 16, ksw_narrow_p_bytes(qeff, tmax)) + 64;
 		b->cig_cap = qeff + tmax + 8;
 	}
-	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_KSW_WAVES") ? atoi(getenv("IHP_KSW_WAVES")) : 32);
-	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), getenv("IHP_TALLY_WAVES") ? atoi(getenv("IHP_TALLY_WAVES")) : 32);
+	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), g_knob.ksw_waves ? g_knob.ksw_waves : 32);
+	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), g_knob.tally_waves ? g_knob.tally_waves : 32);
 	const long long njobs_cap = std::min<long long>(slots, (long long)R * std::max(1, p->max_pre_contigs));
 	b->njobs_cap = njobs_cap;
 	b->cig_bump_cap = 8 * njobs_cap + 4096;                      // CIGARs longer than CIG_SLOT words
@@ -1090,7 +1129,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	{ int rc1 = alloc_work(b); if (rc1) return rc1; }
 	// counters, stamps, work queues and per-region hit counts are zero: cleared at upload and by the previous run's k_summary
 	int *wq = b->queues_dev();
-	const bool profiling = getenv("IHP_PROFILE") != nullptr;
+	const bool profiling = g_knob.profile != 0;
+	if (b->dirty) HIPC(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));     // the previous run ended before its k_summary was enqueued
+	b->dirty = true;
 	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
 	int *misc = b->misc.as<int>();
 	unsigned long long *tm = b->timing ? b->times_dev() : nullptr;
@@ -1175,17 +1216,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ra.region_read_off = x.region_read_off; ra.read_off = x.read_off; ra.read_start = x.read_start; ra.mapq = x.mapq;
 			ra.read_skip = x.read_skip; ra.v2_read_bad = x.v2_read_bad; ra.v2_trim_lo = x.v2_trim_lo; ra.v2_trim_hi = x.v2_trim_hi;
 			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
-			static const bool lpt_on = !(getenv("IHP_V2_LPT") && atoi(getenv("IHP_V2_LPT")) == 0);   // diagnostics: region order of the combine launch
+			const bool lpt_on = g_knob.lpt != 0;                   // region order of the combine launch
 			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
 			ra.tier_a_cap = b->v2_arena - 16; ra.n_tier_b = misc + M_NTIERB;     // tier_a_cap = Arena::cap of the first launch
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
-			{
-				static const int minw = getenv("IHP_ASMR_MINW") ? atoi(getenv("IHP_ASMR_MINW")) : 8;    // diagnostics: VGPR budget of the read kernel
-				if (minw >= 8) hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
-				else if (minw >= 6) hipLaunchKernelGGL((k_asm_reads<6>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
-				else hipLaunchKernelGGL((k_asm_reads<4>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
-			}
+			hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
 			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS; x.v2_pm_dw = b->v2_pm;
 			x.lpt_cnt = ra.lpt_cnt; x.lpt_seg = ra.lpt_seg; x.lpt_stride = ra.lpt_stride;
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
@@ -1258,8 +1294,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>();
 		a.bases = b->bases.as<uint8_t>(); a.mapq = b->mapq.as<uint8_t>();
 		{
-			static const bool tally_pk = !(getenv("IHP_TALLY_PK") && atoi(getenv("IHP_TALLY_PK")) == 0);   // diagnostics
-			const bool have = b->v2 && b->n_cls[0] > 0 && tally_pk;    // k_prepack ran in this chain
+			const bool have = b->v2 && b->n_cls[0] > 0 && g_knob.tally_pk;    // k_prepack ran in this chain
 			a.pk = have ? b->v2_pk.as<uint32_t>() : nullptr; a.read_bad = have ? b->v2_read_bad.as<uint8_t>() : nullptr;
 		}
 		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();
@@ -1320,6 +1355,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	}
 	HIPC(hipEventRecord(b->ev[4], s));
 	b->ran = true;
+	b->acc_pending = b->timing;
+	b->dirty = false;                                      // k_summary is in the stream: it leaves `misc` clear for the next run
 	return 0;
 }
 
@@ -1336,12 +1373,45 @@ static int report_overflow(const ihp_batch *b)
 
 // Waits for the batch's run; a pool that overflowed during it (CIGAR / event / hit pools, ksw2 scratch) is reported
 // here as IHP_E_CAPACITY, not only when the results are fetched.
+static void stage_ms_from_report(const ihp_batch *b, float ms[4])
+{
+	unsigned long long t[8];
+	memcpy(t, (const char *)b->report + ihp_batch::Z_TIMES, sizeof(t));
+	// stamps: [0] assembly, [2] ksw2, [4] tally, [6] fallback (0 when that stage was not launched), [7] summary
+	for (int k = 0; k < 4; ++k) {
+		unsigned long long end = 0;
+		for (int j = 2 * k + 2; j <= 6 && !end; j += 2) end = t[j];
+		if (!end) end = t[7];
+		ms[k] = (t[2 * k] && end > t[2 * k] && g.wall_khz > 0) ? (float)((double)(end - t[2 * k]) / (double)g.wall_khz) : 0.0f;
+	}
+}
+
 extern "C" int ihp_batch_sync(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
+	if (b->ran && b->acc_pending && b->R > 0) {
+		// the run's stamps are in the report page (host memory): adding them up here costs no HIP call, so a caller can time
+		// every run of a loop without reading anything inside it
+		float ms[4];
+		stage_ms_from_report(b, ms);
+		for (int k = 0; k < 4; ++k) b->acc_ms[k] += ms[k];
+		b->acc_n++;
+		b->acc_pending = false;
+	}
 	if (b->ran && b->R > 0) return report_overflow(b);
+	return 0;
+}
+
+// Mean stage times (as ihp_batch_kernel_ms) over the runs that were waited for with ihp_batch_sync since timing was
+// switched on or since the last call with reset != 0.
+extern "C" int ihp_batch_kernel_ms_mean(ihp_batch *b, float ms[4], int64_t *n_runs, int reset)
+{
+	if (!b || !ms) return IHP_E_ARG;
+	for (int k = 0; k < 4; ++k) ms[k] = b->acc_n ? (float)(b->acc_ms[k] / (double)b->acc_n) : 0.0f;
+	if (n_runs) *n_runs = b->acc_n;
+	if (reset) { for (int k = 0; k < 4; ++k) b->acc_ms[k] = 0; b->acc_n = 0; }
 	return 0;
 }
 
@@ -1359,6 +1429,7 @@ extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
 extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
 {
 	if (!b || !out) return IHP_E_ARG;
+	if (!b->ran || !b->work_live) return IHP_E_ARG;           // no run yet, or its scratch went back to the pool (ihp_batch_release_outputs)
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
 	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
@@ -1385,19 +1456,9 @@ extern "C" int ihp_batch_set_timing(ihp_batch *b, int on)
 extern "C" int ihp_batch_kernel_ms(ihp_batch *b, float ms[4])
 {
 	if (!b || !b->ran || !b->timing || !ms) return IHP_E_ARG;
-	unsigned long long t[8];
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
-	memcpy(t, (const char *)b->report + ihp_batch::Z_TIMES, sizeof(t));
-	int khz = 0;
-	HIPC(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g.device));
-	// stamps: [0] assembly, [2] ksw2, [4] tally, [6] fallback (0 when that stage was not launched), [7] summary
-	for (int k = 0; k < 4; ++k) {
-		unsigned long long end = 0;
-		for (int j = 2 * k + 2; j <= 6 && !end; j += 2) end = t[j];
-		if (!end) end = t[7];
-		ms[k] = (t[2 * k] && end > t[2 * k] && khz > 0) ? (float)((double)(end - t[2 * k]) / (double)khz) : 0.0f;
-	}
+	stage_ms_from_report(b, ms);
 	return 0;
 }
 

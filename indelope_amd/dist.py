@@ -54,7 +54,7 @@ def summaries_from_result(res):
     return out
 
 
-def gather_payload(slab, counts, rank, world, dst=0):
+def gather_payload(slab, counts, rank, world, dst=0, force=False):
     """The variable-length half of the end-of-job gather: every rank's packed result slab (a uint8
     tensor on the process group's device: the device slab of ihp_batch_pack_dev under "nccl", host bytes under "gloo")
     travels to `dst` point to point -- each peer over its own xGMI link to the root, no ring -- after one all_gather of
@@ -62,7 +62,7 @@ def gather_payload(slab, counts, rank, world, dst=0):
     import torch
     import torch.distributed as dist
     meta = torch.tensor([slab.numel()] + [int(c) for c in counts], dtype=torch.int64, device=slab.device)
-    if world == 1:
+    if world == 1 and not force:                           # force: the collective runs even in a group of one (tests)
         return [(slab, meta[1:].cpu().numpy())]
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
@@ -85,13 +85,13 @@ def gather_payload(slab, counts, rank, world, dst=0):
     return out
 
 
-def gather_summaries(local, rank, world, dst=0):
+def gather_summaries(local, rank, world, dst=0, force=False):
     """One gather of the per-region records to `dst`.  `local`: int32 tensor [n_local, SUMMARY_WORDS] on the
     device the process group uses.  Shards may differ in size: they are padded to the longest and trimmed
     again on `dst`.  Returns the concatenation in rank (= region) order on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]

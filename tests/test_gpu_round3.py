@@ -1,0 +1,163 @@
+"""Round-3 GPU tests: every path switch of the library (ihp_debug_set) against the oracle on C2 / C3 / C5-shaped batches,
+C5 at full size and a 20 000-region C3 slice, the RCCL branch of bench.py on the one GPU at hand (group of one: NCCL
+process group, per-step gather, payload slabs), stage-time accumulation, and the report page of a freed batch."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from indelope_amd import synth
+from indelope_amd import _abi as A
+from indelope_amd.host import BatchResult, IhpError
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def assert_same(got, exp):
+    d = BatchResult.first_difference(got, exp)
+    assert d is None, d
+    np.testing.assert_allclose(got.events["gl"], exp.events["gl"], rtol=1e-12)
+
+
+SHAPES = [("C2", 600, 27), ("C3", 400, 27), ("C5", 200, 31)]
+
+
+@pytest.fixture(scope="module")
+def shaped(oracle):
+    out = []
+    for name, n, K in SHAPES:
+        b, _ = synth.config(name, n_regions=n)
+        out.append((name, K, b, oracle.run_regions_mt(b, oracle.params(K=K), 16)))
+    # a batch with everything the packed path refuses in it (lower case, N, short and long reads) beside clean regions
+    b, _ = synth.generate(300, n_reads=(8, 96), err_rate=2e-3, config_id=77, dup_frac=0.2)
+    rng = np.random.default_rng(3)
+    bases = b.bases.copy()
+    idx = rng.integers(0, len(bases), 40)
+    bases[idx[:20]] = ord("N")
+    bases[idx[20:]] |= 0x20
+    b.bases = bases
+    out.append(("mixed", 27, b, oracle.run_regions_mt(b, oracle.params(K=27), 16)))
+    return out
+
+
+@pytest.mark.parametrize("knobs", [dict(asm_v1=1), dict(tally_pk=0), dict(lpt=0), dict(pm=0), dict(asm_v1=1, tally_pk=0),
+                                    dict(comb_occ=8), dict(asm_waves=6, asmr_waves=12, ksw_waves=9, tally_waves=5)],
+                         ids=lambda k: ",".join("%s=%d" % kv for kv in k.items()))
+def test_results_do_not_depend_on_the_path(hip, shaped, knobs):
+    """`asm_v1` forces the byte-based passes on class-1 input, `tally_pk=0` the ASCII tally, `lpt=0` / `pm=0`
+    the combine launch without cost classes / without its packed mirror; occupancies are free parameters."""
+    hip.debug_set(**knobs)
+    try:
+        for name, K, b, exp in shaped:
+            assert_same(hip.run_regions(b, hip.params(K=K)), exp)
+    finally:
+        hip.debug_set()
+
+
+def test_unknown_knob_is_refused(hip):
+    with pytest.raises(IhpError) as e:
+        hip.debug_set(no_such_switch=1)
+    assert e.value.code == A.IHP_E_ARG
+
+
+def test_c5_full_size_and_c3_20000(hip, oracle):
+    """BASELINE configs[4] at full size (10 000 regions of 64 x 300 bp, K = 31) and 20 000 regions of configs[2]
+    (16-256 reads per region: every arena tier and assembly class) region by region against the oracle."""
+    b, _ = synth.config("C5")
+    assert_same(hip.run_regions(b, hip.params(K=31)), oracle.run_regions_mt(b, oracle.params(K=31), 64))
+    b, _ = synth.config("C3", n_regions=20_000)
+    assert_same(hip.run_regions(b), oracle.run_regions_mt(b, None, 64))
+
+
+def test_stage_times_add_up_without_reading_them_in_the_loop(hip):
+    b, _ = synth.config("C2", n_regions=2000)
+    h = hip.batch_upload(b.with_trim_bounds())
+    try:
+        hip.batch_set_timing(h, True)
+        for _ in range(3):
+            hip.batch_run(h)
+            hip.batch_sync(h)
+            hip.batch_sync(h)                                   # a second wait does not count the run twice
+        ms, n = hip.batch_kernel_ms_mean(h)
+        one = hip.batch_kernel_ms(h)
+        assert n == 3 and all(m > 0 for m in ms[:3])
+        assert 0.5 * one[0] < ms[0] < 2.0 * one[0]
+        ms2, n2 = hip.batch_kernel_ms_mean(h, reset=True)
+        assert n2 == 3 and hip.batch_kernel_ms_mean(h)[1] == 0
+    finally:
+        hip.batch_free(h)
+
+
+def test_free_while_running_does_not_disturb_the_next_batch(hip, oracle):
+    """a batch freed with a run in flight must not hand its report slot to another batch before the run is over."""
+    b, _ = synth.config("C2", n_regions=1500)
+    small, _ = synth.generate(8, n_reads=(20, 30), err_rate=0.0, config_id=5)
+    exp = oracle.run_regions(small)
+    for _ in range(6):
+        h = hip.batch_upload(b)
+        hip.batch_run(h)
+        hip.batch_free(h)                                       # run in flight
+        h2 = hip.batch_upload(small)
+        hip.batch_run(h2)
+        hip.batch_sync(h2)                                      # would raise IHP_E_CAPACITY on a spurious overflow flag
+        assert_same(hip.batch_fetch(h2), exp)
+        hip.batch_free(h2)
+
+
+def test_profile_after_release_is_an_argument_error(hip):
+    b, _ = synth.generate(16, n_reads=(20, 30), err_rate=0.0, config_id=5)
+    h = hip.batch_upload(b)
+    try:
+        hip.batch_run(h)
+        hip.batch_sync(h)
+        hip.batch_release_outputs(h)
+        with pytest.raises(IhpError) as e:
+            hip.batch_profile(h)
+        assert e.value.code == A.IHP_E_ARG
+        hip.batch_run(h)                                        # takes buffers again
+        hip.batch_sync(h)
+        hip.batch_profile(h)
+    finally:
+        hip.batch_free(h)
+
+
+def _bench(args, launcher):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable]
+    if launcher:                                                # a fresh child started by torch.distributed.run, as the driver does
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29611"]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    pr = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert pr.returncode == 0, (pr.stdout[-1500:], pr.stderr[-3000:])
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_branch_on_one_gpu_weak():
+    """bench.py under torch.distributed.run --nproc-per-node 1 with --force-dist: NCCL (= RCCL) process group, zero-copy
+    tensors over the library's device memory, the per-step dist.gather, --payload slabs; rank 0 checks what it gathered
+    against summaries_from_result / its own fetched results."""
+    out = _bench(["--gpus", "1", "--force-dist", "--payload", "--verify-gather", "--regions", "3000", "--steps", "3", "--warmup", "1",
+                  "--no-cpu", "--no-e2e", "--no-other"], launcher=True)
+    g = out["gather_check"]
+    assert g["backend"] == "nccl" and g["records"] == 3000 and g["records_identical_to_own_results"]
+    assert g["payload_identical_to_own_results"] and g["payload_bytes"] > 0
+    assert out["oracle_check"]["identical"] and out["n_gpus"] == 1
+
+
+def test_rccl_branch_on_one_gpu_strong():
+    """The strong-scaling form (C4 regions walked in resident chunks, two in flight, one gather per step) in a group of one."""
+    out = _bench(["--force-dist", "--verify-gather", "--scaling", "strong", "--config", "C4", "--regions", "40000", "--chunk", "10000",
+                  "--steps", "2", "--warmup", "1", "--no-cpu", "--no-e2e"], launcher=False)
+    g = out["gather_check"]
+    assert g["backend"] == "nccl" and g["records"] == 40000
+    assert out["oracle_check"]["identical"] and out["scaling"] == "strong"

@@ -31,7 +31,7 @@ python3 bench.py --config C5 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>>
 python3 bench.py --no-cpu --no-e2e --no-check --quals >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --no-cpu --no-e2e --no-check --dup-frac 0.1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --no-cpu --no-e2e --no-check --sub-batches 1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
-IHP_ASM_V1=1 python3 bench.py --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --knob asm_v1=1 --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --scaling strong --config C4 --regions 1250000 --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/c4_strong_1gpu.json 2>> $OUT/err
 timeout 120 tools/ubench_issue.bin > $OUT/ubench_issue.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
