@@ -436,8 +436,9 @@ int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
  * [13] target-offset filter, [14] query-offset phase, [15] insert, [27] set-up.  Always filled: [24]/[25]/[26] regions
  * forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [23] regions the packed pass handed
  * back to the byte-based class-1 kernel, [28] regions sent on to the roomy combine launch, [29] regions the read phase
- * filed under the second (larger-arena) combine launch, [22] ksw2 kernel mode. */
-int  ihp_batch_profile(ihp_batch *b, int64_t out[32]);
+ * filed under the second (larger-arena) combine launch, [22] ksw2 kernel mode; [32..39] event counts of the combine kernel
+ * (best_match calls, exact candidates, verification passes, vote scans, merges, filter passes, query-phase target looks, trims that read supports). */
+int  ihp_batch_profile(ihp_batch *b, int64_t out[64]);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
  * ihp_batch_run used: 3/4 = top-byte register sweep (left/right gaps; the production
  * kernels), 0/1 = masked register sweep (scoring schemes or base codes the former does
@@ -452,7 +453,6 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *   "asm_v1" 1      class-1 regions through the byte-based k_assemble passes only (no packed assembly)
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
  *   "lpt" 0         k_asm_combine in input order: no cost classes, no second arena tier
- *   "pm" 0          no packed mirror in k_asm_combine (its exact scans run on the byte arena)
  *   "asm_waves", "asmr_waves", "comb_occ", "ksw_waves", "tally_waves"   waves per CU of a kernel (0 = library sizing)
  *   "v2_arena", "v2_pdw"   LDS bytes / dwords per wave of the packed assembly (0 = library sizing)
  *   "profile" 1     per-phase cycle counters (ihp_batch_profile)

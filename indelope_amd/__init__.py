@@ -118,7 +118,7 @@ class HipApi(Api):
 
     def batch_profile(self, h):
         import numpy as np
-        out = np.zeros(32, np.int64)
+        out = np.zeros(64, np.int64)
         self._chk_hip(self.b.batch_profile(h, _abi.ptr(out, _abi.i64p)), "batch_profile")
         return out
 

@@ -530,511 +530,16 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	V2_LAP(7);
 #undef V2_LAP
 	n_contigs = n;
-	// what combine needs of its byte arena: every contig in a slot of its own and the longest one's difference array
-	// (v2_take_over), plus room for a merge or two of the longest contigs before the first compaction
+	// what combine (asm3_dev.h) needs of its support bytes: every contig in a slot of its own plus room for merges of the
+	// longest contigs (a merge that makes a contig longer takes a new slot of 1.5 x the new length; nothing is compacted)
 	{
 		const int bl = lane < n ? align4(d_len) + SLOT_PAD : 0;
 		const int mxl = wave_max_i32s(lane < n ? d_len : 0);
-		const int btotal = wave_sum_i(bl) + mxl + 64, mx4 = 4 * (mxl + 2);
-		arena_need = btotal > mx4 ? btotal : mx4;
+		arena_need = wave_sum_i(bl) + 3 * mxl + 128;
 	}
 	return 0;
 }
-
-struct PackedMirror {
-	uint32_t *PM; int cap, bump;                               // dwords
-	unsigned short *pm_dw; unsigned char *pm_sh;               // per slot (LDS)
-	bool on;
-};
-
-// Build what the combine phase works on from a hand-over record: slot metadata in S (as materialize_supports() leaves it),
-// bases unpacked into the byte arena A.seq, supports counted from the read records into A.sup.  Returns 1 if the region
-// was not taken by the read phase (another pass has it), 0 when ready, IHP_E_CAPACITY when it does not fit this arena.
-template <class ST>
-__device__ inline int v2_take_over(const AsmArgs &a, ST &S, Arena &A, PackedMirror &M, int r, int &n_pre)
-{
-	const int lane = lane_id();
-	const uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
-	const int n = uni((int)H[0]), nrr = uni((int)H[1]);
-	n_pre = 0;
-	if (n < 0) return 1;
-	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
-	if (lane < n) {
-		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
-		d_poff = (int)a0.x; d_len = (int)a0.y; d_nreads = (int)a0.z; d_slo = (int)a0.w; d_shi = (int)a1.x; d_anchor = (int)a1.y;
-	}
-	const uint32_t *REC = H + V2_HDR + V2_DIRW * n;
-	n_pre = n;
-	const int blen = lane < n ? align4(d_len) + SLOT_PAD : 0;
-	const unsigned bincl = wave_scan_add((unsigned)blen);
-	const int boff = (int)bincl - blen, btotal = __builtin_amdgcn_readlane((int)bincl, 63);
-	const int maxl = wave_max_i32s(lane < n ? d_len : 0);
-	if (btotal > A.cap || 4 * (maxl + 2) > A.cap) return IHP_E_CAPACITY;
-	for (int i = lane; i <= ST::MAXC; i += 64) S.alive[i] = 0;
-	WSYNC();
-	if (lane < n) {
-		S.off[lane] = boff; S.len[lane] = d_len; S.cap[lane] = align4(d_len); S.nreads[lane] = d_nreads;
-		S.start[lane] = ((long long)d_shi << 32) | (unsigned)d_slo; S.alive[lane] = 1; S.listA[lane] = (short)lane;
-	}
-	if (lane == 0) { S.bump = btotal; S.err = 0; }
-	// the records of up to 256 reads stay in registers for all contigs
-	unsigned rc0 = 0xffffffffu, rc1 = 0xffffffffu, rc2 = 0xffffffffu, rc3 = 0xffffffffu;
-	if (lane < nrr) rc0 = REC[lane];
-	if (64 + lane < nrr) rc1 = REC[64 + lane];
-	if (128 + lane < nrr) rc2 = REC[128 + lane];
-	if (192 + lane < nrr) rc3 = REC[192 + lane];
-	uint32_t *scratch = (uint32_t *)A.seq;                       // the byte arena is still empty: difference array of one contig
-	for (int c = 0; c < n; ++c) {
-		const int len = bcast(d_len, c), bo = bcast(boff, c), nr = bcast(d_nreads, c), anchor = bcast(d_anchor, c);
-		uint32_t *sup = A.sup + bo;
-		if (nr == 1) {                                           // a single read: support 1 everywhere
-			for (int i = lane; i < len; i += 64) sup[i] = 1u;
-			if (lane == 0) { S.smin[c] = 1; S.smax[c] = 1; S.lo3[c] = 0x3fffffff; S.hi3[c] = 0; }
-			continue;
-		}
-		for (int i = lane; i <= len; i += 64) scratch[i] = 0;
-		LDS_ORDER();
-		auto scatter = [&](unsigned rc) {
-			if (rc != 0xffffffffu && (int)(rc & 63u) == c) {
-				const int s = (int)((rc >> 6) & 0x7fffu) - 16384 + anchor, e = s + (int)(rc >> 21);
-				atomicAdd(&scratch[s], 1u);
-				atomicAdd(&scratch[e], 0xffffffffu);
-			}
-		};
-		scatter(rc0); scatter(rc1); scatter(rc2); scatter(rc3);
-		for (int i0 = 256; i0 < nrr; i0 += 64) { const int i = i0 + lane; scatter(i < nrr ? REC[i] : 0xffffffffu); }
-		LDS_ORDER();
-		unsigned carry = 0, mn = 0xffffffffu, mx = 0;
-		int first = 0x7fffffff, last = -1, cnt = 0;
-		for (int i0 = 0; i0 < len; i0 += 64) {
-			const int i = i0 + lane;
-			unsigned v = i < len ? scratch[i] : 0u;
-			v = wave_scan_add(v) + carry;
-			if (i < len) {
-				sup[i] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
-				if (v >= 3u) { first = i < first ? i : first; last = i; cnt++; }
-			}
-			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-		}
-		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
-		first = wave_min_i32(first); last = wave_max_i32s(last); cnt = wave_sum_i(cnt);
-		if (lane == 0) {
-			S.smin[c] = mn; S.smax[c] = mx;
-			const bool clean = last >= first && cnt == last - first + 1;
-			S.lo3[c] = clean ? first : 0x3fffffff; S.hi3[c] = clean ? last + 1 : 0;
-		}
-		LDS_ORDER();
-	}
-	LDS_ORDER();
-	// the packed bases go into the mirror as they are (one pad dword behind every contig), and as bytes into the arena
-	const int pnd = lane < n ? ((d_len + 15) >> 4) + 1 : 0;
-	const unsigned pincl = wave_scan_add((unsigned)pnd);
-	const int pmo = (int)pincl - pnd, ptotal = __builtin_amdgcn_readlane((int)pincl, 63);
-	M.on = ptotal + 2 <= M.cap;
-	M.bump = M.on ? ptotal : 0;
-	if (M.on && lane < n) { M.pm_dw[lane] = (unsigned short)pmo; M.pm_sh[lane] = 0; }
-	for (int c = 0; c < n; ++c) {                                // bases: four per lane, one dword store
-		const int len = bcast(d_len, c), bo = bcast(boff, c), po = bcast(pmo, c);
-		const uint32_t *src = H + bcast(d_poff, c);
-		uint32_t *dst = (uint32_t *)(A.seq + bo);
-		for (int i4 = lane; 4 * i4 < len; i4 += 64) {
-			const int i = 4 * i4;
-			const unsigned c8 = (src[i >> 4] >> (2 * (i & 15))) & 0xffu;
-			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
-			dst[i4] = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
-		}
-		if (M.on) for (int d = lane; d <= (len + 15) >> 4; d += 64) M.PM[po + d] = 16 * d < len ? src[d] : 0u;
-	}
-	WSYNC();
-	return 0;
-}
-
-
-// ------------------------------------------------------------------------------------------------ combine phase
-// Packed mirror of the byte arena for the exact scans of combine (contig.nim:254-281): slot s has its bases 2 bits each
-// at dword pm_dw[s] of PM, starting pm_sh[s] bases into that dword (trim only moves the start).  The bytes stay the
-// authoritative copy: votes, corrections, inserts and trims work on them (contig_dev.h); a contig that an insert has
-// changed is packed again.  When the mirror runs out of room it is switched off and the byte scans take over.
-// Pack slot s again from its bytes (after an insert changed them).
-template <class ST>
-__device__ inline void pm_repack(const ST &S, const Arena &A, PackedMirror &M, int s)
-{
-	if (!M.on) return;
-	const int lane = lane_id();
-	const int len = uni(S.len[s]), off = uni(S.off[s]);
-	const int nd = (len + 15) >> 4;
-	if (M.bump + nd + 2 > M.cap) { M.on = false; return; }
-	const uint32_t *a32 = (const uint32_t *)A.seq;
-	for (int d = lane; d <= nd; d += 64) {
-		unsigned out = 0;
-		if (d < nd) {
-			unsigned junk = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) out |= pack4(ld32u(a32, off + 16 * d + 4 * k), junk) << (8 * k);
-			const int rem = len - 16 * d;
-			if (rem < 16) out &= (1u << (2 * rem)) - 1u;
-		}
-		M.PM[M.bump + d] = out;
-	}
-	if (lane == 0) { M.pm_dw[s] = (unsigned short)M.bump; M.pm_sh[s] = 0; }
-	M.bump += nd + 1;
-	LDS_ORDER();
-}
-
-// best_match (contig.nim:224-240) in the combine phase.  Pairs for which the vote rule can fire (may_allow) get the generic
-// byte scan one after the other, as in best_match_all<ST, true>; all others are exact matches and are found on the packed
-// mirror: target offsets with one dword of one contig per lane (16 windows against the query's first 16 bases), query
-// offsets with one offset per lane against the contigs' first 16 bases; survivors verified on the whole overlap and
-// ranked under the reference's total order.
-template <class ST>
-__device__ inline Best best_match_combine_packed(const ST &S, const Arena &A, const PackedMirror &M, int qs, const short *list, int n,
-                                                 int min_overlap, int max_mm)
-{
-	const int lane = lane_id();
-	n = uni(n); min_overlap = uni(min_overlap); qs = uni(qs);
-	const int qlen = uni(S.len[qs]);
-	const int omin = qlen - min_overlap;                         // contig.nim:78
-	if (!M.on || max_mm != 0 || min_overlap < 17 || omin < 0 || qlen < 16) return best_match_combine(S, A, qs, list, n, min_overlap, max_mm);
-	IHP_T0(A);
-	const uint32_t *PM = M.PM;
-	const int qd = uni((int)M.pm_dw[qs]), qsh = uni((int)M.pm_sh[qs]);
-	const unsigned qh = (unsigned)uni((int)fsh(PM[qd + 1], PM[qd], 2u * (unsigned)qsh));
-	const unsigned qmin = (unsigned)uni((int)S.smin[qs]), qmax = (unsigned)uni((int)S.smax[qs]);
-	const long long qreads = uni(S.nreads[qs]);
-	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
-	Best G = {0, 0, 0, -1, -1, 0};                               // best of the pairs that need the generic scan
-	for (int c0 = 0; c0 < n; c0 += 64) {
-		const int m = n - c0 < 64 ? n - c0 : 64;
-		int m_ts = 0, m_len = 0, m_d = 0, m_sh = 0; unsigned m_head = 0;
-		bool use = lane < m, votes = false;
-		if (use) {
-			m_ts = list[c0 + lane]; m_len = S.len[m_ts]; m_d = M.pm_dw[m_ts]; m_sh = M.pm_sh[m_ts];
-			m_head = fsh(PM[m_d + 1], PM[m_d], 2u * (unsigned)m_sh);
-			if (m_ts == qs) use = false;                         // :227
-			else {
-				const unsigned tmin = S.smin[m_ts], tmax = S.smax[m_ts];
-				const long long treads = S.nreads[m_ts];
-				votes = (qmin < 3u && tmax > 3u * qmin && qreads > 3ll * (long long)qmin) ||
-				        (tmin < 3u && qmax > 3u * tmin && treads > 3ll * (long long)tmin);
-				if (votes) use = false;
-			}
-		}
-		if (ballot(lane < m && m_len < 16)) { IHP_T1(A, 5); return best_match_combine(S, A, qs, list, n, min_overlap, max_mm); }
-		unsigned long long gm = ballot(votes);
-		while (gm) {                                             // the vote rule may fire: generic scan on the bytes
-			const int i = ctz64(gm);
-			gm &= gm - 1;
-			IHP_T0(A);
-			slide_scan(S, A, qs, __builtin_amdgcn_readlane(m_ts, i), c0 + i, min_overlap, max_mm, IHP_ALLOW_DEFAULT, G);
-			IHP_T1(A, 4);
-		}
-		// ---- offsets 0 .. len(t) - min_overlap on the contigs (:79-111): items = dwords that hold such an offset
-		const int nit = use && m_len >= min_overlap ? ((m_sh + m_len - min_overlap) >> 4) + 1 : 0;
-		const unsigned incl = wave_scan_add((unsigned)nit), excl = incl - (unsigned)nit;
-		const int Q = __builtin_amdgcn_readlane((int)incl, 63);
-		for (int g0 = 0; g0 < Q; g0 += 64) {
-			const int g = g0 + lane;
-			int own = 0;                                         // the last entry that starts at or before g owns it
-			for (int i = 0; i < m; ++i) own = g >= __builtin_amdgcn_readlane((int)excl, i) && __builtin_amdgcn_readlane(nit, i) ? i : own;
-			const int o_d = __builtin_amdgcn_ds_bpermute(own << 2, m_d), o_ex = __builtin_amdgcn_ds_bpermute(own << 2, (int)excl);
-			unsigned w0 = 0, w1 = 0;
-			bool any = false;
-			if (g < Q) {
-				const int dw = o_d + (g - o_ex);
-				w0 = PM[dw]; w1 = PM[dw + 1];
-				any = window_any(w0, w1, qh);
-			}
-			unsigned long long hm = ballot(any);
-			while (hm) {
-				const int e = ctz64(hm);
-				hm &= hm - 1;
-				unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
-				const int i = __builtin_amdgcn_readlane(own, e);
-				const int k = g0 + e - __builtin_amdgcn_readlane((int)excl, i);
-				const int tlen = __builtin_amdgcn_readlane(m_len, i), td = __builtin_amdgcn_readlane(m_d, i), tsh = __builtin_amdgcn_readlane(m_sh, i);
-				const int ts = __builtin_amdgcn_readlane(m_ts, i);
-				while (bits) {
-					const int o = 16 * k + __builtin_ctz(bits) - tsh;
-					bits &= bits - 1;
-					if (o < 0 || o > tlen - min_overlap) continue;
-					const int cn = qlen < tlen - o ? qlen : tlen - o;
-					const int pos = c0 + i;
-					if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (0 > B.ph || (0 == B.ph && o >= B.o))))))) continue;
-					if (bits_equal(PM, qd, 2u * (unsigned)qsh, td + ((tsh + o) >> 4), 2u * (unsigned)((tsh + o) & 15), cn)) {
-						B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = o; B.ph = 0; B.o = o;
-					}
-				}
-			}
-		}
-		// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
-		const unsigned long long usem = ballot(use);
-		for (int ob = 0; ob <= omin; ob += 64) {
-			const int o_l = ob + lane;
-			const bool valid = o_l >= 1 && o_l <= omin;
-			unsigned wq = 0;
-			if (valid) { const int b = qsh + o_l; wq = fsh(PM[qd + (b >> 4) + 1], PM[qd + (b >> 4)], 2u * (unsigned)(b & 15)); }
-			unsigned long long anym = 0;
-			for (int i = 0; i < m; ++i) anym |= ballot(wq == (unsigned)__builtin_amdgcn_readlane((int)m_head, i));
-			if (!(anym & ballot(valid))) continue;               // the usual case: no contig starts inside the query
-			for (int i = 0; i < m; ++i) {
-				if (!((usem >> i) & 1)) continue;
-				unsigned long long mask = ballot(valid && wq == (unsigned)__builtin_amdgcn_readlane((int)m_head, i));
-				if (!mask) continue;
-				const int tlen = __builtin_amdgcn_readlane(m_len, i), td = __builtin_amdgcn_readlane(m_d, i), tsh = __builtin_amdgcn_readlane(m_sh, i);
-				const int ts = __builtin_amdgcn_readlane(m_ts, i);
-				while (mask) {
-					const int o = ob + ctz64(mask);
-					mask &= mask - 1;
-					const int cn = qlen - o < tlen ? qlen - o : tlen;
-					const int pos = c0 + i;
-					if (cn < min_overlap - 1) continue;
-					if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (1 > B.ph || (1 == B.ph && o >= B.o))))))) continue;
-					const int b = qsh + o;
-					if (bits_equal(PM, qd + (b >> 4), 2u * (unsigned)(b & 15), td, 2u * (unsigned)tsh, cn)) {
-						B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = -o; B.ph = 1; B.o = o;
-					}
-				}
-			}
-		}
-	}
-	IHP_T1(A, 5);
-	// more matches, then fewer mismatches, then the earlier contig (contig.nim:32-36, :107, :239)
-	if (G.found && (!B.b.found || G.ma > B.b.ma || (G.ma == B.b.ma && (G.mm < B.b.mm || (G.mm == B.b.mm && G.pos < B.b.pos))))) return G;
-	return B.b;
-}
-
-// ---- the candidates of a combine pass kept in registers --------------------------------------------------------------------
-// best_match_combine_packed() gathers, for every call, the metadata of every candidate from LDS (slot, length, mirror
-// position, first 16 bases, support extrema, reads) and works out which lane gets which (contig, dword) of the target-offset
-// scan.  Within one pass that changes only when a contig is merged into another: lane j holds contig in[j] of the pass for
-// its whole length, the (contig, dword) map of up to 128 items is kept with it, and a call only masks them with the set of
-// contigs that are in `out` so far (list order = lane order, so the lane index is the position of contig.nim:239).
-struct CombDir {
-	int ts, len, d, sh, nr, nit; unsigned head, smin, smax, excl;   // lane j <-> in[j]
-	int own0, own1, dw0, dw1;                                       // lane g <-> item g (own0, dw0) and item 64 + g (own1, dw1)
-	int Q, n;                                                       // items, contigs
-	unsigned long long inout;                                       // lanes whose contig is in `out`
-	bool valid;
-};
 
 __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
-
-template <class ST>
-__device__ inline void comb_dir_build(const ST &S, const PackedMirror &M, const short *in, int n, int min_overlap, CombDir &D)
-{
-	const int lane = lane_id();
-	n = uni(n);
-	D.n = n; D.ts = 0; D.len = 0; D.d = 0; D.sh = 0; D.nr = 0; D.nit = 0; D.head = 0; D.smin = 0; D.smax = 0; D.excl = 0;
-	D.own0 = D.own1 = D.dw0 = D.dw1 = 0; D.Q = 0;
-	bool bad = false;
-	D.valid = M.on && n <= 64 && n > 0 && min_overlap >= 17;
-	if (!D.valid) return;
-	if (lane < n) {
-		D.ts = in[lane]; D.len = S.len[D.ts]; D.d = M.pm_dw[D.ts]; D.sh = M.pm_sh[D.ts];
-		D.head = fsh(M.PM[D.d + 1], M.PM[D.d], 2u * (unsigned)D.sh);
-		D.smin = S.smin[D.ts]; D.smax = S.smax[D.ts];
-		const long long nr = S.nreads[D.ts];
-		D.nr = (int)nr;
-		bad = D.len < 16 || nr <= 0 || nr > 0x3fffffffll;
-	}
-	if (ballot(bad)) { D.valid = false; return; }
-	D.nit = lane < n && D.len >= min_overlap ? ((D.sh + D.len - min_overlap) >> 4) + 1 : 0;
-	const unsigned incl = wave_scan_add((unsigned)D.nit);
-	D.excl = incl - (unsigned)D.nit;
-	D.Q = __builtin_amdgcn_readlane((int)incl, 63);
-	if (D.Q > 128) { D.valid = false; return; }
-	int own0 = 0, own1 = 0;                                        // the last entry that starts at or before the item owns it
-	for (int i = 0; i < n; ++i) {
-		const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
-		if (ni) { own0 = lane >= ex ? i : own0; own1 = 64 + lane >= ex ? i : own1; }
-	}
-	D.own0 = own0; D.own1 = own1;
-	D.dw0 = __builtin_amdgcn_ds_bpermute(own0 << 2, D.d) + (lane - __builtin_amdgcn_ds_bpermute(own0 << 2, (int)D.excl));
-	D.dw1 = __builtin_amdgcn_ds_bpermute(own1 << 2, D.d) + (64 + lane - __builtin_amdgcn_ds_bpermute(own1 << 2, (int)D.excl));
-}
-
-// best_match (contig.nim:224-240) of contig in[qi] against the contigs of D.inout; same result as
-// best_match_combine_packed(S, A, M, in[qi], out, nout, ...) with Best::pos counted in lanes.
-template <class ST>
-__device__ inline Best best_match_dir(const ST &S, const Arena &A, const PackedMirror &M, const CombDir &D, int qi, int min_overlap)
-{
-	const int lane = lane_id();
-	qi = uni(qi);
-	const int qs = __builtin_amdgcn_readlane(D.ts, qi), qlen = __builtin_amdgcn_readlane(D.len, qi);
-	const int omin = qlen - min_overlap;                         // contig.nim:78
-	IHP_T0(A);
-	const uint32_t *PM = M.PM;
-	const int qd = __builtin_amdgcn_readlane(D.d, qi), qsh = __builtin_amdgcn_readlane(D.sh, qi);
-	const unsigned qh = (unsigned)__builtin_amdgcn_readlane((int)D.head, qi);
-	const unsigned qmin = (unsigned)__builtin_amdgcn_readlane((int)D.smin, qi), qmax = (unsigned)__builtin_amdgcn_readlane((int)D.smax, qi);
-	const int qreads = __builtin_amdgcn_readlane(D.nr, qi);
-	BestOrd B; B.b = {0, 0, 0, -1, -1, 0}; B.ph = 0; B.o = 0;
-	Best G = {0, 0, 0, -1, -1, 0};                               // best of the pairs that need the generic scan
-	const bool in = lane_of(D.inout);
-	const bool votes = in && ((qmin < 3u && D.smax > 3u * qmin && (long long)qreads > 3ll * (long long)qmin) ||
-	                          (D.smin < 3u && qmax > 3u * D.smin && (long long)D.nr > 3ll * (long long)D.smin));
-	const unsigned long long vm = ballot(votes);
-	unsigned long long gm = vm;
-	while (gm) {                                                 // the vote rule may fire: generic scan on the bytes
-		const int i = ctz64(gm);
-		gm &= gm - 1;
-		IHP_T0(A);
-		slide_scan(S, A, qs, __builtin_amdgcn_readlane(D.ts, i), i, min_overlap, 0, IHP_ALLOW_DEFAULT, G);
-		IHP_T1(A, 4);
-	}
-	const unsigned long long usem = D.inout & ~vm;
-	// ---- offsets 0 .. len(t) - min_overlap on the contigs (:79-111): items = dwords that hold such an offset
-	for (int w = 0; w * 64 < D.Q; ++w) {
-		const int own = w ? D.own1 : D.own0, dw = w ? D.dw1 : D.dw0;
-		unsigned w0 = 0, w1 = 0;
-		bool any = false;
-		if (64 * w + lane < D.Q && ((usem >> own) & 1ull)) {
-			w0 = PM[dw]; w1 = PM[dw + 1];
-			any = window_any(w0, w1, qh);
-		}
-		unsigned long long hm = ballot(any);
-		while (hm) {
-			const int e = ctz64(hm);
-			hm &= hm - 1;
-			unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
-			const int i = __builtin_amdgcn_readlane(own, e);
-			const int k = 64 * w + e - __builtin_amdgcn_readlane((int)D.excl, i);
-			const int tlen = __builtin_amdgcn_readlane(D.len, i), td = __builtin_amdgcn_readlane(D.d, i), tsh = __builtin_amdgcn_readlane(D.sh, i);
-			const int ts = __builtin_amdgcn_readlane(D.ts, i);
-			while (bits) {
-				const int o = 16 * k + __builtin_ctz(bits) - tsh;
-				bits &= bits - 1;
-				if (o < 0 || o > tlen - min_overlap) continue;
-				const int cn = qlen < tlen - o ? qlen : tlen - o;
-				const int pos = i;
-				if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (0 > B.ph || (0 == B.ph && o >= B.o))))))) continue;
-				if (bits_equal(PM, qd, 2u * (unsigned)qsh, td + ((tsh + o) >> 4), 2u * (unsigned)((tsh + o) & 15), cn)) {
-					B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = o; B.ph = 0; B.o = o;
-				}
-			}
-		}
-	}
-	// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
-	for (int ob = 0; ob <= omin; ob += 64) {
-		const int o_l = ob + lane;
-		const bool valid = o_l >= 1 && o_l <= omin;
-		unsigned wq = 0;
-		if (valid) { const int b = qsh + o_l; wq = fsh(PM[qd + (b >> 4) + 1], PM[qd + (b >> 4)], 2u * (unsigned)(b & 15)); }
-		const unsigned long long okm = ballot(valid);
-		unsigned long long um = usem;
-		while (um) {
-			const int i = ctz64(um);
-			um &= um - 1;
-			unsigned long long mask = ballot(wq == (unsigned)__builtin_amdgcn_readlane((int)D.head, i)) & okm;
-			if (!mask) continue;                                 // the usual case: the contig does not start inside the query
-			const int tlen = __builtin_amdgcn_readlane(D.len, i), td = __builtin_amdgcn_readlane(D.d, i), tsh = __builtin_amdgcn_readlane(D.sh, i);
-			const int ts = __builtin_amdgcn_readlane(D.ts, i);
-			while (mask) {
-				const int o = ob + ctz64(mask);
-				mask &= mask - 1;
-				const int cn = qlen - o < tlen ? qlen - o : tlen;
-				const int pos = i;
-				if (cn < min_overlap - 1) continue;
-				if (B.b.found && (cn < B.b.ma || (cn == B.b.ma && (pos > B.b.pos || (pos == B.b.pos && (1 > B.ph || (1 == B.ph && o >= B.o))))))) continue;
-				const int b = qsh + o;
-				if (bits_equal(PM, qd + (b >> 4), 2u * (unsigned)(b & 15), td, 2u * (unsigned)tsh, cn)) {
-					B.b.found = 1; B.b.ma = cn; B.b.mm = 0; B.b.pos = pos; B.b.slot = ts; B.b.off = -o; B.ph = 1; B.o = o;
-				}
-			}
-		}
-	}
-	IHP_T1(A, 5);
-	// more matches, then fewer mismatches, then the earlier contig (contig.nim:32-36, :107, :239)
-	if (G.found && (!B.b.found || G.ma > B.b.ma || (G.ma == B.b.ma && (G.mm < B.b.mm || (G.mm == B.b.mm && G.pos < B.b.pos))))) return G;
-	return B.b;
-}
-
-// combine_pass (contig_dev.h; contig.nim:263-281) with the exact scans on the packed mirror.
-template <class ST>
-__device__ inline int combine_pass_packed(ST &S, Arena &A, PackedMirror &M, short *in, int n, short *out, long long min_support,
-                                          int combine_min_overlap, int max_mm)
-{
-	const int lane = lane_id();
-	int nout = 0, usedi = 0;
-	for (int i = 0; i < n; ++i) {                                  // :265-271
-		const int c = in[i];
-		if (min_support > 0) {
-			const long long ms = S.nreads[c] < min_support ? S.nreads[c] : min_support;
-			IHP_T0(A);
-			// every support >= ms on two or more bases: trim (contig.nim:49-68) keeps the contig as it is -- the usual case of
-			// a single-read contig (support 1 everywhere, ms = 1) -- and the supports in HBM need not be looked at
-			const int len0 = uni(S.len[c]), lo3 = uni(S.lo3[c]), hi3 = uni(S.hi3[c]);
-			if ((long long)uni((int)S.smin[c]) >= ms && len0 >= 2) {
-			} else if (ms == 3 && hi3 > lo3 && len0 >= 2) {
-				// the supports >= 3 are one run [lo3, hi3) (recompute_minmax): the trim is known without reading them.
-				// a = first i < len-1 with support >= 3, b = last i > a with support >= 3 (contig.nim:52-64)
-				if (lo3 >= len0 - 1) {                              // :56-60: nothing qualifies below the last base
-					if (lane == 0) { S.start[c] += len0 - 1; S.len[c] = 0; S.nreads[c] = 0; }
-				} else {
-					const int a0 = lo3, b0 = hi3 - 1 > lo3 ? hi3 - 1 : lo3;
-					if (lane == 0) {
-						S.start[c] += a0; S.off[c] += a0; S.cap[c] -= a0; S.len[c] = b0 - a0 + 1;
-						// what is left has every support >= 3: the extrema only gate the vote rule (a bound will do), the zone is all of it
-						S.smin[c] = 3u; S.lo3[c] = 0; S.hi3[c] = b0 - a0 + 1;
-						if (a0 && M.on) { const int b = M.pm_sh[c] + a0; M.pm_dw[c] = (unsigned short)(M.pm_dw[c] + (b >> 4)); M.pm_sh[c] = (unsigned char)(b & 15); }
-					}
-				}
-				LDS_ORDER();
-			} else {
-				const int off0 = uni(S.off[c]);
-				trim_dev(S, A, c, ms);
-				const int moved = uni(S.off[c]) - off0;            // the trim only moves the slot's start (and length)
-				if (moved && M.on && lane == 0) { const int b = M.pm_sh[c] + moved; M.pm_dw[c] = (unsigned short)(M.pm_dw[c] + (b >> 4)); M.pm_sh[c] = (unsigned char)(b & 15); }
-				recompute_minmax(S, A, c);
-			}
-			IHP_T1(A, 7);
-		}
-		if (S.nreads[c] > 0 && nout == 0) {
-			if (lane == 0) out[0] = (short)c;
-			nout = 1; usedi = i;
-		}
-	}
-	WSYNC();
-	if (nout == 0) {                                               // :272
-		for (int i = lane; i < n; i += 64) S.alive[in[i]] = 0;
-		WSYNC();
-		return 0;
-	}
-	// the candidates in registers for the whole pass (see CombDir); anything outside its preconditions takes the per-call path
-	CombDir D;
-	D.valid = false;
-	if (max_mm == 0 && usedi == 0) comb_dir_build(S, M, in, n, combine_min_overlap, D);
-	D.inout = 1ull;
-	for (int i = 0; i < n; ++i) {                                  // :274-281
-		if (i == usedi) continue;
-		const int c = in[i];
-		const bool dir = D.valid && __builtin_amdgcn_readlane(D.len, i) >= combine_min_overlap;
-		Best b = dir ? best_match_dir(S, A, M, D, i, combine_min_overlap) : best_match_combine_packed(S, A, M, c, out, nout, combine_min_overlap, max_mm);
-		if (b.found) {
-			IHP_T0(A);
-			const int nc = emit_corrections(S, A, c, b.slot, b.off, IHP_ALLOW_DEFAULT);
-			if (nc < 0) return IHP_E_CAPACITY;
-			const int rc = insert_dev(S, A, b.slot, c, b.off, nc);
-			if (rc) return rc;
-			if (lane == 0) S.alive[c] = 0;
-			recompute_minmax(S, A, b.slot);
-			pm_repack(S, A, M, b.slot);
-			if (D.valid) {                                         // the target changed: its lane and the item map again
-				const unsigned long long keep = D.inout;
-				comb_dir_build(S, M, in, n, combine_min_overlap, D);
-				D.inout = keep;
-			}
-			IHP_T1(A, 6);
-		} else if (S.nreads[c] > 0) {
-			if (lane == 0) out[nout] = (short)c;
-			nout++;
-			D.inout |= 1ull << i;
-		} else {
-			if (lane == 0) S.alive[c] = 0;
-		}
-		WSYNC();
-	}
-	return nout;
-}
 
 }  // namespace ihp

@@ -1,0 +1,793 @@
+// asm3_dev.h -- combine (contig.nim:254-281) on what the read phase leaves: 2-bit packed bases and u8 supports, both in LDS.
+//
+// Round 2's k_asm_combine unpacked the hand-over record into a byte arena (LDS), kept the supports in HBM (4 B per base;
+// every trim, merge and min/max update was an HBM round trip in the region's serial chain: 57% of its wave cycles were
+// s_waitcnt) and mirrored the bytes in packed form for the exact scans.  Here the packed bases are the only copy and the
+// supports are one byte per base beside them (a region of at most 255 reads cannot exceed 255 on any base: a base's
+// support is a number of distinct reads), 1.25 B per base as before -- and nothing of a region's chain leaves the CU
+// until the epilogue writes the final contigs.
+//   * exact candidates of a best_match call (16-base seed hits of the target- and query-offset phases) are collected into
+//     lanes and verified TOGETHER: lane <-> (candidate, 16-base chunk), one LDS round trip for all of them instead of one
+//     dependent round trip per seed hit; the winner is the smallest (matches desc, contig asc, phase, offset asc) key;
+//   * pairs for which the vote rule (contig.nim:44-47) can fire are scanned with lanes <-> offsets on the packed bases;
+//     the supports are only looked at where two bases differ;
+//   * corrections live in LDS; insert (contig.nim:156-222) is funnel-shift copies of packed dwords and byte adds.
+// Preconditions (anything else is handed to the byte-based passes, whose results are identical): the region has at most
+// 255 reads, max_mismatch == 0, contigs shorter than 2048 bases, at most 64 contigs, combine_min_overlap >= 17.
+#pragma once
+#include "asm2_dev.h"
+
+namespace ihp {
+
+constexpr int V3_MAXC = 64;
+constexpr int V3_MAXLEN = 2047;           // longest contig: 11 bits in the ranking key
+constexpr int V3_CORR = 256;              // corrections of one merge (LDS)
+constexpr int V3_NOZONE = 0x3fff;
+
+struct V3State {                          // static LDS, one per wave
+	int dw[V3_MAXC];                      // packed slot: first dword in PM
+	int so[V3_MAXC];                      // support slot: first byte in SUP
+	int len[V3_MAXC], cap[V3_MAXC];       // bases; cap = bases both slots have room for from the current start
+	int nreads[V3_MAXC];
+	long long start[V3_MAXC];
+	short lo3[V3_MAXC], hi3[V3_MAXC];     // every base in [lo3, hi3) has support >= 3 and no other has (V3_NOZONE / 0: not one run)
+	short loT[V3_MAXC], hiT[V3_MAXC];     // the same for support >= v3_thr(nreads): the bases no vote can overrule (see v3_slide_votes)
+	unsigned char sh[V3_MAXC];            // bases into dword dw where the contig starts (trim moves it)
+	unsigned char smin[V3_MAXC], smax[V3_MAXC];
+	short listA[V3_MAXC], listB[V3_MAXC];
+	short qt[V3_MAXC], mt[V3_MAXC];       // step at which the contig was the query of pass 1 (0: never), step of its last change (0: none)
+	unsigned corr[V3_CORR];               // qoff | toff << 11 | qbest << 22 (| t's final support at the site << 23 once v3_insert has applied it)
+	long long prof[16];
+	int cnt[16];                          // diagnostics (profile): see ihp_batch_profile [32..47]
+};
+
+struct V3Ctx {
+	uint32_t *PM; uint8_t *SUP;           // SUP first, PM right behind it (one dynamic LDS block)
+	int pm_cap, sup_cap;                  // dwords, bytes
+	int bump_pm, bump_sup;
+	unsigned long long alive;             // contigs (slots of V3State) whose bases and supports are still needed
+	int clock;                            // best_match calls of this region so far, over both passes (see V3State::qt)
+	long long *prof; int *cnt;
+};
+#define V3_CNT(C, k, n) do { if ((C).cnt && lane_id() == 0) (C).cnt[k] += (n); } while (0)
+
+#define V3_T0(C) const long long t0_ = (C).prof ? (long long)clock64() : 0
+#define V3_T1(C, k) do { if ((C).prof && lane_id() == 0) (C).prof[k] += (long long)clock64() - t0_; } while (0)
+
+// 16 bases from base address b (dword index * 16 + base in dword) of PM
+__device__ __forceinline__ unsigned pk16(const uint32_t *PM, int b)
+{
+	const int d = b >> 4;
+	return fsh(PM[d + 1], PM[d], 2u * (unsigned)(b & 15));
+}
+// differing bases of two 16-base words: bit 2k set <-> base k differs
+__device__ __forceinline__ unsigned diff16(unsigned a, unsigned b) { const unsigned x = a ^ b; return (x | (x >> 1)) & 0x55555555u; }
+
+// contig.nim:44-47 overrules a base only if its support s is below 3 AND the contig's reads exceed 3 s: a base with
+// support >= min(3, ceil(nreads / 3)) can never be voted away.
+__device__ __forceinline__ int v3_thr(int nreads) { return nreads >= 7 ? 3 : (nreads + 2) / 3; }
+
+// Running summary of a contig's supports (one value per lane and step): extrema, the ">= 3" run, the ">= thr" run.
+struct SupStats {
+	unsigned mn, mx; int f3, l3, c3, fT, lT, cT, thr;
+	__device__ __forceinline__ void init(int thr_) { mn = 255u; mx = 0; f3 = fT = 0x7fff; l3 = lT = -1; c3 = cT = 0; thr = thr_; }
+	__device__ __forceinline__ void add(unsigned v, int i)
+	{
+		mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+		if (v >= 3u) { f3 = i < f3 ? i : f3; l3 = i; c3++; }
+		if (thr < 3 && (int)v >= thr) { fT = i < fT ? i : fT; lT = i; cT++; }
+	}
+	__device__ __forceinline__ void store(V3State &S, int c)
+	{   // wave-uniform control flow; lane 0 writes
+		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+		f3 = wave_min_i32(f3); l3 = wave_max_i32s(l3); c3 = wave_sum_i(c3);
+		if (thr < 3) { fT = wave_min_i32(fT); lT = wave_max_i32s(lT); cT = wave_sum_i(cT); } else { fT = f3; lT = l3; cT = c3; }
+		if (lane_id() == 0) {
+			S.smin[c] = (unsigned char)mn; S.smax[c] = (unsigned char)mx;
+			const bool clean = l3 >= f3 && c3 == l3 - f3 + 1, cleanT = lT >= fT && cT == lT - fT + 1;
+			S.lo3[c] = (short)(clean ? f3 : V3_NOZONE); S.hi3[c] = (short)(clean ? l3 + 1 : 0);
+			S.loT[c] = (short)(cleanT ? fT : V3_NOZONE); S.hiT[c] = (short)(cleanT ? lT + 1 : 0);
+		}
+		LDS_ORDER();
+	}
+};
+
+__device__ __forceinline__ bool allowed3(unsigned qs, unsigned ts, int qreads, int treads)
+{   // contig.nim:44-47
+	return (qs < 3u && ts > 3u * qs && qreads > 3 * (int)qs) || (ts < 3u && qs > 3u * ts && treads > 3 * (int)ts);
+}
+
+// ------------------------------------------------------------------------------------------------ take-over
+// Support extrema and zones of SUP[so .. so + len), one base per lane.
+__device__ inline void v3_stats(V3State &S, const V3Ctx &C, int c)
+{
+	const int lane = lane_id();
+	const int so = uni(S.so[c]), n = uni(S.len[c]);
+	SupStats st; st.init(v3_thr(uni(S.nreads[c])));
+	for (int i = lane; i < n; i += 64) st.add(C.SUP[so + i], i);
+	st.store(S, c);
+}
+
+// Hand-over record of k_asm_reads -> directory in S, packed bases in PM, supports counted from the read records in SUP.
+// Returns 1 if the read phase did not take the region, 0 when ready, IHP_E_CAPACITY when it does not fit / is not for this path.
+__device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r, int &n_pre)
+{
+	const int lane = lane_id();
+	const uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
+	const int n = uni((int)H[0]), nrr = uni((int)H[1]);
+	n_pre = 0;
+	if (n < 0) return 1;
+	n_pre = n;
+	if (nrr > 255 || n > V3_MAXC) return IHP_E_CAPACITY;
+	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
+	if (lane < n) {
+		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
+		d_poff = (int)a0.x; d_len = (int)a0.y; d_nreads = (int)a0.z; d_slo = (int)a0.w; d_shi = (int)a1.x; d_anchor = (int)a1.y;
+	}
+	const uint32_t *REC = H + V2_HDR + V2_DIRW * n;
+	const int scap = lane < n ? align4(d_len) + SLOT_PAD : 0, pnd = lane < n ? ((d_len + 15) >> 4) + 1 : 0;
+	const unsigned sincl = wave_scan_add((unsigned)scap), pincl = wave_scan_add((unsigned)pnd);
+	const int soff = (int)sincl - scap, stotal = __builtin_amdgcn_readlane((int)sincl, 63);
+	const int poff = (int)pincl - pnd, ptotal = __builtin_amdgcn_readlane((int)pincl, 63);
+	const int maxl = wave_max_i32s(lane < n ? d_len : 0);
+	// the difference array of one contig (4 B per base) sits at the tail of the block while the supports are counted
+	const int scratch_b = (C.sup_cap + 4 * C.pm_cap - 4 * (maxl + 2)) & ~15;
+	if (maxl > V3_MAXLEN || stotal > C.sup_cap || ptotal + 2 > C.pm_cap || stotal > scratch_b) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
+	if (lane < n) {
+		S.dw[lane] = poff; S.so[lane] = soff; S.len[lane] = d_len; S.cap[lane] = align4(d_len); S.nreads[lane] = d_nreads;
+		S.start[lane] = ((long long)d_shi << 32) | (unsigned)d_slo; S.sh[lane] = 0; S.listA[lane] = (short)lane;
+		S.qt[lane] = 0; S.mt[lane] = 0;
+	}
+	C.clock = 0;
+	C.bump_sup = stotal; C.bump_pm = ptotal;
+	C.alive = n >= 64 ? ~0ull : (1ull << n) - 1ull;
+	unsigned rc0 = 0xffffffffu, rc1 = 0xffffffffu, rc2 = 0xffffffffu, rc3 = 0xffffffffu;     // nrr <= 255
+	if (lane < nrr) rc0 = REC[lane];
+	if (64 + lane < nrr) rc1 = REC[64 + lane];
+	if (128 + lane < nrr) rc2 = REC[128 + lane];
+	if (192 + lane < nrr) rc3 = REC[192 + lane];
+	uint32_t *scratch = (uint32_t *)(C.SUP + scratch_b);
+	for (int c = 0; c < n; ++c) {
+		const int len = bcast(d_len, c), so = bcast(soff, c), nr = bcast(d_nreads, c), anchor = bcast(d_anchor, c);
+		if (nr == 1) {                                           // a single read: support 1 everywhere
+			uint32_t *s32 = (uint32_t *)(C.SUP + so);
+			for (int i = lane; 4 * i < len; i += 64) s32[i] = 0x01010101u;
+			if (lane == 0) { S.smin[c] = 1; S.smax[c] = 1; S.lo3[c] = V3_NOZONE; S.hi3[c] = 0; S.loT[c] = 0; S.hiT[c] = (short)len; }
+			continue;
+		}
+		for (int i = lane; i <= len; i += 64) scratch[i] = 0;
+		LDS_ORDER();
+		auto scatter = [&](unsigned rc) {
+			if (rc != 0xffffffffu && (int)(rc & 63u) == c) {
+				const int s = (int)((rc >> 6) & 0x7fffu) - 16384 + anchor, e = s + (int)(rc >> 21);
+				atomicAdd(&scratch[s], 1u);
+				atomicAdd(&scratch[e], 0xffffffffu);
+			}
+		};
+		scatter(rc0); scatter(rc1); scatter(rc2); scatter(rc3);
+		LDS_ORDER();
+		unsigned carry = 0;
+		SupStats st; st.init(v3_thr(nr));
+		for (int i0 = 0; i0 < len; i0 += 64) {
+			const int i = i0 + lane;
+			unsigned v = i < len ? scratch[i] : 0u;
+			v = wave_scan_add(v) + carry;
+			if (i < len) { C.SUP[so + i] = (uint8_t)v; st.add(v, i); }
+			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+		}
+		st.store(S, c);
+	}
+	LDS_ORDER();
+	// the packed bases as they are, one zero pad dword behind every contig (the scratch area overlapped PM: bases last)
+	for (int c = 0; c < n; ++c) {
+		const int len = bcast(d_len, c), po = bcast(poff, c);
+		const uint32_t *src = H + bcast(d_poff, c);
+		for (int d = lane; d <= (len + 15) >> 4; d += 64) C.PM[po + d] = 16 * d < len ? src[d] : 0u;
+	}
+	LDS_ORDER();
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ trim
+// trim(c, min_support) of contig.nim:49-68 on the u8 supports; only the slot's start / length move.
+__device__ inline void v3_trim(V3State &S, const V3Ctx &C, int c, int ms)
+{
+	const int lane = lane_id();
+	const int so = uni(S.so[c]), len = uni(S.len[c]);
+	const uint8_t *sup = C.SUP + so;
+	int a = len - 1 > 0 ? len - 1 : 0;
+	for (int b = 0; b < len - 1; b += 64) {
+		const int i = b + lane;
+		const unsigned long long m = ballot(i < len - 1 && (int)sup[i] >= ms);
+		if (m) { a = b + ctz64(m); break; }
+	}
+	if (a >= len - 1) {                                              // :56-60
+		if (lane == 0) { S.start[c] += a; S.len[c] = 0; S.nreads[c] = 0; }
+		LDS_ORDER();
+		return;
+	}
+	int bb = a;                                                      // :62-64
+	for (int top = len - 1; top > a; top -= 64) {
+		const int i = top - lane;
+		const unsigned long long m = ballot(i > a && (int)sup[i] >= ms);
+		if (m) { bb = top - ctz64(m); break; }
+	}
+	if (lane == 0) {
+		const int b = S.sh[c] + a;
+		S.start[c] += a; S.so[c] = so + a; S.cap[c] -= a; S.len[c] = bb - a + 1;
+		S.dw[c] += b >> 4; S.sh[c] = (unsigned char)(b & 15);
+	}
+	LDS_ORDER();
+}
+
+// ------------------------------------------------------------------------------------------------ best_match
+// The candidates of a pass in registers: lane j <-> contig in[j] (see CombDir in asm2_dev.h; same idea on V3State).
+struct Dir3 {
+	int ts, len, pb, nr, nit, mt; unsigned head, smin, smax, excl; // pb = base address of the contig's first base in PM; mt = V3State::mt
+	int own0, own1, ib0, ib1;                                       // lane g <-> item g / 64 + g: owner lane, dword index of the item
+	int Q, n;
+	unsigned long long inout;
+	bool valid;
+};
+
+__device__ inline void dir3_build(const V3State &S, const V3Ctx &C, const short *in, int n, int min_overlap, Dir3 &D)
+{
+	const int lane = lane_id();
+	n = uni(n);
+	D.n = n; D.ts = 0; D.len = 0; D.pb = 0; D.nr = 0; D.nit = 0; D.mt = 0; D.head = 0; D.smin = 0; D.smax = 0; D.excl = 0;
+	D.own0 = D.own1 = D.ib0 = D.ib1 = 0; D.Q = 0;
+	D.valid = n <= 64 && n > 0 && min_overlap >= 17;
+	if (!D.valid) return;
+	if (lane < n) {
+		// (a contig shorter than 16 bases has a head that runs into its padding: harmless, an overlap with it is shorter than
+		// min_overlap - 1 and is never a candidate)
+		D.ts = in[lane]; D.len = S.len[D.ts]; D.pb = 16 * S.dw[D.ts] + S.sh[D.ts];
+		D.head = pk16(C.PM, D.pb);
+		D.smin = S.smin[D.ts]; D.smax = S.smax[D.ts]; D.nr = S.nreads[D.ts]; D.mt = S.mt[D.ts];
+	}
+	// items of the target-offset scan: the dwords of a contig that hold an offset 0 .. len - min_overlap
+	D.nit = lane < n && D.len >= min_overlap ? (((D.pb & 15) + D.len - min_overlap) >> 4) + 1 : 0;
+	const unsigned incl = wave_scan_add((unsigned)D.nit);
+	D.excl = incl - (unsigned)D.nit;
+	D.Q = __builtin_amdgcn_readlane((int)incl, 63);
+	int own0 = 0, own1 = 0;                                          // items 0 .. 127 are mapped here; any beyond them when they are looked at
+	for (int i = 0; i < n; ++i) {
+		const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
+		if (ni) { own0 = lane >= ex ? i : own0; own1 = 64 + lane >= ex ? i : own1; }
+	}
+	D.own0 = own0; D.own1 = own1;
+	D.ib0 = (__builtin_amdgcn_ds_bpermute(own0 << 2, D.pb) >> 4) + (lane - __builtin_amdgcn_ds_bpermute(own0 << 2, (int)D.excl));
+	D.ib1 = (__builtin_amdgcn_ds_bpermute(own1 << 2, D.pb) >> 4) + (64 + lane - __builtin_amdgcn_ds_bpermute(own1 << 2, (int)D.excl));
+}
+
+// Candidates of one best_match call: lane i <-> candidate i (key, base addresses of the two sides, overlap length).
+struct Cand3 { unsigned key; int xb, yb, cn; int n; };
+__device__ __forceinline__ unsigned cand_key(int cn, int pos, int ph, int o)
+{   // smaller is better: more matches, then the earlier contig, then the target-offset phase, then the smaller offset
+	return ((unsigned)(V3_MAXLEN - cn) << 18) | ((unsigned)pos << 12) | ((unsigned)ph << 11) | (unsigned)o;
+}
+
+// Verify all candidates together and fold the best passing one into `bestkey` (0xffffffff: none yet).
+__device__ inline void cand_flush(const V3Ctx &C, Cand3 &K, unsigned &bestkey)
+{
+	const int lane = lane_id();
+	const int nc = K.n;
+	if (nc == 0) return;
+	K.n = 0;
+	// a candidate that cannot beat the best so far needs no look (keys are unique per (contig, phase, offset))
+	const bool live = lane < nc && K.key < bestkey;
+	const int nch = live ? (K.cn + 15) >> 4 : 0;
+	const unsigned incl = wave_scan_add((unsigned)nch), excl = incl - (unsigned)nch;
+	const int T = __builtin_amdgcn_readlane((int)incl, 63);
+	V3_CNT(C, 1, nc); V3_CNT(C, 2, (T + 63) / 64);
+	bool fail = false;
+	for (int g0 = 0; g0 < T; g0 += 64) {
+		const int g = g0 + lane;
+		int own = 0;
+		for (int i = 0; i < nc; ++i) own = ((unsigned)g >= (unsigned)__builtin_amdgcn_readlane((int)excl, i) && __builtin_amdgcn_readlane(nch, i)) ? i : own;
+		const int ox = __builtin_amdgcn_ds_bpermute(own << 2, K.xb), oy = __builtin_amdgcn_ds_bpermute(own << 2, K.yb);
+		const int ocn = __builtin_amdgcn_ds_bpermute(own << 2, K.cn), oex = __builtin_amdgcn_ds_bpermute(own << 2, (int)excl);
+		bool bad = false;
+		if (g < T) {
+			const int k = g - oex, rem = ocn - 16 * k;
+			unsigned x = pk16(C.PM, ox + 16 * k) ^ pk16(C.PM, oy + 16 * k);
+			if (rem < 16) x &= (1u << (2 * rem)) - 1u;
+			bad = x != 0;
+		}
+		const unsigned long long fm = ballot(bad);
+		// candidate lane: did any of my chunks in this pass fail?
+		const int s0 = (int)excl - g0, e0 = s0 + nch;
+		const int lo = s0 < 0 ? 0 : s0, hi = e0 > 64 ? 64 : e0;
+		if (live && hi > lo) fail |= (fm & lane_range64(lo, hi - 1)) != 0;
+	}
+	const unsigned k = live && !fail ? K.key : 0xffffffffu;
+	const unsigned kmin = wave_min_u32(k);
+	bestkey = kmin < bestkey ? kmin : bestkey;
+}
+
+__device__ __forceinline__ void cand_push(const V3Ctx &C, Cand3 &K, unsigned &bestkey, unsigned key, int xb, int yb, int cn)
+{
+	const bool sel = lane_id() == K.n;
+	K.key = sel ? key : K.key; K.xb = sel ? xb : K.xb; K.yb = sel ? yb : K.yb; K.cn = sel ? cn : K.cn;
+	if (++K.n == 64) cand_flush(C, K, bestkey);
+}
+
+struct Best3 { int found, ma, pos, slot, off; };
+
+// slide_align (contig.nim:70-141) of contig qs on contig ts when the vote rule may fire for the pair, max_mismatch 0:
+// an offset stands iff every differing base is an allowed mismatch; its matches are the equal bases.  Lanes are offsets
+// for the filter: 16 bases where neither contig can be overruled (the [loT, hiT) runs of both) must be equal; an offset
+// without such a window must have allowed mismatches among its first 16 bases.  Every survivor is then checked over its
+// whole overlap by the wave (16 bases per lane; supports are only read where the bases differ).
+// `best` is shared by the targets of one best_match call in list order: strictly more matches win (contig.nim:107, :239).
+__device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, int ts, int pos, int min_overlap, Best3 &best)
+{
+	const int lane = lane_id();
+	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
+	const int qpb = uni(16 * S.dw[qs] + S.sh[qs]), tpb = uni(16 * S.dw[ts] + S.sh[ts]);
+	const int qso = uni(S.so[qs]), tso = uni(S.so[ts]);
+	const int qreads = uni(S.nreads[qs]), treads = uni(S.nreads[ts]);
+	const int qloT = uni((int)S.loT[qs]), qhiT = uni((int)S.hiT[qs]), tloT = uni((int)S.loT[ts]), thiT = uni((int)S.hiT[ts]);
+	const int omax = tlen - min_overlap;                             // :79
+	int omin_abs = qlen - min_overlap;                               // :78, :114
+	if (omin_abs < 0) omin_abs = -omin_abs;
+	const int n1 = omax >= 0 ? omax + 1 : 0;
+	const int total = n1 + omin_abs;
+	V3_CNT(C, 14, (total + 63) / 64);
+	for (int base = 0; base < total; base += 64) {
+		const int idx = base + lane;
+		int qo0 = 0, to0 = 0;
+		if (idx < n1) to0 = idx; else qo0 = idx - n1 + 1;
+		int n = qlen - qo0 < tlen - to0 ? qlen - qo0 : tlen - to0;
+		if (n < 0) n = 0;
+		const int need = best.found && best.ma + 1 > min_overlap - 1 ? best.ma + 1 : min_overlap - 1;   // matches <= n
+		bool surv = idx < total && n >= need;
+		bool loop = false;
+		unsigned m = 0;
+		if (surv) {
+			int klo = qloT - qo0 > tloT - to0 ? qloT - qo0 : tloT - to0;
+			if (klo < 0) klo = 0;
+			int khi = qhiT - qo0 < thiT - to0 ? qhiT - qo0 : thiT - to0;
+			if (khi > n) khi = n;
+			if (khi - klo >= 16) {
+				const int k = klo + ((khi - klo - 16) >> 1);             // the middle of the run both are strong on
+				surv = pk16(C.PM, qpb + qo0 + k) == pk16(C.PM, tpb + to0 + k);
+			} else {
+				m = diff16(pk16(C.PM, qpb + qo0), pk16(C.PM, tpb + to0));
+				if (n < 16) m &= (1u << (2 * n)) - 1u;
+				loop = m != 0;
+			}
+		}
+		if (ballot(loop)) {
+			for (int t = 0; t < 6 && m && surv; ++t) {               // the first differing bases must be allowed ones
+				const int k = __builtin_ctz(m) >> 1;
+				m &= m - 1;
+				surv = allowed3(C.SUP[qso + qo0 + k], C.SUP[tso + to0 + k], qreads, treads);
+			}
+		}
+		unsigned long long mask = ballot(surv);
+		V3_CNT(C, 15, popc64(mask));
+		while (mask) {
+			const int sl = ctz64(mask);
+			mask &= mask - 1;
+			const int cq = bcast(qo0, sl), ct = bcast(to0, sl), cn = bcast(n, sl);
+			if (best.found && cn <= best.ma) continue;               // cannot have more matches than the best so far
+			int mmiss = 0;
+			bool bad = false;
+			for (int k0 = 0; k0 < cn && !bad; k0 += 1024) {
+				const int k = k0 + 16 * lane;
+				unsigned mm = 0;
+				if (k < cn) {
+					mm = diff16(pk16(C.PM, qpb + cq + k), pk16(C.PM, tpb + ct + k));
+					const int rem = cn - k;
+					if (rem < 16) mm &= (1u << (2 * rem)) - 1u;
+				}
+				mmiss += __popc(mm);
+				bool lbad = false;
+				if (ballot(mm != 0)) {
+					while (mm && !lbad) {
+						const int j = __builtin_ctz(mm) >> 1;
+						mm &= mm - 1;
+						lbad = !allowed3(C.SUP[qso + cq + k + j], C.SUP[tso + ct + k + j], qreads, treads);
+					}
+				}
+				bad = ballot(lbad) != 0;
+			}
+			if (bad) continue;
+			const int ma = cn - wave_sum_i(mmiss);
+			if (ma >= min_overlap - 1 && (!best.found || ma > best.ma)) {
+				best.found = 1; best.ma = ma; best.pos = pos; best.slot = ts; best.off = cq ? -cq : ct;
+			}
+		}
+	}
+}
+
+// since > 0 (pass 2, a query that has not changed since it was the query of pass 1 at step `since`): only the contigs that
+// have changed since then are looked at -- against the others slide_align found nothing then and would find nothing now.
+__device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since)
+{
+	const int lane = lane_id();
+	qi = uni(qi);
+	const int qs = __builtin_amdgcn_readlane(D.ts, qi), qlen = __builtin_amdgcn_readlane(D.len, qi);
+	const int qpb = __builtin_amdgcn_readlane(D.pb, qi);
+	const int omin = qlen - min_overlap;                             // contig.nim:78 (>= 0: the caller checked)
+	const unsigned qh = (unsigned)__builtin_amdgcn_readlane((int)D.head, qi);
+	const unsigned qmin = (unsigned)__builtin_amdgcn_readlane((int)D.smin, qi), qmax = (unsigned)__builtin_amdgcn_readlane((int)D.smax, qi);
+	const int qreads = __builtin_amdgcn_readlane(D.nr, qi);
+	const uint32_t *PM = C.PM;
+	Best3 G = {0, 0, -1, -1, 0};                                     // best of the pairs that need the vote scan
+	const bool in = lane_of(D.inout) && D.mt >= since;
+	const unsigned long long inm = ballot(in);
+	if (!inm) return G;
+	const bool votes = in && ((qmin < 3u && D.smax > 3u * qmin && qreads > 3 * (int)qmin) ||
+	                          (D.smin < 3u && qmax > 3u * D.smin && D.nr > 3 * (int)D.smin));
+	const unsigned long long vm = ballot(votes);
+	{
+		V3_T0(C);
+		unsigned long long gm = vm;
+		while (gm) {
+			const int i = ctz64(gm);
+			gm &= gm - 1;
+			v3_slide_votes(S, C, qs, __builtin_amdgcn_readlane(D.ts, i), i, min_overlap, G);
+			V3_CNT(C, 3, 1);
+		}
+		if (vm) V3_T1(C, 4);
+	}
+	V3_T0(C);
+	long long tl_ = t0_;
+#define V3_LAP(k) do { if (C.prof) { const long long t_ = (long long)clock64(); if (lane == 0) C.prof[k] += t_ - tl_; tl_ = t_; } } while (0)
+	const unsigned long long usem = inm & ~vm;
+	Cand3 K; K.key = 0; K.xb = K.yb = K.cn = 0; K.n = 0;
+	unsigned bestkey = 0xffffffffu;
+	V3_CNT(C, 0, 1); V3_CNT(C, 5, (__builtin_amdgcn_readlane((int)D.excl, qi) + 63) / 64); V3_CNT(C, 6, popc64(usem) * (omin / 64 + 1));
+	// ---- offsets 0 .. len(t) - min_overlap on the contigs (:79-111): items = dwords that hold such an offset
+	// (the contigs of `out` all come before the query in the list: only the items below the query's own are looked at)
+	const int qlim = (int)__builtin_amdgcn_readlane((int)D.excl, qi);
+	for (int w = 0; w * 64 < qlim; ++w) {
+		int own = w ? D.own1 : D.own0, ib = w ? D.ib1 : D.ib0;
+		if (w >= 2) {                                                // long contigs: more than 128 items
+			const int g = 64 * w + lane;
+			own = 0;
+			for (int i = 0; i < qi; ++i) {
+				const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
+				if (ni) own = g >= ex ? i : own;
+			}
+			ib = (__builtin_amdgcn_ds_bpermute(own << 2, D.pb) >> 4) + (g - __builtin_amdgcn_ds_bpermute(own << 2, (int)D.excl));
+		}
+		unsigned w0 = 0, w1 = 0;
+		bool any = false;
+		if (!ballot(64 * w + lane < qlim && ((usem >> own) & 1ull))) continue;
+		if (64 * w + lane < qlim && ((usem >> own) & 1ull)) {
+			w0 = PM[ib]; w1 = PM[ib + 1];
+			any = window_any(w0, w1, qh);
+		}
+		unsigned long long hm = ballot(any);
+		while (hm) {
+			const int e = ctz64(hm);
+			hm &= hm - 1;
+			unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
+			const int i = __builtin_amdgcn_readlane(own, e);
+			const int tlen = __builtin_amdgcn_readlane(D.len, i), tpb = __builtin_amdgcn_readlane(D.pb, i);
+			const int ibe = __builtin_amdgcn_readlane(ib, e);
+			while (bits) {
+				const int o = 16 * ibe + __builtin_ctz(bits) - tpb;    // base address of the window minus the contig's first base
+				bits &= bits - 1;
+				if (o < 0 || o > tlen - min_overlap) continue;
+				const int cn = qlen < tlen - o ? qlen : tlen - o;
+				cand_push(C, K, bestkey, cand_key(cn, i, 0, o), qpb, tpb + o, cn);
+			}
+		}
+	}
+	V3_LAP(9);
+	// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
+	for (int ob = 0; ob <= omin; ob += 64) {
+		const int o_l = ob + lane;
+		const bool valid = o_l >= 1 && o_l <= omin;
+		const unsigned wq = valid ? pk16(PM, qpb + o_l) : 0u;
+		const unsigned long long okm = ballot(valid);
+		unsigned long long um = usem;
+		while (um) {
+			const int i = ctz64(um);
+			um &= um - 1;
+			unsigned long long mask = ballot(wq == (unsigned)__builtin_amdgcn_readlane((int)D.head, i)) & okm;
+			if (!mask) continue;                                     // the usual case: the contig does not start inside the query
+			const int tlen = __builtin_amdgcn_readlane(D.len, i), tpb = __builtin_amdgcn_readlane(D.pb, i);
+			while (mask) {
+				const int o = ob + ctz64(mask);
+				mask &= mask - 1;
+				const int cn = qlen - o < tlen ? qlen - o : tlen;
+				if (cn < min_overlap - 1) continue;                  // best_ma starts at min_overlap - 1 (:81, :107)
+				cand_push(C, K, bestkey, cand_key(cn, i, 1, o), qpb + o, tpb, cn);
+			}
+		}
+	}
+	V3_LAP(10);
+	cand_flush(C, K, bestkey);
+	V3_LAP(11);
+#undef V3_LAP
+	V3_T1(C, 5);
+	Best3 B = {0, 0, -1, -1, 0};
+	if (bestkey != 0xffffffffu) {
+		const int o = (int)(bestkey & 2047u), ph = (int)((bestkey >> 11) & 1u), pos = (int)((bestkey >> 12) & 63u);
+		B.found = 1; B.ma = V3_MAXLEN - (int)(bestkey >> 18); B.pos = pos; B.slot = __builtin_amdgcn_readlane(D.ts, pos); B.off = ph ? -o : o;
+	}
+	// more matches, then (no mismatches either way) the earlier contig (contig.nim:32-36, :107, :239)
+	if (G.found && (!B.found || G.ma > B.ma || (G.ma == B.ma && G.pos < B.pos))) return G;
+	return B;
+}
+
+// ------------------------------------------------------------------------------------------------ corrections + insert
+// The allowed mismatches of (q, t, offset) in scan order into S.corr (contig.nim:99, :128).  Returns the count or -1.
+__device__ inline int v3_corrections(V3State &S, const V3Ctx &C, int qs, int ts, int off)
+{
+	const int lane = lane_id();
+	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
+	const int qpb = uni(16 * S.dw[qs] + S.sh[qs]), tpb = uni(16 * S.dw[ts] + S.sh[ts]);
+	const int qso = uni(S.so[qs]), tso = uni(S.so[ts]);
+	const int qo0 = off < 0 ? -off : 0, to0 = off < 0 ? 0 : off;
+	const int n = qlen - qo0 < tlen - to0 ? qlen - qo0 : tlen - to0;
+	int cnt = 0;
+	for (int k0 = 0; k0 < n; k0 += 1024) {
+		const int k = k0 + 16 * lane;
+		unsigned m = 0;
+		if (k < n) {
+			m = diff16(pk16(C.PM, qpb + qo0 + k), pk16(C.PM, tpb + to0 + k));
+			const int rem = n - k;
+			if (rem < 16) m &= (1u << (2 * rem)) - 1u;
+		}
+		if (!ballot(m != 0)) continue;
+		// with max_mismatch 0 every difference of the accepted offset is an allowed one
+		const int mine = __popc(m);
+		const unsigned incl = wave_scan_add((unsigned)mine);
+		int w = cnt + (int)incl - mine;
+		while (m) {
+			const int j = __builtin_ctz(m) >> 1;
+			m &= m - 1;
+			const unsigned a = C.SUP[qso + qo0 + k + j], b = C.SUP[tso + to0 + k + j];
+			if (w < V3_CORR) S.corr[w] = (unsigned)(qo0 + k + j) | ((unsigned)(to0 + k + j) << 11) | ((a > b ? 1u : 0u) << 22);
+			++w;
+		}
+		cnt += __builtin_amdgcn_readlane((int)incl, 63);
+	}
+	LDS_ORDER();
+	return cnt <= V3_CORR ? cnt : -1;
+}
+
+// Close the holes of both areas: the live contigs, in slot order, move down to the start (ascending copies, 64 elements
+// at a time through registers, so a slot may overlap its own old place).
+__device__ inline void v3_compact(V3State &S, V3Ctx &C)
+{
+	const int lane = lane_id();
+	V3_CNT(C, 13, 1);
+	const bool live = lane_of(C.alive);
+	int key = live ? S.so[lane] : 0x7fffffff;
+	int nsup = 0, npm = 0;
+	for (;;) {
+		const int k = wave_min_i32(key);
+		if (k == 0x7fffffff) break;
+		const int c = ctz64(ballot(key == k));
+		key = lane == c ? 0x7fffffff : key;
+		const int so = uni(S.so[c]), dw = uni(S.dw[c]), sh = uni((int)S.sh[c]), len = uni(S.len[c]);
+		const int nd = ((sh + len + 15) >> 4) + 1;                   // dwords incl. the pad
+		if (so != nsup) {
+			for (int i0 = 0; i0 < len; i0 += 64) {
+				const int i = i0 + lane;
+				const unsigned v = i < len ? C.SUP[so + i] : 0u;
+				LDS_ORDER();
+				if (i < len) C.SUP[nsup + i] = (uint8_t)v;
+				LDS_ORDER();
+			}
+		}
+		if (dw != npm) {
+			for (int i0 = 0; i0 < nd; i0 += 64) {
+				const int i = i0 + lane;
+				const unsigned v = i < nd - 1 ? C.PM[dw + i] : 0u;
+				LDS_ORDER();
+				if (i < nd) C.PM[npm + i] = v;
+				LDS_ORDER();
+			}
+		}
+		if (lane == 0) { S.so[c] = nsup; S.dw[c] = npm; S.cap[c] = align4(len); }
+		nsup += align4(len) + SLOT_PAD; npm += nd;
+	}
+	C.bump_sup = nsup; C.bump_pm = npm;
+	LDS_ORDER();
+}
+
+__device__ __forceinline__ bool v3_room(const V3Ctx &C, int ncap)
+{
+	return C.bump_sup + ncap + SLOT_PAD <= C.sup_cap && C.bump_pm + ((ncap + 15) >> 4) + 2 <= C.pm_cap;
+}
+
+__device__ __forceinline__ unsigned pk_base(const uint32_t *PM, int b) { return (PM[b >> 4] >> (2 * (b & 15))) & 3u; }
+
+// insert(t, q, m) of contig.nim:156-222 with the corrections in S.corr[0 .. ncorr).  q is not kept up to date (combine
+// drops it right after: its corrected bases and supports are never looked at again).  Leaves t's support extrema / zone.
+__device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, int ncorr)
+{
+	const int lane = lane_id();
+	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
+	const int aoff = off < 0 ? -off : off;
+	int newlen;
+	if (off < 0) { newlen = aoff + tlen; if (qlen > newlen) newlen = qlen; }
+	else { newlen = tlen; if (off + qlen > newlen) newlen = off + qlen; }
+	if (newlen > V3_MAXLEN) return IHP_E_CAPACITY;
+	const bool reloc = off < 0 || newlen > uni(S.cap[ts]);
+	int ncap = align4(newlen + headroom(newlen));
+	if (reloc && !v3_room(C, ncap)) {
+		v3_compact(S, C);                                            // (before any address of q or t is taken)
+		if (!v3_room(C, ncap)) {
+			ncap = align4(newlen);
+			if (!v3_room(C, ncap)) { V3_CNT(C, 9, 1); return IHP_E_CAPACITY; }
+		}
+	}
+	const int qpb = uni(16 * S.dw[qs] + S.sh[qs]), qso = uni(S.so[qs]);
+	int tpb = uni(16 * S.dw[ts] + S.sh[ts]), tso = uni(S.so[ts]);
+	// ---- corrections (:161-173): the winner's base and support go to the loser; t's value at such a site is final
+	for (int c = lane; c < ncorr; c += 64) {
+		const unsigned cr = S.corr[c];
+		const int qoff = (int)(cr & 2047u), toff = (int)((cr >> 11) & 2047u);
+		const bool qbest = (cr >> 22) & 1u;
+		unsigned val = C.SUP[tso + toff];
+		if (qbest) {
+			const unsigned b = pk_base(C.PM, qpb + qoff);
+			const int tb = tpb + toff;
+			atomicAnd(&C.PM[tb >> 4], ~(3u << (2 * (tb & 15))));
+			atomicOr(&C.PM[tb >> 4], b << (2 * (tb & 15)));
+			val = C.SUP[qso + qoff];
+			C.SUP[tso + toff] = (uint8_t)val;
+		}
+		S.corr[c] = (cr & 0x7fffffu) | (val << 23);                  // the site keeps this support whatever is added below (:198, :217)
+	}
+	LDS_ORDER();
+	int ndw = tpb >> 4, nsh = tpb & 15, nso = tso;
+	if (reloc) {
+		ndw = C.bump_pm; nsh = 0; nso = C.bump_sup;
+		const int nw = (ncap + 15) >> 4;
+		for (int i = lane; i <= nw; i += 64) C.PM[ndw + i] = 0;
+		LDS_ORDER();
+		if (off < 0) {                                               // :180-195
+			copy_bits(C.PM, ndw, 0, qpb >> 4, 2 * (qpb & 15), 2 * aoff);
+			LDS_ORDER();
+			copy_bits(C.PM, ndw, 2 * aoff, tpb >> 4, 2 * (tpb & 15), 2 * tlen);
+			LDS_ORDER();
+			copy_bits(C.PM, ndw, 2 * (aoff + tlen), qpb >> 4, 2 * ((qpb & 15) + aoff + tlen), 2 * (qlen - aoff - tlen));
+		} else {
+			copy_bits(C.PM, ndw, 0, tpb >> 4, 2 * (tpb & 15), 2 * tlen);
+			LDS_ORDER();
+			copy_bits(C.PM, ndw, 2 * tlen, qpb >> 4, 2 * ((qpb & 15) + tlen - off), 2 * (newlen - tlen));   // :220-221
+		}
+		C.bump_pm += nw + 1; C.bump_sup += ncap + SLOT_PAD;
+	} else if (newlen > tlen) {
+		// in place: the new bases behind t's last one; the slot's dwords past the old end may hold anything
+		const int d0 = ndw, b0 = 2 * (nsh + tlen);
+		copy_bits(C.PM, d0, b0, qpb >> 4, 2 * ((qpb & 15) + tlen - off), 2 * (newlen - tlen));
+		LDS_ORDER();
+		// zero the tail of the last dword and the pad dword (windows read one dword past the end)
+		const int endb = nsh + newlen;
+		if (lane == 0) {
+			if (endb & 15) C.PM[d0 + (endb >> 4)] &= (1u << (2 * (endb & 15))) - 1u;
+			C.PM[d0 + ((endb + 15) >> 4)] = 0;
+		}
+	}
+	LDS_ORDER();
+	// ---- supports: new[i] = T(i) + Q(i) (:198-200, :216-219), then the corrected sites get their final value back
+	const int tshift = off < 0 ? aoff : 0, qshift = off < 0 ? 0 : off;
+	const uint8_t *ts_ = C.SUP + tso, *qs_ = C.SUP + qso;
+	uint8_t *ns_ = C.SUP + nso;
+	const int lo = reloc ? 0 : off, hi = reloc ? newlen : (off + qlen < newlen ? off + qlen : newlen);
+	for (int i = lo + lane; i < hi; i += 64) {
+		const int ti = i - tshift, qi = i - qshift;
+		unsigned v = (ti >= 0 && ti < tlen) ? ts_[ti] : 0u;
+		if (qi >= 0 && qi < qlen) v += qs_[qi];
+		ns_[i] = (uint8_t)v;
+	}
+	LDS_ORDER();
+	for (int c = lane; c < ncorr; c += 64) {
+		const unsigned cr = S.corr[c];
+		ns_[off < 0 ? (int)(cr & 2047u) : (int)((cr >> 11) & 2047u)] = (uint8_t)(cr >> 23);   // index in the merged contig (:170-173)
+	}
+	LDS_ORDER();
+	const int nreads_new = uni(S.nreads[ts]) + uni(S.nreads[qs]);  // :203, :222
+	SupStats st; st.init(v3_thr(nreads_new));
+	for (int i = lane; i < newlen; i += 64) st.add(ns_[i], i);
+	if (lane == 0) {
+		S.dw[ts] = ndw; S.sh[ts] = (unsigned char)nsh; S.so[ts] = nso; S.len[ts] = newlen;
+		if (reloc) S.cap[ts] = ncap;
+		S.nreads[ts] = nreads_new;
+		if (off < 0) S.start[ts] = S.start[qs];                      // :204
+	}
+	st.store(S, ts);
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ one pass of combine
+// contig.nim:263-281: `in` -> `out`, returns the new count or < 0.
+__device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, short *out, int min_support, int min_overlap)
+{
+	const int lane = lane_id();
+	int nout = 0, usedi = 0;
+	for (int i = 0; i < n; ++i) {                                    // :265-271
+		const int c = uni((int)in[i]);
+		if (min_support > 0) {
+			V3_T0(C);
+			const int nr = uni(S.nreads[c]);
+			const int ms = nr < min_support ? nr : min_support;
+			const int len0 = uni(S.len[c]), lo3 = uni((int)S.lo3[c]), hi3 = uni((int)S.hi3[c]);
+			const long long start0 = uni(S.start[c]);
+			if ((int)uni((int)S.smin[c]) >= ms && len0 >= 2) {
+				// every support >= ms on two or more bases: trim (contig.nim:49-68) keeps the contig as it is
+			} else if (ms == 3 && hi3 > lo3 && len0 >= 2) {
+				// the supports >= 3 are one run [lo3, hi3): a = lo3 (first i < len - 1), b = hi3 - 1 (last i > a)
+				if (lo3 >= len0 - 1) {                               // :56-60
+					if (lane == 0) { S.start[c] += len0 - 1; S.len[c] = 0; S.nreads[c] = 0; }
+				} else {
+					const int a0 = lo3, b0 = hi3 - 1 > lo3 ? hi3 - 1 : lo3;
+					if (lane == 0) {
+						const int b = S.sh[c] + a0;
+						S.start[c] += a0; S.so[c] += a0; S.cap[c] -= a0; S.len[c] = b0 - a0 + 1;
+						S.dw[c] += b >> 4; S.sh[c] = (unsigned char)(b & 15);
+						S.smin[c] = 3; S.lo3[c] = 0; S.hi3[c] = (short)(b0 - a0 + 1);   // what is left has every support >= 3 (a bound will do for smin)
+						S.loT[c] = 0; S.hiT[c] = (short)(b0 - a0 + 1);
+					}
+				}
+				LDS_ORDER();
+			} else {
+				v3_trim(S, C, c, ms);
+				v3_stats(S, C, c);
+				V3_CNT(C, 7, 1);
+			}
+			if (uni(S.len[c]) != len0 || uni(S.start[c]) != start0) { if (lane == 0) S.mt[c] = (short)(C.clock + 1); LDS_ORDER(); }
+			V3_T1(C, 7);
+		}
+		if (uni(S.nreads[c]) > 0 && nout == 0) {
+			if (lane == 0) out[0] = (short)c;
+			nout = 1; usedi = i;
+		}
+	}
+	LDS_ORDER();
+	if (nout == 0) return 0;                                         // :272
+	Dir3 D;
+	dir3_build(S, C, in, n, min_overlap, D);
+	if (!D.valid) { V3_CNT(C, 11, 1); return IHP_E_CAPACITY; }
+	D.inout = 1ull << usedi;
+	for (int i = 0; i < n; ++i) {                                    // :274-281
+		if (i == usedi) continue;
+		const int c = uni((int)in[i]);
+		Best3 b = {0, 0, -1, -1, 0};
+		C.clock++;
+		int since = 0;
+		if (min_support == 0) { if (lane == 0) S.qt[c] = (short)C.clock; }
+		else { const int qt = uni((int)S.qt[c]); if (qt > 0 && uni((int)S.mt[c]) < qt) since = qt; }
+		{
+			// a query shorter than min_overlap - 1 cannot reach min_overlap - 1 matches at any offset (contig.nim:107); one of
+			// exactly that length can, at a target offset only (omin = -1: the abs() of contig.nim:114 gives one query offset,
+			// whose overlap is one base short)
+			const int ql = __builtin_amdgcn_readlane(D.len, i);
+			if (ql >= min_overlap - 1) b = v3_best_match(S, C, D, i, min_overlap, since);
+		}
+		if (b.found) {
+			V3_T0(C);
+			const int nc = v3_corrections(S, C, c, b.slot, b.off);
+			if (nc < 0) { V3_CNT(C, 10, 1); return IHP_E_CAPACITY; }
+			const int rc = v3_insert(S, C, b.slot, c, b.off, nc);
+			if (rc) return rc;
+			C.alive &= ~(1ull << c);                                 // q is gone (contig.nim:279)
+			if (lane == 0) S.mt[b.slot] = (short)C.clock;
+			LDS_ORDER();
+			V3_CNT(C, 4, 1);
+			const unsigned long long keep = D.inout;
+			dir3_build(S, C, in, n, min_overlap, D);                 // the target changed: its lane and the item map again
+			D.inout = keep;
+			V3_T1(C, 6);
+		} else if (uni(S.nreads[c]) > 0) {
+			if (lane == 0) out[nout] = (short)c;
+			nout++;
+			D.inout |= 1ull << i;
+		} else C.alive &= ~(1ull << c);                              // trimmed to nothing: dropped (:280)
+		LDS_ORDER();
+	}
+	return nout;
+}
+
+}  // namespace ihp

@@ -66,7 +66,6 @@ struct Knobs {
 	int asm_v1 = 0;        // 1: class 1 through the byte-based k_assemble passes only (no packed assembly)
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
-	int pm = 1;            // 0: no packed mirror in k_asm_combine (exact scans on the bytes)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
 	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
 	int profile = 0;       // 1: kernels sum shader-clock cycles per phase (ihp_batch_profile)
@@ -296,7 +295,7 @@ extern "C" int ihp_init(int device)
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
 		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
-		(void)hipFuncSetAttribute((const void *)k_asm_combine<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -340,7 +339,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"pm", &g_knob.pm},
+		{"asm_v1", &g_knob.asm_v1}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -739,9 +738,9 @@ struct ihp_batch {
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
 	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
 	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
-	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_sup, v2_hoff, v2_hand, lpt_seg;
+	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_hoff, v2_hand, lpt_seg;
 	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, v2_arena_b = 0, v2_pm_b = 0, grid_v2 = 0, grid_v2b = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
-	DBuf retry_listc, v2_sup_big, v2_sup_b;
+	DBuf retry_listc;
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
 	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bfork = nullptr, ev_bjoin = nullptr;
@@ -811,8 +810,8 @@ static int alloc_work(ihp_batch *b)
 	AL(lds_sup2, sizeof(uint32_t) * (size_t)b->lds_arena2 * b->grid_asm2);
 	AL(lds_sup3, sizeof(uint32_t) * (size_t)b->lds_arena3 * b->grid_asm3);
 	AL(retry_list, sizeof(int) * (size_t)R);
-	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_sup, sizeof(uint32_t) * (size_t)b->v2_arena * b->grid_v2); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords);
-		AL(retry_listc, sizeof(int) * (size_t)R); AL(lpt_seg, sizeof(int) * (size_t)R * LPT_CLASSES * LPT_TIERS); AL(v2_sup_b, sizeof(uint32_t) * (size_t)b->v2_arena_b * b->grid_v2b); AL(v2_sup_big, sizeof(uint32_t) * (size_t)b->v2_arena_big * b->grid_v2big); }
+	if (b->v2) { AL(retry_list0, sizeof(int) * (size_t)R); AL(v2_hand, sizeof(uint32_t) * (size_t)b->v2_hand_dwords);
+		AL(retry_listc, sizeof(int) * (size_t)R); AL(lpt_seg, sizeof(int) * (size_t)R * LPT_CLASSES * LPT_TIERS); }
 	AL(retry_list2, sizeof(int) * (size_t)R);
 	AL(retry_list3, sizeof(int) * (size_t)R);
 	AL(corr2, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(b->grid_asm2, b->grid_asm3), std::max(b->grid_retry, b->grid_v2b)));
@@ -824,7 +823,7 @@ static int alloc_work(ihp_batch *b)
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
 		AL(fb_cig_tmp, sizeof(uint32_t) * (size_t)b->fb_cig_cap * b->grid_fb);
 	}
-	AL(prof, sizeof(long long) * 32);
+	AL(prof, sizeof(long long) * 64);
 	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
 	AL(ctg_start, 8 * slots); AL(ctg_nreads, 8 * slots); AL(ctg_seq_off, 8 * slots);
 	AL(ctg_len, 4 * slots); AL(aln_flags, 4 * slots); AL(aln_ref_len, 4 * slots); AL(aln_ref_start, 8 * slots);
@@ -844,7 +843,7 @@ static int alloc_work(ihp_batch *b)
 
 static void release_work(ihp_batch *b)
 {
-	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_sup_b, &b->v2_sup_big, &b->v2_sup, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
+	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
 	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
@@ -982,43 +981,43 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 				if (nb * 3 / 10 + 2 * b->stage_cap <= b->lds_arena1) { nb1 = std::max(nb1, nb); nr1 = std::max<long long>(nr1, rro[r + 1] - rro[r]); }
 			}
 			// what a region needs at least ...
-			long long need_arena = (nb1 * 36 / 100 + 512 + 15) / 16 * 16;
 			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
-			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave
-			// combine kernel: RegionStateT<64> + mirror arrays (4 KB static) + byte arena + packed mirror
-			const bool pm_on = g_knob.pm != 0;                            // packed mirror for combine's exact scans
-			const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 16;       // 16: the arena then holds every C2-like region (a region sent to the roomy launch costs a whole serial chain)
-			const long long need_pm = pm_on ? (nb1 / 16 * 4 / 10 + 96 + 3) / 4 * 4 : 0;
-			b->v2_pm = (int)need_pm;
-			need_arena = std::max<long long>(1024, need_arena - 768);       // the usual region needs ~0.25 of its read bases; the rest goes to the roomy launch
-			const int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / (need_arena + 4 * need_pm + 4096)));
+			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave.
+			// Combine kernel (asm3_dev.h): C bases of capacity = C bytes of supports + C / 16 + 96 dwords of packed bases
+			// (1.25 B per base + slot padding) beside ~3.5 KB of static LDS.
+			auto pm_of = [](long long C) { return C / 16 + 96; };
+			auto wave_bytes = [&](long long C) { return C + 4 * pm_of(C) + 3968; };
+			auto cap_for = [&](int occ) { return (long long)(((long long)g.max_lds / occ - 3968 - 384) * 4 / 5) / 16 * 16; };
+			// 16 waves per CU when the launch is long enough to be bound by throughput; a launch of about one round of regions per
+			// wave slot lasts as long as its heaviest regions, and those run faster with fewer waves beside them on their SIMD
+			// (C2, 5 000 regions per launch: 14 waves per CU 5.33 M regions/s, 16: 4.98 M, 12: 5.22 M)
+			const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : (b->n_cls[0] >= 40 * g.cus ? 16 : 14);
+			long long need_C = std::max<long long>(1024, (nb1 * 36 / 100 + 512 + 15) / 16 * 16 - 768);   // the usual region needs ~0.25 of its read bases; the rest goes to the roomier launches
+			const int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes(need_C)));
 			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
-			need_arena = std::max<long long>(need_arena, (g.max_lds / occ_c - 4096 - 4 * need_pm) / 16 * 16);
+			need_C = std::max(need_C, cap_for(occ_c));
 			// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
-			b->v2_arena_big = (int)std::min<long long>(g.max_lds - 32768, std::max<long long>(4 * need_arena, (nb1 + 1024 + 15) / 16 * 16));
-			b->v2_pm_big = (int)std::min<long long>(4096, 4 * need_pm);
-			(void)pm_on;
-			b->grid_v2big = grid_for(R, std::max(1, std::min(2, g.max_lds / (b->v2_arena_big + 4 * b->v2_pm_big + 4096))));
+			b->v2_arena_big = (int)std::min<long long>(cap_for(2), std::max<long long>(4 * need_C, (nb1 + 1024 + 15) / 16 * 16));
+			b->grid_v2big = grid_for(R, std::max(1, std::min<int>(2, (int)(g.max_lds / wave_bytes(b->v2_arena_big)))));
 			// the second tier: regions whose contigs (known when the read phase ends) need more than the first arena -- many
 			// single-read contigs, long reads -- at half the occupancy
 			{
 				const int occ_b = std::max(1, occ_c / 2);
-				b->v2_pm_b = (int)std::min<long long>(4096, 2 * need_pm);
-				b->v2_arena_b = (int)std::max<long long>(need_arena, (g.max_lds / occ_b - 4096 - 4 * b->v2_pm_b) / 16 * 16);
+				b->v2_arena_b = (int)std::max(need_C, cap_for(occ_b));
 				b->grid_v2b = std::min(grid_for(R, occ_b), std::max(1, b->n_cls[0]));
 			}
 			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
-			b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena : (int)need_arena;
+			b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena / 16 * 16 : (int)need_C;
 			b->v2_pdw = g_knob.v2_pdw ? g_knob.v2_pdw : (int)need_pdw;
 			b->v2_pdw = b->v2_pdw / 4 * 4;
-			const int per_wave = b->v2_arena + 4 * b->v2_pm + 4096, per_wave_r = 4 * b->v2_pdw + 256;
-			// every combine launch must fit what hipFuncSetAttribute allows (max_lds - 8192 of dynamic LDS beside ~4 KB static):
+			// every combine launch must fit what hipFuncSetAttribute allows (max_lds - 8192 of dynamic LDS beside the static part):
 			// the second tier and the roomy launch give up arena first, the packed path is switched off only when the first tier does not fit
 			const int dyn_max = g.max_lds - 8192 - 1024;
-			b->v2_pm_b = std::min(b->v2_pm_b, dyn_max / 8 / 4 * 4); b->v2_pm_big = std::min(b->v2_pm_big, dyn_max / 8 / 4 * 4);
-			b->v2_arena_b = std::min(b->v2_arena_b, (dyn_max - 4 * b->v2_pm_b) / 16 * 16);
-			b->v2_arena_big = std::min(b->v2_arena_big, (dyn_max - 4 * b->v2_pm_big) / 16 * 16);
+			while (b->v2_arena_b > 1024 && b->v2_arena_b + 4 * pm_of(b->v2_arena_b) > dyn_max) b->v2_arena_b -= 256;
+			while (b->v2_arena_big > 1024 && b->v2_arena_big + 4 * pm_of(b->v2_arena_big) > dyn_max) b->v2_arena_big -= 256;
+			b->v2_pm = (int)pm_of(b->v2_arena); b->v2_pm_b = (int)pm_of(b->v2_arena_b); b->v2_pm_big = (int)pm_of(b->v2_arena_big);
+			const int per_wave = (int)wave_bytes(b->v2_arena), per_wave_r = 4 * b->v2_pdw + 256;
 			if (b->v2_arena + 4 * b->v2_pm > dyn_max || per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
 			else {
 				b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
@@ -1132,7 +1131,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	const bool profiling = g_knob.profile != 0;
 	if (b->dirty) HIPC(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));     // the previous run ended before its k_summary was enqueued
 	b->dirty = true;
-	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 32, s));
+	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 64, s));
 	int *misc = b->misc.as<int>();
 	unsigned long long *tm = b->timing ? b->times_dev() : nullptr;
 	HIPC(hipEventRecord(b->ev[0], s));
@@ -1209,7 +1208,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			AsmArgs x = a;
 			x.v2_pk = pa.pk; x.v2_trim_lo = pa.trim_lo; x.v2_trim_hi = pa.trim_hi; x.v2_read_bad = pa.read_bad; x.v2_pdw = b->v2_pdw;
 			x.v2_hand = b->v2_hand.as<uint32_t>(); x.v2_hoff = b->v2_hoff.as<long long>();
-			x.arena_seq = nullptr; x.arena_sup = b->v2_sup.as<uint32_t>(); x.arena_cap = b->v2_arena; x.lds_arena = b->v2_arena;
+			x.arena_seq = nullptr; x.arena_sup = nullptr; x.arena_cap = b->v2_arena; x.lds_arena = b->v2_arena;
 			x.in_list = cl; x.n_in = cn; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0; x.work_counter = wq + 10 * WQ_WORDS;
 			x.t_start = nullptr;
 			ReadArgs ra;
@@ -1218,7 +1217,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
 			const bool lpt_on = g_knob.lpt != 0;                   // region order of the combine launch
 			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
-			ra.tier_a_cap = b->v2_arena - 16; ra.n_tier_b = misc + M_NTIERB;     // tier_a_cap = Arena::cap of the first launch
+			ra.tier_a_cap = b->v2_arena; ra.n_tier_b = misc + M_NTIERB;     // tier_a_cap = Arena::cap of the first launch
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
 			hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
@@ -1232,20 +1231,20 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
 				AsmArgs y = x;
 				y.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
-				y.arena_sup = b->v2_sup_b.as<uint32_t>(); y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
+				y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
 				y.work_counter = wq + 13 * WQ_WORDS; y.corr = b->corr2.as<Corr>();
-				hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
 				HIPC(hipEventRecord(b->ev_bjoin, s2));
 			} else HIPC(hipEventRecord(b->ev_bjoin, s));
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
-			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
 			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second tier)
 			// regions whose contigs did not fit that arena: the same kernel with a roomy one (few workgroups per CU)
 			x.in_list = b->retry_listc.as<int>(); x.n_in = misc + M_NRETRYC; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0;
 			x.lpt_cnt = nullptr;
-			x.arena_sup = b->v2_sup_big.as<uint32_t>(); x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
+			x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
 			x.work_counter = wq + 12 * WQ_WORDS;
-			hipLaunchKernelGGL((k_asm_combine<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
+			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
 			HIPC(hipGetLastError());
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = b->retry_list0.as<int>(); a.n_in = misc + M_NRETRY0; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
@@ -1426,13 +1425,13 @@ extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
 
 // Diagnostics (IHP_PROFILE=1): shader-clock cycles summed over waves.
 // [0] assemble total, [1] combine, [2] assemble+output, [3] regions; [8] ksw init, [9] ksw DP, [10] ksw traceback, [11] jobs
-extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[32])
+extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64])
 {
 	if (!b || !out) return IHP_E_ARG;
 	if (!b->ran || !b->work_live) return IHP_E_ARG;           // no run yet, or its scratch went back to the pool (ihp_batch_release_outputs)
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	HIPC(hipStreamSynchronize(b->stream));
-	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
+	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 64, hipMemcpyDeviceToHost));
 	out[24] = b->report[M_NRETRY];                    // regions forwarded at run time to the second pass's overflow list
 	out[25] = b->report[M_NRETRY2];                   // ... to the third pass's
 	out[26] = b->report[M_NRETRY3];                   // ... and to the catch-all (HBM-arena) pass

@@ -48,7 +48,7 @@ struct AsmArgs {
 };
 
 }  // namespace ihp
-#include "asm2_dev.h"
+#include "asm3_dev.h"
 namespace ihp {
 
 // Kernel execution time without a profiler: workgroup 0 is dispatched first, so its entry time is when the launch starts
@@ -407,10 +407,10 @@ __global__ __launch_bounds__(64, MINW) void k_assemble(const AsmArgs a)
 
 
 // Class 1 with the packed read phase (asm2_dev.h), as two kernels so that each runs at the occupancy its own state allows:
-//   k_asm_reads    the read insertions on 2-bit bases: registers + a small packed area in LDS, 32 waves per CU; leaves one
-//                  hand-over record per region in HBM (contig directory, read records, packed bases);
-//   k_asm_combine  takes a record over into the byte representation (bases in the LDS arena, supports counted from the
-//                  records) and runs combine (contig.nim:254-281) and the epilogue on it.
+//   k_asm_reads     the read insertions on 2-bit bases: registers + a small packed area in LDS, 32 waves per CU; leaves one
+//                   hand-over record per region in HBM (contig directory, read records, packed bases);
+//   k_asm_combine3  takes a record over (packed bases as they are, supports counted from the records into one byte per
+//                   base, both in LDS: asm3_dev.h) and runs combine (contig.nim:254-281) and the epilogue on it.
 // A region that does not meet the packed path's preconditions, or runs out of room in either kernel, goes to out_list and
 // is assembled from scratch by the byte-based passes (k_assemble); results never depend on the pass.
 template <int MINW>
@@ -449,24 +449,85 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 	if (a.prof && lane < 16 && s_prof[lane]) atomicAdd((unsigned long long *)&a.prof[lane == 7 ? 27 : lane], (unsigned long long)s_prof[lane]);
 }
 
-template <int MINW>
-__global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
+// Final contigs of one region from the packed representation (asm3_dev.h) -> output slots, alignment jobs; see region_epilogue.
+__device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ctx &C, int r, int err, int n_pre, int &n_final)
 {
-	typedef RegionStateT<64> ST;
-	__shared__ ST S;
+	const int lane = lane_id();
+	if (err) n_final = 0;
+	const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
+	long long mstop = -0x7fffffffffffffffll - 1;                   // max_stop over reads with mapq > 5 (indelope.nim:213-216)
+	for (long long ri = r0 + lane; ri < r1; ri += 64)
+		if (a.mapq[ri] > a.min_mapq_stop && a.read_stop[ri] > mstop) mstop = a.read_stop[ri];
+	mstop = -wave_min_ll(-mstop - 1) - 1;
+	const long long seq_base = r0 < r1 ? a.read_off[r0] : 0;
+	const long long origin = a.ref_origin[r];
+	const long long L = a.ref_off[r + 1] - a.ref_off[r];
+	const int width = (int)((double)(a.K + 1) / 2.0 - 1.0);       // :218
+	long long cursor = 0;
+	for (int k = 0; k < n_final; ++k) {
+		const int c = uni((int)S.listA[k]);
+		const long long slot = r0 + k;
+		const int len = uni(S.len[c]), pb = uni(16 * S.dw[c] + S.sh[c]), so = uni(S.so[c]);
+		uint8_t *oseq = a.out_seq + seq_base + cursor; uint32_t *osup = a.out_sup + seq_base + cursor;
+		for (int i = 4 * lane; i < len; i += 256) {                  // four bases per lane: 2-bit codes -> "ACTG" bytes
+			const int b = pb + i;
+			const unsigned c8 = (fsh(C.PM[(b >> 4) + 1], C.PM[b >> 4], 2u * (unsigned)(b & 15))) & 0xffu;
+			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
+			const unsigned w = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
+			const unsigned sv = ld32u((const uint32_t *)C.SUP, so + i);     // four supports (the slot is padded: reading past len is fine)
+			if (i + 4 <= len) {
+				*(u32_unaligned *)(oseq + i) = w;
+				osup[i] = sv & 0xffu; osup[i + 1] = (sv >> 8) & 0xffu; osup[i + 2] = (sv >> 16) & 0xffu; osup[i + 3] = sv >> 24;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 3; ++j) if (i + j < len) { oseq[i + j] = (uint8_t)(w >> (8 * j)); osup[i + j] = (sv >> (8 * j)) & 0xffu; }
+			}
+		}
+		if (lane == 0) {
+			const long long cstart = S.start[c], cn = S.nreads[c];
+			a.ctg_start[slot] = cstart; a.ctg_nreads[slot] = cn; a.ctg_len[slot] = len;
+			a.ctg_seq_off[slot] = seq_base + cursor;
+			int flags = 0; long long rs = 0; int rl = 0;
+			if (n_pre <= a.max_pre_contigs && cn >= a.min_reads && len >= a.min_ctg_len) {   // :209-211
+				const long long max_stop = cstart > mstop ? cstart : mstop;
+				long long beg = cstart - origin, end = max_stop + width + a.ref_pad - origin;   // :220, faidx clamping
+				int clamped = 0;
+				if (end < beg) { beg = end; clamped = 1; }
+				if (beg < 0) { beg = 0; clamped = 1; } else if (L <= beg) { beg = L - 1; clamped = 1; }
+				if (end < 0) { end = 0; clamped = 1; } else if (L <= end) { end = L - 1; clamped = 1; }
+				long long reflen = L > 0 ? end - beg + 1 : 0;
+				if (L <= 0) { beg = 0; clamped = 1; }
+				flags = IHP_ALN_DONE | (clamped ? IHP_ALN_REF_CLAMPED : 0);
+				rs = origin + beg; rl = (int)reflen;
+				const int j = atomicAdd(a.n_jobs, 1);
+				AlnJob jb;
+				jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
+				jb.out = (int)slot; jb.region = r;
+				a.jobs[j] = jb;
+			}
+			a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
+		}
+		cursor += len;
+	}
+	if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
+}
+
+// combine + epilogue on packed bases and u8 supports (asm3_dev.h).  Dynamic LDS: a.lds_arena bytes of supports, then
+// a.v2_pm_dw dwords of packed bases.  A region outside this path's preconditions, or one that runs out of room, goes to
+// out_list (the next, roomier launch of this kernel, or the byte-based passes).
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
+{
+	__shared__ V3State S;
 	__shared__ int s_item;
-	__shared__ unsigned short s_pm_dw[ST::MAXC + 1];
-	__shared__ unsigned char s_pm_sh[ST::MAXC + 1];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
 	const int lane = lane_id();
-	Arena A;
-	A.sup = a.arena_sup + (size_t)blockIdx.x * a.arena_cap;
-	A.seq = lds_arena; A.cap = a.lds_arena - 16; A.stage_off = a.lds_arena - 16;        // no staging area: reads never enter the byte arena
-	A.corr = a.corr + (size_t)blockIdx.x * a.corr_cap; A.corr_cap = a.corr_cap; A.prof = a.prof ? S.prof : nullptr;
-	PackedMirror M;
-	M.PM = (uint32_t *)(lds_arena + a.lds_arena); M.cap = a.v2_pm_dw; M.bump = 0; M.pm_dw = s_pm_dw; M.pm_sh = s_pm_sh; M.on = false;
+	V3Ctx C;
+	C.SUP = lds_arena; C.sup_cap = a.lds_arena; C.PM = (uint32_t *)(lds_arena + a.lds_arena); C.pm_cap = a.v2_pm_dw;
+	C.bump_pm = C.bump_sup = 0; C.prof = a.prof ? S.prof : nullptr; C.cnt = a.prof ? S.cnt : nullptr;
 	mark_start(a.t_start);
 	if (lane < 16) S.prof[lane] = 0;
+	if (lane < 16) S.cnt[lane] = 0;
 	WSYNC();
 	int lpt[LPT_CLASSES];
 	int n_items = a.in_list ? *a.n_in : a.n_regions;
@@ -490,32 +551,36 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine(const AsmArgs a)
 		} else if (a.in_list) r = a.in_list[r];
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
-		int err = v2_take_over(a, S, A, M, r, n_pre);
+		int err = v3_take_over(a, S, C, r, n_pre);
 		if (err == 1) continue;                                // the read phase did not take this region
 		const long long tcA = a.prof ? (long long)clock64() : 0;
 		if (!err) {
-			const int n2 = combine_pass_packed(S, A, M, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, a.max_mismatch);
+			const int n2 = v3_combine_pass(S, C, S.listA, n_pre, S.listB, 0, a.combine_min_overlap);
 			if (n2 < 0) err = n2;
 			else {
-				WSYNC();
-				const int n3 = combine_pass_packed(S, A, M, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap, a.max_mismatch);
+				const int n3 = v3_combine_pass(S, C, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap);
 				if (n3 < 0) err = n3; else n_final = n3;
 			}
 		}
-		WSYNC();
 		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[1] += (long long)clock64() - tcA; S.prof[3] += 1; }
-		if (err == IHP_E_CAPACITY && a.out_list) {             // no room here: the next, roomier launch (or the byte-based passes) take it
+		if (err == IHP_E_CAPACITY && a.out_list) {             // not here: the next, roomier launch (or the byte-based passes) take it
 			if (lane == 0) a.out_list[atomicAdd(a.n_out, 1)] = r;
-			WSYNC();
 			continue;
 		}
-		region_epilogue(a, S, A, r, err, n_pre, n_final);
-		if (a.prof && lane == 0) S.prof[2] += (long long)clock64() - tcR;
-		WSYNC();
+		region_epilogue3(a, S, C, r, err, n_pre, n_final);
+		if (a.prof && lane == 0) {
+			const long long dt_ = (long long)clock64() - tcR;
+			S.prof[2] += dt_;
+			atomicMax((unsigned long long *)&a.prof[53], (unsigned long long)dt_);     // the longest region of the launch
+			atomicAdd((unsigned long long *)&a.prof[54 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], (unsigned long long)dt_);
+			atomicAdd((unsigned long long *)&a.prof[57 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], 1ull);
+		}
 	}
 	WSYNC();
 	if (a.prof && lane < 16 && lane != 8 && lane != 9 && lane != 10 && lane != 11 && S.prof[lane])
 		atomicAdd((unsigned long long *)&a.prof[lane], (unsigned long long)S.prof[lane]);
+	if (a.prof && lane >= 8 && lane < 12 && S.prof[lane]) atomicAdd((unsigned long long *)&a.prof[40 + lane], (unsigned long long)S.prof[lane]);
+	if (a.prof && lane < 16 && S.cnt[lane]) atomicAdd((unsigned long long *)&a.prof[32 + lane], (unsigned long long)S.cnt[lane]);
 }
 
 // ---------------------------------------------------------------------- ksw2
