@@ -13,7 +13,7 @@
 //     the supports are only looked at where two bases differ;
 //   * corrections live in LDS; insert (contig.nim:156-222) is funnel-shift copies of packed dwords and byte adds.
 // Preconditions (anything else is handed to the byte-based passes, whose results are identical): the region has at most
-// 255 reads, max_mismatch == 0, contigs shorter than 2048 bases, at most 64 contigs, combine_min_overlap >= 17.
+// 256 reads and no base is covered by all 256 of them, max_mismatch == 0, contigs shorter than 2048 bases, at most 64 contigs, combine_min_overlap >= 17.
 #pragma once
 #include "asm2_dev.h"
 
@@ -118,7 +118,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 	n_pre = 0;
 	if (n < 0) return 1;
 	n_pre = n;
-	if (nrr > 255 || n > V3_MAXC) return IHP_E_CAPACITY;
+	if (nrr > 256 || n > V3_MAXC) return IHP_E_CAPACITY;           // (the records of a region are kept in four registers)
 	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
 	if (lane < n) {
 		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
@@ -141,7 +141,8 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 	C.clock = 0;
 	C.bump_sup = stotal; C.bump_pm = ptotal;
 	C.alive = n >= 64 ? ~0ull : (1ull << n) - 1ull;
-	unsigned rc0 = 0xffffffffu, rc1 = 0xffffffffu, rc2 = 0xffffffffu, rc3 = 0xffffffffu;     // nrr <= 255
+	unsigned rc0 = 0xffffffffu, rc1 = 0xffffffffu, rc2 = 0xffffffffu, rc3 = 0xffffffffu;     // nrr <= 256
+	bool over = false;                                               // a support that does not fit its byte
 	if (lane < nrr) rc0 = REC[lane];
 	if (64 + lane < nrr) rc1 = REC[64 + lane];
 	if (128 + lane < nrr) rc2 = REC[128 + lane];
@@ -172,12 +173,13 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 			const int i = i0 + lane;
 			unsigned v = i < len ? scratch[i] : 0u;
 			v = wave_scan_add(v) + carry;
-			if (i < len) { C.SUP[so + i] = (uint8_t)v; st.add(v, i); }
+			if (i < len) { C.SUP[so + i] = (uint8_t)v; st.add(v, i); over |= v > 255u; }
 			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 		}
 		st.store(S, c);
 	}
 	LDS_ORDER();
+	if (ballot(over)) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }  // 256 reads on one base: the byte-based passes (u32 supports) take the region
 	// the packed bases as they are, one zero pad dword behind every contig (the scratch area overlapped PM: bases last)
 	for (int c = 0; c < n; ++c) {
 		const int len = bcast(d_len, c), po = bcast(poff, c);
@@ -676,12 +678,17 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 	const uint8_t *ts_ = C.SUP + tso, *qs_ = C.SUP + qso;
 	uint8_t *ns_ = C.SUP + nso;
 	const int lo = reloc ? 0 : off, hi = reloc ? newlen : (off + qlen < newlen ? off + qlen : newlen);
+	bool over = false;
 	for (int i = lo + lane; i < hi; i += 64) {
 		const int ti = i - tshift, qi = i - qshift;
 		unsigned v = (ti >= 0 && ti < tlen) ? ts_[ti] : 0u;
 		if (qi >= 0 && qi < qlen) v += qs_[qi];
+		over |= v > 255u;
 		ns_[i] = (uint8_t)v;
 	}
+	// (only a region of 256 reads can get here: the sum of two contigs' supports on a base is at most the reads of the region.
+	// A sum at a corrected site is replaced below and would not matter; the region is handed over all the same.)
+	if (ballot(over)) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
 	LDS_ORDER();
 	for (int c = lane; c < ncorr; c += 64) {
 		const unsigned cr = S.corr[c];

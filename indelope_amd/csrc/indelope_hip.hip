@@ -64,6 +64,7 @@ int g_ksw_status = 0;                      // result of the most recent ksw_extz
 // never depend on them (tests/test_gpu_round3.py runs the parity suite's workloads under every path switch).
 struct Knobs {
 	int asm_v1 = 0;        // 1: class 1 through the byte-based k_assemble passes only (no packed assembly)
+	int no_rich = 0;       // 1: read-rich regions (classes 2-4) stay with the byte-based passes
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
@@ -339,7 +340,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -722,7 +723,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 15 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; the last one holds the combine cost-class counters
+enum { WQ_SETS = 16 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch
 enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_WORDS = 24 };
 struct ihp_batch {
 	ihp_params P;
@@ -743,6 +744,9 @@ struct ihp_batch {
 	DBuf retry_listc;
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
+	int n_small = 0, n_rich = 0;                           // class 1 = the regions of the usual size + the read-rich ones the packed path takes (its own k_asm_reads launch)
+	int v2_pdw_rich = 0, grid_v2r_rich = 0;
+	hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr;
 	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bfork = nullptr, ev_bjoin = nullptr;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
@@ -787,6 +791,8 @@ struct ihp_batch {
 		if (ev_join) (void)hipEventDestroy(ev_join);
 		if (ev_bfork) (void)hipEventDestroy(ev_bfork);
 		if (ev_bjoin) (void)hipEventDestroy(ev_bjoin);
+		if (ev_rfork) (void)hipEventDestroy(ev_rfork);
+		if (ev_rjoin) (void)hipEventDestroy(ev_rjoin);
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 	}
 };
@@ -946,24 +952,32 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		// does (live contig bytes stay below ~30% of the read bases): class k runs in pass k's kernel from the start,
 		// on a second stream beside pass 1, instead of waiting for pass 1 to forward it.  Within a class the regions
 		// with the most reads go first (their serial latency is what the launch waits for at the end).
-		std::vector<std::pair<long long, int>> cls[4];
+		// The packed assembly (k_asm_reads + k_asm_combine3) also takes the read-rich regions of classes 2-4 when its
+		// preconditions can hold (exact matching, at most 256 reads): they join class 1 behind the usual ones and get a
+		// k_asm_reads launch of their own with a larger packed area; the byte-based passes keep what is left.
+		std::vector<std::pair<long long, int>> cls[4], rich;
 		const long long lim[3] = {b->lds_arena1, b->lds_arena2, b->lds_arena3};
+		const bool packed_ok = !g_knob.asm_v1 && !g_knob.no_rich && p->max_mismatch == 0 && p->min_overlap_pct > 0 && p->min_overlap_pct <= 1.0;
 		for (int r = 0; r < R; ++r) {
 			const long long nb = ro[rro[r + 1]] - ro[rro[r]];
 			const long long want = nb * 3 / 10 + 2 * b->stage_cap;
 			int k = 0;
 			while (k < 3 && want > lim[k]) ++k;
-			cls[k].push_back({-nb, r});
+			if (k > 0 && packed_ok && rro[r + 1] - rro[r] <= 256 && nb <= 120000) rich.push_back({-nb, r});
+			else cls[k].push_back({-nb, r});
 		}
 		std::vector<int> order;
 		order.reserve((size_t)R);
+		std::sort(rich.begin(), rich.end());
 		for (int k = 0; k < 4; ++k) {
 			std::sort(cls[k].begin(), cls[k].end());
 			b->n_cls[k] = (int)cls[k].size();
 			for (auto &e : cls[k]) order.push_back(e.second);
+			if (k == 0) { for (auto &e : rich) order.push_back(e.second); b->n_small = b->n_cls[0]; b->n_rich = (int)rich.size(); b->n_cls[0] += b->n_rich; }
 		}
+		const int cn_host[6] = {b->n_cls[0], b->n_cls[1], b->n_cls[2], b->n_cls[3], b->n_small, b->n_rich};
 		if ((rc = b->cls_list.upload(order.data(), sizeof(int) * (size_t)R, s))) { delete b; return rc; }
-		if ((rc = b->cls_n.upload(b->n_cls, sizeof(b->n_cls), s))) { delete b; return rc; }
+		if ((rc = b->cls_n.upload(cn_host, sizeof(cn_host), s))) { delete b; return rc; }
 		HIPB(hipStreamSynchronize(s));                         // `order` goes out of scope
 	}
 	b->grid_asm = std::min(b->grid_asm, std::max(1, b->n_cls[0]));
@@ -975,11 +989,13 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 		// staging); the packed area holds the longest read, one record per read and the 2-bit contig slots.
 		b->v2 = !g_knob.asm_v1 && p->max_mismatch == 0 && p->min_overlap_pct > 0 && p->min_overlap_pct <= 1.0 && b->n_cls[0] > 0;
 		if (b->v2) {
-			long long nb1 = 0, nr1 = 0;
+			long long nb1 = 0, nr1 = 0, nbL = 0, nrL = 0;
 			for (int r = 0; r < R; ++r) {
 				const long long nb = ro[rro[r + 1]] - ro[rro[r]];
 				if (nb * 3 / 10 + 2 * b->stage_cap <= b->lds_arena1) { nb1 = std::max(nb1, nb); nr1 = std::max<long long>(nr1, rro[r + 1] - rro[r]); }
+				else if (b->n_rich && rro[r + 1] - rro[r] <= 256 && nb <= 120000) { nbL = std::max(nbL, nb); nrL = std::max<long long>(nrL, rro[r + 1] - rro[r]); }
 			}
+			if (nb1 == 0) { nb1 = std::min<long long>(nbL, 16384); nr1 = std::min<long long>(nrL, 64); }   // no region of the usual size: size the first tier for small ones
 			// what a region needs at least ...
 			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
@@ -1023,6 +1039,16 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 				b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
 				b->grid_v2r = std::min(grid_for(R, std::max(1, std::min(g_knob.asmr_waves ? g_knob.asmr_waves : 32, g.max_lds / per_wave_r))), std::max(1, b->n_cls[0]));
 				b->grid_pack = grid_for((int)std::min<long long>((NR + 3) / 4, 1 << 30), 32);
+				if (b->n_rich) {
+					// the read-rich launch: the same kernel with the packed area its largest region needs (reads + slots of ~0.4
+					// of the read bases + relocations), at the occupancy that leaves
+					long long pdwL = 1 + (b->max_read_len + 15) / 16 + 2 + nrL + nbL / 16 * (b->max_read_len > 200 ? 12 : 7) / 10 + 192 + (b->max_read_len > 200 ? V2_WLX : 0);
+					pdwL = std::min<long long>(pdwL, (g.max_lds - 4096) / 4);
+					const int occL = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * pdwL + 256)));
+					pdwL = std::max<long long>(pdwL, (g.max_lds / occL - 256) / 4);
+					b->v2_pdw_rich = (int)(pdwL / 4 * 4);
+					b->grid_v2r_rich = std::min(grid_for(R, occL), b->n_rich);
+				}
 				// hand-over records between the two kernels: 8 + 9 min(64, reads) + reads + bases / 16 + 8 dwords per region
 				std::vector<long long> hoff((size_t)R + 1, 0);
 				for (int r = 0; r < R; ++r) {
@@ -1110,6 +1136,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	HIPB(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_bfork, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_bjoin, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_rfork, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_rjoin, hipEventDisableTiming));
 	b->report = g_reports.get();
 	if (!b->report) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of the report page failed"); return IHP_E_NOMEM; }
 	HIPB(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // the only memset of the batch's life (see ihp_batch::misc)
@@ -1220,7 +1248,18 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ra.tier_a_cap = b->v2_arena; ra.n_tier_b = misc + M_NTIERB;     // tier_a_cap = Arena::cap of the first launch
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
+			if (b->n_rich) {
+				// the read-rich regions (longest chains) on the second stream beside the usual ones
+				HIPC(hipEventRecord(b->ev_rfork, s));
+				HIPC(hipStreamWaitEvent(s2, b->ev_rfork, 0));
+				ReadArgs rl = ra;
+				rl.in_list = cl + b->n_small; rl.n_in = cn + 5; rl.v2_pdw = b->v2_pdw_rich; rl.work_counter = wq + 15 * WQ_WORDS;
+				hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r_rich), dim3(64), 4 * b->v2_pdw_rich, s2, rl);
+				HIPC(hipEventRecord(b->ev_rjoin, s2));
+				ra.n_in = cn + 4;                                      // the first n_small entries of the class-1 list
+			}
 			hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
+			if (b->n_rich) HIPC(hipStreamWaitEvent(s, b->ev_rjoin, 0));
 			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS; x.v2_pm_dw = b->v2_pm;
 			x.lpt_cnt = ra.lpt_cnt; x.lpt_seg = ra.lpt_seg; x.lpt_stride = ra.lpt_stride;
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
