@@ -140,51 +140,100 @@ def cpu_baseline(batch, K, want_seconds=16.0):
 
 
 # ------------------------------------------------------------------------------------------------------ e2e
-def e2e_rates(api, batch, params, threads=3, reps=4):
-    """Host buffers in -> host buffers out (upload + run + device pack + fetch + host genotype): one batch at a time and
-    sustained with `threads` host threads, each driving batches of its own (every batch has its own stream)."""
+def e2e_rates(api, batch, params, threads=3, reps=5):
+    """Host buffers in -> host buffers out through the C ABI, PCIe included (never `value`).
+    `slab`: what a stager written for this library hands over -- ONE page-locked slab per batch (ihp_slab_layout: 4-bit
+    bases as BAM stores them, trim bounds), uploaded with a single copy; results fetched without the contigs' bases and
+    supports (IHP_FETCH_NO_BASES: events, k-mer counts, CIGARs, alignment records) or in full.  `threads` host threads
+    each drive batches of their own (every batch has its own stream), so upload(k+1), run(k) and fetch(k-1) overlap.
+    `arrays`: the separate pageable ASCII arrays of ihp_batch_in through ihp_run_regions (round 2's leg)."""
     import ctypes as C
     import threading
     from indelope_amd import _abi as A
-    t = {"upload": [], "run": [], "fetch": [], "total": []}
-    for _ in range(reps + 1):
+
+    def one(slab, no_bases):
         t0 = time.perf_counter()
-        h = api.batch_upload(batch, params)
+        h = api.batch_upload_slab(slab, params)
         t1 = time.perf_counter()
         api.batch_run(h)
         api.batch_sync(h)
         t2 = time.perf_counter()
+        api.batch_set_fetch(h, no_bases=no_bases)
         out = A.BatchOut()
         rc = api.b.batch_fetch(h, C.byref(out))              # device pack + one copy + genotype(): the C call alone
         assert rc == 0, rc
         t3 = time.perf_counter()
         api.b.free_out(C.byref(out))
         api.batch_free(h)
-        for k, v in zip(("upload", "run", "fetch", "total"), (t1 - t0, t2 - t1, t3 - t2, t3 - t0)):
-            t[k].append(v * 1e3)
-    med = {k: sorted(v[1:])[len(v[1:]) // 2] for k, v in t.items()}
-    n_each = max(4, reps * 2)
+        return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
 
-    def worker():
+    slabs = [api.make_slab(batch) for _ in range(threads)]
+    try:
+        res = {}
+        for name, nb in (("events_only", True), ("full", False)):
+            t = np.array([one(slabs[0], nb) for _ in range(reps + 1)][1:]) * 1e3
+            med = np.median(t, axis=0)
+            n_each = max(4, reps * 2)
+
+            gate = threading.Barrier(threads + 1)
+
+            def worker(k, nb=nb):
+                one(slabs[k], nb)                                # untimed: this thread's buffers come out of the pools from here on
+                gate.wait()
+                for _ in range(n_each):
+                    one(slabs[k], nb)
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+            for x in th:
+                x.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            for x in th:
+                x.join()
+            dt = time.perf_counter() - t0
+            res[name] = {"one_batch_ms": {k: round(float(v), 3) for k, v in zip(("upload", "run", "fetch", "total"), med)},
+                         "one_batch_regions_per_s": round(batch.n_regions / (med[3] * 1e-3), 1),
+                         "sustained": {"threads": threads, "batches": n_each * threads,
+                                       "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
+                                       "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)}}
+        slab_bytes = int(slabs[0].layout.bytes)
+    finally:
+        for sl in slabs:
+            sl.free()
+    # round 2's leg for comparison: separate pageable arrays, ASCII bases, full results
+    n_each = max(3, reps)
+
+    def worker_arrays_once():
+        out = A.BatchOut()
+        cin = batch.as_c()
+        assert api.b.run_regions(C.byref(params), C.byref(cin), C.byref(out)) == 0
+        api.b.free_out(C.byref(out))
+
+    def worker_arrays():
         for _ in range(n_each):
-            out = A.BatchOut()
-            cin = batch.as_c()
-            assert api.b.run_regions(C.byref(params), C.byref(cin), C.byref(out)) == 0
-            api.b.free_out(C.byref(out))
-    th = [threading.Thread(target=worker) for _ in range(threads)]
-    t0 = time.perf_counter()
+            worker_arrays_once()
+    gate = threading.Barrier(threads + 1)
+
+    def timed_arrays():
+        worker_arrays_once()
+        gate.wait()
+        worker_arrays()
+    th = [threading.Thread(target=timed_arrays) for _ in range(threads)]
     for x in th:
         x.start()
+    gate.wait()
+    t0 = time.perf_counter()
     for x in th:
         x.join()
     dt = time.perf_counter() - t0
-    return {"one_batch_ms": {k: round(v, 3) for k, v in med.items()},
-            "one_batch_regions_per_s": round(batch.n_regions / (med["total"] * 1e-3), 1),
-            "sustained": {"threads": threads, "batches": n_each * threads, "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
-                          "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)},
-            "inputs": "pageable host arrays, trim bounds" if batch.trim_lo is not None else "pageable host arrays, qualities",
-            "note": "upload + run + pack + fetch + genotype through the C ABI (ihp_batch_upload/run/fetch, ihp_run_regions); "
-                    "PCIe-inclusive, never `value`"}
+    ev = res["events_only"]
+    return {"one_batch_ms": ev["one_batch_ms"], "one_batch_regions_per_s": ev["one_batch_regions_per_s"], "sustained": ev["sustained"],
+            "inputs": "one page-locked slab per batch (%d bytes: 4-bit bases, trim bounds), a single upload copy; results without contig "
+                      "bases/supports (IHP_FETCH_NO_BASES)" % slab_bytes,
+            "full_results": res["full"],
+            "pageable_arrays": {"threads": threads, "batches": n_each * threads, "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
+                                "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1),
+                                "inputs": "ihp_run_regions on separate pageable arrays, ASCII bases, full results"},
+            "note": "upload + run + device pack + fetch + genotype through the C ABI; PCIe-inclusive, never `value`"}
 
 
 # ------------------------------------------------------------------------------------------ other configs

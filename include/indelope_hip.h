@@ -226,6 +226,26 @@ typedef struct {
 	const int32_t *trim_lo, *trim_hi; /* [n_reads]                               */
 } ihp_batch_in;
 
+/*
+ * The same batch as ONE caller-filled slab -- what a stager that wants the copy engines to itself hands over: allocate
+ * `bytes` with ihp_host_alloc (page-locked), fill the sections at the byte offsets below, and ihp_batch_upload_slab sends
+ * the whole slab with a single asynchronous copy.  The read bases are 4 bits each, exactly as a BAM record stores them
+ * (Record.sequence decodes these, src/indelope.nim:166): read i starts at byte (read_off[i] >> 1) + i of `bases4`, first
+ * base in the high nibble, codes "=ACMGRSVTWYHKDBN" -- a memcpy of bam_get_seq(), half the bytes of the
+ * ASCII form.  The device writes the ASCII bases it needs itself.  The read trim (indelope.nim:23-38) comes as bounds
+ * (trim_lo / trim_hi, as in ihp_batch_in); base qualities are not part of a slab.
+ */
+typedef struct {
+	int64_t region_read_off, read_off, read_start, read_stop, ref_off, ref_origin;   /* int64 sections, as in ihp_batch_in */
+	int64_t trim_lo, trim_hi;                                                        /* int32 [n_reads]                    */
+	int64_t mapq, read_skip;                                                         /* uint8 [n_reads]; read_skip only with IHP_SLAB_HAS_SKIP */
+	int64_t ref_bases;                                                               /* ASCII                              */
+	int64_t bases4;                                                                  /* (n_bases >> 1) + n_reads bytes      */
+	int64_t bytes;                                                                   /* size of the slab                   */
+} ihp_slab_layout;
+#define IHP_SLAB_HAS_SKIP 1
+int  ihp_slab_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, ihp_slab_layout *out);
+
 /* event status: why the tally did or did not run for an alignment event.      */
 #define IHP_EV_TALLIED     0
 #define IHP_EV_SHORT       1   /* tloc.len < min_event_len     indelope.nim:234 */
@@ -399,6 +419,15 @@ int  ihp_batch_run(ihp_batch *b);                     /* async on the batch stre
 int  ihp_batch_sync(ihp_batch *b);                    /* waits; IHP_E_CAPACITY if a device pool overflowed in the run */
 int  ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out);
 void ihp_batch_free(ihp_batch *b);
+/* ihp_batch_upload for a slab (see ihp_slab_layout).  The copy is asynchronous on the batch's stream: the slab must stay
+ * untouched until the first ihp_batch_sync / fetch of the batch has returned.                                         */
+int  ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab,
+                           const ihp_slab_layout *layout, int32_t flags, ihp_batch **out);
+/* What ihp_batch_fetch / ihp_batch_pack_dev bring back.  IHP_FETCH_NO_BASES: everything but the contigs' bases and
+ * supports (n_bases = 0; ctg_seq_off still holds the lengths) -- events, k-mer counts, CIGARs, alignment records and the
+ * contig directory, a tenth of the bytes; a later fetch with flags 0 brings the bases of the same run.               */
+#define IHP_FETCH_NO_BASES 1
+int  ihp_batch_set_fetch(ihp_batch *b, int32_t flags);
 /* Hand the batch's scratch and result buffers back to the device pool; its inputs and the per-region summary
  * records (ihp_batch_summary_dev) stay.  For callers that walk through more regions than one GPU holds results for
  * (C4 on fewer than 8 GPUs): every chunk's inputs stay resident, one chunk's results at a time.  The next

@@ -51,6 +51,21 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_upload(C.byref(p), C.byref(cin), C.byref(h)), "batch_upload")
         return h
 
+    def make_slab(self, batch):
+        """The batch as one page-locked slab (ihp_slab_layout; 4-bit bases as BAM holds them, trim bounds): what a stager
+        fills instead of the separate arrays of ihp_batch_in.  Returns a Slab; free it with slab.free()."""
+        return Slab(self, batch)
+
+    def batch_upload_slab(self, slab, params=None):
+        p = params if params is not None else self.params()
+        h = C.c_void_p()
+        self._chk_hip(self.b.batch_upload_slab(C.byref(p), slab.n_regions, slab.n_reads, slab.ptr, C.byref(slab.layout), slab.flags,
+                                               C.byref(h)), "batch_upload_slab")
+        return h
+
+    def batch_set_fetch(self, h, no_bases=False):
+        self._chk_hip(self.b.batch_set_fetch(h, _abi.IHP_FETCH_NO_BASES if no_bases else 0), "batch_set_fetch")
+
     def batch_run(self, h):
         self._chk_hip(self.b.batch_run(h), "batch_run")
 
@@ -141,6 +156,49 @@ class HipApi(Api):
 
     def batch_free(self, h):
         self.b.batch_free(h)
+
+
+class Slab:
+    """A RegionBatch laid out in one ihp_host_alloc'ed slab (see include/indelope_hip.h, ihp_slab_layout)."""
+
+    def __init__(self, api_, batch):
+        import numpy as np
+        from . import synth
+        b = batch if batch.trim_lo is not None else batch.with_trim_bounds()
+        self.api, self.n_regions, self.n_reads = api_, b.n_regions, b.n_reads
+        self.layout = _abi.SlabLayout()
+        api_._chk_hip(api_.b.slab_layout_for(b.n_regions, b.n_reads, len(b.bases), len(b.ref_bases), C.byref(self.layout)), "slab_layout_for")
+        self.ptr = api_.b.host_alloc(self.layout.bytes)
+        if not self.ptr:
+            raise MemoryError("ihp_host_alloc(%d)" % self.layout.bytes)
+        mem = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), (self.layout.bytes,))
+        L = self.layout
+
+        def put(off, a, dt):
+            a = np.ascontiguousarray(a, dt).view(np.uint8).reshape(-1)
+            mem[off:off + len(a)] = a
+        put(L.region_read_off, b.region_read_off, np.int64); put(L.read_off, b.read_off, np.int64)
+        put(L.read_start, b.read_start, np.int64); put(L.read_stop, b.read_stop, np.int64)
+        put(L.ref_off, b.ref_off, np.int64); put(L.ref_origin, b.ref_origin, np.int64)
+        put(L.trim_lo, b.trim_lo, np.int32); put(L.trim_hi, b.trim_hi, np.int32)
+        put(L.mapq, b.mapq, np.uint8); put(L.ref_bases, b.ref_bases, np.uint8)
+        self.flags = 0
+        if b.read_skip is not None:
+            put(L.read_skip, b.read_skip, np.uint8)
+            self.flags |= _abi.IHP_SLAB_HAS_SKIP
+        lib = synth._lib()
+        lib.ihp_synth_pack4.argtypes = [_abi.u8p, _abi.i64p, C.c_int64, C.c_void_p]
+        ro = np.ascontiguousarray(b.read_off, np.int64)
+        bases = np.ascontiguousarray(b.bases if len(b.bases) else np.zeros(1, np.uint8), np.uint8)
+        rc = lib.ihp_synth_pack4(_abi.ptr(bases, _abi.u8p), _abi.ptr(ro, _abi.i64p), b.n_reads, self.ptr + L.bases4)
+        if rc != 0:
+            self.free()
+            raise ValueError("a base that BAM's 4-bit alphabet (=ACMGRSVTWYHKDBN) cannot hold")
+
+    def free(self):
+        if self.ptr:
+            self.api.b.host_free(self.ptr)
+            self.ptr = None
 
 
 def api():

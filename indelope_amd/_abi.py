@@ -93,6 +93,14 @@ class BatchIn(C.Structure):
                 ("trim_lo", i32p), ("trim_hi", i32p)]
 
 
+class SlabLayout(C.Structure):        # ihp_slab_layout
+    _fields_ = [(n, C.c_int64) for n in ("region_read_off", "read_off", "read_start", "read_stop", "ref_off", "ref_origin",
+                                          "trim_lo", "trim_hi", "mapq", "read_skip", "ref_bases", "bases4", "bytes")]
+
+
+IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES = 1, 1
+
+
 class Event(C.Structure):
     _fields_ = [("tstart", C.c_int64), ("tstop", C.c_int64), ("qstart", C.c_int64), ("qstop", C.c_int64),
                 ("len", C.c_uint32), ("type", C.c_uint8), ("status", C.c_uint8),
@@ -204,6 +212,10 @@ _PRODUCT_ONLY = {
     "host_free": (None, [C.c_void_p]),
     "copy_to_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "batch_upload": (C.c_int, [C.POINTER(Params), C.POINTER(BatchIn), C.POINTER(C.c_void_p)]),
+    "slab_layout_for": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(SlabLayout)]),
+    "batch_upload_slab": (C.c_int, [C.POINTER(Params), C.c_int32, C.c_int64, C.c_void_p, C.POINTER(SlabLayout), C.c_int32,
+                                    C.POINTER(C.c_void_p)]),
+    "batch_set_fetch": (C.c_int, [C.c_void_p, C.c_int32]),
     "batch_run": (C.c_int, [C.c_void_p]),
     "batch_sync": (C.c_int, [C.c_void_p]),
     "batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(BatchOut)]),

@@ -38,6 +38,8 @@ struct PrepackArgs {
 	long long n_reads;
 	const long long *read_off;
 	const uint8_t *bases, *quals;             // quals may be null
+	const uint8_t *bases4;                    // or null: the bases 4 bits each as BAM stores them (read i from byte (read_off[i] >> 1) + i, first base in
+	uint8_t *bases_w;                         //   the high nibble); their ASCII form ("=ACMGRSVTWYHKDBN") is then written to bases_w (= bases)
 	const int *trim_lo_in, *trim_hi_in;       // the stager's trim bounds, or null
 	int trim_min_qual;
 	uint32_t *pk;                             // read i at dword (read_off[i] >> 4) + i, ceil(len / 16) dwords, tail bits zero
@@ -103,11 +105,29 @@ __global__ __launch_bounds__(64) void k_prepack(const PrepackArgs a)
 		const long long pkb = (off >> 4) + ri;
 		const int nd = (len + 15) >> 4;
 		for (int d = sub; d < nd; d += 16) {
-			const uint8_t *p = a.bases + off + 16 * d;
 			unsigned w[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) w[k] = *(const u32_unaligned_t *)(p + 4 * k);
 			const int rem = len - 16 * d;                        // valid bases in this dword (>= 1)
+			if (a.bases4) {
+				const uint8_t *q = a.bases4 + (off >> 1) + ri + 8 * d;
+				const unsigned n0 = *(const u32_unaligned_t *)q, n1 = *(const u32_unaligned_t *)(q + 4);
+				uint8_t *o = a.bases_w + off + 16 * d;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const unsigned x = ((k < 2 ? n0 : n1) >> (16 * (k & 1))) & 0xffffu;          // two bytes = four bases
+					const unsigned sel = ((x >> 4) & 0xfu) | ((x & 0xfu) << 8) | (((x >> 12) & 0xfu) << 16) | (((x >> 8) & 0xfu) << 24);
+					const unsigned lo8 = __builtin_amdgcn_perm(0x56535247u, 0x4d43413du, sel & 0x07070707u);   // "=ACM" "GRSV"
+					const unsigned hi8 = __builtin_amdgcn_perm(0x4e42444bu, 0x48595754u, sel & 0x07070707u);   // "TWYH" "KDBN"
+					const unsigned m = ((sel >> 3) & 0x01010101u) * 0xffu;
+					w[k] = (lo8 & ~m) | (hi8 & m);
+					const int v = rem - 4 * k;
+					if (v >= 4) *(u32_unaligned_t *)(o + 4 * k) = w[k];
+					else for (int j = 0; j < v; ++j) o[4 * k + j] = (uint8_t)(w[k] >> (8 * j));
+				}
+			} else {
+				const uint8_t *p = a.bases + off + 16 * d;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) w[k] = *(const u32_unaligned_t *)(p + 4 * k);
+			}
 			unsigned out = 0, df = 0;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {

@@ -174,6 +174,8 @@ ReportPool g_reports;
 // device buffer; returned to the pool on scope exit / batch free
 struct DBuf {
 	void *p = nullptr; size_t n = 0, cap = 0;
+	bool view_ = false;                                      // part of another buffer (the batch's input slab): not given back on its own
+	void view(void *base, size_t off, size_t bytes) { release(); p = (char *)base + off; n = bytes; cap = 0; view_ = true; }
 	int alloc(size_t bytes) {
 		release();
 		n = bytes;
@@ -189,7 +191,7 @@ struct DBuf {
 	}
 	int zero(hipStream_t s) { if (n) HIPC(hipMemsetAsync(p, 0, n, s)); return 0; }
 	template <class T> T *as() const { return (T *)p; }
-	void release() { if (p) g_pool.put(p, cap); p = nullptr; n = cap = 0; }
+	void release() { if (p && !view_) g_pool.put(p, cap); p = nullptr; n = cap = 0; view_ = false; }
 	~DBuf() { release(); }
 	DBuf() = default;
 	DBuf(const DBuf &) = delete;
@@ -733,7 +735,9 @@ struct ihp_batch {
 	// inputs
 	DBuf region_read_off, read_off, bases, quals, read_start, read_stop, mapq, read_skip, ref_off, ref_bases, ref_origin;
 	DBuf trim_lo, trim_hi;
-	bool has_quals = false, has_skip = false, has_trim = false;
+	DBuf in_slab, bases4;                                  // ihp_batch_upload_slab: every input in one device buffer; BAM 4-bit bases (k_prepack writes the ASCII ones)
+	bool has_quals = false, has_skip = false, has_trim = false, has_b4 = false;
+	int fetch_flags = 0;                                   // IHP_FETCH_*
 	// scratch
 	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
@@ -858,14 +862,56 @@ static void release_work(ihp_batch *b)
 	b->work_live = false;
 }
 
+static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout);
+
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
+{
+	if (!in || (in->n_reads > 0 && !in->bases)) return IHP_E_ARG;
+	return batch_upload_common(p, in, nullptr, nullptr, bout);
+}
+
+// Section offsets (bytes, 64-byte aligned) of the one-slab batch input; see include/indelope_hip.h.
+extern "C" int ihp_slab_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, ihp_slab_layout *L)
+{
+	if (!L || n_regions < 0 || n_reads < 0 || n_bases < 0 || n_ref < 0) return IHP_E_ARG;
+	int64_t o = 0;
+	auto sec = [&](int64_t bytes) { const int64_t at = o; o += (bytes + 63) / 64 * 64; return at; };
+	L->region_read_off = sec(8 * ((int64_t)n_regions + 1)); L->read_off = sec(8 * (n_reads + 1));
+	L->read_start = sec(8 * n_reads); L->read_stop = sec(8 * n_reads);
+	L->ref_off = sec(8 * ((int64_t)n_regions + 1)); L->ref_origin = sec(8 * (int64_t)n_regions);
+	L->trim_lo = sec(4 * n_reads); L->trim_hi = sec(4 * n_reads);
+	L->mapq = sec(n_reads); L->read_skip = sec(n_reads);
+	L->ref_bases = sec(n_ref + 64);
+	L->bases4 = sec((n_bases >> 1) + n_reads + 64);
+	L->bytes = o;
+	return 0;
+}
+
+extern "C" int ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab, const ihp_slab_layout *L,
+                                     int32_t flags, ihp_batch **bout)
+{
+	if (!slab || !L || n_regions < 0 || n_reads < 0) return IHP_E_ARG;
+	const char *h = (const char *)slab;
+	ihp_batch_in in;
+	memset(&in, 0, sizeof(in));
+	in.n_regions = n_regions; in.n_reads = n_reads;
+	in.region_read_off = (const int64_t *)(h + L->region_read_off); in.read_off = (const int64_t *)(h + L->read_off);
+	in.read_start = (const int64_t *)(h + L->read_start); in.read_stop = (const int64_t *)(h + L->read_stop);
+	in.mapq = (const uint8_t *)(h + L->mapq); in.read_skip = (flags & IHP_SLAB_HAS_SKIP) ? (const uint8_t *)(h + L->read_skip) : nullptr;
+	in.ref_off = (const int64_t *)(h + L->ref_off); in.ref_bases = (const uint8_t *)(h + L->ref_bases);
+	in.ref_origin = (const int64_t *)(h + L->ref_origin);
+	in.trim_lo = (const int32_t *)(h + L->trim_lo); in.trim_hi = (const int32_t *)(h + L->trim_hi);
+	return batch_upload_common(p, &in, slab, L, bout);
+}
+
+static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout)
 {
 	if (!p || !in || !bout || p->struct_size != (int32_t)sizeof(ihp_params)) return IHP_E_ARG;
 	if (p->K < 1 || p->K > 31 || in->n_regions < 0 || in->n_reads < 0) return IHP_E_ARG;
 	if (!ksw_flags_supported(p->ksw_flag)) return IHP_E_UNSUPPORTED;
 	if (p->fallback && !ksw_flags_supported(p->fb_flag)) return IHP_E_UNSUPPORTED;
 	if (in->n_regions && (!in->region_read_off || !in->ref_off || !in->ref_origin)) return IHP_E_ARG;
-	if (in->n_reads && (!in->read_off || !in->bases || !in->read_start || !in->read_stop || !in->mapq)) return IHP_E_ARG;
+	if (in->n_reads && (!in->read_off || (!in->bases && !slab) || !in->read_start || !in->read_stop || !in->mapq)) return IHP_E_ARG;
 	int rc = ensure_init();
 	if (rc) return rc;
 	ihp_batch *b = new (std::nothrow) ihp_batch();
@@ -896,11 +942,27 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	if (!b->stream || !b->stream2) { delete b; snprintf(g.err, sizeof(g.err), "hipStreamCreate failed"); return IHP_E_HIP; }
 	hipStream_t s = b->stream;
 #define UP(buf, ptr, bytes) do { if ((rc = b->buf.upload(ptr, (size_t)(bytes), s))) { delete b; return rc; } } while (0)
+	b->has_trim = in->trim_lo != nullptr && in->trim_hi != nullptr;     // trim() done by the stager: qualities not needed
+	b->has_quals = in->quals != nullptr && !b->has_trim; b->has_skip = in->read_skip != nullptr;
+	if (slab) {
+		// one copy for everything (the caller filled a page-locked slab: ihp_host_alloc); the read bases come 4 bits each as
+		// BAM stores them, k_prepack writes the ASCII ones the byte-based kernels read
+		if ((rc = b->in_slab.alloc((size_t)SL->bytes + 64))) { delete b; return rc; }
+		HIPB(hipMemcpyAsync(b->in_slab.p, slab, (size_t)SL->bytes, hipMemcpyHostToDevice, s));
+		void *d = b->in_slab.p;
+		b->region_read_off.view(d, SL->region_read_off, sizeof(int64_t) * (R + 1)); b->read_off.view(d, SL->read_off, sizeof(int64_t) * (NR + 1));
+		b->read_start.view(d, SL->read_start, sizeof(int64_t) * NR); b->read_stop.view(d, SL->read_stop, sizeof(int64_t) * NR);
+		b->mapq.view(d, SL->mapq, NR); if (b->has_skip) b->read_skip.view(d, SL->read_skip, NR);
+		b->ref_off.view(d, SL->ref_off, sizeof(int64_t) * (R + 1)); b->ref_bases.view(d, SL->ref_bases, b->n_ref);
+		b->ref_origin.view(d, SL->ref_origin, sizeof(int64_t) * R);
+		b->trim_lo.view(d, SL->trim_lo, sizeof(int32_t) * NR); b->trim_hi.view(d, SL->trim_hi, sizeof(int32_t) * NR);
+		b->bases4.view(d, SL->bases4, (size_t)(b->n_bases >> 1) + NR);
+		b->has_b4 = true;
+		if ((rc = b->bases.alloc(b->n_bases))) { delete b; return rc; }
+	} else {
 	UP(region_read_off, rro, sizeof(int64_t) * (R + 1));
 	UP(read_off, ro, sizeof(int64_t) * (NR + 1));
 	UP(bases, in->bases, b->n_bases);
-	b->has_trim = in->trim_lo != nullptr && in->trim_hi != nullptr;     // trim() done by the stager: qualities not needed
-	b->has_quals = in->quals != nullptr && !b->has_trim; b->has_skip = in->read_skip != nullptr;
 	if (b->has_quals) UP(quals, in->quals, b->n_bases);
 	if (b->has_trim) { UP(trim_lo, in->trim_lo, sizeof(int32_t) * NR); UP(trim_hi, in->trim_hi, sizeof(int32_t) * NR); }
 	UP(read_start, in->read_start, sizeof(int64_t) * NR);
@@ -910,6 +972,7 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	UP(ref_off, fo, sizeof(int64_t) * (R + 1));
 	UP(ref_bases, in->ref_bases, b->n_ref);
 	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
+	}
 #undef UP
 	// scratch sizing
 	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
@@ -1126,7 +1189,8 @@ extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp
 	if ((rc = b->misc.alloc(b->z_bytes())) || (rc = b->summary.alloc(sizeof(ihp_region_summary) * (size_t)R))) { delete b; return rc; }
 	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
 	if (g_limits[2] > 0) b->hit_cap = std::min(b->hit_cap, std::max(g_limits[2], 2 * HIT_SLOTS * NR));   // the fixed slots stay; the bump region shrinks
-	if (b->v2) {
+	if (b->v2 || b->has_b4) {
+		b->grid_pack = grid_for((int)std::min<long long>((NR + 3) / 4, 1 << 30), 32);
 		if ((rc = b->v2_pk.alloc(sizeof(uint32_t) * (size_t)((b->n_bases >> 4) + NR + 4))) || (rc = b->v2_trim_lo.alloc(sizeof(int) * (size_t)NR)) ||
 		    (rc = b->v2_trim_hi.alloc(sizeof(int) * (size_t)NR)) || (rc = b->v2_read_bad.alloc((size_t)NR))) { delete b; return rc; }
 	}
@@ -1214,6 +1278,22 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			x.in_list = in; x.n_in = n_in; x.out_list = nullptr; x.n_out = nullptr; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
 			hipLaunchKernelGGL((k_assemble<1024, false, 1>), dim3(grid), dim3(64), 0, st, x);
 		};
+		// k_prepack first: the 2-bit reads, the kept ranges and the "not ACGT" flags of every read (and, for a batch that came
+		// with 4-bit bases, the ASCII bases every other kernel reads)
+		const bool prepacked = (n1 && b->v2) || b->has_b4;
+		PrepackArgs pa;
+		memset(&pa, 0, sizeof(pa));
+		if (prepacked) {
+			pa.n_reads = b->n_reads; pa.read_off = b->read_off.as<long long>(); pa.bases = b->bases.as<uint8_t>();
+			pa.bases4 = b->has_b4 ? b->bases4.as<uint8_t>() : nullptr; pa.bases_w = b->bases.as<uint8_t>();
+			pa.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr;
+			pa.trim_lo_in = b->has_trim ? b->trim_lo.as<int>() : nullptr; pa.trim_hi_in = b->has_trim ? b->trim_hi.as<int>() : nullptr;
+			pa.trim_min_qual = p.trim_min_qual; pa.pk = b->v2_pk.as<uint32_t>(); pa.trim_lo = b->v2_trim_lo.as<int>();
+			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
+			pa.t_start = tm;                                       // the first launch of the stage
+			hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			HIPC(hipGetLastError());
+		}
 		if (side) {
 			HIPC(hipEventRecord(b->ev_fork, s));                   // the counters are cleared
 			HIPC(hipStreamWaitEvent(s2, b->ev_fork, 0));
@@ -1225,14 +1305,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		}
 		if (n1 && b->v2) {
 			// class 1 through the packed read phase; what it cannot take goes to the byte-based class-1 kernel behind it
-			PrepackArgs pa;
-			pa.n_reads = b->n_reads; pa.read_off = b->read_off.as<long long>(); pa.bases = b->bases.as<uint8_t>();
-			pa.quals = b->has_quals ? b->quals.as<uint8_t>() : nullptr;
-			pa.trim_lo_in = b->has_trim ? b->trim_lo.as<int>() : nullptr; pa.trim_hi_in = b->has_trim ? b->trim_hi.as<int>() : nullptr;
-			pa.trim_min_qual = p.trim_min_qual; pa.pk = b->v2_pk.as<uint32_t>(); pa.trim_lo = b->v2_trim_lo.as<int>();
-			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
-			pa.t_start = tm;                                       // the first launch of the stage
-			hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			AsmArgs x = a;
 			x.v2_pk = pa.pk; x.v2_trim_lo = pa.trim_lo; x.v2_trim_hi = pa.trim_hi; x.v2_read_bad = pa.read_bad; x.v2_pdw = b->v2_pdw;
 			x.v2_hand = b->v2_hand.as<uint32_t>(); x.v2_hoff = b->v2_hoff.as<long long>();
@@ -1292,7 +1364,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		} else if (n1) {
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = cl; a.n_in = cn; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
-			a.t_start = tm;                                        // the first launch of the stage
+			a.t_start = prepacked ? nullptr : tm;                  // the first launch of the stage
 			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_asm), dim3(64), b->lds_arena1, s, a);
 			HIPC(hipGetLastError());
 		}
@@ -1332,7 +1404,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>();
 		a.bases = b->bases.as<uint8_t>(); a.mapq = b->mapq.as<uint8_t>();
 		{
-			const bool have = b->v2 && b->n_cls[0] > 0 && g_knob.tally_pk;    // k_prepack ran in this chain
+			const bool have = ((b->v2 && b->n_cls[0] > 0) || b->has_b4) && g_knob.tally_pk;    // k_prepack ran in this chain
 			a.pk = have ? b->v2_pk.as<uint32_t>() : nullptr; a.read_bad = have ? b->v2_read_bad.as<uint8_t>() : nullptr;
 		}
 		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();
@@ -1527,6 +1599,13 @@ extern "C" int ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int
 
 extern "C" void ihp_batch_free(ihp_batch *b) { delete b; }
 
+extern "C" int ihp_batch_set_fetch(ihp_batch *b, int32_t flags)
+{
+	if (!b || (flags & ~IHP_FETCH_NO_BASES)) return IHP_E_ARG;
+	b->fetch_flags = flags;
+	return 0;
+}
+
 // Hands the batch's scratch and result buffers back to the device pool (its inputs and per-region summary records stay):
 // a caller that walks through more regions than one GPU holds results for keeps every chunk's inputs resident and only
 // one chunk's results at a time.  The results are gone (fetch / pack need another run); the next run takes buffers again.
@@ -1667,7 +1746,9 @@ extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, 
 	for (int k = 0; k < 5; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
 	HIPC(hipStreamSynchronize(s));
 	if (R > 0) { const int rc = report_overflow(b); if (rc) return rc; }
-	const long long C = tot[0], B = tot[1], W = tot[2], E = tot[3], Hn = tot[4];
+	// IHP_FETCH_NO_BASES: the contigs' bases and supports stay on the device (ctg_seq_off still tells the lengths)
+	const bool no_bases = (b->fetch_flags & IHP_FETCH_NO_BASES) != 0;
+	const long long C = tot[0], B = no_bases ? 0 : tot[1], W = tot[2], E = tot[3], Hn = tot[4];
 	const OutLayout L(R, C, B, W, E, Hn);
 	if (b->pack_slab.n < L.bytes) {
 		int rc = b->pack_slab.alloc(L.bytes + L.bytes / 8);
@@ -1688,7 +1769,8 @@ extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, 
 	a.o_hit_off = (int64_t *)(dev + L.hit_off); a.o_ref_hit = (int32_t *)(dev + L.ref_hit); a.o_alt_hit = (int32_t *)(dev + L.alt_hit);
 	a.o_status = (int32_t *)(dev + L.status); a.o_n_pre = (int32_t *)(dev + L.n_pre); a.o_contig_off = (int64_t *)(dev + L.contig_off);
 	a.o_ctg_start = (int64_t *)(dev + L.ctg_start); a.o_ctg_nreads = (int64_t *)(dev + L.ctg_nreads);
-	a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off); a.o_seq = (uint8_t *)(dev + L.ctg_seq); a.o_sup = (uint32_t *)(dev + L.ctg_support);
+	a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off);
+	a.o_seq = no_bases ? nullptr : (uint8_t *)(dev + L.ctg_seq); a.o_sup = no_bases ? nullptr : (uint32_t *)(dev + L.ctg_support);
 	a.o_aln_flags = (int32_t *)(dev + L.aln_flags); a.o_aln_ref_start = (int64_t *)(dev + L.aln_ref_start);
 	a.o_aln_ref_len = (int32_t *)(dev + L.aln_ref_len); a.o_ez = (ihp_ez *)(dev + L.aln_ez);
 	a.o_cigar_off = (int64_t *)(dev + L.cigar_off); a.o_cigar = (uint32_t *)(dev + L.cigar);

@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_pack(const PackArgs a)
 			const int len = a.ctg_len[sl], flags = a.aln_flags[sl];
 			const bool done = (flags & IHP_ALN_DONE) != 0;
 			const long long so = a.ctg_seq_off[sl];
-			for (int i = lane; i < len; i += 64) { a.o_seq[bb + i] = a.out_seq[so + i]; a.o_sup[bb + i] = a.out_sup[so + i]; }
+			if (a.o_seq) for (int i = lane; i < len; i += 64) { a.o_seq[bb + i] = a.out_seq[so + i]; a.o_sup[bb + i] = a.out_sup[so + i]; }
 			KswOut z;
 			z.max = z.zdropped = z.max_q = z.max_t = z.mqe = z.mqe_t = z.mte = z.mte_q = z.score = z.n_cigar = 0;
 			if (done) z = a.ez[sl];

@@ -193,4 +193,26 @@ int ihp_synth_fill(const ihp_synth_cfg *c, int64_t *region_read_off, int64_t *re
 	return 0;
 }
 
+// The read bases 4 bits each the way a BAM record holds them (what a stager memcpy's out of bam_get_seq): read i from byte
+// (read_off[i] >> 1) + i of `out`, first base in the high nibble, codes "=ACMGRSVTWYHKDBN".  Returns -1 if a base has no code.
+int ihp_synth_pack4(const uint8_t *bases, const int64_t *read_off, int64_t n_reads, uint8_t *out)
+{
+	static const char codes[] = "=ACMGRSVTWYHKDBN";
+	int8_t lut[256];
+	for (int i = 0; i < 256; ++i) lut[i] = -1;
+	for (int i = 0; i < 16; ++i) lut[(unsigned char)codes[i]] = (int8_t)i;
+	int bad = 0;
+	for (int64_t i = 0; i < n_reads; ++i) {
+		const uint8_t *s = bases + read_off[i];
+		const int64_t len = read_off[i + 1] - read_off[i];
+		uint8_t *o = out + (read_off[i] >> 1) + i;
+		for (int64_t j = 0; j < len; j += 2) {
+			const int a = lut[s[j]], b = j + 1 < len ? lut[s[j + 1]] : 0;
+			if (a < 0 || b < 0) bad = 1;
+			o[j >> 1] = (uint8_t)(((a & 15) << 4) | (b & 15));
+		}
+	}
+	return bad ? -1 : 0;
+}
+
 }  // extern "C"

@@ -162,3 +162,36 @@ def test_rccl_branch_on_one_gpu_strong():
     g = out["gather_check"]
     assert g["backend"] == "nccl" and g["records"] == 40000
     assert out["oracle_check"]["identical"] and out["scaling"] == "strong"
+
+
+def test_slab_upload_with_4bit_bases_gives_the_same_results(hip, shaped, oracle):
+    """ihp_batch_upload_slab (one page-locked slab, BAM 4-bit bases, trim bounds) against the separate ASCII arrays of
+    ihp_batch_in and against the oracle; IUPAC codes other than ACGT travel too (a read that holds one leaves the packed path)."""
+    for name, K, b, exp in shaped:
+        if name == "mixed":
+            bases = b.bases.copy()
+            bases[(bases >= 97) & (bases <= 122)] -= 32                  # BAM has no lower case
+            b = type(b)(b.region_read_off, b.read_off, bases, b.quals, b.read_start, b.read_stop, b.mapq, b.read_skip,
+                        b.ref_off, b.ref_bases, b.ref_origin)
+            exp = oracle.run_regions_mt(b, oracle.params(K=K), 16)
+        bt = b.with_trim_bounds()
+        slab = hip.make_slab(bt)
+        try:
+            h = hip.batch_upload_slab(slab, hip.params(K=K))
+            try:
+                hip.batch_run(h)
+                hip.batch_sync(h)
+                got = hip.batch_fetch(h)
+                hip.batch_set_fetch(h, no_bases=True)
+                lean = hip.batch_fetch(h)
+            finally:
+                hip.batch_free(h)
+        finally:
+            slab.free()
+        assert_same(got, exp)
+        # the lean fetch: everything but the contigs' bases and supports
+        assert len(lean.ctg_seq) == 0 and len(lean.ctg_support) == 0
+        for f in ("status", "n_contigs_pre", "contig_off", "ctg_start", "ctg_nreads", "ctg_seq_off", "aln_flags", "aln_ref_start",
+                  "aln_ref_len", "aln_ez", "cigar_off", "cigar", "event_off", "hit_off", "ref_hit", "alt_hit"):
+            assert np.array_equal(getattr(lean, f), getattr(got, f)), f
+        assert np.array_equal(lean.events, got.events)
