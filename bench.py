@@ -36,8 +36,21 @@ ISSUE_PEAK = 1.0               # wave64 instructions per cycle per CU and per un
                                # the scalar unit serves one SIMD per cycle, so a CU retires at most 1 VALU + 1 SALU per cycle (rocprofv3's
                                # VALUBusy / SALUBusy definitions; tools/ubench_issue.hip reaches 0.93 / 0.96 by wall clock)
 KERNELS = ["k_assemble", "k_ksw", "k_tally"]
-PMC_FILE = os.path.join("profiles", "r02_c2_pmc.json")
-MIX_FILE = os.path.join("profiles", "r02_c2_pmc_mix.json")
+PMC_FILE = os.path.join("profiles", "r03_c2_pmc.json")
+MIX_FILE = os.path.join("profiles", "r03_c2_pmc_mix.json")
+
+
+def src_sha16():
+    """Hash of the library's sources: the committed PMC passes carry it, so that a bench line can say whether the counters it
+    quotes were taken from the code it just ran."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "indelope_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hip", ".cpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 class _DevArray:
@@ -560,25 +573,33 @@ def main():
         same = args.config == "C2" and R == 10_000 and S == 2 and not strong
         # the launches a stage consists of (the assembly stage is the packed read phase, the combine phase and the byte-based
         # passes behind them; the empty ones count too)
-        members = {"k_assemble": ("k_prepack", "k_asm_reads", "k_asm_combine", "k_assemble"), "k_ksw": ("k_ksw",), "k_tally": ("k_tally",)}[KERNELS[dom]]
+        members = {"k_assemble": ("k_prepack", "k_asm_reads", "k_asm_combine3", "k_assemble"), "k_ksw": ("k_ksw",), "k_tally": ("k_tally",)}[KERNELS[dom]]
         base = lambda n: n.split("<")[0].split("::")[-1].strip()
+        sha = src_sha16()
+        stale = None
         if same and os.path.exists(pmc):
-            k = json.load(open(pmc))["kernels"]
+            pj = json.load(open(pmc))
+            k = pj["kernels"]
+            stale = pj.get("src_sha16") != sha
             t = [v["traffic"] * v.get("launches_per_stage", 1) for n, v in k.items() if base(n) in members and v.get("traffic")]
             if t:
-                traffic, traffic_source = int(sum(t)), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload; sum over the stage's launches)"
+                traffic, traffic_source = int(sum(t)), PMC_FILE + (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload; "
+                                                                   "2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; sum over the stage's launches; "
+                                                                   + ("TAKEN FROM ANOTHER BUILD of the library (src_sha16 differs): stale)" if stale else "same sources as this run)"))
         if same and os.path.exists(mix):
             try:
                 k = json.load(open(mix))
                 va = sa = vb = sb = cyc = 0.0
                 for n, v in k.items():
+                    if not isinstance(v, dict):
+                        continue
                     if base(n) in members and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
                         # GRBM_GUI_ACTIVE is summed over the 8 XCDs: CU-cycles of a launch = (GUI / 8) x 256 CUs.  The SQ_ACTIVE_INST_*
                         # / SQ_INST_CYCLES_* counters are in quad-cycles per SIMD, i.e. in CU-cycles once summed over a CU's 4 SIMDs
                         va += float(v["SQ_INSTS_VALU"]); sa += float(v.get("SQ_INSTS_SALU", 0)); cyc += float(v["GRBM_GUI_ACTIVE"]) * 32
                         vb += float(v.get("SQ_ACTIVE_INST_VALU", 0)); sb += float(v.get("SQ_INST_CYCLES_SALU", 0))
                 if cyc:
-                    issue = {"valu_per_cycle_per_cu": round(va / cyc, 3), "salu_per_cycle_per_cu": round(sa / cyc, 3),
+                    issue = {"stale": json.load(open(mix)).get("_src_sha16") != sha, "valu_per_cycle_per_cu": round(va / cyc, 3), "salu_per_cycle_per_cu": round(sa / cyc, 3),
                              "valu_busy": round(vb / cyc, 3), "salu_busy": round(sb / cyc, 3),
                              "issue_frac": round(max(va, sa) / cyc / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
                              "source": MIX_FILE + " (SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_ACTIVE_INST_VALU, SQ_INST_CYCLES_SALU over GRBM_GUI_ACTIVE/8 x 256 "
@@ -607,6 +628,7 @@ def main():
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_stale": stale,
                          "algorithmic_bytes_per_launch": int(by_kernel[KERNELS[dom]]),
                          "algorithmic_bytes_per_region": round(by_kernel[KERNELS[dom]] * len(keep) / max(n_kept, 1), 1),
                          "launches_per_step": S,
@@ -615,6 +637,7 @@ def main():
                          "whole_path": {"algorithmic_bytes_per_step": int(alg_bytes * world),
                                         "achieved": round(alg_bytes * world / (dt / args.steps) / 1e9, 2),
                                         "frac": round(alg_bytes * world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}},
+            "build": {"src_sha16": sha},
             "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),
                         "tallied": int((res.events["status"] == 0).sum()),
                         "fallback_events": int((res.events["aligned"] == 1).sum()), "regions_inspected": n_kept},

@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 5 --warmup 2 --no-cpu --no-e2e --no-check"
+ARGS="--steps 5 --warmup 2 --no-cpu --no-e2e --no-check --no-other"
 stats() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py "$@" > $OUT/$name.log 2>&1; f=$(find $OUT/$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv; }
 stats c2 $ARGS
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
@@ -18,7 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py
 python3 tools/pmc_sum.py $OUT/fetch $OUT/write --json $OUT/pmc_raw.json > $OUT/pmc_raw.txt 2>&1
 bash tools/pmc_mix.sh > /dev/null 2>&1
 cp gpurun_out/pmc_mix/mix.json $OUT/c2_pmc_mix.json
-STEADY="--no-cpu --no-e2e --no-check --regions 100000 --steps 3 --warmup 1 --sub-batches 1"
+STEADY="--no-cpu --no-e2e --no-check --no-other --regions 100000 --steps 3 --warmup 1 --sub-batches 1"
 stats steady100k $STEADY
 bash tools/pmc_mix.sh --regions 100000 --sub-batches 1 > /dev/null 2>&1
 cp gpurun_out/pmc_mix/mix.json $OUT/steady100k_pmc_mix.json
@@ -28,27 +28,39 @@ stats c5 --config C5 --steps 5 --warmup 2 --no-cpu --no-e2e --no-check
 : > $OUT/other_workloads.jsonl
 python3 bench.py --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --config C5 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
-python3 bench.py --no-cpu --no-e2e --no-check --quals >> $OUT/other_workloads.jsonl 2>> $OUT/err
-python3 bench.py --no-cpu --no-e2e --no-check --dup-frac 0.1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
-python3 bench.py --no-cpu --no-e2e --no-check --sub-batches 1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
-python3 bench.py --knob asm_v1=1 --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --no-other --quals >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --no-other --dup-frac 0.1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --no-other --sub-batches 1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --knob asm_v1=1 --no-cpu --no-e2e --no-check --no-other >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --config C3 --knob no_rich=1 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --scaling strong --config C4 --regions 1250000 --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/c4_strong_1gpu.json 2>> $OUT/err
 timeout 120 tools/ubench_issue.bin > $OUT/ubench_issue.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --no-cpu --no-e2e --no-other --no-check --profile --sub-batches 1 > $OUT/c2_phase_cycles.json 2>> $OUT/err
+python3 bench.py --config C5 --no-cpu --no-e2e --no-other --no-check --profile --sub-batches 1 > $OUT/c5_phase_cycles.json 2>> $OUT/err
 python3 - <<'PY'
-import json
+import json, sys
+sys.path.insert(0, ".")
+import bench
+sha = bench.src_sha16()
+for f in ("gpurun_out/prof/c2_pmc_mix.json", "gpurun_out/prof/steady100k_pmc_mix.json"):
+    try:
+        m = json.load(open(f)); m["_src_sha16"] = sha; json.dump(m, open(f, "w"), indent=1)
+    except Exception as e:
+        print("mix", f, e)
 raw = json.load(open("gpurun_out/prof/pmc_raw.json"))
 out = {"workload": "C2 (10000 regions x 64 x 150bp), bench.py --steps 5 --warmup 2 (two sub-batches of 5000 regions per step)",
-       "unit": "bytes per launch",
-       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = counter(KB) * 1024; "
-               "FETCH_SIZE is uncalibrated for narrow accesses on gfx950 (MI355X_MICROARCH.md: reads exactly 1/2 for wide "
-               "coalesced streams) so fetch may be under-counted by up to 2x",
+       "unit": "bytes per launch", "src_sha16": sha,
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = counter(KB) * 1024; traffic = "
+               "2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read "
+               "(MI355X_MICROARCH.md, HBM section: double it); narrower accesses and WRITE_SIZE are uncalibrated, so the corrected "
+               "figure is an upper bound for the byte-wise kernels; `traffic_raw` = FETCH_SIZE + WRITE_SIZE as counted",
        "kernels": {}}
 for k, v in raw.items():
     f, w = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
     if f is None or w is None:
         continue
-    out["kernels"][k] = {"FETCH_SIZE": int(f * 1024), "WRITE_SIZE": int(w * 1024), "traffic": int((f + w) * 1024),
+    out["kernels"][k] = {"FETCH_SIZE": int(f * 1024), "WRITE_SIZE": int(w * 1024), "traffic": int((2 * f + w) * 1024), "traffic_raw": int((f + w) * 1024),
                          "launches_averaged": v.get("_launches")}
     if k.startswith("k_asm_combine"):
         out["kernels"][k]["launches_per_stage"] = 3      # first tier, second tier and the roomy launch (the average is over all three)

@@ -26,6 +26,7 @@ __global__ void k_bench(Res *out, int iters, int *sink)
 	const int lane = threadIdx.x & 63;
 	int v0 = lane, v1 = lane + 1, v2 = lane + 2, v3 = lane + 3, v4 = lane + 4, v5 = lane + 5, v6 = lane + 6, v7 = lane + 7;
 	int s0 = 1, s1 = 2, s2 = 3, s3 = 4, s4 = 5, s5 = 6, s6 = 7, s7 = 8;
+	double d0 = lane, d1 = lane + 1, d2 = lane + 2, d3 = lane + 3;          // 64-bit register pairs for v_pk_fma_f32
 	for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = (i * 4 + 64) & 16383;   // pointer chase table (byte offsets)
 	__syncthreads();
 	const long long t0 = clock64();
@@ -78,6 +79,164 @@ __global__ void k_bench(Res *out, int iters, int *sink)
 			asm volatile(REP8("v_perm_b32 %0, %0, %1, %8\n v_perm_b32 %1, %1, %2, %8\n v_perm_b32 %2, %2, %3, %8\n v_perm_b32 %3, %3, %4, %8\n"
 			                  "v_perm_b32 %4, %4, %5, %8\n v_perm_b32 %5, %5, %6, %8\n v_perm_b32 %6, %6, %7, %8\n v_perm_b32 %7, %7, %0, %8\n")
 			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(0x03020100 + s0));
+		} else if (KIND == 14) {  // control: 64 v_fma_f32 (8 chains)
+			asm volatile(REP8("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
+			                  "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+		} else if (KIND == 15) {  // control: 64 v_pk_fma_f32 on register pairs (4 chains of 64-bit operands)
+			asm volatile(REP8("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3\n"
+			                  "v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3\n")
+			             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+		} else if (KIND == 16) {  // the ops of this library's inner loops: v_alignbit_b32, v_xor_b32, v_min3_u32, v_cndmask (8 chains)
+			asm volatile(REP8("v_alignbit_b32 %0, %1, %0, 7\n v_xor_b32 %1, %1, %2\n v_min3_u32 %2, %2, %3, %4\n v_cndmask_b32 %3, %3, %4, vcc\n"
+			                  "v_alignbit_b32 %4, %5, %4, 9\n v_xor_b32 %5, %5, %6\n v_min3_u32 %6, %6, %7, %0\n v_cndmask_b32 %7, %7, %0, vcc\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) :: "vcc");
+		} else if (KIND == 17) {  // 64 v_mov_b32 (8 chains)
+			asm volatile(REP8("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+			                  "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+		} else if (KIND == 18) {  // v_xor_b32 with two DIFFERENT vector sources (8 chains)
+			asm volatile(REP8("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %4\n"
+			                  "v_xor_b32 %4, %4, %5\n v_xor_b32 %5, %5, %6\n v_xor_b32 %6, %6, %7\n v_xor_b32 %7, %7, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+		} else if (KIND == 19) {  // control: v_fma_f32 with three DIFFERENT vector sources (8 chains)
+			asm volatile(REP8("v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %1, %2, %3, %4\n v_fma_f32 %2, %3, %4, %5\n v_fma_f32 %3, %4, %5, %6\n"
+			                  "v_fma_f32 %4, %5, %6, %7\n v_fma_f32 %5, %6, %7, %0\n v_fma_f32 %6, %7, %0, %1\n v_fma_f32 %7, %0, %1, %2\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+		} else if (KIND == 20) {  // v_xor_b32 with ONE vector source and an inline constant (8 chains)
+			asm volatile(REP8("v_xor_b32 %0, 5, %0\n v_xor_b32 %1, 5, %1\n v_xor_b32 %2, 5, %2\n v_xor_b32 %3, 5, %3\n"
+			                  "v_xor_b32 %4, 5, %4\n v_xor_b32 %5, 5, %5\n v_xor_b32 %6, 5, %6\n v_xor_b32 %7, 5, %7\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+		} else if (KIND == 21) {
+			asm volatile(REP8("v_alignbit_b32 %0, %1, %0, 7\n"
+			                  "v_alignbit_b32 %1, %2, %1, 7\n"
+			                  "v_alignbit_b32 %2, %3, %2, 7\n"
+			                  "v_alignbit_b32 %3, %4, %3, 7\n"
+			                  "v_alignbit_b32 %4, %5, %4, 7\n"
+			                  "v_alignbit_b32 %5, %6, %5, 7\n"
+			                  "v_alignbit_b32 %6, %7, %6, 7\n"
+			                  "v_alignbit_b32 %7, %0, %7, 7\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 22) {
+			asm volatile(REP8("v_min3_u32 %0, %0, %1, %2\n"
+			                  "v_min3_u32 %1, %1, %2, %3\n"
+			                  "v_min3_u32 %2, %2, %3, %4\n"
+			                  "v_min3_u32 %3, %3, %4, %5\n"
+			                  "v_min3_u32 %4, %4, %5, %6\n"
+			                  "v_min3_u32 %5, %5, %6, %7\n"
+			                  "v_min3_u32 %6, %6, %7, %0\n"
+			                  "v_min3_u32 %7, %7, %0, %1\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 23) {
+			asm volatile(REP8("v_cndmask_b32 %0, %0, %1, vcc\n"
+			                  "v_cndmask_b32 %1, %1, %2, vcc\n"
+			                  "v_cndmask_b32 %2, %2, %3, vcc\n"
+			                  "v_cndmask_b32 %3, %3, %4, vcc\n"
+			                  "v_cndmask_b32 %4, %4, %5, vcc\n"
+			                  "v_cndmask_b32 %5, %5, %6, vcc\n"
+			                  "v_cndmask_b32 %6, %6, %7, vcc\n"
+			                  "v_cndmask_b32 %7, %7, %0, vcc\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "vcc");
+		} else if (KIND == 24) {
+			asm volatile(REP8("v_max_u32 %0, %0, %1\n"
+			                  "v_max_u32 %1, %1, %2\n"
+			                  "v_max_u32 %2, %2, %3\n"
+			                  "v_max_u32 %3, %3, %4\n"
+			                  "v_max_u32 %4, %4, %5\n"
+			                  "v_max_u32 %5, %5, %6\n"
+			                  "v_max_u32 %6, %6, %7\n"
+			                  "v_max_u32 %7, %7, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 25) {
+			asm volatile(REP8("v_cmp_lt_u32 vcc, %0, %1\n"
+			                  "v_cmp_lt_u32 vcc, %1, %2\n"
+			                  "v_cmp_lt_u32 vcc, %2, %3\n"
+			                  "v_cmp_lt_u32 vcc, %3, %4\n"
+			                  "v_cmp_lt_u32 vcc, %4, %5\n"
+			                  "v_cmp_lt_u32 vcc, %5, %6\n"
+			                  "v_cmp_lt_u32 vcc, %6, %7\n"
+			                  "v_cmp_lt_u32 vcc, %7, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "vcc");
+		} else if (KIND == 26) {
+			asm volatile(REP8("v_sub_u32 %0, %0, %1\n"
+			                  "v_sub_u32 %1, %1, %2\n"
+			                  "v_sub_u32 %2, %2, %3\n"
+			                  "v_sub_u32 %3, %3, %4\n"
+			                  "v_sub_u32 %4, %4, %5\n"
+			                  "v_sub_u32 %5, %5, %6\n"
+			                  "v_sub_u32 %6, %6, %7\n"
+			                  "v_sub_u32 %7, %7, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 27) {
+			asm volatile(REP8("v_xor_b32 %0, %8, %0\n"
+			                  "v_xor_b32 %1, %8, %1\n"
+			                  "v_xor_b32 %2, %8, %2\n"
+			                  "v_xor_b32 %3, %8, %3\n"
+			                  "v_xor_b32 %4, %8, %4\n"
+			                  "v_xor_b32 %5, %8, %5\n"
+			                  "v_xor_b32 %6, %8, %6\n"
+			                  "v_xor_b32 %7, %8, %7\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 28) {
+			asm volatile(REP8("v_lshl_add_u32 %0, %0, 3, %1\n"
+			                  "v_lshl_add_u32 %1, %1, 3, %2\n"
+			                  "v_lshl_add_u32 %2, %2, 3, %3\n"
+			                  "v_lshl_add_u32 %3, %3, 3, %4\n"
+			                  "v_lshl_add_u32 %4, %4, 3, %5\n"
+			                  "v_lshl_add_u32 %5, %5, 3, %6\n"
+			                  "v_lshl_add_u32 %6, %6, 3, %7\n"
+			                  "v_lshl_add_u32 %7, %7, 3, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 29) {
+			asm volatile(REP8("v_bfe_u32 %0, %0, 3, 9\n"
+			                  "v_bfe_u32 %1, %1, 3, 9\n"
+			                  "v_bfe_u32 %2, %2, 3, 9\n"
+			                  "v_bfe_u32 %3, %3, 3, 9\n"
+			                  "v_bfe_u32 %4, %4, 3, 9\n"
+			                  "v_bfe_u32 %5, %5, 3, 9\n"
+			                  "v_bfe_u32 %6, %6, 3, 9\n"
+			                  "v_bfe_u32 %7, %7, 3, 9\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 30) {
+			asm volatile(REP8("v_and_b32 %0, 0x55555555, %0\n"
+			                  "v_and_b32 %1, 0x55555555, %1\n"
+			                  "v_and_b32 %2, 0x55555555, %2\n"
+			                  "v_and_b32 %3, 0x55555555, %3\n"
+			                  "v_and_b32 %4, 0x55555555, %4\n"
+			                  "v_and_b32 %5, 0x55555555, %5\n"
+			                  "v_and_b32 %6, 0x55555555, %6\n"
+			                  "v_and_b32 %7, 0x55555555, %7\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 31) {
+			asm volatile(REP8("v_add_u32 %0, %0, %1\n"
+			                  "v_add_u32 %1, %1, %2\n"
+			                  "v_add_u32 %2, %2, %3\n"
+			                  "v_add_u32 %3, %3, %4\n"
+			                  "v_add_u32 %4, %4, %5\n"
+			                  "v_add_u32 %5, %5, %6\n"
+			                  "v_add_u32 %6, %6, %7\n"
+			                  "v_add_u32 %7, %7, %0\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
+		} else if (KIND == 32) {
+			asm volatile(REP8("v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
+			                  "v_addc_co_u32 %1, vcc, %1, %1, vcc\n"
+			                  "v_addc_co_u32 %2, vcc, %2, %2, vcc\n"
+			                  "v_addc_co_u32 %3, vcc, %3, %3, vcc\n"
+			                  "v_addc_co_u32 %4, vcc, %4, %4, vcc\n"
+			                  "v_addc_co_u32 %5, vcc, %5, %5, vcc\n"
+			                  "v_addc_co_u32 %6, vcc, %6, %6, vcc\n"
+			                  "v_addc_co_u32 %7, vcc, %7, %7, vcc\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "vcc");
+		} else if (KIND == 33) {
+			asm volatile(REP8("v_readlane_b32 %8, %0, 5\n"
+			                  "v_readlane_b32 %8, %1, 5\n"
+			                  "v_readlane_b32 %8, %2, 5\n"
+			                  "v_readlane_b32 %8, %3, 5\n"
+			                  "v_readlane_b32 %8, %4, 5\n"
+			                  "v_readlane_b32 %8, %5, 5\n"
+			                  "v_readlane_b32 %8, %6, 5\n"
+			                  "v_readlane_b32 %8, %7, 5\n")
+			             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0) : "memory");
 		} else if (KIND == 13) {  // 16 x (v_cmp_eq -> s_ff1 -> v_readlane(sgpr idx via m0-free form) ...): ballot + ctz + bcast hop
 			asm volatile(REP8("v_cmp_ne_u32 vcc, %0, %2\n s_ff1_i32_b64 %1, vcc\n s_and_b32 %1, %1, 63\n v_readlane_b32 %1, %0, %1\n v_add_u32 %0, %0, %1\n"
 			                  "v_cmp_ne_u32 vcc, %0, %2\n s_ff1_i32_b64 %1, vcc\n s_and_b32 %1, %1, 63\n")
@@ -86,9 +245,11 @@ __global__ void k_bench(Res *out, int iters, int *sink)
 	}
 	const long long t1 = clock64();
 	if (lane == 0) out[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)].cycles = t1 - t0;
+	if (d0 + d1 + d2 + d3 == 12345.0) *sink = 2;
 	if (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7 == 0x7fffffff) *sink = 1;
 }
 
+static int g_khz = 2400000;
 template <int KIND>
 static void run(const char *name, int instr_per_iter, int cus)
 {
@@ -115,7 +276,9 @@ static void run(const char *name, int instr_per_iter, int cus)
 		double avg = 0; for (auto &r : h) avg += (double)r.cycles; avg /= (double)h.size();
 		const double per_wave = avg / ((double)iters * instr_per_iter);          // cycles per instruction seen by one wave
 		const double per_cu = (double)w / per_wave;                             // instructions per cycle per CU
-		printf(" | W=%2d %6.2f cyc/instr/wave %5.2f instr/cyc/CU (%.2f ms)", w, per_wave, per_cu, ms);
+		// wall clock: what the whole launch retired per cycle and CU (the per-wave clock64 column over-counts above one wave per SIMD)
+		const double wall = (double)cus * w * iters * instr_per_iter / ((double)ms * 1e-3 * (double)g_khz * 1e3) / cus;
+		printf(" | W=%2d %6.2f cyc/instr/wave %5.2f instr/cyc/CU (%.2f ms, wall %.2f instr/cyc/CU)", w, per_wave, per_cu, ms, wall);
 	}
 	printf("\n");
 	CHECK(hipFree(d)); CHECK(hipFree(sink));
@@ -126,12 +289,32 @@ int main()
 	hipDeviceProp_t pr;
 	CHECK(hipGetDeviceProperties(&pr, 0));
 	const int cus = pr.multiProcessorCount;
+	g_khz = pr.clockRate;
 	printf("%s, %d CUs, clock %d kHz; W = waves per CU (one workgroup per CU; 32 = two workgroups)\n", pr.gcnArchName, cus, pr.clockRate);
 	run<0>("VALU v_add_u32 x64 (8 chains)", 64, cus);
 	run<3>("VALU v_add_u32 x64 (1 dep chain)", 64, cus);
 	run<1>("SALU s_add_u32 x64 (8 chains)", 64, cus);
 	run<2>("VALU+SALU interleaved 32+32", 64, cus);
 	run<4>("VALU DPP row_shr:1 x64", 64, cus);
+	run<14>("control: v_fma_f32 x64", 64, cus);
+	run<15>("control: v_pk_fma_f32 x64", 64, cus);
+	run<19>("control: v_fma_f32 3 srcs x64", 64, cus);
+	run<17>("v_mov_b32 x64", 64, cus);
+	run<20>("v_xor_b32 v, const, v x64", 64, cus);
+	run<18>("v_xor_b32 v, v, v' x64", 64, cus);
+	run<16>("alignbit/xor/min3/cndmask x64", 64, cus);
+	run<21>("v_alignbit_b32", 64, cus);
+	run<22>("v_min3_u32", 64, cus);
+	run<23>("v_cndmask_b32 (vcc)", 64, cus);
+	run<24>("v_max_u32 v,v,v'", 64, cus);
+	run<25>("v_cmp_lt_u32 -> vcc", 64, cus);
+	run<26>("v_sub_u32 v,v,v'", 64, cus);
+	run<27>("v_xor_b32 v, s, v", 64, cus);
+	run<28>("v_lshl_add_u32", 64, cus);
+	run<29>("v_bfe_u32", 64, cus);
+	run<30>("v_and_b32 literal", 64, cus);
+	run<31>("v_add_u32 v,v,v'", 64, cus);
+	run<32>("v_addc_co_u32 (vcc in/out)", 64, cus);
 	run<8>("v_pk_add_u16 x64", 64, cus);
 	run<9>("v_pk_max_i16/min_u16 x64", 64, cus);
 	run<12>("v_perm_b32 x64", 64, cus);
