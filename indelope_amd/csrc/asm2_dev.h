@@ -234,8 +234,14 @@ __device__ __forceinline__ long long bcast64(long long v, int src)
 // (contig.nim:254-281), so its time grows with the square of the contigs the read phase leaves.  k_asm_reads files every
 // region under its class and k_asm_combine takes the classes in order -- the longest chains start first and the short ones
 // fill the end of the launch instead of the other way round.
-constexpr int LPT_CLASSES = 8, LPT_TIERS = 2;      // two combine launches: the usual arena, and one ~2.5x as large at half the occupancy
-__device__ __forceinline__ int lpt_class(int n) { return n >= 19 ? 0 : n >= 17 ? 1 : n >= 15 ? 2 : n >= 13 ? 3 : n >= 11 ? 4 : n >= 9 ? 5 : n >= 7 ? 6 : 7; }
+constexpr int LPT_CLASSES = 16, LPT_TIERS = 3;     // three combine launches: arenas of growing size at falling occupancy
+// (16 classes: two contigs apart over the range of 150 bp pile-ups, wider above.  The contig count is the best predictor the
+// read phase has -- correlation with the measured cycles 0.88 on C2, 0.65 on C5; counting the multi-read contigs in made it worse)
+__device__ __forceinline__ int lpt_class(int n)
+{
+	return n >= 48 ? 0 : n >= 40 ? 1 : n >= 34 ? 2 : n >= 29 ? 3 : n >= 25 ? 4 : n >= 22 ? 5 : n >= 19 ? 6 : n >= 17 ? 7 : n >= 15 ? 8
+	     : n >= 13 ? 9 : n >= 11 ? 10 : n >= 9 ? 11 : n >= 7 ? 12 : n >= 5 ? 13 : n >= 3 ? 14 : 15;
+}
 
 // Candidate ranking of best_match (contig.nim:32-36, :107, :239) for exact matches: more matches, then the earlier contig,
 // then the target-offset phase before the query-offset phase, then the smaller offset.
@@ -258,8 +264,8 @@ struct ReadArgs {
 	const uint32_t *v2_pk;
 	uint32_t *v2_hand; const long long *v2_hoff;
 	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by arena tier and cost class, longest first (see lpt_class)
-	int *n_tier_b;                                            // counts the regions filed under the second tier (diagnostics)
-	int tier_a_cap;                                           // bytes of the first combine launch's arena (a region that needs more is filed under the second tier)
+	int *n_tier_b;                                            // counts the regions filed under the second and third tier (diagnostics)
+	int tier_a_cap, tier_b_cap;                               // arena capacities of the first two combine launches: a region is filed under the first that holds it
 	double min_overlap_pct;
 	int min_mapq_assemble, v2_pdw, n_regions;
 	const int *in_list, *n_in; int *out_list, *n_out; int *work_counter;
@@ -550,12 +556,18 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	V2_LAP(7);
 #undef V2_LAP
 	n_contigs = n;
-	// what combine (asm3_dev.h) needs of its support bytes: every contig in a slot of its own plus room for merges of the
-	// longest contigs (a merge that makes a contig longer takes a new slot of 1.5 x the new length; nothing is compacted)
+	// what combine (asm3_dev.h) needs of its two areas.
+	// In capacity units C of a combine launch (C bytes of supports, C / 8 + 128 dwords of packed bases): support bytes are kept
+	// for multi-read contigs only (half of the single-read ones is set aside for those that will merge), a merge takes a
+	// slot of its new length in both areas, nothing is compacted until room runs out.
 	{
+		const bool multi = lane < n && d_nreads != 1;
 		const int bl = lane < n ? align4(d_len) + SLOT_PAD : 0;
 		const int mxl = wave_max_i32s(lane < n ? d_len : 0);
-		arena_need = wave_sum_i(bl) + 3 * mxl + 128;
+		const int need_sup = wave_sum_i(multi ? bl : bl >> 1) + 2 * mxl + 256;
+		const int need_pm = wave_sum_i(lane < n ? ((d_len + 15) >> 4) + 1 : 0) + ((2 * mxl + 15) >> 4) + 8;
+		const int c_pm = 8 * (need_pm - 128);
+		arena_need = need_sup > c_pm ? need_sup : c_pm;
 	}
 	return 0;
 }

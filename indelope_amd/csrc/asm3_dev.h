@@ -21,22 +21,21 @@ namespace ihp {
 
 constexpr int V3_MAXC = 64;
 constexpr int V3_MAXLEN = 2047;           // longest contig: 11 bits in the ranking key
-constexpr int V3_CORR = 256;              // corrections of one merge (LDS)
+constexpr int V3_CORR = 1024;             // most corrections one merge may have (they sit at the top of the packed area, counting down)
 constexpr int V3_NOZONE = 0x3fff;
 
 struct V3State {                          // static LDS, one per wave
 	int dw[V3_MAXC];                      // packed slot: first dword in PM
-	int so[V3_MAXC];                      // support slot: first byte in SUP
+	int so[V3_MAXC];                      // support slot: first byte in SUP; -1: a contig of one read, support 1 on every base, no bytes kept
 	int len[V3_MAXC], cap[V3_MAXC];       // bases; cap = bases both slots have room for from the current start
 	int nreads[V3_MAXC];
 	long long start[V3_MAXC];
 	short lo3[V3_MAXC], hi3[V3_MAXC];     // every base in [lo3, hi3) has support >= 3 and no other has (V3_NOZONE / 0: not one run)
-	short loT[V3_MAXC], hiT[V3_MAXC];     // the same for support >= v3_thr(nreads): the bases no vote can overrule (see v3_slide_votes)
+	short loT[V3_MAXC], hiT[V3_MAXC];     // the longest run of bases with support >= v3_thr(nreads): bases no vote can overrule (see v3_slide_votes)
 	unsigned char sh[V3_MAXC];            // bases into dword dw where the contig starts (trim moves it)
 	unsigned char smin[V3_MAXC], smax[V3_MAXC];
 	short listA[V3_MAXC], listB[V3_MAXC];
 	short qt[V3_MAXC], mt[V3_MAXC];       // step at which the contig was the query of pass 1 (0: never), step of its last change (0: none)
-	unsigned corr[V3_CORR];               // qoff | toff << 11 | qbest << 22 (| t's final support at the site << 23 once v3_insert has applied it)
 	long long prof[16];
 	int cnt[16];                          // diagnostics (profile): see ihp_batch_profile [32..47]
 };
@@ -67,26 +66,38 @@ __device__ __forceinline__ unsigned diff16(unsigned a, unsigned b) { const unsig
 // support >= min(3, ceil(nreads / 3)) can never be voted away.
 __device__ __forceinline__ int v3_thr(int nreads) { return nreads >= 7 ? 3 : (nreads + 2) / 3; }
 
-// Running summary of a contig's supports (one value per lane and step): extrema, the ">= 3" run, the ">= thr" run.
+// Running summary of a contig's supports, 64 consecutive bases per step (every lane calls add(); `valid` = the lane holds a
+// base): extrema, the ">= 3" bases when they form exactly one run (what the trim shortcut needs), and the LONGEST run of
+// bases with support >= thr (what the vote filter needs: any 16 of them will do).
 struct SupStats {
-	unsigned mn, mx; int f3, l3, c3, fT, lT, cT, thr;
-	__device__ __forceinline__ void init(int thr_) { mn = 255u; mx = 0; f3 = fT = 0x7fff; l3 = lT = -1; c3 = cT = 0; thr = thr_; }
-	__device__ __forceinline__ void add(unsigned v, int i)
+	unsigned mn, mx; int f3, l3, c3, thr;
+	unsigned carry;                                      // 1 + the last base seen so far that is below thr (0: none)
+	int blen, bend;                                      // per lane: the longest run ending at one of this lane's bases, and where
+	__device__ __forceinline__ void init(int thr_) { mn = 255u; mx = 0; f3 = 0x7fff; l3 = -1; c3 = 0; thr = thr_; carry = 0; blen = 0; bend = 0; }
+	__device__ __forceinline__ void add(unsigned v, int i, bool valid)
 	{
-		mn = v < mn ? v : mn; mx = v > mx ? v : mx;
-		if (v >= 3u) { f3 = i < f3 ? i : f3; l3 = i; c3++; }
-		if (thr < 3 && (int)v >= thr) { fT = i < fT ? i : fT; lT = i; cT++; }
+		if (valid) {
+			mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+			if (v >= 3u) { f3 = i < f3 ? i : f3; l3 = i; c3++; }
+		}
+		const bool strong = valid && (int)v >= thr;
+		unsigned pb = wave_scan_max(strong ? 0u : (unsigned)(i + 1));
+		pb = pb > carry ? pb : carry;
+		const int run = strong ? i + 1 - (int)pb : 0;                    // bases of the run that ends here
+		if (run > blen) { blen = run; bend = i; }
+		carry = (unsigned)__builtin_amdgcn_readlane((int)pb, 63);
 	}
 	__device__ __forceinline__ void store(V3State &S, int c)
 	{   // wave-uniform control flow; lane 0 writes
 		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
 		f3 = wave_min_i32(f3); l3 = wave_max_i32s(l3); c3 = wave_sum_i(c3);
-		if (thr < 3) { fT = wave_min_i32(fT); lT = wave_max_i32s(lT); cT = wave_sum_i(cT); } else { fT = f3; lT = l3; cT = c3; }
+		const int best = wave_max_i32s(blen);
+		const int end = best > 0 ? __builtin_amdgcn_readlane(bend, ctz64(ballot(blen == best))) : 0;
 		if (lane_id() == 0) {
 			S.smin[c] = (unsigned char)mn; S.smax[c] = (unsigned char)mx;
-			const bool clean = l3 >= f3 && c3 == l3 - f3 + 1, cleanT = lT >= fT && cT == lT - fT + 1;
+			const bool clean = l3 >= f3 && c3 == l3 - f3 + 1;
 			S.lo3[c] = (short)(clean ? f3 : V3_NOZONE); S.hi3[c] = (short)(clean ? l3 + 1 : 0);
-			S.loT[c] = (short)(cleanT ? fT : V3_NOZONE); S.hiT[c] = (short)(cleanT ? lT + 1 : 0);
+			S.loT[c] = (short)(best > 0 ? end + 1 - best : V3_NOZONE); S.hiT[c] = (short)(best > 0 ? end + 1 : 0);
 		}
 		LDS_ORDER();
 	}
@@ -103,8 +114,13 @@ __device__ inline void v3_stats(V3State &S, const V3Ctx &C, int c)
 {
 	const int lane = lane_id();
 	const int so = uni(S.so[c]), n = uni(S.len[c]);
+	if (so < 0) {                                                    // a single read: 1 everywhere
+		if (lane == 0) { S.smin[c] = 1; S.smax[c] = 1; S.lo3[c] = V3_NOZONE; S.hi3[c] = 0; S.loT[c] = 0; S.hiT[c] = (short)n; }
+		LDS_ORDER();
+		return;
+	}
 	SupStats st; st.init(v3_thr(uni(S.nreads[c])));
-	for (int i = lane; i < n; i += 64) st.add(C.SUP[so + i], i);
+	for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; st.add(i < n ? C.SUP[so + i] : 0u, i, i < n); }
 	st.store(S, c);
 }
 
@@ -125,7 +141,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 		d_poff = (int)a0.x; d_len = (int)a0.y; d_nreads = (int)a0.z; d_slo = (int)a0.w; d_shi = (int)a1.x; d_anchor = (int)a1.y;
 	}
 	const uint32_t *REC = H + V2_HDR + V2_DIRW * n;
-	const int scap = lane < n ? align4(d_len) + SLOT_PAD : 0, pnd = lane < n ? ((d_len + 15) >> 4) + 1 : 0;
+	const int scap = lane < n && d_nreads != 1 ? align4(d_len) + SLOT_PAD : 0, pnd = lane < n ? ((d_len + 15) >> 4) + 1 : 0;
 	const unsigned sincl = wave_scan_add((unsigned)scap), pincl = wave_scan_add((unsigned)pnd);
 	const int soff = (int)sincl - scap, stotal = __builtin_amdgcn_readlane((int)sincl, 63);
 	const int poff = (int)pincl - pnd, ptotal = __builtin_amdgcn_readlane((int)pincl, 63);
@@ -134,7 +150,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 	const int scratch_b = (C.sup_cap + 4 * C.pm_cap - 4 * (maxl + 2)) & ~15;
 	if (maxl > V3_MAXLEN || stotal > C.sup_cap || ptotal + 2 > C.pm_cap || stotal > scratch_b) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
 	if (lane < n) {
-		S.dw[lane] = poff; S.so[lane] = soff; S.len[lane] = d_len; S.cap[lane] = align4(d_len); S.nreads[lane] = d_nreads;
+		S.dw[lane] = poff; S.so[lane] = d_nreads != 1 ? soff : -1; S.len[lane] = d_len; S.cap[lane] = align4(d_len); S.nreads[lane] = d_nreads;
 		S.start[lane] = ((long long)d_shi << 32) | (unsigned)d_slo; S.sh[lane] = 0; S.listA[lane] = (short)lane;
 		S.qt[lane] = 0; S.mt[lane] = 0;
 	}
@@ -150,9 +166,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 	uint32_t *scratch = (uint32_t *)(C.SUP + scratch_b);
 	for (int c = 0; c < n; ++c) {
 		const int len = bcast(d_len, c), so = bcast(soff, c), nr = bcast(d_nreads, c), anchor = bcast(d_anchor, c);
-		if (nr == 1) {                                           // a single read: support 1 everywhere
-			uint32_t *s32 = (uint32_t *)(C.SUP + so);
-			for (int i = lane; 4 * i < len; i += 64) s32[i] = 0x01010101u;
+		if (nr == 1) {                                           // a single read: support 1 everywhere, no bytes
 			if (lane == 0) { S.smin[c] = 1; S.smax[c] = 1; S.lo3[c] = V3_NOZONE; S.hi3[c] = 0; S.loT[c] = 0; S.hiT[c] = (short)len; }
 			continue;
 		}
@@ -173,7 +187,8 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 			const int i = i0 + lane;
 			unsigned v = i < len ? scratch[i] : 0u;
 			v = wave_scan_add(v) + carry;
-			if (i < len) { C.SUP[so + i] = (uint8_t)v; st.add(v, i); over |= v > 255u; }
+			if (i < len) { C.SUP[so + i] = (uint8_t)v; over |= v > 255u; }
+			st.add(v, i, i < len);
 			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 		}
 		st.store(S, c);
@@ -196,6 +211,7 @@ __device__ inline void v3_trim(V3State &S, const V3Ctx &C, int c, int ms)
 {
 	const int lane = lane_id();
 	const int so = uni(S.so[c]), len = uni(S.len[c]);
+	if (so < 0) return;                                              // support 1 everywhere: the caller never gets here with ms > 1 (ms <= nreads = 1)
 	const uint8_t *sup = C.SUP + so;
 	int a = len - 1 > 0 ? len - 1 : 0;
 	for (int b = 0; b < len - 1; b += 64) {
@@ -344,7 +360,7 @@ __device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, 
 		if (n < 0) n = 0;
 		const int need = best.found && best.ma + 1 > min_overlap - 1 ? best.ma + 1 : min_overlap - 1;   // matches <= n
 		bool surv = idx < total && n >= need;
-		bool loop = false;
+		bool nozone = false;
 		unsigned m = 0;
 		if (surv) {
 			int klo = qloT - qo0 > tloT - to0 ? qloT - qo0 : tloT - to0;
@@ -357,15 +373,24 @@ __device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, 
 			} else {
 				m = diff16(pk16(C.PM, qpb + qo0), pk16(C.PM, tpb + to0));
 				if (n < 16) m &= (1u << (2 * n)) - 1u;
-				loop = m != 0;
+				nozone = true;
 			}
 		}
-		if (ballot(loop)) {
-			for (int t = 0; t < 6 && m && surv; ++t) {               // the first differing bases must be allowed ones
-				const int k = __builtin_ctz(m) >> 1;
-				m &= m - 1;
-				surv = allowed3(C.SUP[qso + qo0 + k], C.SUP[tso + to0 + k], qreads, treads);
+		// an offset without a window that both contigs are strong on: its differing bases at four places of the overlap
+		// must be allowed ones (each probe is exact; most such offsets meet a base neither side can be overruled on)
+		unsigned long long weak = ballot(surv && nozone);
+		for (int pr = 0; pr < 4 && weak; ++pr) {
+			if (surv && nozone) {
+				const int k = pr == 0 ? 0 : n > 16 ? ((n - 16) * pr) / 3 : 0;
+				unsigned mm = pr == 0 ? m : diff16(pk16(C.PM, qpb + qo0 + k), pk16(C.PM, tpb + to0 + k));
+				if (pr && n < 16) mm &= (1u << (2 * n)) - 1u;
+				for (int t = 0; t < 8 && mm && surv; ++t) {
+					const int j = __builtin_ctz(mm) >> 1;
+					mm &= mm - 1;
+					surv = allowed3(C.SUP[qso + qo0 + k + j], C.SUP[tso + to0 + k + j], qreads, treads);
+				}
 			}
+			weak = ballot(surv && nozone);
 		}
 		unsigned long long mask = ballot(surv);
 		V3_CNT(C, 15, popc64(mask));
@@ -464,10 +489,12 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 			any = window_any(w0, w1, qh);
 		}
 		unsigned long long hm = ballot(any);
+		V3_CNT(C, 11, popc64(hm));
 		while (hm) {
 			const int e = ctz64(hm);
 			hm &= hm - 1;
 			unsigned bits = window_bits((unsigned)__builtin_amdgcn_readlane((int)w0, e), (unsigned)__builtin_amdgcn_readlane((int)w1, e), qh);
+			V3_CNT(C, 12, __popc(bits));
 			const int i = __builtin_amdgcn_readlane(own, e);
 			const int tlen = __builtin_amdgcn_readlane(D.len, i), tpb = __builtin_amdgcn_readlane(D.pb, i);
 			const int ibe = __builtin_amdgcn_readlane(ib, e);
@@ -519,16 +546,21 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 }
 
 // ------------------------------------------------------------------------------------------------ corrections + insert
-// The allowed mismatches of (q, t, offset) in scan order into S.corr (contig.nim:99, :128).  Returns the count or -1.
-__device__ inline int v3_corrections(V3State &S, const V3Ctx &C, int qs, int ts, int off)
+__device__ inline void v3_compact(V3State &S, V3Ctx &C);
+
+// The allowed mismatches of (q, t, offset) in scan order to the top of the packed area, counting down (contig.nim:99, :128).  Returns the count or -1.
+__device__ inline int v3_corrections(V3State &S, V3Ctx &C, int qs, int ts, int off)
 {
 	const int lane = lane_id();
+	if (C.pm_cap - C.bump_pm < 160) v3_compact(S, C);                // the corrections go to the top of the packed area: make room there first
 	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
 	const int qpb = uni(16 * S.dw[qs] + S.sh[qs]), tpb = uni(16 * S.dw[ts] + S.sh[ts]);
 	const int qso = uni(S.so[qs]), tso = uni(S.so[ts]);
 	const int qo0 = off < 0 ? -off : 0, to0 = off < 0 ? 0 : off;
 	const int n = qlen - qo0 < tlen - to0 ? qlen - qo0 : tlen - to0;
 	int cnt = 0;
+	int lim = C.pm_cap - C.bump_pm - 4;                              // free dwords above everything that is allocated
+	lim = lim < V3_CORR ? lim : V3_CORR;
 	for (int k0 = 0; k0 < n; k0 += 1024) {
 		const int k = k0 + 16 * lane;
 		unsigned m = 0;
@@ -546,13 +578,14 @@ __device__ inline int v3_corrections(V3State &S, const V3Ctx &C, int qs, int ts,
 			const int j = __builtin_ctz(m) >> 1;
 			m &= m - 1;
 			const unsigned a = C.SUP[qso + qo0 + k + j], b = C.SUP[tso + to0 + k + j];
-			if (w < V3_CORR) S.corr[w] = (unsigned)(qo0 + k + j) | ((unsigned)(to0 + k + j) << 11) | ((a > b ? 1u : 0u) << 22);
+			// qoff | toff << 11 | qbest << 22 (| t's final support at the site << 23 once v3_insert has applied it)
+			if (w < lim) C.PM[C.pm_cap - 1 - w] = (unsigned)(qo0 + k + j) | ((unsigned)(to0 + k + j) << 11) | ((a > b ? 1u : 0u) << 22);
 			++w;
 		}
 		cnt += __builtin_amdgcn_readlane((int)incl, 63);
 	}
 	LDS_ORDER();
-	return cnt <= V3_CORR ? cnt : -1;
+	return cnt <= lim ? cnt : -1;
 }
 
 // Close the holes of both areas: the live contigs, in slot order, move down to the start (ascending copies, 64 elements
@@ -562,7 +595,7 @@ __device__ inline void v3_compact(V3State &S, V3Ctx &C)
 	const int lane = lane_id();
 	V3_CNT(C, 13, 1);
 	const bool live = lane_of(C.alive);
-	int key = live ? S.so[lane] : 0x7fffffff;
+	int key = live ? S.dw[lane] : 0x7fffffff;                        // both areas were filled in the same order
 	int nsup = 0, npm = 0;
 	for (;;) {
 		const int k = wave_min_i32(key);
@@ -571,7 +604,7 @@ __device__ inline void v3_compact(V3State &S, V3Ctx &C)
 		key = lane == c ? 0x7fffffff : key;
 		const int so = uni(S.so[c]), dw = uni(S.dw[c]), sh = uni((int)S.sh[c]), len = uni(S.len[c]);
 		const int nd = ((sh + len + 15) >> 4) + 1;                   // dwords incl. the pad
-		if (so != nsup) {
+		if (so >= 0 && so != nsup) {
 			for (int i0 = 0; i0 < len; i0 += 64) {
 				const int i = i0 + lane;
 				const unsigned v = i < len ? C.SUP[so + i] : 0u;
@@ -589,21 +622,22 @@ __device__ inline void v3_compact(V3State &S, V3Ctx &C)
 				LDS_ORDER();
 			}
 		}
-		if (lane == 0) { S.so[c] = nsup; S.dw[c] = npm; S.cap[c] = align4(len); }
-		nsup += align4(len) + SLOT_PAD; npm += nd;
+		if (lane == 0) { S.so[c] = so >= 0 ? nsup : -1; S.dw[c] = npm; S.cap[c] = align4(len); }
+		if (so >= 0) nsup += align4(len) + SLOT_PAD;
+		npm += nd;
 	}
 	C.bump_sup = nsup; C.bump_pm = npm;
 	LDS_ORDER();
 }
 
-__device__ __forceinline__ bool v3_room(const V3Ctx &C, int ncap)
-{
-	return C.bump_sup + ncap + SLOT_PAD <= C.sup_cap && C.bump_pm + ((ncap + 15) >> 4) + 2 <= C.pm_cap;
+__device__ __forceinline__ bool v3_room(const V3Ctx &C, int ncap, int ncorr)
+{   // (the corrections of the merge sit at the top of the packed area until the insert is done)
+	return C.bump_sup + ncap + SLOT_PAD <= C.sup_cap && C.bump_pm + ((ncap + 15) >> 4) + 2 + ncorr <= C.pm_cap;
 }
 
 __device__ __forceinline__ unsigned pk_base(const uint32_t *PM, int b) { return (PM[b >> 4] >> (2 * (b & 15))) & 3u; }
 
-// insert(t, q, m) of contig.nim:156-222 with the corrections in S.corr[0 .. ncorr).  q is not kept up to date (combine
+// insert(t, q, m) of contig.nim:156-222 with the ncorr corrections v3_corrections left at the top of the packed area.  q is not kept up to date (combine
 // drops it right after: its corrected bases and supports are never looked at again).  Leaves t's support extrema / zone.
 __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, int ncorr)
 {
@@ -614,20 +648,21 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 	if (off < 0) { newlen = aoff + tlen; if (qlen > newlen) newlen = qlen; }
 	else { newlen = tlen; if (off + qlen > newlen) newlen = off + qlen; }
 	if (newlen > V3_MAXLEN) return IHP_E_CAPACITY;
-	const bool reloc = off < 0 || newlen > uni(S.cap[ts]);
+	// (a target of one read has no support bytes: the merged contig gets a slot of its own whatever the offset)
+	const bool reloc = off < 0 || newlen > uni(S.cap[ts]) || uni(S.so[ts]) < 0;
 	int ncap = align4(newlen + headroom(newlen));
-	if (reloc && !v3_room(C, ncap)) {
+	if (reloc && !v3_room(C, ncap, ncorr)) {
 		v3_compact(S, C);                                            // (before any address of q or t is taken)
-		if (!v3_room(C, ncap)) {
+		if (!v3_room(C, ncap, ncorr)) {
 			ncap = align4(newlen);
-			if (!v3_room(C, ncap)) { V3_CNT(C, 9, 1); return IHP_E_CAPACITY; }
+			if (!v3_room(C, ncap, ncorr)) { V3_CNT(C, 9, 1); return IHP_E_CAPACITY; }
 		}
 	}
 	const int qpb = uni(16 * S.dw[qs] + S.sh[qs]), qso = uni(S.so[qs]);
 	int tpb = uni(16 * S.dw[ts] + S.sh[ts]), tso = uni(S.so[ts]);
 	// ---- corrections (:161-173): the winner's base and support go to the loser; t's value at such a site is final
-	for (int c = lane; c < ncorr; c += 64) {
-		const unsigned cr = S.corr[c];
+	for (int c = lane; c < ncorr; c += 64) {                       // (corrections come from vote scans: both contigs have support bytes)
+		const unsigned cr = C.PM[C.pm_cap - 1 - c];
 		const int qoff = (int)(cr & 2047u), toff = (int)((cr >> 11) & 2047u);
 		const bool qbest = (cr >> 22) & 1u;
 		unsigned val = C.SUP[tso + toff];
@@ -639,7 +674,7 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 			val = C.SUP[qso + qoff];
 			C.SUP[tso + toff] = (uint8_t)val;
 		}
-		S.corr[c] = (cr & 0x7fffffu) | (val << 23);                  // the site keeps this support whatever is added below (:198, :217)
+		C.PM[C.pm_cap - 1 - c] = (cr & 0x7fffffu) | (val << 23);     // the site keeps this support whatever is added below (:198, :217)
 	}
 	LDS_ORDER();
 	int ndw = tpb >> 4, nsh = tpb & 15, nso = tso;
@@ -681,8 +716,8 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 	bool over = false;
 	for (int i = lo + lane; i < hi; i += 64) {
 		const int ti = i - tshift, qi = i - qshift;
-		unsigned v = (ti >= 0 && ti < tlen) ? ts_[ti] : 0u;
-		if (qi >= 0 && qi < qlen) v += qs_[qi];
+		unsigned v = (ti >= 0 && ti < tlen) ? (tso >= 0 ? ts_[ti] : 1u) : 0u;
+		if (qi >= 0 && qi < qlen) v += qso >= 0 ? qs_[qi] : 1u;
 		over |= v > 255u;
 		ns_[i] = (uint8_t)v;
 	}
@@ -691,13 +726,13 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 	if (ballot(over)) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
 	LDS_ORDER();
 	for (int c = lane; c < ncorr; c += 64) {
-		const unsigned cr = S.corr[c];
+		const unsigned cr = C.PM[C.pm_cap - 1 - c];
 		ns_[off < 0 ? (int)(cr & 2047u) : (int)((cr >> 11) & 2047u)] = (uint8_t)(cr >> 23);   // index in the merged contig (:170-173)
 	}
 	LDS_ORDER();
 	const int nreads_new = uni(S.nreads[ts]) + uni(S.nreads[qs]);  // :203, :222
 	SupStats st; st.init(v3_thr(nreads_new));
-	for (int i = lane; i < newlen; i += 64) st.add(ns_[i], i);
+	for (int i0 = 0; i0 < newlen; i0 += 64) { const int i = i0 + lane; st.add(i < newlen ? ns_[i] : 0u, i, i < newlen); }
 	if (lane == 0) {
 		S.dw[ts] = ndw; S.sh[ts] = (unsigned char)nsh; S.so[ts] = nso; S.len[ts] = newlen;
 		if (reloc) S.cap[ts] = ncap;
@@ -732,7 +767,7 @@ __device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, sh
 					const int a0 = lo3, b0 = hi3 - 1 > lo3 ? hi3 - 1 : lo3;
 					if (lane == 0) {
 						const int b = S.sh[c] + a0;
-						S.start[c] += a0; S.so[c] += a0; S.cap[c] -= a0; S.len[c] = b0 - a0 + 1;
+						S.start[c] += a0; S.so[c] += a0; S.cap[c] -= a0; S.len[c] = b0 - a0 + 1;    // (a contig with a ">= 3" run has support bytes)
 						S.dw[c] += b >> 4; S.sh[c] = (unsigned char)(b & 15);
 						S.smin[c] = 3; S.lo3[c] = 0; S.hi3[c] = (short)(b0 - a0 + 1);   // what is left has every support >= 3 (a bound will do for smin)
 						S.loT[c] = 0; S.hiT[c] = (short)(b0 - a0 + 1);
@@ -756,7 +791,7 @@ __device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, sh
 	if (nout == 0) return 0;                                         // :272
 	Dir3 D;
 	dir3_build(S, C, in, n, min_overlap, D);
-	if (!D.valid) { V3_CNT(C, 11, 1); return IHP_E_CAPACITY; }
+	if (!D.valid) return IHP_E_CAPACITY;
 	D.inout = 1ull << usedi;
 	for (int i = 0; i < n; ++i) {                                    // :274-281
 		if (i == usedi) continue;

@@ -71,6 +71,22 @@ __device__ __forceinline__ unsigned wave_scan_add(unsigned v)
 	    : "=&v"(t) : "v"(v));
 	return t;
 }
+// Inclusive prefix maximum of unsigned values over the 64 lanes (same DPP walk; 0 is the identity: zero fill at row starts).
+__device__ __forceinline__ unsigned wave_scan_max(unsigned v)
+{
+	unsigned t;
+	asm("s_nop 4\n\t"
+	    "v_mov_b32 %0, %1\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+	    "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+	    : "=&v"(t) : "v"(v));
+	return t;
+}
 __device__ __forceinline__ int first_lane_val(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // A wave-uniform value that was loaded through the vector memory path sits in a VGPR, and the compiler then
 // does all the scalar arithmetic and branching that depends on it on the vector ALU.  uni() moves it to an SGPR.

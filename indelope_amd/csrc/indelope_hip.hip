@@ -30,6 +30,7 @@ struct Ctx {
 	int wall_khz = 0;                                      // rate of the device wall clock (wall_clock64) in kHz
 	int64_t hbm = 0;
 	int max_lds = 65536;
+	int comb_static = 4608;                                // static LDS of k_asm_combine3 (hipFuncGetAttributes)
 	hipStream_t stream = nullptr;
 	char err[512] = "";
 };
@@ -299,6 +300,10 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
 		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		{
+			hipFuncAttributes fa;
+			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static = (int)fa.sharedSizeBytes;
+		}
 		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
 		(void)hipFuncSetAttribute((const void *)k_ksw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -725,7 +730,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 16 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch
+enum { WQ_SETS = 17 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier
 enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_WORDS = 24 };
 struct ihp_batch {
 	ihp_params P;
@@ -744,7 +749,7 @@ struct ihp_batch {
 	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
 	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
 	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_hoff, v2_hand, lpt_seg;
-	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, v2_arena_b = 0, v2_pm_b = 0, grid_v2 = 0, grid_v2b = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
+	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, v2_arena_b = 0, v2_pm_b = 0, v2_arena_c = 0, v2_pm_c = 0, grid_v2c = 0, grid_v2 = 0, grid_v2b = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
 	DBuf retry_listc;
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
@@ -1063,28 +1068,33 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave.
-			// Combine kernel (asm3_dev.h): C bases of capacity = C bytes of supports + C / 16 + 96 dwords of packed bases
-			// (1.25 B per base + slot padding) beside ~3.5 KB of static LDS.
-			auto pm_of = [](long long C) { return C / 16 + 96; };
-			auto wave_bytes = [&](long long C) { return C + 4 * pm_of(C) + 3968; };
-			auto cap_for = [&](int occ) { return (long long)(((long long)g.max_lds / occ - 3968 - 384) * 4 / 5) / 16 * 16; };
+			// Combine kernel (asm3_dev.h): capacity C = C bytes of supports (kept for multi-read contigs only) + C / 8 + 128
+			// dwords of packed bases (every contig) beside the kernel's static LDS (asked of the runtime: a stale constant here once
+			// cost every tier a wave per CU).
+			const long long stat = (g.comb_static + 255) / 256 * 256 + 256;          // + allocation granularity
+			auto pm_of = [](long long C) { return C / 8 + 128; };
+			auto wave_bytes = [&](long long C) { return C + 4 * pm_of(C) + stat; };
+			auto cap_for = [&](int occ) { return (long long)(((long long)g.max_lds / occ - stat - 512) * 2 / 3) / 16 * 16; };
 			// 16 waves per CU when the launch is long enough to be bound by throughput; a launch of about one round of regions per
 			// wave slot lasts as long as its heaviest regions, and those run faster with fewer waves beside them on their SIMD
 			// (C2, 5 000 regions per launch: 14 waves per CU 5.33 M regions/s, 16: 4.98 M, 12: 5.22 M)
 			const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : (b->n_cls[0] >= 40 * g.cus ? 16 : 14);
-			long long need_C = std::max<long long>(1024, (nb1 * 36 / 100 + 512 + 15) / 16 * 16 - 768);   // the usual region needs ~0.25 of its read bases; the rest goes to the roomier launches
+			long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
 			const int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes(need_C)));
 			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
 			need_C = std::max(need_C, cap_for(occ_c));
 			// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
 			b->v2_arena_big = (int)std::min<long long>(cap_for(2), std::max<long long>(4 * need_C, (nb1 + 1024 + 15) / 16 * 16));
 			b->grid_v2big = grid_for(R, std::max(1, std::min<int>(2, (int)(g.max_lds / wave_bytes(b->v2_arena_big)))));
-			// the second tier: regions whose contigs (known when the read phase ends) need more than the first arena -- many
-			// single-read contigs, long reads -- at half the occupancy
+			// the second and third tier: regions whose contigs (known when the read phase ends) need more than the first arena
+			// -- many single-read contigs, long reads -- at about two thirds and a third of its occupancy (C5, 300 bp reads:
+			// nearly every region needs 8-10 KB; with only a half-occupancy tier of 18 KB behind the first, 5 waves per CU ran them)
 			{
-				const int occ_b = std::max(1, occ_c / 2);
+				const int occ_b = std::max(1, (occ_c * 2 + 1) / 3), occ_t = std::max(1, occ_c / 3);
 				b->v2_arena_b = (int)std::max(need_C, cap_for(occ_b));
 				b->grid_v2b = std::min(grid_for(R, occ_b), std::max(1, b->n_cls[0]));
+				b->v2_arena_c = (int)std::max<long long>(b->v2_arena_b, cap_for(occ_t));
+				b->grid_v2c = std::min(grid_for(R, occ_t), std::max(1, b->n_cls[0]));
 			}
 			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
 			b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena / 16 * 16 : (int)need_C;
@@ -1094,6 +1104,8 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			// the second tier and the roomy launch give up arena first, the packed path is switched off only when the first tier does not fit
 			const int dyn_max = g.max_lds - 8192 - 1024;
 			while (b->v2_arena_b > 1024 && b->v2_arena_b + 4 * pm_of(b->v2_arena_b) > dyn_max) b->v2_arena_b -= 256;
+			while (b->v2_arena_c > 1024 && b->v2_arena_c + 4 * pm_of(b->v2_arena_c) > dyn_max) b->v2_arena_c -= 256;
+			b->v2_pm_c = (int)pm_of(b->v2_arena_c);
 			while (b->v2_arena_big > 1024 && b->v2_arena_big + 4 * pm_of(b->v2_arena_big) > dyn_max) b->v2_arena_big -= 256;
 			b->v2_pm = (int)pm_of(b->v2_arena); b->v2_pm_b = (int)pm_of(b->v2_arena_b); b->v2_pm_big = (int)pm_of(b->v2_arena_big);
 			const int per_wave = (int)wave_bytes(b->v2_arena), per_wave_r = 4 * b->v2_pdw + 256;
@@ -1317,7 +1329,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
 			const bool lpt_on = g_knob.lpt != 0;                   // region order of the combine launch
 			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
-			ra.tier_a_cap = b->v2_arena; ra.n_tier_b = misc + M_NTIERB;     // tier_a_cap = Arena::cap of the first launch
+			ra.tier_a_cap = b->v2_arena; ra.tier_b_cap = b->v2_arena_b; ra.n_tier_b = misc + M_NTIERB;
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
 			if (b->n_rich) {
@@ -1346,6 +1358,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				y.work_counter = wq + 13 * WQ_WORDS; y.corr = b->corr2.as<Corr>();
 				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
 				HIPC(hipEventRecord(b->ev_bjoin, s2));
+				// the third tier (the roomiest arena, the regions with the most to merge) first on this stream, the first tier behind it
+				AsmArgs z = x;
+				z.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; z.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
+				z.arena_cap = b->v2_arena_c; z.lds_arena = b->v2_arena_c; z.v2_pm_dw = b->v2_pm_c;
+				z.work_counter = wq + 16 * WQ_WORDS;
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2c), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
 			} else HIPC(hipEventRecord(b->ev_bjoin, s));
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
 			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);

@@ -438,10 +438,16 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		if (err) {                                             // not for this path: the byte-based passes take it
 			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 		} else if (a.lpt_cnt && lane == 0) {
-			const bool tier_b = need > a.tier_a_cap;
-			const int c = lpt_class(nc) + (tier_b ? LPT_CLASSES : 0);
+			const int tier = need <= a.tier_a_cap ? 0 : need <= a.tier_b_cap ? 1 : 2;
+			const int c = lpt_class(nc) + tier * LPT_CLASSES;
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
-			if (tier_b) atomicAdd(a.n_tier_b, 1);
+			if (tier) atomicAdd(a.n_tier_b, 1);
+			if (a.prof) {                                          // diagnostics: what the regions ask of the combine arena
+				atomicAdd((unsigned long long *)&a.prof[62], (unsigned long long)need);
+				atomicMax((unsigned long long *)&a.prof[63], (unsigned long long)need);
+				atomicAdd((unsigned long long *)&a.prof[20 + 0], 0ull);
+				atomicAdd((unsigned long long *)&a.prof[24 + (need <= 6144 ? 0 : need <= 8192 ? 1 : need <= 10240 ? 2 : need <= 12288 ? 3 : need <= 16384 ? 4 : 5)], 1ull);
+			}
 		}
 		WSYNC();
 	}
@@ -474,7 +480,7 @@ __device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ct
 			const unsigned c8 = (fsh(C.PM[(b >> 4) + 1], C.PM[b >> 4], 2u * (unsigned)(b & 15))) & 0xffu;
 			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
 			const unsigned w = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
-			const unsigned sv = ld32u((const uint32_t *)C.SUP, so + i);     // four supports (the slot is padded: reading past len is fine)
+			const unsigned sv = so >= 0 ? ld32u((const uint32_t *)C.SUP, so + i) : 0x01010101u;   // four supports (the slot is padded: reading past len is fine)
 			if (i + 4 <= len) {
 				*(u32_unaligned *)(oseq + i) = w;
 				osup[i] = sv & 0xffu; osup[i + 1] = (sv >> 8) & 0xffu; osup[i + 2] = (sv >> 16) & 0xffu; osup[i + 3] = sv >> 24;
@@ -529,12 +535,10 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 	if (lane < 16) S.prof[lane] = 0;
 	if (lane < 16) S.cnt[lane] = 0;
 	WSYNC();
-	int lpt[LPT_CLASSES];
 	int n_items = a.in_list ? *a.n_in : a.n_regions;
 	if (a.lpt_cnt) {
 		n_items = 0;
-#pragma unroll
-		for (int c = 0; c < LPT_CLASSES; ++c) { lpt[c] = uni(a.lpt_cnt[c]); n_items += lpt[c]; }
+		for (int c = 0; c < LPT_CLASSES; ++c) n_items += uni(a.lpt_cnt[c]);
 	}
 	unsigned wq_dead = 0;
 	for (;;) {
@@ -545,8 +549,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 		if (r < 0) break;
 		if (a.lpt_cnt) {                                        // item -> (class, position): the classes laid end to end
 			int c = 0;
-#pragma unroll
-			for (int k = 0; k < LPT_CLASSES - 1; ++k) if (c == k && r >= lpt[k]) { r -= lpt[k]; c = k + 1; }
+			for (; c < LPT_CLASSES - 1; ++c) { const int nc_ = uni(a.lpt_cnt[c]); if (r < nc_) break; r -= nc_; }
 			r = uni(a.lpt_seg[(size_t)c * a.lpt_stride + r]);
 		} else if (a.in_list) r = a.in_list[r];
 		int n_pre = 0, n_final = 0;
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 		if (a.prof && lane == 0) {
 			const long long dt_ = (long long)clock64() - tcR;
 			S.prof[2] += dt_;
-			atomicMax((unsigned long long *)&a.prof[53], (unsigned long long)dt_);     // the longest region of the launch
+			atomicMax((unsigned long long *)&a.prof[53], ((unsigned long long)dt_ << 20) | (unsigned long long)(r & 0xfffff));   // the longest region of the launch (cycles << 20 | region)
 			atomicAdd((unsigned long long *)&a.prof[54 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], (unsigned long long)dt_);
 			atomicAdd((unsigned long long *)&a.prof[57 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], 1ull);
 		}
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 	{
 		const KswArgsK a = a0;
 		mark_start(a->t_start);
-		if (a->prof && lane < 4) ((long long *)(lds + a->lds_budget + 16))[lane] = 0;   // per-wave cycle counters live past the sweep's LDS
+		if (a->prof && lane < 6) ((long long *)(lds + a->lds_budget + 16))[lane] = 0;   // per-wave cycle counters live past the sweep's LDS
 	}
 	WSYNC();
 	{
@@ -712,8 +715,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 	WSYNC();
 	{
 		const KswArgsK a = ksw_args_again(a0);
-		if (a->prof && lane < 4)
-			atomicAdd((unsigned long long *)&a->prof[8 + lane], (unsigned long long)((long long *)(lds + a->lds_budget + 16))[lane]);
+		if (a->prof && lane < 6)      // [8..11] init, DP, traceback, alignments; [60], [61] early / tail diagonals of the narrow sweep
+			atomicAdd((unsigned long long *)&a->prof[lane < 4 ? 8 + lane : 56 + lane], (unsigned long long)((long long *)(lds + a->lds_budget + 16))[lane]);
 	}
 }
 

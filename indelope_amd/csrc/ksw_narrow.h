@@ -152,6 +152,7 @@ struct NarrowEnv {
 	int qlen, tlen, w, qe, e, zdrop;
 	int q24, ZW24;                                       // q << 24, z of a never-refreshed cell << 24
 	unsigned M24;                                        // max_sc << 24
+	long long *pacc;                                     // diagnostics: per-wave cycle counters or null ([4] early, [5] tail diagonals)
 };
 
 __device__ __forceinline__ int narrow_z(unsigned T0, unsigned T1, unsigned sel) { return (int)__builtin_amdgcn_perm(T0, T1, sel); }
@@ -511,10 +512,12 @@ __device__ __forceinline__ bool narrow_steady_loop(NarrowState &F, const NarrowE
 	if (r < w + 31) {                                    // the caller starts this early only when the job has room (EDGE = 2)
 		C.st0 = C.st0 > 0 ? C.st0 : 0; C.en0 = C.en0 < r ? C.en0 : r;
 		C.lim = r_hi < w + 31 ? r_hi : w + 31;
+		const long long te0 = E.pacc ? (long long)clock64() : 0;
 		while (C.r < C.lim) {
 			if (C.en0 < 64) narrow_steady_step<RIGHT, false, 2, -1>(F, E, C);
 			else narrow_steady_step<RIGHT, true, 2, -1>(F, E, C);
 		}
+		if (E.pacc && lane == 0) E.pacc[4] += (long long)clock64() - te0;
 	}
 	while (C.r < r_hi && C.stop_r < 0) {
 		C.lim = r_hi;
@@ -865,6 +868,7 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	F.ez_max = 0; F.ez_max_t = F.ez_max_q = -1; F.mqe = F.mte = F.score = KSW_NEG_INF; F.mqe_t = F.mte_q = -1;
 	NarrowEnv E;
 	E.tg = tg; E.qs = qs; E.tbl = tbl; E.p = (unsigned *)p; E.qlen = qlen; E.tlen = tlen; E.w = w; E.qe = qe; E.e = e;
+	E.pacc = pacc;
 	E.zdrop = P.zdrop; E.ZW24 = (int)(ZW << 24); E.M24 = ZM << 24; E.q24 = (int)(((unsigned)q & 0xff) << 24);
 	const int total = qlen + tlen - 1;
 	// steady diagonals: st0 = (r-w+1)>>1 > r-qlen+1, en0 = (r+w)>>1 < tlen-1, en < r
@@ -888,7 +892,9 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	}
 	if (!stop) {
 		if (!tracked) F.rlB = lane <= F.last_sc - 64 ? r - 1 : -1;   // what the growing diagonals did not track (see narrow_diag)
+		const long long tt0 = pacc ? (long long)clock64() : 0;
 		stop = narrow_tail_loop<RIGHT>(F, E, r, total);
+		if (pacc && lane == 0) pacc[5] += (long long)clock64() - tt0;
 	}
 	{
 		const int r_last = stop ? (F.band_exit ? r - 1 : r) : total - 1;     // the last diagonal whose cells were computed
