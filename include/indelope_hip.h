@@ -480,6 +480,7 @@ int  ihp_debug_last_ksw_mode(void);
 int  ihp_debug_limits(const int64_t limits[4]);
 /* Test / diagnostics switches for batches uploaded (and runs started) from now on; results never depend on them.
  *   "asm_v1" 1      class-1 regions through the byte-based k_assemble passes only (no packed assembly)
+ *   "no_hint" 1     every combine launch with its full grid (default: a launch the previous batch left empty gets a token grid)
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
  *   "lpt" 0         k_asm_combine in input order: no cost classes, no second arena tier

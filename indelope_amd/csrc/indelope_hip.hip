@@ -66,6 +66,7 @@ int g_ksw_status = 0;                      // result of the most recent ksw_extz
 struct Knobs {
 	int asm_v1 = 0;        // 1: class 1 through the byte-based k_assemble passes only (no packed assembly)
 	int no_rich = 0;       // 1: read-rich regions (classes 2-4) stay with the byte-based passes
+	int no_hint = 0;       // 1: every combine launch with its full grid whatever the last batch needed
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
@@ -74,6 +75,13 @@ struct Knobs {
 	int strict_ksw = 0;    // 1: ksw_extz2_sse aborts on failure (also IHP_KSW_STRICT=1 in the environment)
 };
 Knobs g_knob;
+
+// What the last finished batch needed of the combine launches behind the first tier (regions filed under the second and the
+// third tier, regions that ran out of room and went to the roomy launch).  A sweep uploads batch after batch of the same
+// kind: a launch nobody needed last time is started with a token grid -- an empty launch of workgroups that each ask for
+// 25-60 KB of LDS still has to get every one of them scheduled, 50-280 us on the batch's stream in front of k_ksw.
+struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}; };
+TierHint g_hint;
 std::atomic<int> g_live_batches{0};
 
 // Device memory comes from a caching pool: a BAM sweep uploads batch after batch of similar shape, and hipMalloc /
@@ -347,7 +355,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -731,7 +739,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 
 // ------------------------------------------------------- the batched region path
 enum { WQ_SETS = 17 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_WORDS = 24 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_WORDS = 25 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -1356,24 +1364,34 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				y.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
 				y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
 				y.work_counter = wq + 13 * WQ_WORDS; y.corr = b->corr2.as<Corr>();
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
+				const bool hint = g_hint.valid.load() != 0 && !g_knob.no_hint;
+				const int token = 128;                                 // enough to get through a few stragglers; a batch unlike the last one is correct, only slower
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(hint && g_hint.n_b.load() == 0 ? std::min(b->grid_v2b, token) : b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
 				HIPC(hipEventRecord(b->ev_bjoin, s2));
 				// the third tier (the roomiest arena, the regions with the most to merge) first on this stream, the first tier behind it
 				AsmArgs z = x;
 				z.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; z.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
 				z.arena_cap = b->v2_arena_c; z.lds_arena = b->v2_arena_c; z.v2_pm_dw = b->v2_pm_c;
 				z.work_counter = wq + 16 * WQ_WORDS;
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2c), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
-			} else HIPC(hipEventRecord(b->ev_bjoin, s));
-			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
-			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+				if (!(hint && g_hint.n_c.load() == 0))                 // (with regions to run it goes first: the roomiest arena holds the longest chains)
+					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2c), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
+				x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+				if (hint && g_hint.n_c.load() == 0)
+					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(std::min(b->grid_v2c, token)), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
+			} else {
+				HIPC(hipEventRecord(b->ev_bjoin, s));
+				x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			}
 			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second tier)
 			// regions whose contigs did not fit that arena: the same kernel with a roomy one (few workgroups per CU)
 			x.in_list = b->retry_listc.as<int>(); x.n_in = misc + M_NRETRYC; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0;
 			x.lpt_cnt = nullptr;
 			x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
 			x.work_counter = wq + 12 * WQ_WORDS;
-			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
+			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(g_hint.valid.load() && !g_knob.no_hint && g_hint.n_big.load() == 0 ? std::min(b->grid_v2big, 64) : b->grid_v2big),
+			                   dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
 			HIPC(hipGetLastError());
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = b->retry_list0.as<int>(); a.n_in = misc + M_NRETRY0; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
@@ -1528,6 +1546,9 @@ extern "C" int ihp_batch_sync(ihp_batch *b)
 		b->acc_n++;
 		b->acc_pending = false;
 	}
+	if (b->ran && b->R > 0 && b->v2 && g_knob.lpt) {
+		g_hint.n_b = b->report[M_NTIERB]; g_hint.n_c = b->report[M_NTIERC]; g_hint.n_big = b->report[M_NRETRYC]; g_hint.valid = 1;
+	}
 	if (b->ran && b->R > 0) return report_overflow(b);
 	return 0;
 }
@@ -1568,6 +1589,7 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64])
 	out[23] = b->report[M_NRETRY0];                   // regions the packed path handed back to the byte-based class-1 kernel
 	out[28] = b->report[M_NRETRYC];                   // regions whose contigs needed the roomy combine launch
 	out[29] = b->report[M_NTIERB];                    // regions the read phase filed under the second (larger-arena) combine launch
+	out[30] = b->report[M_NTIERC];                    // ... and under the third
 	return 0;
 }
 

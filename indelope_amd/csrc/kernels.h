@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 			const int tier = need <= a.tier_a_cap ? 0 : need <= a.tier_b_cap ? 1 : 2;
 			const int c = lpt_class(nc) + tier * LPT_CLASSES;
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
-			if (tier) atomicAdd(a.n_tier_b, 1);
+			if (tier) atomicAdd(a.n_tier_b + (tier - 1), 1);
 			if (a.prof) {                                          // diagnostics: what the regions ask of the combine arena
 				atomicAdd((unsigned long long *)&a.prof[62], (unsigned long long)need);
 				atomicMax((unsigned long long *)&a.prof[63], (unsigned long long)need);
