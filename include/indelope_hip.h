@@ -465,7 +465,8 @@ int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
  * [13] target-offset filter, [14] query-offset phase, [15] insert, [27] set-up.  Always filled: [24]/[25]/[26] regions
  * forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [23] regions the packed pass handed
  * back to the byte-based class-1 kernel, [28] regions sent on to the roomy combine launch, [29] regions the read phase
- * filed under the second (larger-arena) combine launch, [22] ksw2 kernel mode; [32..39] event counts of the combine kernel
+ * filed under the second (larger-arena) combine launch, [30] under the third, [21] 1 if the last run left the retry
+ * launches out, [31] runs of this batch repeated in full because of that, [22] ksw2 kernel mode; [32..39] event counts of the combine kernel
  * (best_match calls, exact candidates, verification passes, vote scans, merges, filter passes, query-phase target looks, trims that read supports). */
 int  ihp_batch_profile(ihp_batch *b, int64_t out[64]);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
@@ -481,6 +482,9 @@ int  ihp_debug_limits(const int64_t limits[4]);
 /* Test / diagnostics switches for batches uploaded (and runs started) from now on; results never depend on them.
  *   "asm_v1" 1      class-1 regions through the byte-based k_assemble passes only (no packed assembly)
  *   "no_hint" 1     every combine launch with its full grid (default: a launch the previous batch left empty gets a token grid)
+ *   "no_spec" 1     the retry launches (roomy combine, byte-based overflow passes) are always enqueued (default: left out of a
+ *                   run when the previous batch needed none of them; whoever waits for the run checks, and repeats it in full)
+ *   "spec_fail" 1   test hook: such a run is treated as if a region had needed them
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
  *   "lpt" 0         k_asm_combine in input order: no cost classes, no second arena tier
@@ -497,7 +501,8 @@ typedef struct {
 	int32_t status, n_contigs_pre, n_contigs, n_aligned, n_events, n_tallied;
 	int32_t ref_support, alt_support;     /* of the first tallied event, else -1 */
 } ihp_region_summary;
-/* Device pointer (valid until the next run/free) + count of the summaries.    */
+/* Device pointer (valid until the next run/free) + count of the summaries.  Read the records after ihp_batch_sync
+ * has returned for the run: it is the wait that confirms the run (a run may be repeated there, see "no_spec").        */
 int  ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n);
 /* The same records copied to the host (cap >= n_regions entries).             */
 int  ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int64_t cap);

@@ -263,6 +263,7 @@ struct ReadArgs {
 	const int *v2_trim_lo, *v2_trim_hi;
 	const uint32_t *v2_pk;
 	uint32_t *v2_hand; const long long *v2_hoff;
+	int *n_final;                                             // per region: 0 for a region handed to out_list (nobody may take that list in this run)
 	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by arena tier and cost class, longest first (see lpt_class)
 	int *n_tier_b;                                            // counts the regions filed under the second and third tier (diagnostics)
 	int tier_a_cap, tier_b_cap;                               // arena capacities of the first two combine launches: a region is filed under the first that holds it

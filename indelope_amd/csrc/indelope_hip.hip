@@ -67,6 +67,8 @@ struct Knobs {
 	int asm_v1 = 0;        // 1: class 1 through the byte-based k_assemble passes only (no packed assembly)
 	int no_rich = 0;       // 1: read-rich regions (classes 2-4) stay with the byte-based passes
 	int no_hint = 0;       // 1: every combine launch with its full grid whatever the last batch needed
+	int no_spec = 0;       // 1: the retry launches are always enqueued (default: left out when the last batch needed none, checked at the wait)
+	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
@@ -80,7 +82,7 @@ Knobs g_knob;
 // third tier, regions that ran out of room and went to the roomy launch).  A sweep uploads batch after batch of the same
 // kind: a launch nobody needed last time is started with a token grid -- an empty launch of workgroups that each ask for
 // 25-60 KB of LDS still has to get every one of them scheduled, 50-280 us on the batch's stream in front of k_ksw.
-struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}; };
+struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}; };
 TierHint g_hint;
 std::atomic<int> g_live_batches{0};
 
@@ -355,7 +357,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -793,6 +795,9 @@ struct ihp_batch {
 	bool ran = false, work_live = false;
 	double acc_ms[4] = {0, 0, 0, 0}; long long acc_n = 0;  // stage times summed over the runs since the last reset (ihp_batch_kernel_ms_mean)
 	bool acc_pending = false;                              // the last run's stamps have not been added yet
+	bool spec_skipped = false;                             // the run left out the retry launches (nobody needed them in the last batch): checked when it is waited for
+	bool force_full = false;
+	long long n_reruns = 0;
 	bool dirty = false;                                    // a run was cut short after some launches: `misc` is not known to be clear
 	int *report = nullptr;                                 // page-locked host block: the last run's counters, flags and stamps
 	int grid_ovf2 = 0, grid_ovf3 = 0, grid_ovf4 = 0;       // grids of the run-time overflow launches
@@ -1247,6 +1252,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	int *misc = b->misc.as<int>();
 	unsigned long long *tm = b->timing ? b->times_dev() : nullptr;
 	HIPC(hipEventRecord(b->ev[0], s));
+	bool spec_skipped_run = false;
 	if (b->R > 0) {
 		AsmArgs a;
 		a.n_regions = b->R;
@@ -1271,7 +1277,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.jobs = b->jobs.as<AlnJob>(); a.n_jobs = misc + M_NJOBS; a.work_counter = wq;
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.t_start = nullptr;
-		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_pm_dw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr; a.lpt_cnt = nullptr; a.lpt_seg = nullptr; a.lpt_stride = 0;
+		a.v2_pk = nullptr; a.v2_trim_lo = a.v2_trim_hi = nullptr; a.v2_read_bad = nullptr; a.v2_pdw = 0; a.v2_pm_dw = 0; a.v2_hand = nullptr; a.v2_hoff = nullptr; a.lpt_cnt = nullptr; a.lpt_seg = nullptr; a.lpt_stride = 0; a.lpt_nclass = 0;
 		// Passes 1-3: LDS arenas of growing size (falling occupancy); pass 4: HBM arena (catch-all).  Every region
 		// starts in the pass its read bases predict (classes built at upload): class 1 on the batch stream, classes
 		// 2-4 one after the other on a second stream beside it, so the long serial latency of the read-rich regions
@@ -1279,6 +1285,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		// forwarded at run time to the next pass's overflow list; those lists (empty on pile-ups like C2, well used
 		// when long reads with errors leave many single-read contigs) are processed after both streams have joined.
 		int *o2 = b->retry_list.as<int>(), *o3 = b->retry_list2.as<int>(), *o4 = b->retry_list3.as<int>();
+		bool spec_skip = false;
 		const int *cl = b->cls_list.as<int>(), *cn = b->cls_n.as<int>();
 		const int n1 = b->n_cls[0], n2 = b->n_cls[1], n3 = b->n_cls[2], n4 = b->n_cls[3];
 		hipStream_t s2 = b->stream2;
@@ -1334,7 +1341,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			ReadArgs ra;
 			ra.region_read_off = x.region_read_off; ra.read_off = x.read_off; ra.read_start = x.read_start; ra.mapq = x.mapq;
 			ra.read_skip = x.read_skip; ra.v2_read_bad = x.v2_read_bad; ra.v2_trim_lo = x.v2_trim_lo; ra.v2_trim_hi = x.v2_trim_hi;
-			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.min_overlap_pct = x.min_overlap_pct;
+			ra.v2_pk = x.v2_pk; ra.v2_hand = x.v2_hand; ra.v2_hoff = x.v2_hoff; ra.n_final = x.n_final; ra.min_overlap_pct = x.min_overlap_pct;
 			const bool lpt_on = g_knob.lpt != 0;                   // region order of the combine launch
 			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
 			ra.tier_a_cap = b->v2_arena; ra.tier_b_cap = b->v2_arena_b; ra.n_tier_b = misc + M_NTIERB;
@@ -1353,50 +1360,63 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			hipLaunchKernelGGL((k_asm_reads<8>), dim3(b->grid_v2r), dim3(64), 4 * b->v2_pdw, s, ra);
 			if (b->n_rich) HIPC(hipStreamWaitEvent(s, b->ev_rjoin, 0));
 			x.t_start = nullptr; x.work_counter = wq + 11 * WQ_WORDS; x.v2_pm_dw = b->v2_pm;
-			x.lpt_cnt = ra.lpt_cnt; x.lpt_seg = ra.lpt_seg; x.lpt_stride = ra.lpt_stride;
+			x.lpt_cnt = ra.lpt_cnt; x.lpt_seg = ra.lpt_seg; x.lpt_stride = ra.lpt_stride; x.lpt_nclass = LPT_CLASSES;
 			x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
-			// the second tier's regions (those whose contigs need more than the first arena; the read phase knows): the same kernel
-			// with a larger arena at half the occupancy, on the second stream beside the first tier's launch
+			// The regions by the arena their contigs need (the read phase knows): the first tier on this stream; the second
+			// (larger arena, about two thirds of the occupancy) on the second stream beside it; the third (the roomiest, the
+			// longest chains) on this stream in front of the first.  A tier the previous batch left empty gets no launch of its
+			// own -- an empty launch of workgroups that each ask for 25-60 KB of LDS still has to get every one of them
+			// scheduled, 0.05-0.3 ms on the critical path in front of k_ksw while another batch's kernels fill the CUs: the first
+			// tier's launch walks its lists behind its own instead (a straggler does not fit there and takes the retry route).
+			const bool hint = g_hint.valid.load() != 0 && !g_knob.no_hint;
+			const bool fold_c = hint && g_hint.n_c.load() == 0, fold_b = fold_c && g_hint.n_b.load() == 0;
 			HIPC(hipEventRecord(b->ev_bfork, s));
 			if (ra.lpt_cnt) {
-				HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
-				AsmArgs y = x;
-				y.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
-				y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
-				y.work_counter = wq + 13 * WQ_WORDS; y.corr = b->corr2.as<Corr>();
-				const bool hint = g_hint.valid.load() != 0 && !g_knob.no_hint;
-				const int token = 128;                                 // enough to get through a few stragglers; a batch unlike the last one is correct, only slower
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(hint && g_hint.n_b.load() == 0 ? std::min(b->grid_v2b, token) : b->grid_v2b), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
-				HIPC(hipEventRecord(b->ev_bjoin, s2));
-				// the third tier (the roomiest arena, the regions with the most to merge) first on this stream, the first tier behind it
-				AsmArgs z = x;
-				z.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; z.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
-				z.arena_cap = b->v2_arena_c; z.lds_arena = b->v2_arena_c; z.v2_pm_dw = b->v2_pm_c;
-				z.work_counter = wq + 16 * WQ_WORDS;
-				if (!(hint && g_hint.n_c.load() == 0))                 // (with regions to run it goes first: the roomiest arena holds the longest chains)
+				if (!fold_b) {
+					HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
+					AsmArgs y = x;
+					y.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
+					y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
+					y.work_counter = wq + 13 * WQ_WORDS;
+					const int gb = hint && g_hint.n_b.load() == 0 ? std::min(b->grid_v2b, 128) : b->grid_v2b;
+					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(gb), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
+					HIPC(hipEventRecord(b->ev_bjoin, s2));
+				} else HIPC(hipEventRecord(b->ev_bjoin, s));
+				if (!fold_c) {
+					AsmArgs z = x;
+					z.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; z.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
+					z.arena_cap = b->v2_arena_c; z.lds_arena = b->v2_arena_c; z.v2_pm_dw = b->v2_pm_c;
+					z.work_counter = wq + 16 * WQ_WORDS;
 					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2c), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
-				x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
-				if (hint && g_hint.n_c.load() == 0)
-					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(std::min(b->grid_v2c, token)), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
-			} else {
-				HIPC(hipEventRecord(b->ev_bjoin, s));
-				x.out_list = b->retry_listc.as<int>(); x.n_out = misc + M_NRETRYC;
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
-			}
-			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second tier)
-			// regions whose contigs did not fit that arena: the same kernel with a roomy one (few workgroups per CU)
+				}
+				x.lpt_nclass = LPT_CLASSES * (fold_b ? 3 : fold_c ? 2 : 1);
+			} else HIPC(hipEventRecord(b->ev_bjoin, s));
+			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second-tier launch)
+			// regions that ran out of room in their launch: the same kernel with a roomy arena, few workgroups per CU -- or, when
+			// the previous batch had none, a token launch with the first tier's arena (it gets scheduled at once; a region that
+			// does turn up is handed on to the byte-based passes)
 			x.in_list = b->retry_listc.as<int>(); x.n_in = misc + M_NRETRYC; x.out_list = b->retry_list0.as<int>(); x.n_out = misc + M_NRETRY0;
 			x.lpt_cnt = nullptr;
-			x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
 			x.work_counter = wq + 12 * WQ_WORDS;
-			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(g_hint.valid.load() && !g_knob.no_hint && g_hint.n_big.load() == 0 ? std::min(b->grid_v2big, 64) : b->grid_v2big),
-			                   dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
+			// The retry route -- the roomy launch, then the byte-based passes for what the packed path hands back -- is five
+			// launches that are empty for batch after batch, each waiting for wave slots while another batch's persistent grids
+			// fill the chip (0.2-0.4 ms in front of k_ksw).  When the last batch needed none of them they are left out, and
+			// whoever waits for this run checks the counters: a region that did need the route makes the run repeat in full.
+			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && g_hint.n_big.load() == 0 && g_hint.n_back.load() == 0;
+			if (!spec_skip) {
+			if (hint && g_hint.n_big.load() == 0) {
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(std::min(b->grid_v2big, 64)), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			} else {
+				x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
+				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
+			}
 			HIPC(hipGetLastError());
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = b->retry_list0.as<int>(); a.n_in = misc + M_NRETRY0; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
 			hipLaunchKernelGGL((k_assemble<64, true, 4>), dim3(b->grid_ovf1), dim3(64), b->lds_arena1, s, a);
 			HIPC(hipGetLastError());
+			}
 		} else if (n1) {
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;
 			a.in_list = cl; a.n_in = cn; a.out_list = o2; a.n_out = misc + M_NRETRY; a.work_counter = wq;
@@ -1406,10 +1426,13 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		}
 		a.t_start = nullptr;
 		if (side) HIPC(hipStreamWaitEvent(s, b->ev_join, 0));
-		pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>(), b->grid_ovf2);
-		pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>(), b->grid_ovf3);
-		pass4(a, s, o4, misc + M_NRETRY3, 6, b->corr.as<Corr>(), b->grid_ovf4);
+		if (!spec_skip) {
+			pass2(a, s, o2, misc + M_NRETRY, 4, b->corr.as<Corr>(), b->grid_ovf2);
+			pass3(a, s, o3, misc + M_NRETRY2, 5, b->corr.as<Corr>(), b->grid_ovf3);
+			pass4(a, s, o4, misc + M_NRETRY3, 6, b->corr.as<Corr>(), b->grid_ovf4);
+		}
 		HIPC(hipGetLastError());
+		spec_skipped_run = spec_skip;
 	}
 	HIPC(hipEventRecord(b->ev[1], s));
 	if (b->R > 0 && b->n_reads > 0) {
@@ -1501,6 +1524,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	}
 	HIPC(hipEventRecord(b->ev[4], s));
 	b->ran = true;
+	b->spec_skipped = spec_skipped_run;
 	b->acc_pending = b->timing;
 	b->dirty = false;                                      // k_summary is in the stream: it leaves `misc` clear for the next run
 	return 0;
@@ -1517,8 +1541,31 @@ static int report_overflow(const ihp_batch *b)
 	return 0;
 }
 
-// Waits for the batch's run; a pool that overflowed during it (CIGAR / event / hit pools, ksw2 scratch) is reported
-// here as IHP_E_CAPACITY, not only when the results are fetched.
+// Waits for the batch's run.  A run that left out the retry launches (see ihp_batch_run) is repeated in full when a region
+// turned out to need them: the counters in the report say so.
+static bool spec_failed(const ihp_batch *b)
+{
+	return b->ran && b->spec_skipped && (b->report[M_NRETRYC] > 0 || b->report[M_NRETRY0] > 0 || g_knob.spec_fail);
+}
+static int run_again_in_full(ihp_batch *b)
+{
+	b->force_full = true;
+	const int rc = ihp_batch_run(b);
+	b->force_full = false;
+	b->n_reruns++;
+	return rc;
+}
+static int finish_run(ihp_batch *b)
+{
+	HIPC(hipStreamSynchronize(b->stream));
+	if (spec_failed(b)) {
+		const int rc = run_again_in_full(b);
+		if (rc) return rc;
+		HIPC(hipStreamSynchronize(b->stream));
+	}
+	return 0;
+}
+
 static void stage_ms_from_report(const ihp_batch *b, float ms[4])
 {
 	unsigned long long t[8];
@@ -1532,11 +1579,13 @@ static void stage_ms_from_report(const ihp_batch *b, float ms[4])
 	}
 }
 
+// Waits for the batch's run; a pool that overflowed during it (CIGAR / event / hit pools, ksw2 scratch) is reported
+// here as IHP_E_CAPACITY, not only when the results are fetched.
 extern "C" int ihp_batch_sync(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
-	HIPC(hipStreamSynchronize(b->stream));
+	{ int rc1 = finish_run(b); if (rc1) return rc1; }
 	if (b->ran && b->acc_pending && b->R > 0) {
 		// the run's stamps are in the report page (host memory): adding them up here costs no HIP call, so a caller can time
 		// every run of a loop without reading anything inside it
@@ -1547,7 +1596,8 @@ extern "C" int ihp_batch_sync(ihp_batch *b)
 		b->acc_pending = false;
 	}
 	if (b->ran && b->R > 0 && b->v2 && g_knob.lpt) {
-		g_hint.n_b = b->report[M_NTIERB]; g_hint.n_c = b->report[M_NTIERC]; g_hint.n_big = b->report[M_NRETRYC]; g_hint.valid = 1;
+		g_hint.n_b = b->report[M_NTIERB]; g_hint.n_c = b->report[M_NTIERC]; g_hint.n_big = b->report[M_NRETRYC];
+		g_hint.n_back = b->report[M_NRETRY0]; g_hint.valid = 1;
 	}
 	if (b->ran && b->R > 0) return report_overflow(b);
 	return 0;
@@ -1580,7 +1630,7 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64])
 	if (!b || !out) return IHP_E_ARG;
 	if (!b->ran || !b->work_live) return IHP_E_ARG;           // no run yet, or its scratch went back to the pool (ihp_batch_release_outputs)
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
-	HIPC(hipStreamSynchronize(b->stream));
+	{ int rc1 = finish_run(b); if (rc1) return rc1; }
 	HIPC(hipMemcpy(out, b->prof.p, sizeof(long long) * 64, hipMemcpyDeviceToHost));
 	out[24] = b->report[M_NRETRY];                    // regions forwarded at run time to the second pass's overflow list
 	out[25] = b->report[M_NRETRY2];                   // ... to the third pass's
@@ -1590,6 +1640,8 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64])
 	out[28] = b->report[M_NRETRYC];                   // regions whose contigs needed the roomy combine launch
 	out[29] = b->report[M_NTIERB];                    // regions the read phase filed under the second (larger-arena) combine launch
 	out[30] = b->report[M_NTIERC];                    // ... and under the third
+	out[31] = b->n_reruns;                            // runs of this batch repeated in full because a run without the retry launches met a region that needed them
+	out[21] = b->spec_skipped ? 1 : 0;                // the last run left the retry launches out
 	return 0;
 }
 
@@ -1607,7 +1659,7 @@ extern "C" int ihp_batch_kernel_ms(ihp_batch *b, float ms[4])
 {
 	if (!b || !b->ran || !b->timing || !ms) return IHP_E_ARG;
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
-	HIPC(hipStreamSynchronize(b->stream));
+	{ int rc1 = finish_run(b); if (rc1) return rc1; }
 	stage_ms_from_report(b, ms);
 	return 0;
 }
@@ -1632,7 +1684,7 @@ extern "C" int ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int
 {
 	if (!b || !b->ran || (!out && b->R) || cap < b->R) return IHP_E_ARG;
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
-	HIPC(hipStreamSynchronize(b->stream));
+	{ int rc1 = finish_run(b); if (rc1) return rc1; }
 	if (b->R) HIPC(hipMemcpy(out, b->summary.p, sizeof(ihp_region_summary) * (size_t)b->R, hipMemcpyDeviceToHost));
 	return 0;
 }
@@ -1785,6 +1837,10 @@ extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, 
 	long long tot[5];
 	for (int k = 0; k < 5; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
 	HIPC(hipStreamSynchronize(s));
+	if (spec_failed(b)) {                                       // the run left the retry launches out and a region needed them (ihp_batch_run)
+		const int rc = run_again_in_full(b);
+		return rc ? rc : ihp_batch_pack_dev(b, dev_ptr, bytes, counts);
+	}
 	if (R > 0) { const int rc = report_overflow(b); if (rc) return rc; }
 	// IHP_FETCH_NO_BASES: the contigs' bases and supports stay on the device (ctg_seq_off still tells the lengths)
 	const bool no_bases = (b->fetch_flags & IHP_FETCH_NO_BASES) != 0;

@@ -43,8 +43,8 @@ struct AsmArgs {
 	int v2_pdw;                                        // dwords of the per-wave packed area in LDS (k_asm_reads)
 	int v2_pm_dw;                                      // dwords of the packed mirror behind the byte arena (k_asm_combine)
 	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine: region r at v2_hand + v2_hoff[r]
-	const int *lpt_cnt, *lpt_seg; int lpt_stride;      // k_asm_combine: its regions by cost class (asm2_dev.h lpt_class; the LPT_CLASSES counters and
-	                                                   // list segments of this launch's tier), or null
+	const int *lpt_cnt, *lpt_seg; int lpt_stride;      // k_asm_combine3: its regions by cost class (asm2_dev.h lpt_class; the counters and list
+	int lpt_nclass;                                    // segments of this launch's tier -- or tiers: lpt_nclass of them, laid end to end), or null
 };
 
 }  // namespace ihp
@@ -436,17 +436,17 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		int nc = 0, need = 0;
 		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr, nc, need);
 		if (err) {                                             // not for this path: the byte-based passes take it
-			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.out_list[atomicAdd(a.n_out, 1)] = r; }
+			// (n_final = 0: the launches that take the list may have been left out of this run -- ihp_batch_run -- and k_summary walks n_final contigs)
+			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 		} else if (a.lpt_cnt && lane == 0) {
-			const int tier = need <= a.tier_a_cap ? 0 : need <= a.tier_b_cap ? 1 : 2;
+			// the tiers in memory: first, third, second (the first tier's launch can then walk the third's lists, or all, behind its own)
+			const int tier = need <= a.tier_a_cap ? 0 : need <= a.tier_b_cap ? 2 : 1;
 			const int c = lpt_class(nc) + tier * LPT_CLASSES;
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
-			if (tier) atomicAdd(a.n_tier_b + (tier - 1), 1);
-			if (a.prof) {                                          // diagnostics: what the regions ask of the combine arena
+			if (tier) atomicAdd(a.n_tier_b + (tier == 2 ? 0 : 1), 1);
+			if (a.prof) {                                          // what the regions ask of the combine arena: sum and maximum of the capacity units
 				atomicAdd((unsigned long long *)&a.prof[62], (unsigned long long)need);
 				atomicMax((unsigned long long *)&a.prof[63], (unsigned long long)need);
-				atomicAdd((unsigned long long *)&a.prof[20 + 0], 0ull);
-				atomicAdd((unsigned long long *)&a.prof[24 + (need <= 6144 ? 0 : need <= 8192 ? 1 : need <= 10240 ? 2 : need <= 12288 ? 3 : need <= 16384 ? 4 : 5)], 1ull);
 			}
 		}
 		WSYNC();
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 	int n_items = a.in_list ? *a.n_in : a.n_regions;
 	if (a.lpt_cnt) {
 		n_items = 0;
-		for (int c = 0; c < LPT_CLASSES; ++c) n_items += uni(a.lpt_cnt[c]);
+		for (int c = 0; c < a.lpt_nclass; ++c) n_items += uni(a.lpt_cnt[c]);
 	}
 	unsigned wq_dead = 0;
 	for (;;) {
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 		if (r < 0) break;
 		if (a.lpt_cnt) {                                        // item -> (class, position): the classes laid end to end
 			int c = 0;
-			for (; c < LPT_CLASSES - 1; ++c) { const int nc_ = uni(a.lpt_cnt[c]); if (r < nc_) break; r -= nc_; }
+			for (; c < a.lpt_nclass - 1; ++c) { const int nc_ = uni(a.lpt_cnt[c]); if (r < nc_) break; r -= nc_; }
 			r = uni(a.lpt_seg[(size_t)c * a.lpt_stride + r]);
 		} else if (a.in_list) r = a.in_list[r];
 		int n_pre = 0, n_final = 0;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 		}
 		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[1] += (long long)clock64() - tcA; S.prof[3] += 1; }
 		if (err == IHP_E_CAPACITY && a.out_list) {             // not here: the next, roomier launch (or the byte-based passes) take it
-			if (lane == 0) a.out_list[atomicAdd(a.n_out, 1)] = r;
+			if (lane == 0) { a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 			continue;
 		}
 		region_epilogue3(a, S, C, r, err, n_pre, n_final);

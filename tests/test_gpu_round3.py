@@ -195,3 +195,39 @@ def test_slab_upload_with_4bit_bases_gives_the_same_results(hip, shaped, oracle)
                   "aln_ref_len", "aln_ez", "cigar_off", "cigar", "event_off", "hit_off", "ref_hit", "alt_hit"):
             assert np.array_equal(getattr(lean, f), getattr(got, f)), f
         assert np.array_equal(lean.events, got.events)
+
+
+def test_a_run_without_the_retry_launches_is_checked_and_repeated(hip, shaped, oracle):
+    """ihp_batch_run leaves the roomy combine launch and the byte-based overflow passes out when the previous batch needed
+    none of them; the wait (sync / fetch / summary) looks at the run's counters and repeats the run in full if a region did."""
+    clean, _ = synth.generate(64, n_reads=(30, 40), err_rate=0.0, config_id=9)
+    exp_clean = oracle.run_regions(clean)
+    mixed = [x for x in shaped if x[0] == "mixed"][0]
+    try:
+        for how in ("fetch", "sync", "summary"):
+            h = hip.batch_upload(clean)                         # leaves the hint "nothing needed the retry route"
+            hip.batch_run(h); hip.batch_sync(h)
+            assert_same(hip.batch_fetch(h), exp_clean)
+            hip.batch_free(h)
+            h = hip.batch_upload(mixed[2], hip.params(K=mixed[1]))
+            try:
+                hip.batch_run(h)
+                if how == "sync":
+                    hip.batch_sync(h)
+                elif how == "summary":
+                    from indelope_amd.dist import summaries_from_result
+                    rec = hip.batch_summary_host(h, mixed[2].n_regions)
+                    assert np.array_equal(rec, summaries_from_result(mixed[3]))
+                prof = hip.batch_profile(h)
+                assert prof[23] > 0 and prof[31] == 1 and prof[21] == 0, (how, prof[20:32])   # lower case / N reads leave the packed path
+                assert_same(hip.batch_fetch(h), mixed[3])
+            finally:
+                hip.batch_free(h)
+        # the test hook: every run that left the launches out is repeated; results are the same, and so with the switch off
+        for kn in (dict(spec_fail=1), dict(no_spec=1)):
+            hip.debug_set(**kn)
+            for _ in range(2):
+                assert_same(hip.run_regions(clean), exp_clean)
+            hip.debug_set()
+    finally:
+        hip.debug_set()
