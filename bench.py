@@ -153,48 +153,65 @@ def cpu_baseline(batch, K, want_seconds=16.0):
 
 
 # ------------------------------------------------------------------------------------------------------ e2e
-def e2e_rates(api, batch, params, threads=3, reps=5):
+def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
     """Host buffers in -> host buffers out through the C ABI, PCIe included (never `value`).
     `slab`: what a stager written for this library hands over -- ONE page-locked slab per batch (ihp_slab_layout: 4-bit
     bases as BAM stores them, trim bounds), uploaded with a single copy; results fetched without the contigs' bases and
     supports (IHP_FETCH_NO_BASES: events, k-mer counts, CIGARs, alignment records) or in full.  `threads` host threads
-    each drive batches of their own (every batch has its own stream), so upload(k+1), run(k) and fetch(k-1) overlap.
+    each keep `depth` batches of their own in flight (ihp_batch_upload_slab and ihp_batch_run only enqueue: a thread
+    starts batch k+1 before it waits for and fetches batch k), so uploads, runs and fetches of different batches overlap.
     `arrays`: the separate pageable ASCII arrays of ihp_batch_in through ihp_run_regions (round 2's leg)."""
     import ctypes as C
     import threading
     from indelope_amd import _abi as A
 
-    def one(slab, no_bases):
-        t0 = time.perf_counter()
+    def start(slab, no_bases):
         h = api.batch_upload_slab(slab, params)
-        t1 = time.perf_counter()
+        api.batch_set_fetch(h, no_bases=no_bases, eager=True)
         api.batch_run(h)
+        return h
+
+    def finish(h, no_bases):
         api.batch_sync(h)
         t2 = time.perf_counter()
-        api.batch_set_fetch(h, no_bases=no_bases)
         out = A.BatchOut()
         rc = api.b.batch_fetch(h, C.byref(out))              # device pack + one copy + genotype(): the C call alone
         assert rc == 0, rc
         t3 = time.perf_counter()
         api.b.free_out(C.byref(out))
         api.batch_free(h)
+        return t2, t3
+
+    def one(slab, no_bases):
+        t0 = time.perf_counter()
+        h = api.batch_upload_slab(slab, params)
+        api.batch_sync(h)                                    # the copy alone (the call itself only enqueues it)
+        t1 = time.perf_counter()
+        api.batch_set_fetch(h, no_bases=no_bases, eager=True)
+        api.batch_run(h)
+        t2, t3 = finish(h, no_bases)
         return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
 
-    slabs = [api.make_slab(batch) for _ in range(threads)]
+    slabs = [[api.make_slab(batch) for _ in range(depth)] for _ in range(threads)]
     try:
         res = {}
         for name, nb in (("events_only", True), ("full", False)):
-            t = np.array([one(slabs[0], nb) for _ in range(reps + 1)][1:]) * 1e3
+            t = np.array([one(slabs[0][0], nb) for _ in range(reps + 1)][1:]) * 1e3
             med = np.median(t, axis=0)
-            n_each = max(4, reps * 2)
+            n_each = max(12, reps * 4)
 
             gate = threading.Barrier(threads + 1)
 
             def worker(k, nb=nb):
-                one(slabs[k], nb)                                # untimed: this thread's buffers come out of the pools from here on
+                finish(start(slabs[k][0], nb), nb)                   # untimed: this thread's buffers come out of the pools from here on
                 gate.wait()
-                for _ in range(n_each):
-                    one(slabs[k], nb)
+                q = []
+                for i in range(n_each):
+                    q.append(start(slabs[k][i % depth], nb))         # a slab is reused only after its batch has been fetched
+                    if len(q) == depth:
+                        finish(q.pop(0), nb)
+                while q:
+                    finish(q.pop(0), nb)
             th = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
             for x in th:
                 x.start()
@@ -205,13 +222,14 @@ def e2e_rates(api, batch, params, threads=3, reps=5):
             dt = time.perf_counter() - t0
             res[name] = {"one_batch_ms": {k: round(float(v), 3) for k, v in zip(("upload", "run", "fetch", "total"), med)},
                          "one_batch_regions_per_s": round(batch.n_regions / (med[3] * 1e-3), 1),
-                         "sustained": {"threads": threads, "batches": n_each * threads,
+                         "sustained": {"threads": threads, "in_flight_per_thread": depth, "batches": n_each * threads,
                                        "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
                                        "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)}}
-        slab_bytes = int(slabs[0].layout.bytes)
+        slab_bytes = int(slabs[0][0].layout.bytes)
     finally:
-        for sl in slabs:
-            sl.free()
+        for row in slabs:
+            for sl in row:
+                sl.free()
     # round 2's leg for comparison: separate pageable arrays, ASCII bases, full results
     n_each = max(3, reps)
 

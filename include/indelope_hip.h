@@ -427,6 +427,10 @@ int  ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_rea
  * supports (n_bases = 0; ctg_seq_off still holds the lengths) -- events, k-mer counts, CIGARs, alignment records and the
  * contig directory, a tenth of the bytes; a later fetch with flags 0 brings the bases of the same run.               */
 #define IHP_FETCH_NO_BASES 1
+/* IHP_FETCH_EAGER: every ihp_batch_run from now on also counts what its results will take (two small kernels behind the
+ * last stage, totals into page-locked memory), so that the fetch after it is one enqueue (compaction + copy) and one wait
+ * instead of three round trips -- for callers that fetch every run (a sweep); leave it off for runs nobody fetches.      */
+#define IHP_FETCH_EAGER 2
 int  ihp_batch_set_fetch(ihp_batch *b, int32_t flags);
 /* Hand the batch's scratch and result buffers back to the device pool; its inputs and the per-region summary
  * records (ihp_batch_summary_dev) stay.  For callers that walk through more regions than one GPU holds results for

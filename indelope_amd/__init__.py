@@ -63,8 +63,9 @@ class HipApi(Api):
                                                C.byref(h)), "batch_upload_slab")
         return h
 
-    def batch_set_fetch(self, h, no_bases=False):
-        self._chk_hip(self.b.batch_set_fetch(h, _abi.IHP_FETCH_NO_BASES if no_bases else 0), "batch_set_fetch")
+    def batch_set_fetch(self, h, no_bases=False, eager=False):
+        fl = (_abi.IHP_FETCH_NO_BASES if no_bases else 0) | (_abi.IHP_FETCH_EAGER if eager else 0)
+        self._chk_hip(self.b.batch_set_fetch(h, fl), "batch_set_fetch")
 
     def batch_run(self, h):
         self._chk_hip(self.b.batch_run(h), "batch_run")

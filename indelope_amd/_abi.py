@@ -98,7 +98,7 @@ class SlabLayout(C.Structure):        # ihp_slab_layout
                                           "trim_lo", "trim_hi", "mapq", "read_skip", "ref_bases", "bases4", "bytes")]
 
 
-IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES = 1, 1
+IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES, IHP_FETCH_EAGER = 1, 1, 2
 
 
 class Event(C.Structure):

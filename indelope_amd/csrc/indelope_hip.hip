@@ -156,6 +156,7 @@ StreamCache g_streams;
 // A run's counters, overflow flags and stamps are left by its last kernel in a 256-byte block of page-locked host
 // memory (k_summary writes it over PCIe), so that ihp_batch_sync / fetch / profile read them without a device copy.
 constexpr int REPORT_INTS = 64;
+constexpr int REPORT_BLOCK = 128;                            // ints per block: the report, then the five totals of k_pack_scan (int64 each, from int 64)
 struct ReportPool {
 	std::mutex mu;
 	std::vector<int *> free_list, pages;
@@ -165,10 +166,10 @@ struct ReportPool {
 			void *pg = nullptr;
 			if (hipHostMalloc(&pg, 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
 			pages.push_back((int *)pg);
-			for (int k = 0; k < 4096 / (int)(sizeof(int) * REPORT_INTS); ++k) free_list.push_back((int *)pg + k * REPORT_INTS);
+			for (int k = 0; k < 4096 / (int)(sizeof(int) * REPORT_BLOCK); ++k) free_list.push_back((int *)pg + k * REPORT_BLOCK);
 		}
 		int *r = free_list.back(); free_list.pop_back();
-		memset(r, 0, sizeof(int) * REPORT_INTS);
+		memset(r, 0, sizeof(int) * REPORT_BLOCK);
 		return r;
 	}
 	void put(int *r) { std::lock_guard<std::mutex> l(mu); free_list.push_back(r); }
@@ -181,6 +182,51 @@ struct ReportPool {
 	}
 };
 ReportPool g_reports;
+
+// Page-locked host slabs (results of ihp_batch_fetch, staging blocks of ihp_batch_upload*): pinning is expensive, so freed
+// slabs are kept and reused.  64-byte header + payload.
+struct SlabHdr { uint64_t magic; size_t cap; uint64_t pad[6]; };
+static_assert(sizeof(SlabHdr) == 64, "slab header");
+constexpr uint64_t SLAB_MAGIC = 0x49485053'4c414231ull;
+struct SlabCache {
+	std::mutex mu;
+	std::vector<std::pair<void *, size_t>> free_list;      // (base, capacity)
+	void *get(size_t bytes) {
+		{
+			std::lock_guard<std::mutex> l(mu);
+			int best = -1;
+			for (int i = 0; i < (int)free_list.size(); ++i)
+				if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = i;
+			if (best >= 0 && free_list[best].second <= 4 * bytes + (1u << 20)) {
+				void *p = free_list[best].first;
+				free_list.erase(free_list.begin() + best);
+				return p;
+			}
+		}
+		const size_t cap = bytes + bytes / 4 + 4096;
+		void *p = nullptr;
+		if (hipHostMalloc(&p, cap + sizeof(SlabHdr), hipHostMallocDefault) != hipSuccess) return nullptr;
+		SlabHdr *h = (SlabHdr *)p;
+		h->magic = SLAB_MAGIC; h->cap = cap;
+		return p;
+	}
+	void put(void *base) {
+		std::lock_guard<std::mutex> l(mu);
+		free_list.push_back({base, ((SlabHdr *)base)->cap});
+		while (free_list.size() > 24) {                      // keep some (result slabs and staging blocks of the batches in flight); drop the smallest
+			int w = 0;
+			for (int i = 1; i < (int)free_list.size(); ++i) if (free_list[i].second < free_list[w].second) w = i;
+			(void)hipHostFree(free_list[w].first);
+			free_list.erase(free_list.begin() + w);
+		}
+	}
+	void clear() {
+		std::lock_guard<std::mutex> l(mu);
+		for (auto &e : free_list) (void)hipHostFree(e.first);
+		free_list.clear();
+	}
+};
+SlabCache g_slabs;
 
 // device buffer; returned to the pool on scope exit / batch free
 struct DBuf {
@@ -756,7 +802,8 @@ struct ihp_batch {
 	// scratch
 	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
 	int grid_retry = 0, grid_asm2 = 0, grid_asm3 = 0, lds_arena1 = 0, lds_arena2 = 0, lds_arena3 = 0;
-	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n;
+	DBuf lds_sup3, retry_list3, corr2, cls_list, cls_n, aux;
+	void *aux_host = nullptr;                              // page-locked staging block of `aux` (from the slab cache)
 	// packed read phase (asm2_dev.h): per-read outputs of k_prepack (they persist with the inputs) and the pass's sizes
 	DBuf v2_pk, v2_trim_lo, v2_trim_hi, v2_read_bad, retry_list0, v2_hoff, v2_hand, lpt_seg;
 	bool v2 = false; int v2_arena = 0, v2_pdw = 0, v2_pm = 0, v2_arena_big = 0, v2_pm_big = 0, v2_arena_b = 0, v2_pm_b = 0, v2_arena_c = 0, v2_pm_c = 0, grid_v2c = 0, grid_v2 = 0, grid_v2b = 0, grid_v2r = 0, grid_v2big = 0, grid_pack = 0, grid_ovf1 = 0;
@@ -797,6 +844,7 @@ struct ihp_batch {
 	bool acc_pending = false;                              // the last run's stamps have not been added yet
 	bool spec_skipped = false;                             // the run left out the retry launches (nobody needed them in the last batch): checked when it is waited for
 	bool force_full = false;
+	bool counted = false;                                  // k_pack_count / k_pack_scan of the last run are enqueued (or done)
 	long long n_reruns = 0;
 	bool dirty = false;                                    // a run was cut short after some launches: `misc` is not known to be clear
 	int *report = nullptr;                                 // page-locked host block: the last run's counters, flags and stamps
@@ -808,6 +856,7 @@ struct ihp_batch {
 		if (stream) { (void)hipStreamSynchronize(stream); g_streams.put(stream); }
 		// only now can the report slot be handed to another batch: a run in flight would still write its counters there
 		if (report) g_reports.put(report);
+		if (aux_host) g_slabs.put(aux_host);
 		g_live_batches.fetch_sub(1);
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		if (ev_join) (void)hipEventDestroy(ev_join);
@@ -959,6 +1008,9 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	b->stream2 = g_streams.get();
 	if (!b->stream || !b->stream2) { delete b; snprintf(g.err, sizeof(g.err), "hipStreamCreate failed"); return IHP_E_HIP; }
 	hipStream_t s = b->stream;
+	std::vector<int> order;                                  // regions by assembly class (cls_list), class sizes (cls_n), hand-over record offsets
+	std::vector<long long> hoff;                             // (v2_hoff): staged in one page-locked block, one copy (see `aux` below)
+	int cn_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define UP(buf, ptr, bytes) do { if ((rc = b->buf.upload(ptr, (size_t)(bytes), s))) { delete b; return rc; } } while (0)
 	b->has_trim = in->trim_lo != nullptr && in->trim_hi != nullptr;     // trim() done by the stager: qualities not needed
 	b->has_quals = in->quals != nullptr && !b->has_trim; b->has_skip = in->read_skip != nullptr;
@@ -1047,7 +1099,6 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			if (k > 0 && packed_ok && rro[r + 1] - rro[r] <= 256 && nb <= 120000) rich.push_back({-nb, r});
 			else cls[k].push_back({-nb, r});
 		}
-		std::vector<int> order;
 		order.reserve((size_t)R);
 		std::sort(rich.begin(), rich.end());
 		for (int k = 0; k < 4; ++k) {
@@ -1056,10 +1107,8 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			for (auto &e : cls[k]) order.push_back(e.second);
 			if (k == 0) { for (auto &e : rich) order.push_back(e.second); b->n_small = b->n_cls[0]; b->n_rich = (int)rich.size(); b->n_cls[0] += b->n_rich; }
 		}
-		const int cn_host[6] = {b->n_cls[0], b->n_cls[1], b->n_cls[2], b->n_cls[3], b->n_small, b->n_rich};
-		if ((rc = b->cls_list.upload(order.data(), sizeof(int) * (size_t)R, s))) { delete b; return rc; }
-		if ((rc = b->cls_n.upload(cn_host, sizeof(cn_host), s))) { delete b; return rc; }
-		HIPB(hipStreamSynchronize(s));                         // `order` goes out of scope
+		const int cn6[6] = {b->n_cls[0], b->n_cls[1], b->n_cls[2], b->n_cls[3], b->n_small, b->n_rich};
+		memcpy(cn_host, cn6, sizeof(cn6));
 	}
 	b->grid_asm = std::min(b->grid_asm, std::max(1, b->n_cls[0]));
 	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
@@ -1138,14 +1187,12 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 					b->grid_v2r_rich = std::min(grid_for(R, occL), b->n_rich);
 				}
 				// hand-over records between the two kernels: 8 + 9 min(64, reads) + reads + bases / 16 + 8 dwords per region
-				std::vector<long long> hoff((size_t)R + 1, 0);
+				hoff.assign((size_t)R + 1, 0);
 				for (int r = 0; r < R; ++r) {
 					const long long nr = rro[r + 1] - rro[r], nb = ro[rro[r + 1]] - ro[rro[r]];
 					hoff[(size_t)r + 1] = hoff[(size_t)r] + ((16 + 9 * std::min<long long>(64, nr) + nr + nb / 16 + 3) / 4 * 4);
 				}
 				b->v2_hand_dwords = hoff[(size_t)R];
-				if ((rc = b->v2_hoff.upload(hoff.data(), sizeof(long long) * ((size_t)R + 1), s))) { delete b; return rc; }
-				HIPB(hipStreamSynchronize(s));
 			}
 		}
 	}
@@ -1219,6 +1266,22 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		if ((rc = b->v2_pk.alloc(sizeof(uint32_t) * (size_t)((b->n_bases >> 4) + NR + 4))) || (rc = b->v2_trim_lo.alloc(sizeof(int) * (size_t)NR)) ||
 		    (rc = b->v2_trim_hi.alloc(sizeof(int) * (size_t)NR)) || (rc = b->v2_read_bad.alloc((size_t)NR))) { delete b; return rc; }
 	}
+	{
+		// the small arrays built above travel in one copy from a page-locked block the batch keeps until it is freed:
+		// no wait in here for a copy out of a local
+		const size_t o_cn = ((size_t)R * sizeof(int) + 63) / 64 * 64, o_hoff = o_cn + 64;
+		const size_t total = o_hoff + (hoff.empty() ? 0 : sizeof(long long) * hoff.size());
+		b->aux_host = g_slabs.get(total);
+		if (!b->aux_host) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of %zu bytes failed", total); return IHP_E_NOMEM; }
+		char *h = (char *)b->aux_host + sizeof(SlabHdr);
+		if (R) memcpy(h, order.data(), sizeof(int) * (size_t)R);
+		memcpy(h + o_cn, cn_host, sizeof(cn_host));
+		if (!hoff.empty()) memcpy(h + o_hoff, hoff.data(), sizeof(long long) * hoff.size());
+		if ((rc = b->aux.alloc(total))) { delete b; return rc; }
+		HIPB(hipMemcpyAsync(b->aux.p, h, total, hipMemcpyHostToDevice, s));
+		b->cls_list.view(b->aux.p, 0, sizeof(int) * (size_t)R); b->cls_n.view(b->aux.p, o_cn, sizeof(cn_host));
+		if (!hoff.empty()) b->v2_hoff.view(b->aux.p, o_hoff, sizeof(long long) * hoff.size());
+	}
 	if ((rc = alloc_work(b))) { delete b; return rc; }
 	for (auto &e : b->ev) HIPB(hipEventCreate(&e));
 	HIPB(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1230,11 +1293,15 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	b->report = g_reports.get();
 	if (!b->report) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of the report page failed"); return IHP_E_NOMEM; }
 	HIPB(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // the only memset of the batch's life (see ihp_batch::misc)
-	HIPB(hipStreamSynchronize(s));
+	// separate arrays may change once this returns; a slab stays as it is until a wait for the batch has returned
+	// (ihp_batch_sync, fetch, ...: see ihp_batch_upload_slab in the header), so its copy is left in flight
+	if (!slab) HIPB(hipStreamSynchronize(s));
 #undef HIPB
 	*bout = b;
 	return 0;
 }
+
+static int pack_counts_enqueue(ihp_batch *b);
 
 extern "C" int ihp_batch_run(ihp_batch *b)
 {
@@ -1524,6 +1591,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	}
 	HIPC(hipEventRecord(b->ev[4], s));
 	b->ran = true;
+	b->counted = false;
+	if (b->fetch_flags & IHP_FETCH_EAGER) { const int rcp = pack_counts_enqueue(b); if (rcp) return rcp; }
 	b->spec_skipped = spec_skipped_run;
 	b->acc_pending = b->timing;
 	b->dirty = false;                                      // k_summary is in the stream: it leaves `misc` clear for the next run
@@ -1693,7 +1762,7 @@ extern "C" void ihp_batch_free(ihp_batch *b) { delete b; }
 
 extern "C" int ihp_batch_set_fetch(ihp_batch *b, int32_t flags)
 {
-	if (!b || (flags & ~IHP_FETCH_NO_BASES)) return IHP_E_ARG;
+	if (!b || (flags & ~(IHP_FETCH_NO_BASES | IHP_FETCH_EAGER))) return IHP_E_ARG;
 	b->fetch_flags = flags;
 	return 0;
 }
@@ -1717,48 +1786,6 @@ extern "C" int ihp_batch_release_outputs(ihp_batch *b)
 // the packed device results arrive in a single hipMemcpy at PCIe rate.  Pinning is expensive, so freed slabs
 // are kept and reused by later fetches.
 namespace {
-struct SlabHdr { uint64_t magic; size_t cap; uint64_t pad[6]; };
-static_assert(sizeof(SlabHdr) == 64, "slab header");
-constexpr uint64_t SLAB_MAGIC = 0x49485053'4c414231ull;
-struct SlabCache {
-	std::mutex mu;
-	std::vector<std::pair<void *, size_t>> free_list;      // (base, capacity)
-	void *get(size_t bytes) {
-		{
-			std::lock_guard<std::mutex> l(mu);
-			int best = -1;
-			for (int i = 0; i < (int)free_list.size(); ++i)
-				if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = i;
-			if (best >= 0 && free_list[best].second <= 4 * bytes + (1u << 20)) {
-				void *p = free_list[best].first;
-				free_list.erase(free_list.begin() + best);
-				return p;
-			}
-		}
-		const size_t cap = bytes + bytes / 4 + 4096;
-		void *p = nullptr;
-		if (hipHostMalloc(&p, cap + sizeof(SlabHdr), hipHostMallocDefault) != hipSuccess) return nullptr;
-		SlabHdr *h = (SlabHdr *)p;
-		h->magic = SLAB_MAGIC; h->cap = cap;
-		return p;
-	}
-	void put(void *base) {
-		std::lock_guard<std::mutex> l(mu);
-		free_list.push_back({base, ((SlabHdr *)base)->cap});
-		while (free_list.size() > 4) {                       // keep a few; drop the smallest
-			int w = 0;
-			for (int i = 1; i < (int)free_list.size(); ++i) if (free_list[i].second < free_list[w].second) w = i;
-			(void)hipHostFree(free_list[w].first);
-			free_list.erase(free_list.begin() + w);
-		}
-	}
-	void clear() {
-		std::lock_guard<std::mutex> l(mu);
-		for (auto &e : free_list) (void)hipHostFree(e.first);
-		free_list.clear();
-	}
-};
-SlabCache g_slabs;
 
 // section offsets of the flat result arrays inside a slab (the same on the device and on the host)
 struct OutLayout {
@@ -1813,12 +1840,10 @@ static void carve_out(char *host, const OutLayout &L, long long R, long long C, 
 	}
 }
 
-// Results compacted on the device into one slab (k_pack_count -> k_pack_scan -> k_pack); nothing is copied to the host
-// except the six counts that define the layout.  The slab stays valid until the batch runs, packs or is freed again.
-extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6])
+// k_pack_count + k_pack_scan on the batch's stream: per-region counts -> prefix sums; the five totals land in the page-locked
+// report block (no copy).  Enqueued by ihp_batch_run itself under IHP_FETCH_EAGER, otherwise by the first pack / fetch.
+static int pack_counts_enqueue(ihp_batch *b)
 {
-	if (!b || !b->ran || !dev_ptr || !bytes || !counts) return IHP_E_ARG;
-	{ int rc0 = ensure_init(); if (rc0) return rc0; }
 	const int R = b->R;
 	hipStream_t s = b->stream;
 	const size_t S = (size_t)R + 1;
@@ -1832,15 +1857,31 @@ extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, 
 		hipLaunchKernelGGL(k_pack_count, dim3((R + 255) / 256), dim3(256), 0, s, a);
 		HIPC(hipGetLastError());
 	}
-	hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, R, cnt);
+	hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, R, cnt, (long long *)(b->report + REPORT_INTS));
 	HIPC(hipGetLastError());
-	long long tot[5];
-	for (int k = 0; k < 5; ++k) HIPC(hipMemcpyAsync(&tot[k], cnt + k * S + R, sizeof(long long), hipMemcpyDeviceToHost, s));
-	HIPC(hipStreamSynchronize(s));
-	if (spec_failed(b)) {                                       // the run left the retry launches out and a region needed them (ihp_batch_run)
+	b->counted = true;
+	return 0;
+}
+
+// Results compacted on the device into one slab (k_pack_count -> k_pack_scan -> k_pack); nothing is copied to the host
+// except the totals that define the layout.  k_pack is left in flight on the batch's stream (the callers wait).
+static int pack_enqueue(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6])
+{
+	if (!b->work_live) return IHP_E_ARG;                      // the results went back to the pool (ihp_batch_release_outputs)
+	const int R = b->R;
+	hipStream_t s = b->stream;
+	for (;;) {
+		if (!b->counted) { const int rc = pack_counts_enqueue(b); if (rc) return rc; }
+		HIPC(hipStreamSynchronize(s));
+		if (!spec_failed(b)) break;
+		// the run left the retry launches out and a region needed them (ihp_batch_run): again in full, then count again
 		const int rc = run_again_in_full(b);
-		return rc ? rc : ihp_batch_pack_dev(b, dev_ptr, bytes, counts);
+		if (rc) return rc;
 	}
+	const volatile long long *tot_h = (const volatile long long *)(b->report + REPORT_INTS);
+	long long tot[5];
+	for (int k = 0; k < 5; ++k) tot[k] = tot_h[k];
+	long long *cnt = b->pack_cnt.as<long long>();
 	if (R > 0) { const int rc = report_overflow(b); if (rc) return rc; }
 	// IHP_FETCH_NO_BASES: the contigs' bases and supports stay on the device (ctg_seq_off still tells the lengths)
 	const bool no_bases = (b->fetch_flags & IHP_FETCH_NO_BASES) != 0;
@@ -1873,9 +1914,19 @@ extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, 
 	a.o_event_off = (int64_t *)(dev + L.event_off); a.o_events = (ihp_event *)(dev + L.events);
 	hipLaunchKernelGGL(k_pack, dim3(grid_for(R + 1, 16)), dim3(64), 0, s, a);
 	HIPC(hipGetLastError());
-	HIPC(hipStreamSynchronize(s));
 	*dev_ptr = dev; *bytes = (int64_t)L.bytes;
 	counts[0] = R; counts[1] = C; counts[2] = B; counts[3] = W; counts[4] = E; counts[5] = Hn;
+	return 0;
+}
+
+// The slab stays valid until the batch runs, packs or is freed again.
+extern "C" int ihp_batch_pack_dev(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6])
+{
+	if (!b || !b->ran || !dev_ptr || !bytes || !counts) return IHP_E_ARG;
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
+	const int rc = pack_enqueue(b, dev_ptr, bytes, counts);
+	if (rc) return rc;
+	HIPC(hipStreamSynchronize(b->stream));
 	return 0;
 }
 
@@ -1922,7 +1973,8 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 	if (!b || !out || !b->ran) return IHP_E_ARG;
 	memset(out, 0, sizeof(*out));
 	void *dev = nullptr; int64_t bytes = 0, cnt6[6];
-	int rc = ihp_batch_pack_dev(b, &dev, &bytes, cnt6);
+	{ int rc0 = ensure_init(); if (rc0) return rc0; }
+	int rc = pack_enqueue(b, &dev, &bytes, cnt6);            // k_pack in flight; the copy follows it in stream order: one wait
 	if (rc) return rc;
 	hipStream_t s = b->stream;
 	void *slab = g_slabs.get((size_t)bytes);

@@ -1023,7 +1023,7 @@ __global__ void k_pack_count(const PackCountArgs a)
 }
 
 // in place: counts -> exclusive prefix sums, totals at index R.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_pack_scan(int R, long long *cnt)
+__global__ __launch_bounds__(1024) void k_pack_scan(int R, long long *cnt, long long *host_tot)
 {
 	__shared__ long long part[5][1024];
 	const int t = (int)threadIdx.x;
@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(1024) void k_pack_scan(int R, long long *cnt)
 		long long run = 0;
 		for (int i = 0; i < 1024; ++i) { const long long c = part[t][i]; part[t][i] = run; run += c; }
 		cnt[t * S + R] = run;
+		if (host_tot) host_tot[t] = run;                     // page-locked host memory: the caller sizes the result slab from these
 	}
 	__syncthreads();
 	for (int a = 0; a < 5; ++a) {

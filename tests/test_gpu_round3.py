@@ -231,3 +231,42 @@ def test_a_run_without_the_retry_launches_is_checked_and_repeated(hip, shaped, o
             hip.debug_set()
     finally:
         hip.debug_set()
+
+
+def test_eager_fetch_and_batches_in_flight(hip, shaped, oracle):
+    """IHP_FETCH_EAGER (the run counts its results itself, the fetch is one enqueue and one wait) gives what the plain fetch
+    gives; ihp_batch_upload_slab only enqueues its copy, so two batches of one thread are in flight before the first is fetched."""
+    name, K, b, exp = shaped[0]
+    bt = b.with_trim_bounds()
+    slabs = [hip.make_slab(bt) for _ in range(2)]
+    try:
+        hs = []
+        for sl in slabs:
+            h = hip.batch_upload_slab(sl, hip.params(K=K))
+            hip.batch_set_fetch(h, eager=True)
+            hip.batch_run(h)
+            hs.append(h)
+        for h in hs:
+            assert_same(hip.batch_fetch(h), exp)                # no ihp_batch_sync in between: the fetch waits
+            hip.batch_run(h)                                    # a second run counts again
+            hip.batch_sync(h)
+            assert_same(hip.batch_fetch(h), exp)
+            hip.batch_set_fetch(h, no_bases=True)               # eager off again: the fetch counts by itself
+            hip.batch_run(h)
+            lean = hip.batch_fetch(h)
+            assert len(lean.ctg_seq) == 0 and np.array_equal(lean.events, exp.events)
+            hip.batch_release_outputs(h)
+            with pytest.raises(IhpError) as e:
+                hip.batch_fetch(h)
+            assert e.value.code == A.IHP_E_ARG
+            hip.batch_free(h)
+    finally:
+        for sl in slabs:
+            sl.free()
+    with pytest.raises(IhpError):
+        hip.b.batch_set_fetch  # noqa: B018  (binding exists)
+        h = hip.batch_upload(bt)
+        try:
+            hip._chk_hip(hip.b.batch_set_fetch(h, 64), "batch_set_fetch")   # an unknown flag is refused
+        finally:
+            hip.batch_free(h)
