@@ -473,9 +473,13 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 	for (int w = 0; w * 64 < qlim; ++w) {
 		int own = w ? D.own1 : D.own0, ib = w ? D.ib1 : D.ib0;
 		if (w >= 2) {                                                // long contigs: more than 128 items
+			// items are in contig order: only the contigs whose items reach into [64 w, 64 w + 63] can own one of them
 			const int g = 64 * w + lane;
-			own = 0;
-			for (int i = 0; i < qi; ++i) {
+			const unsigned long long has = ballot(D.nit > 0 && (int)D.excl + D.nit > 64 * w) & ((1ull << qi) - 1ull);
+			const unsigned long long beg = ballot(D.nit > 0 && (int)D.excl <= 64 * w + 63) & ((1ull << qi) - 1ull);
+			const int c_lo = has ? ctz64(has) : 0, c_hi = beg ? 63 - clz64(beg) : -1;
+			own = c_lo;
+			for (int i = c_lo; i <= c_hi; ++i) {
 				const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
 				if (ni) own = g >= ex ? i : own;
 			}
