@@ -470,29 +470,25 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 	// ---- offsets 0 .. len(t) - min_overlap on the contigs (:79-111): items = dwords that hold such an offset
 	// (the contigs of `out` all come before the query in the list: only the items below the query's own are looked at)
 	const int qlim = (int)__builtin_amdgcn_readlane((int)D.excl, qi);
-	for (int w = 0; w * 64 < qlim; ++w) {
-		int own = w ? D.own1 : D.own0, ib = w ? D.ib1 : D.ib0;
-		if (w >= 2) {                                                // long contigs: more than 128 items
-			// items are in contig order: only the contigs whose items reach into [64 w, 64 w + 63] can own one of them
-			const int g = 64 * w + lane;
-			const unsigned long long has = ballot(D.nit > 0 && (int)D.excl + D.nit > 64 * w) & ((1ull << qi) - 1ull);
-			const unsigned long long beg = ballot(D.nit > 0 && (int)D.excl <= 64 * w + 63) & ((1ull << qi) - 1ull);
-			const int c_lo = has ? ctz64(has) : 0, c_hi = beg ? 63 - clz64(beg) : -1;
-			own = c_lo;
-			for (int i = c_lo; i <= c_hi; ++i) {
-				const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
-				if (ni) own = g >= ex ? i : own;
-			}
-			ib = (__builtin_amdgcn_ds_bpermute(own << 2, D.pb) >> 4) + (g - __builtin_amdgcn_ds_bpermute(own << 2, (int)D.excl));
+	// lane <-> item 64 w + lane: its contig and the dword it stands for
+	auto chunk_map = [&](int w, int &own, int &ib) {
+		if (w == 0) { own = D.own0; ib = D.ib0; return; }
+		if (w == 1) { own = D.own1; ib = D.ib1; return; }
+		// long contigs, more than 128 items.  Items are in contig order: only the contigs whose items reach into
+		// [64 w, 64 w + 63] can own one of them (two or three of them, whatever the number of contigs)
+		const int g = 64 * w + lane;
+		const unsigned long long below = (1ull << qi) - 1ull;
+		const unsigned long long has = ballot(D.nit > 0 && (int)D.excl + D.nit > 64 * w) & below;
+		const unsigned long long beg = ballot(D.nit > 0 && (int)D.excl <= 64 * w + 63) & below;
+		const int c_lo = has ? ctz64(has) : 0, c_hi = beg ? 63 - clz64(beg) : -1;
+		own = c_lo; ib = 0;
+		for (int i = c_lo; i <= c_hi; ++i) {
+			const int ex = __builtin_amdgcn_readlane((int)D.excl, i), ni = __builtin_amdgcn_readlane(D.nit, i);
+			const int d0 = (__builtin_amdgcn_readlane(D.pb, i) >> 4) - ex;
+			if (ni) { const bool t = g >= ex; own = t ? i : own; ib = t ? d0 + g : ib; }
 		}
-		unsigned w0 = 0, w1 = 0;
-		bool any = false;
-		if (!ballot(64 * w + lane < qlim && ((usem >> own) & 1ull))) continue;
-		if (64 * w + lane < qlim && ((usem >> own) & 1ull)) {
-			w0 = PM[ib]; w1 = PM[ib + 1];
-			any = window_any(w0, w1, qh);
-		}
-		unsigned long long hm = ballot(any);
+	};
+	auto chunk_hits = [&](int own, int ib, unsigned w0, unsigned w1, unsigned long long hm) {
 		V3_CNT(C, 11, popc64(hm));
 		while (hm) {
 			const int e = ctz64(hm);
@@ -510,6 +506,24 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 				cand_push(C, K, bestkey, cand_key(cn, i, 0, o), qpb, tpb + o, cn);
 			}
 		}
+	};
+	// two chunks a turn: their four loads are in flight together
+	const int nw = (qlim + 63) >> 6;
+	for (int w = 0; w < nw; w += 2) {
+		int ownA, ibA, ownB = 0, ibB = 0;
+		chunk_map(w, ownA, ibA);
+		const bool two = w + 1 < nw;
+		if (two) chunk_map(w + 1, ownB, ibB);
+		const bool actA = 64 * w + lane < qlim && ((usem >> ownA) & 1ull);
+		const bool actB = two && 64 * (w + 1) + lane < qlim && ((usem >> ownB) & 1ull);
+		if (!ballot(actA || actB)) continue;
+		unsigned a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+		if (actA) { a0 = PM[ibA]; a1 = PM[ibA + 1]; }
+		if (actB) { b0 = PM[ibB]; b1 = PM[ibB + 1]; }
+		const bool anyA = actA && window_any(a0, a1, qh), anyB = actB && window_any(b0, b1, qh);
+		const unsigned long long hA = ballot(anyA), hB = ballot(anyB);
+		if (hA) chunk_hits(ownA, ibA, a0, a1, hA);
+		if (hB) chunk_hits(ownB, ibB, b0, b1, hB);
 	}
 	V3_LAP(9);
 	// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
