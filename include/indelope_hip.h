@@ -489,6 +489,7 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *   "no_spec" 1     the retry launches (roomy combine, byte-based overflow passes) are always enqueued (default: left out of a
  *                   run when the previous batch needed none of them; whoever waits for the run checks, and repeats it in full)
  *   "spec_fail" 1   test hook: such a run is treated as if a region had needed them
+ *   "verbose" 1     a line on stderr per run: the combine tiers (waves per CU, arenas, grids) it was launched with
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
  *   "lpt" 0         k_asm_combine in input order: no cost classes, no second arena tier

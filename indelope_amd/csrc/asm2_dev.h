@@ -267,6 +267,8 @@ struct ReadArgs {
 	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by arena tier and cost class, longest first (see lpt_class)
 	int *n_tier_b;                                            // counts the regions filed under the second and third tier (diagnostics)
 	int tier_a_cap, tier_b_cap;                               // arena capacities of the first two combine launches: a region is filed under the first that holds it
+	int hist_cap[7]; int *hist;                               // hist[k] counts the regions whose need fits hist_cap[k] (ascending) and no smaller one: what the
+	                                                          // next batch of this shape sizes its first tier from (TierHint, indelope_hip.hip)
 	double min_overlap_pct;
 	int min_mapq_assemble, v2_pdw, n_regions;
 	const int *in_list, *n_in; int *out_list, *n_out; int *work_counter;

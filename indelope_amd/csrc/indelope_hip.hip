@@ -68,6 +68,7 @@ struct Knobs {
 	int no_rich = 0;       // 1: read-rich regions (classes 2-4) stay with the byte-based passes
 	int no_hint = 0;       // 1: every combine launch with its full grid whatever the last batch needed
 	int no_spec = 0;       // 1: the retry launches are always enqueued (default: left out when the last batch needed none, checked at the wait)
+	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
@@ -82,7 +83,12 @@ Knobs g_knob;
 // third tier, regions that ran out of room and went to the roomy launch).  A sweep uploads batch after batch of the same
 // kind: a launch nobody needed last time is started with a token grid -- an empty launch of workgroups that each ask for
 // 25-60 KB of LDS still has to get every one of them scheduled, 50-280 us on the batch's stream in front of k_ksw.
-struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}; };
+// hist[k]: regions of the last batch whose contigs fit the first-tier arena of HIST_OCC[k] waves per CU and no smaller one
+// (the read kernel files them); sig: the shape of that batch (read length, read bases per region): a batch of another
+// shape does not use the histogram.
+constexpr int HIST_N = 7;
+constexpr int HIST_OCC[HIST_N] = {16, 14, 12, 10, 8, 6, 4};
+struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}, regions{0}, sig{0}; std::atomic<int> hist[HIST_N]; };
 TierHint g_hint;
 std::atomic<int> g_live_batches{0};
 
@@ -403,7 +409,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -787,7 +793,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 
 // ------------------------------------------------------- the batched region path
 enum { WQ_SETS = 17 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_WORDS = 25 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -844,6 +850,7 @@ struct ihp_batch {
 	bool acc_pending = false;                              // the last run's stamps have not been added yet
 	bool spec_skipped = false;                             // the run left out the retry launches (nobody needed them in the last batch): checked when it is waited for
 	bool force_full = false;
+	long long v2_nb1 = 0; int tier_occ = 0, tier_occ_default = 0, tier_sig = 0;   // first-tier sizing of the combine launches (size_combine_tiers)
 	bool counted = false;                                  // k_pack_count / k_pack_scan of the last run are enqueued (or done)
 	long long n_reruns = 0;
 	bool dirty = false;                                    // a run was cut short after some launches: `misc` is not known to be clear
@@ -927,6 +934,56 @@ static void release_work(ihp_batch *b)
 	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab};
 	for (DBuf *d : bufs) d->release();
 	b->work_live = false;
+}
+
+// LDS sizing of the combine launches (k_asm_combine3, asm3_dev.h).  Capacity C = C bytes of supports (kept for multi-read
+// contigs only) + C / 8 + 128 dwords of packed bases (every contig) beside the kernel's static LDS (asked of the runtime: a
+// stale constant here once cost every tier a wave per CU).
+static long long comb_stat() { return (g.comb_static + 255) / 256 * 256 + 256; }          // + allocation granularity
+static long long comb_pm_of(long long C) { return C / 8 + 128; }
+static long long comb_cap_for(int occ) { return (long long)(((long long)g.max_lds / occ - comb_stat() - 512) * 2 / 3) / 16 * 16; }
+
+// The three tiers and the roomy launch for a first tier of at most `occ_first` waves per CU (0: what the read bases of the
+// usual region suggest).  Called at upload, and again by ihp_batch_run when the last batch of this shape showed that most
+// regions need more than the first tier holds (see TierHint): C5's 300 bp reads leave 85 % of the regions above the arena
+// that 0.3 x read bases predicts, and one launch at 8 waves per CU for all of them beats 10 waves for a few + 7 for the rest.
+static void size_combine_tiers(ihp_batch *b, int occ_first)
+{
+	const int R = b->R;
+	const long long nb1 = b->v2_nb1, stat = comb_stat();
+	auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + stat; };
+	// 16 waves per CU when the launch is long enough to be bound by throughput; a launch of about one round of regions per
+	// wave slot lasts as long as its heaviest regions, and those run faster with fewer waves beside them on their SIMD
+	// (C2, 5 000 regions per launch: 14 waves per CU 5.33 M regions/s, 16: 4.98 M, 12: 5.22 M)
+	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : (b->n_cls[0] >= 40 * g.cus ? 16 : 14);
+	long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
+	int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes(need_C)));
+	if (occ_first > 0) occ_c = std::max(1, std::min(occ_c, occ_first));
+	need_C = std::max(need_C, comb_cap_for(occ_c));
+	b->tier_occ = occ_c;
+	// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
+	b->v2_arena_big = (int)std::min<long long>(comb_cap_for(2), std::max<long long>(4 * need_C, (nb1 + 1024 + 15) / 16 * 16));
+	b->grid_v2big = grid_for(R, std::max(1, std::min<int>(2, (int)(g.max_lds / wave_bytes(b->v2_arena_big)))));
+	// the second and third tier: regions whose contigs (known when the read phase ends) need more than the first arena
+	// -- many single-read contigs, long reads -- at about two thirds and a third of its occupancy
+	{
+		const int occ_b = std::max(1, (occ_c * 2 + 1) / 3), occ_t = std::max(1, occ_c / 3);
+		b->v2_arena_b = (int)std::max(need_C, comb_cap_for(occ_b));
+		b->grid_v2b = std::min(grid_for(R, occ_b), std::max(1, b->n_cls[0]));
+		b->v2_arena_c = (int)std::max<long long>(b->v2_arena_b, comb_cap_for(occ_t));
+		b->grid_v2c = std::min(grid_for(R, occ_t), std::max(1, b->n_cls[0]));
+	}
+	b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena / 16 * 16 : (int)need_C;
+	// every combine launch must fit what hipFuncSetAttribute allows (max_lds - 8192 of dynamic LDS beside the static part):
+	// the later tiers and the roomy launch give up arena first, the packed path is switched off only when the first tier does not fit
+	const int dyn_max = g.max_lds - 8192 - 1024;
+	while (b->v2_arena_b > 1024 && b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) > dyn_max) b->v2_arena_b -= 256;
+	while (b->v2_arena_c > 1024 && b->v2_arena_c + 4 * comb_pm_of(b->v2_arena_c) > dyn_max) b->v2_arena_c -= 256;
+	b->v2_pm_c = (int)comb_pm_of(b->v2_arena_c);
+	while (b->v2_arena_big > 1024 && b->v2_arena_big + 4 * comb_pm_of(b->v2_arena_big) > dyn_max) b->v2_arena_big -= 256;
+	b->v2_pm = (int)comb_pm_of(b->v2_arena); b->v2_pm_b = (int)comb_pm_of(b->v2_arena_b); b->v2_pm_big = (int)comb_pm_of(b->v2_arena_big);
+	const int per_wave = (int)wave_bytes(b->v2_arena);
+	b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
 }
 
 static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout);
@@ -1130,50 +1187,19 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave.
-			// Combine kernel (asm3_dev.h): capacity C = C bytes of supports (kept for multi-read contigs only) + C / 8 + 128
-			// dwords of packed bases (every contig) beside the kernel's static LDS (asked of the runtime: a stale constant here once
-			// cost every tier a wave per CU).
-			const long long stat = (g.comb_static + 255) / 256 * 256 + 256;          // + allocation granularity
-			auto pm_of = [](long long C) { return C / 8 + 128; };
-			auto wave_bytes = [&](long long C) { return C + 4 * pm_of(C) + stat; };
-			auto cap_for = [&](int occ) { return (long long)(((long long)g.max_lds / occ - stat - 512) * 2 / 3) / 16 * 16; };
-			// 16 waves per CU when the launch is long enough to be bound by throughput; a launch of about one round of regions per
-			// wave slot lasts as long as its heaviest regions, and those run faster with fewer waves beside them on their SIMD
-			// (C2, 5 000 regions per launch: 14 waves per CU 5.33 M regions/s, 16: 4.98 M, 12: 5.22 M)
-			const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : (b->n_cls[0] >= 40 * g.cus ? 16 : 14);
-			long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
-			const int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes(need_C)));
 			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
-			need_C = std::max(need_C, cap_for(occ_c));
-			// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
-			b->v2_arena_big = (int)std::min<long long>(cap_for(2), std::max<long long>(4 * need_C, (nb1 + 1024 + 15) / 16 * 16));
-			b->grid_v2big = grid_for(R, std::max(1, std::min<int>(2, (int)(g.max_lds / wave_bytes(b->v2_arena_big)))));
-			// the second and third tier: regions whose contigs (known when the read phase ends) need more than the first arena
-			// -- many single-read contigs, long reads -- at about two thirds and a third of its occupancy (C5, 300 bp reads:
-			// nearly every region needs 8-10 KB; with only a half-occupancy tier of 18 KB behind the first, 5 waves per CU ran them)
-			{
-				const int occ_b = std::max(1, (occ_c * 2 + 1) / 3), occ_t = std::max(1, occ_c / 3);
-				b->v2_arena_b = (int)std::max(need_C, cap_for(occ_b));
-				b->grid_v2b = std::min(grid_for(R, occ_b), std::max(1, b->n_cls[0]));
-				b->v2_arena_c = (int)std::max<long long>(b->v2_arena_b, cap_for(occ_t));
-				b->grid_v2c = std::min(grid_for(R, occ_t), std::max(1, b->n_cls[0]));
-			}
 			need_pdw = std::max<long long>(need_pdw, (g.max_lds / occ_r - 256) / 4);
-			b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena / 16 * 16 : (int)need_C;
 			b->v2_pdw = g_knob.v2_pdw ? g_knob.v2_pdw : (int)need_pdw;
 			b->v2_pdw = b->v2_pdw / 4 * 4;
-			// every combine launch must fit what hipFuncSetAttribute allows (max_lds - 8192 of dynamic LDS beside the static part):
-			// the second tier and the roomy launch give up arena first, the packed path is switched off only when the first tier does not fit
+			b->v2_nb1 = nb1;
+			size_combine_tiers(b, 0);
+			b->tier_occ_default = b->tier_occ;
+			b->tier_sig = (b->max_read_len / 32) | ((int)std::min<long long>(nb1 / 2048, 0xffff) << 8) | (b->tier_occ_default << 24);
 			const int dyn_max = g.max_lds - 8192 - 1024;
-			while (b->v2_arena_b > 1024 && b->v2_arena_b + 4 * pm_of(b->v2_arena_b) > dyn_max) b->v2_arena_b -= 256;
-			while (b->v2_arena_c > 1024 && b->v2_arena_c + 4 * pm_of(b->v2_arena_c) > dyn_max) b->v2_arena_c -= 256;
-			b->v2_pm_c = (int)pm_of(b->v2_arena_c);
-			while (b->v2_arena_big > 1024 && b->v2_arena_big + 4 * pm_of(b->v2_arena_big) > dyn_max) b->v2_arena_big -= 256;
-			b->v2_pm = (int)pm_of(b->v2_arena); b->v2_pm_b = (int)pm_of(b->v2_arena_b); b->v2_pm_big = (int)pm_of(b->v2_arena_big);
+			auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + comb_stat(); };
 			const int per_wave = (int)wave_bytes(b->v2_arena), per_wave_r = 4 * b->v2_pdw + 256;
 			if (b->v2_arena + 4 * b->v2_pm > dyn_max || per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
 			else {
-				b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
 				b->grid_v2r = std::min(grid_for(R, std::max(1, std::min(g_knob.asmr_waves ? g_knob.asmr_waves : 32, g.max_lds / per_wave_r))), std::max(1, b->n_cls[0]));
 				b->grid_pack = grid_for((int)std::min<long long>((NR + 3) / 4, 1 << 30), 32);
 				if (b->n_rich) {
@@ -1357,6 +1383,30 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		const int n1 = b->n_cls[0], n2 = b->n_cls[1], n3 = b->n_cls[2], n4 = b->n_cls[3];
 		hipStream_t s2 = b->stream2;
 		const bool side = n2 + n3 + n4 > 0;
+		// The first combine tier is sized from the read bases of the usual region (size_combine_tiers); when the last batch of
+		// this shape filed most of its regions above that, the tiers are cut again so that the first one holds 85 % of them.
+		if (b->v2 && !g_knob.no_hint && !g_knob.comb_occ && !g_knob.v2_arena && g_hint.valid.load() && g_hint.sig.load() == b->tier_sig && g_hint.regions.load() > 0) {
+			const long long tot = g_hint.regions.load();
+			// a tier of its own for a few percent of the regions costs a round of the heaviest ones at the end: when a first tier
+			// of not much lower occupancy holds (nearly) all regions -- a narrow distribution just above the predicted arena --
+			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest
+			int want = 0, want_all = 0;
+			long long cum = 0;
+			for (int k = 0; k < HIST_N; ++k) {
+				cum += g_hint.hist[k].load();
+				if (HIST_OCC[k] > b->tier_occ_default) continue;
+				if (!want && cum * 100 >= 85 * tot) want = HIST_OCC[k];
+				if (!want_all && cum * 200 >= 199 * tot) want_all = HIST_OCC[k];
+			}
+			if (!want) want = HIST_OCC[HIST_N - 1];
+			if (want_all && want_all * 10 >= b->tier_occ_default * 6) want = want_all;
+			want = std::min(want, b->tier_occ_default);
+			if (want != b->tier_occ) size_combine_tiers(b, want == b->tier_occ_default ? 0 : want);
+		}
+		if (g_knob.verbose && b->v2)
+			fprintf(stderr, "[ihp] run: %d regions, first tier %d waves/CU (default %d): arenas %d / %d / %d / %d, grids %d / %d / %d / %d; hint valid %d b %d c %d big %d back %d\n",
+			        b->R, b->tier_occ, b->tier_occ_default, b->v2_arena, b->v2_arena_b, b->v2_arena_c, b->v2_arena_big, b->grid_v2, b->grid_v2b, b->grid_v2c, b->grid_v2big,
+			        g_hint.valid.load(), g_hint.n_b.load(), g_hint.n_c.load(), g_hint.n_big.load(), g_hint.n_back.load());
 		auto pass2 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr, int grid) {
 			x.arena_seq = nullptr; x.arena_sup = b->lds_sup2.as<uint32_t>(); x.arena_cap = b->lds_arena2; x.lds_arena = b->lds_arena2;
 			x.in_list = in; x.n_in = n_in; x.out_list = o3; x.n_out = misc + M_NRETRY2; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
@@ -1412,6 +1462,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			const bool lpt_on = g_knob.lpt != 0;                   // region order of the combine launch
 			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
 			ra.tier_a_cap = b->v2_arena; ra.tier_b_cap = b->v2_arena_b; ra.n_tier_b = misc + M_NTIERB;
+			for (int k = 0; k < HIST_N; ++k) ra.hist_cap[k] = (int)comb_cap_for(HIST_OCC[k]);
+			ra.hist = misc + M_HIST;
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
 			if (b->n_rich) {
@@ -1438,6 +1490,23 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			const bool hint = g_hint.valid.load() != 0 && !g_knob.no_hint;
 			const bool fold_c = hint && g_hint.n_c.load() == 0, fold_b = fold_c && g_hint.n_b.load() == 0;
 			HIPC(hipEventRecord(b->ev_bfork, s));
+			// The second tier runs beside the first on the other stream -- if its workgroups find LDS: the first tier's persistent
+			// grid fills every CU and keeps it until its queue is dry, so a second tier launched next to it in fact ran behind it
+			// (C5: 4 % of the regions, the heaviest, one more round of ~1 ms).  When the last batch says how many regions the second
+			// tier gets, it is launched with about that many workgroups and the first tier leaves their LDS free on every CU.
+			int ga = b->grid_v2, gb = b->grid_v2b;
+			if (hint && ra.lpt_cnt && !fold_b) {
+				const long long nb_hint = g_hint.n_b.load(), reg = std::max(1, g_hint.regions.load());
+				if (nb_hint == 0) gb = std::min(gb, 128);
+				else {
+					const long long nb = nb_hint * std::max(1, b->n_cls[0]) / reg + 1;
+					gb = (int)std::min<long long>(gb, std::max<long long>(g.cus, nb + nb / 4));
+					const long long wb_a = b->v2_arena + 4 * comb_pm_of(b->v2_arena) + comb_stat(), wb_b = b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) + comb_stat();
+					const long long per_cu_b = (gb + g.cus - 1) / g.cus;
+					const long long occ_a = std::max<long long>(1, ((long long)g.max_lds - per_cu_b * wb_b) / wb_a);
+					ga = (int)std::min<long long>(ga, occ_a * g.cus);
+				}
+			}
 			if (ra.lpt_cnt) {
 				if (!fold_b) {
 					HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
@@ -1445,7 +1514,6 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 					y.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
 					y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
 					y.work_counter = wq + 13 * WQ_WORDS;
-					const int gb = hint && g_hint.n_b.load() == 0 ? std::min(b->grid_v2b, 128) : b->grid_v2b;
 					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(gb), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
 					HIPC(hipEventRecord(b->ev_bjoin, s2));
 				} else HIPC(hipEventRecord(b->ev_bjoin, s));
@@ -1458,7 +1526,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				}
 				x.lpt_nclass = LPT_CLASSES * (fold_b ? 3 : fold_c ? 2 : 1);
 			} else HIPC(hipEventRecord(b->ev_bjoin, s));
-			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(ga), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
 			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second-tier launch)
 			// regions that ran out of room in their launch: the same kernel with a roomy arena, few workgroups per CU -- or, when
 			// the previous batch had none, a token launch with the first tier's arena (it gets scheduled at once; a region that
@@ -1666,7 +1734,12 @@ extern "C" int ihp_batch_sync(ihp_batch *b)
 	}
 	if (b->ran && b->R > 0 && b->v2 && g_knob.lpt) {
 		g_hint.n_b = b->report[M_NTIERB]; g_hint.n_c = b->report[M_NTIERC]; g_hint.n_big = b->report[M_NRETRYC];
-		g_hint.n_back = b->report[M_NRETRY0]; g_hint.valid = 1;
+		g_hint.n_back = b->report[M_NRETRY0];
+		if (b->v2) {
+			for (int k = 0; k < HIST_N; ++k) g_hint.hist[k] = b->report[M_HIST + k];
+			g_hint.regions = b->n_cls[0] - b->report[M_NRETRY0]; g_hint.sig = b->tier_sig;
+		}
+		g_hint.valid = 1;
 	}
 	if (b->ran && b->R > 0) return report_overflow(b);
 	return 0;

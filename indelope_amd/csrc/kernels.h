@@ -438,7 +438,10 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		if (err) {                                             // not for this path: the byte-based passes take it
 			// (n_final = 0: the launches that take the list may have been left out of this run -- ihp_batch_run -- and k_summary walks n_final contigs)
 			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
-		} else if (a.lpt_cnt && lane == 0) {
+		} else if (lane == 0 && a.hist) {
+			for (int k = 0; k < 7; ++k) if (need <= a.hist_cap[k]) { atomicAdd(&a.hist[k], 1); break; }
+		}
+		if (!err && a.lpt_cnt && lane == 0) {
 			// the tiers in memory: first, third, second (the first tier's launch can then walk the third's lists, or all, behind its own)
 			const int tier = need <= a.tier_a_cap ? 0 : need <= a.tier_b_cap ? 2 : 1;
 			const int c = lpt_class(nc) + tier * LPT_CLASSES;
