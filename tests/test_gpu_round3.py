@@ -270,3 +270,22 @@ def test_eager_fetch_and_batches_in_flight(hip, shaped, oracle):
             hip._chk_hip(hip.b.batch_set_fetch(h, 64), "batch_set_fetch")   # an unknown flag is refused
         finally:
             hip.batch_free(h)
+
+
+def test_tiers_cut_again_from_the_last_batch_give_the_same_results(hip, oracle):
+    """The first combine tier of a run is sized from the histogram the last batch of the same shape left (C5: most regions need
+    more than 0.3 x read bases predicts, the second run has one roomier tier): first run, adapted runs and `no_hint` agree."""
+    b, _ = synth.config("C5", n_regions=700)
+    exp = oracle.run_regions_mt(b, oracle.params(K=31), 16)
+    h = hip.batch_upload(b, hip.params(K=31))
+    try:
+        for _ in range(3):
+            hip.batch_run(h)
+            hip.batch_sync(h)
+            assert_same(hip.batch_fetch(h), exp)
+        hip.debug_set(no_hint=1)
+        hip.batch_run(h)
+        assert_same(hip.batch_fetch(h), exp)
+    finally:
+        hip.debug_set()
+        hip.batch_free(h)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Sum rocprofv3 --pmc counter_collection CSVs per kernel: mean counter value per launch.
 
-usage: pmc_sum.py DIR [DIR ...] [--json OUT]
-Kernel names are shortened to the function name + template arguments.
+usage: pmc_sum.py DIR [DIR ...] [--json OUT] [--last N]
+Kernel names are shortened to the function name + template arguments.  --last N: only the last N launches of every kernel
+in each file count (the runs after the library has seen a batch: no empty retry launches, tiers cut for the workload).
 """
 import csv
 import glob
@@ -24,12 +25,23 @@ def main():
     if "--json" in sys.argv:
         out = sys.argv[sys.argv.index("--json") + 1]
         args = [a for a in args if a != out]
+    last = 0
+    if "--last" in sys.argv:
+        last = int(sys.argv[sys.argv.index("--last") + 1])
+        args = [a for a in args if a != str(last)]
     acc = defaultdict(lambda: defaultdict(float))
     launches = defaultdict(lambda: defaultdict(set))
     meta = {}
     for d in args:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            if last:
+                ids = defaultdict(set)
+                for row in rows:
+                    ids[short(row["Kernel_Name"])].add(int(row["Dispatch_Id"]))
+                keep = {k: set(sorted(v)[-last:]) for k, v in ids.items()}
+                rows = [row for row in rows if int(row["Dispatch_Id"]) in keep[short(row["Kernel_Name"])]]
+            for row in rows:
                 k = short(row["Kernel_Name"])
                 c = row["Counter_Name"]
                 acc[k][c] += float(row["Counter_Value"])

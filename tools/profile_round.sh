@@ -15,12 +15,12 @@ stats() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -
 stats c2 $ARGS
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1
-python3 tools/pmc_sum.py $OUT/fetch $OUT/write --json $OUT/pmc_raw.json > $OUT/pmc_raw.txt 2>&1
+python3 tools/pmc_sum.py $OUT/fetch $OUT/write --last 10 --json $OUT/pmc_raw.json > $OUT/pmc_raw.txt 2>&1
 bash tools/pmc_mix.sh > /dev/null 2>&1
 cp gpurun_out/pmc_mix/mix.json $OUT/c2_pmc_mix.json
 STEADY="--no-cpu --no-e2e --no-check --no-other --regions 100000 --steps 3 --warmup 1 --sub-batches 1"
 stats steady100k $STEADY
-bash tools/pmc_mix.sh --regions 100000 --sub-batches 1 > /dev/null 2>&1
+PMC_LAST=3 bash tools/pmc_mix.sh --regions 100000 --sub-batches 1 > /dev/null 2>&1
 cp gpurun_out/pmc_mix/mix.json $OUT/steady100k_pmc_mix.json
 python3 bench.py $STEADY > $OUT/steady100k_bench.json 2>> $OUT/err
 stats c3 --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check
@@ -62,8 +62,6 @@ for k, v in raw.items():
         continue
     out["kernels"][k] = {"FETCH_SIZE": int(f * 1024), "WRITE_SIZE": int(w * 1024), "traffic": int((2 * f + w) * 1024), "traffic_raw": int((f + w) * 1024),
                          "launches_averaged": v.get("_launches")}
-    if k.startswith("k_asm_combine"):
-        out["kernels"][k]["launches_per_stage"] = 3      # first tier, second tier and the roomy launch (the average is over all three)
 json.dump(out, open("gpurun_out/prof/c2_pmc.json", "w"), indent=1)
 PY
 # the raw rocprofv3 output directories are large (gpurun merges at most 64 MiB back): keep the summaries only
