@@ -330,7 +330,7 @@ __device__ __forceinline__ void cand_push(const V3Ctx &C, Cand3 &K, unsigned &be
 	if (++K.n == 64) cand_flush(C, K, bestkey);
 }
 
-struct Best3 { int found, ma, pos, slot, off; };
+struct Best3 { int found, ma, pos, slot, off, ord; };   // ord: place of the offset in the scan of its pair (ties between waves)
 
 // slide_align (contig.nim:70-141) of contig qs on contig ts when the vote rule may fire for the pair, max_mismatch 0:
 // an offset stands iff every differing base is an allowed mismatch; its matches are the equal bases.  Lanes are offsets
@@ -338,7 +338,10 @@ struct Best3 { int found, ma, pos, slot, off; };
 // without such a window must have allowed mismatches among its first 16 bases.  Every survivor is then checked over its
 // whole overlap by the wave (16 bases per lane; supports are only read where the bases differ).
 // `best` is shared by the targets of one best_match call in list order: strictly more matches win (contig.nim:107, :239).
-__device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, int ts, int pos, int min_overlap, Best3 &best)
+// (part, nparts, ctr): the 64-offset chunks of all vote pairs of a best_match call are dealt round robin to the waves that
+// share the call (v3_best_match); ctr counts them.
+__device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, int ts, int pos, int min_overlap, Best3 &best,
+                                      int part, int nparts, int &ctr)
 {
 	const int lane = lane_id();
 	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
@@ -353,6 +356,7 @@ __device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, 
 	const int total = n1 + omin_abs;
 	V3_CNT(C, 14, (total + 63) / 64);
 	for (int base = 0; base < total; base += 64) {
+		if (nparts > 1) { const bool mine = ctr == part; ctr = ctr + 1 == nparts ? 0 : ctr + 1; if (!mine) continue; }
 		const int idx = base + lane;
 		int qo0 = 0, to0 = 0;
 		if (idx < n1) to0 = idx; else qo0 = idx - n1 + 1;
@@ -423,7 +427,7 @@ __device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, 
 			if (bad) continue;
 			const int ma = cn - wave_sum_i(mmiss);
 			if (ma >= min_overlap - 1 && (!best.found || ma > best.ma)) {
-				best.found = 1; best.ma = ma; best.pos = pos; best.slot = ts; best.off = cq ? -cq : ct;
+				best.found = 1; best.ma = ma; best.pos = pos; best.slot = ts; best.off = cq ? -cq : ct; best.ord = base + sl;
 			}
 		}
 	}
@@ -431,10 +435,15 @@ __device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, 
 
 // since > 0 (pass 2, a query that has not changed since it was the query of pass 1 at step `since`): only the contigs that
 // have changed since then are looked at -- against the others slide_align found nothing then and would find nothing now.
-__device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since)
+// One wave's share (part of nparts) of a best_match call: the vote pairs' chunks, the target-offset turns and the query-offset
+// chunks are dealt round robin; `bestkey` = its best exact candidate (0xffffffff: none), G = its best vote-pair offset.
+// Reads LDS only.
+__device__ inline void v3_bm_part(const V3State &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since,
+                                  int part, int nparts, unsigned &bestkey_out, Best3 &G)
 {
 	const int lane = lane_id();
 	qi = uni(qi);
+	bestkey_out = 0xffffffffu;
 	const int qs = __builtin_amdgcn_readlane(D.ts, qi), qlen = __builtin_amdgcn_readlane(D.len, qi);
 	const int qpb = __builtin_amdgcn_readlane(D.pb, qi);
 	const int omin = qlen - min_overlap;                             // contig.nim:78 (>= 0: the caller checked)
@@ -442,20 +451,21 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 	const unsigned qmin = (unsigned)__builtin_amdgcn_readlane((int)D.smin, qi), qmax = (unsigned)__builtin_amdgcn_readlane((int)D.smax, qi);
 	const int qreads = __builtin_amdgcn_readlane(D.nr, qi);
 	const uint32_t *PM = C.PM;
-	Best3 G = {0, 0, -1, -1, 0};                                     // best of the pairs that need the vote scan
+	G = Best3{0, 0, -1, -1, 0, 0};                                   // best of the pairs that need the vote scan
 	const bool in = lane_of(D.inout) && D.mt >= since;
 	const unsigned long long inm = ballot(in);
-	if (!inm) return G;
+	if (!inm) return;
 	const bool votes = in && ((qmin < 3u && D.smax > 3u * qmin && qreads > 3 * (int)qmin) ||
 	                          (D.smin < 3u && qmax > 3u * D.smin && D.nr > 3 * (int)D.smin));
 	const unsigned long long vm = ballot(votes);
 	{
 		V3_T0(C);
 		unsigned long long gm = vm;
+		int ctr = 0;
 		while (gm) {
 			const int i = ctz64(gm);
 			gm &= gm - 1;
-			v3_slide_votes(S, C, qs, __builtin_amdgcn_readlane(D.ts, i), i, min_overlap, G);
+			v3_slide_votes(S, C, qs, __builtin_amdgcn_readlane(D.ts, i), i, min_overlap, G, part, nparts, ctr);
 			V3_CNT(C, 3, 1);
 		}
 		if (vm) V3_T1(C, 4);
@@ -508,14 +518,16 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 		}
 	};
 	// two chunks a turn: their four loads are in flight together
+	// (a wave that shares the call takes every nparts-th chunk)
 	const int nw = (qlim + 63) >> 6;
-	for (int w = 0; w < nw; w += 2) {
+	for (int w = part; w < nw; w += 2 * nparts) {
+		const int w2 = w + nparts;
 		int ownA, ibA, ownB = 0, ibB = 0;
 		chunk_map(w, ownA, ibA);
-		const bool two = w + 1 < nw;
-		if (two) chunk_map(w + 1, ownB, ibB);
+		const bool two = w2 < nw;
+		if (two) chunk_map(w2, ownB, ibB);
 		const bool actA = 64 * w + lane < qlim && ((usem >> ownA) & 1ull);
-		const bool actB = two && 64 * (w + 1) + lane < qlim && ((usem >> ownB) & 1ull);
+		const bool actB = two && 64 * w2 + lane < qlim && ((usem >> ownB) & 1ull);
 		if (!ballot(actA || actB)) continue;
 		unsigned a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 		if (actA) { a0 = PM[ibA]; a1 = PM[ibA + 1]; }
@@ -527,7 +539,7 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 	}
 	V3_LAP(9);
 	// ---- offsets 1 .. omin on the query (:114-135): lane <-> offset, the contigs' first 16 bases come by
-	for (int ob = 0; ob <= omin; ob += 64) {
+	for (int ob = 64 * part; ob <= omin; ob += 64 * nparts) {
 		const int o_l = ob + lane;
 		const bool valid = o_l >= 1 && o_l <= omin;
 		const unsigned wq = valid ? pk16(PM, qpb + o_l) : 0u;
@@ -553,7 +565,22 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 	V3_LAP(11);
 #undef V3_LAP
 	V3_T1(C, 5);
-	Best3 B = {0, 0, -1, -1, 0};
+	bestkey_out = bestkey;
+}
+
+// of two vote-pair results the one slide_align / best_match would have kept scanning everything in order: more matches, then
+// the earlier contig, then the earlier offset of the pair's scan (contig.nim:107 replaces on strictly more matches only)
+__device__ __forceinline__ bool best3_before(const Best3 &a, const Best3 &b)
+{
+	if (!a.found || !b.found) return a.found != 0;
+	if (a.ma != b.ma) return a.ma > b.ma;
+	if (a.pos != b.pos) return a.pos < b.pos;
+	return a.ord < b.ord;
+}
+
+__device__ inline Best3 v3_bm_finish(const Dir3 &D, unsigned bestkey, const Best3 &G)
+{
+	Best3 B = {0, 0, -1, -1, 0, 0};
 	if (bestkey != 0xffffffffu) {
 		const int o = (int)(bestkey & 2047u), ph = (int)((bestkey >> 11) & 1u), pos = (int)((bestkey >> 12) & 63u);
 		B.found = 1; B.ma = V3_MAXLEN - (int)(bestkey >> 18); B.pos = pos; B.slot = __builtin_amdgcn_readlane(D.ts, pos); B.off = ph ? -o : o;
@@ -561,6 +588,82 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 	// more matches, then (no mismatches either way) the earlier contig (contig.nim:32-36, :107, :239)
 	if (G.found && (!B.found || G.ma > B.ma || (G.ma == B.ma && G.pos < B.pos))) return G;
 	return B;
+}
+
+// ---- several waves on one best_match call -----------------------------------------------------------------------------
+// A region's combine is one serial chain in ONE wave (wave 0 of the workgroup: everything that writes the region's state),
+// and the LDS a region needs fixes 8-16 regions per CU, so each SIMD hosts two to four such waves and issues a fraction of
+// what it could.  The other waves of the workgroup wait at a barrier; for a best_match call with enough to look at, wave 0
+// leaves the call's parameters in LDS, everybody passes the barrier, takes its share of the call (v3_bm_part reads LDS only:
+// packed bases, supports, the contig table), leaves its result in a mailbox and meets at a second barrier; wave 0 folds the
+// mailboxes.  Between two calls only wave 0 runs, so nothing it writes is read half-done.
+constexpr int V3_MAXW = 4;
+struct V3Par {
+	int cmd;                               // 1: a call; 2: the launch is over
+	int list_b, n, min_overlap, qi, since, dver;
+	unsigned long long inout;
+	unsigned key[V3_MAXW];
+	Best3 g[V3_MAXW];
+};
+struct V3Team { V3Par *par; int nparts; int list_b, n; int dver; };   // wave 0's side: dver counts the dir3_build calls
+
+template <bool TEAM>
+__device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since, const V3Team &T)
+{
+	const int lane = lane_id();
+	unsigned key; Best3 G;
+	if (!TEAM) { v3_bm_part(S, C, D, qi, min_overlap, since, 0, 1, key, G); return v3_bm_finish(D, key, G); }
+	// worth waking the others for?  target-offset turns + query-offset looks + vote pairs of the call
+	bool team = false;
+	if (T.nparts > 1) {
+		const int qlim = (int)__builtin_amdgcn_readlane((int)D.excl, qi), qlen = __builtin_amdgcn_readlane(D.len, qi);
+		const int work = (qlim >> 7) + ((qlen - min_overlap) >> 6) * (popc64(D.inout) >> 3);
+		team = work >= 3;
+	}
+	const int np = team ? T.nparts : 1;
+	V3Par *P = T.par;
+	if (team) {
+		if (lane == 0) {
+			P->cmd = 1; P->list_b = T.list_b; P->n = T.n; P->min_overlap = min_overlap; P->qi = qi; P->since = since; P->dver = T.dver;
+			P->inout = D.inout;
+		}
+		__syncthreads();
+	}
+	v3_bm_part(S, C, D, qi, min_overlap, since, 0, np, key, G);
+	if (!team) return v3_bm_finish(D, key, G);
+	__syncthreads();
+	for (int w = 1; w < T.nparts; ++w) {
+		const unsigned kw = (unsigned)uni((int)P->key[w]);
+		key = kw < key ? kw : key;
+		Best3 gw;
+		gw.found = uni(P->g[w].found); gw.ma = uni(P->g[w].ma); gw.pos = uni(P->g[w].pos); gw.slot = uni(P->g[w].slot);
+		gw.off = uni(P->g[w].off); gw.ord = uni(P->g[w].ord);
+		if (best3_before(gw, G)) G = gw;
+	}
+	return v3_bm_finish(D, key, G);
+}
+
+// waves 1 .. of the workgroup: see V3Par
+__device__ inline void v3_helper_loop(const V3State &S, const V3Ctx &C, V3Par *P, int part, int nparts)
+{
+	const int lane = lane_id();
+	Dir3 D;
+	D.valid = false;
+	int dver = -1;
+	for (;;) {
+		__syncthreads();
+		if (uni(P->cmd) != 1) break;
+		const int mo = uni(P->min_overlap);
+		if (uni(P->dver) != dver) {
+			dir3_build(S, C, uni(P->list_b) ? S.listB : S.listA, uni(P->n), mo, D);
+			dver = uni(P->dver);
+		}
+		D.inout = (unsigned long long)uni((long long)P->inout);
+		unsigned key; Best3 G;
+		v3_bm_part(S, C, D, uni(P->qi), mo, uni(P->since), part, nparts, key, G);
+		if (lane == 0) { P->key[part] = key; P->g[part] = G; }
+		__syncthreads();
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ corrections + insert
@@ -763,7 +866,8 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 
 // ------------------------------------------------------------------------------------------------ one pass of combine
 // contig.nim:263-281: `in` -> `out`, returns the new count or < 0.
-__device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, short *out, int min_support, int min_overlap)
+template <bool TEAM>
+__device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, short *out, int min_support, int min_overlap, V3Team &T)
 {
 	const int lane = lane_id();
 	int nout = 0, usedi = 0;
@@ -810,11 +914,12 @@ __device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, sh
 	Dir3 D;
 	dir3_build(S, C, in, n, min_overlap, D);
 	if (!D.valid) return IHP_E_CAPACITY;
+	T.list_b = in == S.listB; T.n = n; T.dver++;
 	D.inout = 1ull << usedi;
 	for (int i = 0; i < n; ++i) {                                    // :274-281
 		if (i == usedi) continue;
 		const int c = uni((int)in[i]);
-		Best3 b = {0, 0, -1, -1, 0};
+		Best3 b = {0, 0, -1, -1, 0, 0};
 		C.clock++;
 		int since = 0;
 		if (min_support == 0) { if (lane == 0) S.qt[c] = (short)C.clock; }
@@ -824,7 +929,7 @@ __device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, sh
 			// exactly that length can, at a target offset only (omin = -1: the abs() of contig.nim:114 gives one query offset,
 			// whose overlap is one base short)
 			const int ql = __builtin_amdgcn_readlane(D.len, i);
-			if (ql >= min_overlap - 1) b = v3_best_match(S, C, D, i, min_overlap, since);
+			if (ql >= min_overlap - 1) b = v3_best_match<TEAM>(S, C, D, i, min_overlap, since, T);
 		}
 		if (b.found) {
 			V3_T0(C);
@@ -838,6 +943,7 @@ __device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, sh
 			V3_CNT(C, 4, 1);
 			const unsigned long long keep = D.inout;
 			dir3_build(S, C, in, n, min_overlap, D);                 // the target changed: its lane and the item map again
+			T.dver++;
 			D.inout = keep;
 			V3_T1(C, 6);
 		} else if (uni(S.nreads[c]) > 0) {

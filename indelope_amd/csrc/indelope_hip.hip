@@ -68,6 +68,7 @@ struct Knobs {
 	int no_rich = 0;       // 1: read-rich regions (classes 2-4) stay with the byte-based passes
 	int no_hint = 0;       // 1: every combine launch with its full grid whatever the last batch needed
 	int no_spec = 0;       // 1: the retry launches are always enqueued (default: left out when the last batch needed none, checked at the wait)
+	int comb_waves = 0;    // waves per workgroup of k_asm_combine3 (1, 2, 4; 0 = by the tier's occupancy): wave 0 runs the region, the others share its best_match calls
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
@@ -361,10 +362,11 @@ extern "C" int ihp_init(int device)
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
 		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
-		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		{
 			hipFuncAttributes fa;
-			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static = (int)fa.sharedSizeBytes;
+			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5, false>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static = (int)fa.sharedSizeBytes;
 		}
 		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -409,7 +411,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -1494,6 +1496,15 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// grid fills every CU and keeps it until its queue is dry, so a second tier launched next to it in fact ran behind it
 			// (C5: 4 % of the regions, the heaviest, one more round of ~1 ms).  When the last batch says how many regions the second
 			// tier gets, it is launched with about that many workgroups and the first tier leaves their LDS free on every CU.
+			// waves per workgroup: as many as the tier's occupancy leaves wave slots for (32 per CU)
+			// (the team build is for 4 waves per SIMD, 128 VGPRs: 16 waves per CU; measured on C5 at 8 workgroups per CU: 2 waves +3 %,
+			// 4 waves -30 % -- half the workgroups resident)
+			auto launch_comb = [&](int grid, int threads, size_t lds, hipStream_t st, const AsmArgs &args) {
+				if (threads > 64) hipLaunchKernelGGL((k_asm_combine3<4, true>), dim3(grid), dim3(threads), lds, st, args);
+				else hipLaunchKernelGGL((k_asm_combine3<5, false>), dim3(grid), dim3(64), lds, st, args);
+			};
+			auto team = [&](int occ) { const int w = g_knob.comb_waves ? g_knob.comb_waves : occ <= 8 ? 2 : 1; return 64 * std::max(1, std::min(w, (int)V3_MAXW)); };
+			const int tm_a = team(b->tier_occ), tm_b = team(std::max(1, (b->tier_occ * 2 + 1) / 3)), tm_c = team(std::max(1, b->tier_occ / 3)), tm_big = team(2);
 			int ga = b->grid_v2, gb = b->grid_v2b;
 			if (hint && ra.lpt_cnt && !fold_b) {
 				const long long nb_hint = g_hint.n_b.load(), reg = std::max(1, g_hint.regions.load());
@@ -1514,7 +1525,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 					y.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
 					y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
 					y.work_counter = wq + 13 * WQ_WORDS;
-					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(gb), dim3(64), b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
+					launch_comb(gb, tm_b, b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
 					HIPC(hipEventRecord(b->ev_bjoin, s2));
 				} else HIPC(hipEventRecord(b->ev_bjoin, s));
 				if (!fold_c) {
@@ -1522,11 +1533,11 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 					z.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; z.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
 					z.arena_cap = b->v2_arena_c; z.lds_arena = b->v2_arena_c; z.v2_pm_dw = b->v2_pm_c;
 					z.work_counter = wq + 16 * WQ_WORDS;
-					hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2c), dim3(64), b->v2_arena_c + 4 * b->v2_pm_c, s, z);
+					launch_comb(b->grid_v2c, tm_c, b->v2_arena_c + 4 * b->v2_pm_c, s, z);
 				}
 				x.lpt_nclass = LPT_CLASSES * (fold_b ? 3 : fold_c ? 2 : 1);
 			} else HIPC(hipEventRecord(b->ev_bjoin, s));
-			hipLaunchKernelGGL((k_asm_combine3<5>), dim3(ga), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+			launch_comb(ga, tm_a, b->v2_arena + 4 * b->v2_pm, s, x);
 			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second-tier launch)
 			// regions that ran out of room in their launch: the same kernel with a roomy arena, few workgroups per CU -- or, when
 			// the previous batch had none, a token launch with the first tier's arena (it gets scheduled at once; a region that
@@ -1541,10 +1552,10 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && g_hint.n_big.load() == 0 && g_hint.n_back.load() == 0;
 			if (!spec_skip) {
 			if (hint && g_hint.n_big.load() == 0) {
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(std::min(b->grid_v2big, 64)), dim3(64), b->v2_arena + 4 * b->v2_pm, s, x);
+				launch_comb(std::min(b->grid_v2big, 64), tm_a, b->v2_arena + 4 * b->v2_pm, s, x);
 			} else {
 				x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
-				hipLaunchKernelGGL((k_asm_combine3<5>), dim3(b->grid_v2big), dim3(64), b->v2_arena_big + 4 * b->v2_pm_big, s, x);
+				launch_comb(b->grid_v2big, tm_big, b->v2_arena_big + 4 * b->v2_pm_big, s, x);
 			}
 			HIPC(hipGetLastError());
 			a.arena_seq = nullptr; a.arena_sup = b->lds_sup.as<uint32_t>(); a.arena_cap = b->lds_arena1; a.lds_arena = b->lds_arena1;

@@ -524,20 +524,35 @@ __device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ct
 // combine + epilogue on packed bases and u8 supports (asm3_dev.h).  Dynamic LDS: a.lds_arena bytes of supports, then
 // a.v2_pm_dw dwords of packed bases.  A region outside this path's preconditions, or one that runs out of room, goes to
 // out_list (the next, roomier launch of this kernel, or the byte-based passes).
-template <int MINW>
-__global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
+// Two builds.  TEAM = false: one wave per workgroup, 96 VGPRs (the first tiers: 12-16 workgroups per CU).  TEAM = true:
+// workgroups of 2 or 4 waves for the tiers whose arenas leave 8 or fewer workgroups per CU -- wave 0 runs the region, the
+// others join it inside best_match calls (V3Par, asm3_dev.h) and wait at a barrier otherwise; so wave 0 itself never uses a
+// workgroup barrier outside those calls (WAVE_SYNC: its own memory traffic done, nothing more).  128 VGPRs, 16 waves per CU.
+#define WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+template <int MINW, bool TEAM>
+__global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_asm_combine3(const AsmArgs a)
 {
 	__shared__ V3State S;
 	__shared__ int s_item;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
+	__shared__ V3Par s_par;                                    // (dropped from the one-wave build: nobody refers to it there)
+	V3Par *const par = TEAM ? &s_par : nullptr;
 	const int lane = lane_id();
+	const int wave = TEAM ? (int)(threadIdx.x >> 6) : 0, n_waves = TEAM ? (int)(blockDim.x >> 6) : 1;
 	V3Ctx C;
 	C.SUP = lds_arena; C.sup_cap = a.lds_arena; C.PM = (uint32_t *)(lds_arena + a.lds_arena); C.pm_cap = a.v2_pm_dw;
 	C.bump_pm = C.bump_sup = 0; C.prof = a.prof ? S.prof : nullptr; C.cnt = a.prof ? S.cnt : nullptr;
+	if (TEAM && wave != 0) {
+		C.prof = nullptr; C.cnt = nullptr;
+		v3_helper_loop(S, C, par, wave, n_waves);
+		return;
+	}
+	V3Team T;
+	T.par = par; T.nparts = n_waves; T.list_b = 0; T.n = 0; T.dver = 0;
 	mark_start(a.t_start);
 	if (lane < 16) S.prof[lane] = 0;
 	if (lane < 16) S.cnt[lane] = 0;
-	WSYNC();
+	WAVE_SYNC();
 	int n_items = a.in_list ? *a.n_in : a.n_regions;
 	if (a.lpt_cnt) {
 		n_items = 0;
@@ -546,9 +561,9 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 	unsigned wq_dead = 0;
 	for (;;) {
 		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
-		WSYNC();
+		WAVE_SYNC();
 		int r = __builtin_amdgcn_readfirstlane(s_item);
-		WSYNC();
+		WAVE_SYNC();
 		if (r < 0) break;
 		if (a.lpt_cnt) {                                        // item -> (class, position): the classes laid end to end
 			int c = 0;
@@ -561,10 +576,10 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 		if (err == 1) continue;                                // the read phase did not take this region
 		const long long tcA = a.prof ? (long long)clock64() : 0;
 		if (!err) {
-			const int n2 = v3_combine_pass(S, C, S.listA, n_pre, S.listB, 0, a.combine_min_overlap);
+			const int n2 = v3_combine_pass<TEAM>(S, C, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, T);
 			if (n2 < 0) err = n2;
 			else {
-				const int n3 = v3_combine_pass(S, C, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap);
+				const int n3 = v3_combine_pass<TEAM>(S, C, S.listB, n2, S.listA, a.combine_min_support, a.combine_min_overlap, T);
 				if (n3 < 0) err = n3; else n_final = n3;
 			}
 		}
@@ -582,7 +597,11 @@ __global__ __launch_bounds__(64, MINW) void k_asm_combine3(const AsmArgs a)
 			atomicAdd((unsigned long long *)&a.prof[57 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], 1ull);
 		}
 	}
-	WSYNC();
+	if (TEAM && n_waves > 1) {                                 // the others leave their loop
+		if (lane == 0) par->cmd = 2;
+		__syncthreads();
+	}
+	WAVE_SYNC();
 	if (a.prof && lane < 16 && lane != 8 && lane != 9 && lane != 10 && lane != 11 && S.prof[lane])
 		atomicAdd((unsigned long long *)&a.prof[lane], (unsigned long long)S.prof[lane]);
 	if (a.prof && lane >= 8 && lane < 12 && S.prof[lane]) atomicAdd((unsigned long long *)&a.prof[40 + lane], (unsigned long long)S.prof[lane]);

@@ -45,12 +45,14 @@ def shaped(oracle):
 
 
 @pytest.mark.parametrize("knobs", [dict(asm_v1=1), dict(tally_pk=0), dict(lpt=0), dict(no_rich=1), dict(asm_v1=1, tally_pk=0),
-                                    dict(comb_occ=8), dict(asm_waves=6, asmr_waves=12, ksw_waves=9, tally_waves=5)],
+                                    dict(comb_occ=8), dict(asm_waves=6, asmr_waves=12, ksw_waves=9, tally_waves=5),
+                                    dict(comb_waves=2), dict(comb_waves=4, comb_occ=4), dict(comb_waves=1)],
                          ids=lambda k: ",".join("%s=%d" % kv for kv in k.items()))
 def test_results_do_not_depend_on_the_path(hip, shaped, knobs):
     """`asm_v1` forces the byte-based passes on class-1 input, `tally_pk=0` the ASCII tally, `lpt=0` the combine
     launch without cost classes and arena tiers, `no_rich=1` keeps read-rich regions on the byte passes; occupancies are free
-    parameters."""
+    parameters; `comb_waves` = waves per workgroup of the combine kernel (wave 0 runs the region, the others share its
+    best_match calls)."""
     hip.debug_set(**knobs)
     try:
         for name, K, b, exp in shaped:

@@ -20,6 +20,9 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     hip = indelope_amd.api()
     hip.init(0)
+    for kv in sys.argv[3:]:                                      # library switches: key=value (ihp_debug_set)
+        k, v = kv.split("=")
+        hip.debug_set(**{k: int(v)})
     orc = oracle.get()
     bad = 0
     t0 = time.time()
