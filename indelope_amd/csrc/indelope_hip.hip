@@ -88,7 +88,7 @@ Knobs g_knob;
 // (the read kernel files them); sig: the shape of that batch (read length, read bases per region): a batch of another
 // shape does not use the histogram.
 constexpr int HIST_N = 7;
-constexpr int HIST_OCC[HIST_N] = {16, 14, 12, 10, 8, 6, 4};
+constexpr int HIST_OCC[HIST_N] = {16, 14, 12, 10, 9, 8, 6};
 struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}, regions{0}, sig{0}; std::atomic<int> hist[HIST_N]; };
 TierHint g_hint;
 std::atomic<int> g_live_batches{0};
