@@ -743,7 +743,11 @@ __device__ __forceinline__ bool narrow_tail_loop(NarrowState &F, const NarrowEnv
 	const int lane = lane_id();
 	for (; r < total; ++r) {
 		int st0, en0, nst, en;
-		if (ksw_band(r, E.qlen, E.tlen, E.w, st0, en0, nst, en) && en0 - st0 < 48 && r > E.w + 32 && nst > 0) break;
+		// narrow_tail_step needs a band that is narrower than 48 cells AND stays so: a band of w <= 47, or one cut by the end of
+		// the query (st0 = r - qlen + 1 moves every diagonal from now on) or of the target (en0 = tlen - 1 stays).  An uncut band
+		// of w = 48 is 48 and 47 cells wide in turn: its wider diagonals refresh scores in slot B.
+		if (ksw_band(r, E.qlen, E.tlen, E.w, st0, en0, nst, en) && en0 - st0 < 48 && r > E.w + 32 && nst > 0 &&
+		    (E.w <= 47 || r - E.qlen + 1 >= ((r - E.w + 1) >> 1) || ((r + E.w) >> 1) >= E.tlen - 1)) break;
 		if (narrow_diag<RIGHT, ND_ANY>(F, E, r)) return true;
 	}
 	if (r >= total) return false;
@@ -872,7 +876,9 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	E.zdrop = P.zdrop; E.ZW24 = (int)(ZW << 24); E.M24 = ZM << 24; E.q24 = (int)(((unsigned)q & 0xff) << 24);
 	const int total = qlen + tlen - 1;
 	// steady diagonals: st0 = (r-w+1)>>1 > r-qlen+1, en0 = (r+w)>>1 < tlen-1, en < r
-	const bool roomy = qlen >= w + 32 && tlen >= w + 32;   // the first w+31 diagonals stay clear of the sequence ends
+	// the first w+31 diagonals stay clear of the sequence ends (w = 0: diagonal 1 has no cell at all, :200-203 -- the general
+	// narrow_diag sees that)
+	const bool roomy = w >= 1 && qlen >= w + 32 && tlen >= w + 32;
 	int r_hi = 2 * tlen - 3 - w < 2 * qlen - w - 3 ? 2 * tlen - 3 - w : 2 * qlen - w - 3;
 	r_hi = r_hi + 1 < total ? r_hi + 1 : total;
 	bool stop = narrow_diag<RIGHT, ND_FIRST>(F, E, 0);

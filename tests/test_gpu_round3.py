@@ -291,3 +291,26 @@ def test_tiers_cut_again_from_the_last_batch_give_the_same_results(hip, oracle):
     finally:
         hip.debug_set()
         hip.batch_free(h)
+
+
+def test_ksw_band_widths_at_the_edges_of_the_sweeps(hip, oracle):
+    """Band widths where the narrow sweep changes its plan: 0 (diagonal 1 has no cell: the reference stops there), 1, 47 / 48 /
+    49 (an uncut band of 48 is 48 and 47 cells wide in turn: the lean tail loop may only take it once a sequence end cuts it;
+    from 49 on the steady loop runs), 62; found by tools/ksw_stress.py, seed 1."""
+    import test_gpu_round2 as T
+    rng = np.random.default_rng(4848)
+    qs, ts = [], []
+    for _ in range(120):
+        ql, tl = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        q, t = T._pair(rng, ql if rng.random() < 0.6 else min(ql, tl), tl, sub=float(rng.choice([0, 0.01, 0.05, 0.2])),
+                       indel=float(rng.choice([0, 0.01, 0.05])), shift=int(rng.integers(0, max(1, tl // 2))) if rng.random() < 0.5 else None)
+        qs.append(q)
+        ts.append(t)
+    for w in (0, 1, 47, 48, 49, 62):
+        for flag in (0, A.KSW_EZ_RIGHT, A.KSW_EZ_EXTZ_ONLY):
+            for z in (-1, 200):
+                kw = dict(match=1, mismatch=-5, gap_open=5, gap_ext=1, bw=w, z=z, flag=flag)
+                ez, cg = hip.align_batch(qs, ts, **kw)
+                ez2, cg2 = oracle.align_batch(qs, ts, **kw)
+                for i in range(len(qs)):
+                    assert ez[i].tolist() == ez2[i].tolist() and cg[i].tolist() == cg2[i].tolist(), (kw, len(qs[i]), len(ts[i]), ez[i], ez2[i])

@@ -7,7 +7,7 @@ hip=indelope_amd.api(); hip.init(0); orc=oracle.get()
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1)
 bad=0; n=0
 for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
-    w=int(rng.integers(0,63)); z=int(rng.choice([-1,5,20,60,200,400,1000])); flag=int(rng.choice([0,A.KSW_EZ_RIGHT,A.KSW_EZ_EXTZ_ONLY,A.KSW_EZ_RIGHT|A.KSW_EZ_REV_CIGAR]))
+    w=int(rng.integers(0,63)) if rng.random()<0.6 else int(rng.choice([0,1,2,15,16,17,31,32,33,46,47,48,49,50,61,62,63,64,80,-1])); z=int(rng.choice([-1,5,20,60,200,400,1000])); flag=int(rng.choice([0,A.KSW_EZ_RIGHT,A.KSW_EZ_EXTZ_ONLY,A.KSW_EZ_RIGHT|A.KSW_EZ_REV_CIGAR]))
     go=int(rng.integers(2,9)); ge=int(rng.integers(1,4)); ma=int(rng.integers(1,4)); mi=-int(rng.integers(1,6))
     qs,ts=[],[]
     for _ in range(200):
