@@ -15,12 +15,19 @@ from indelope_amd import synth  # noqa: E402
 from indelope_amd.host import BatchResult  # noqa: E402
 
 
+WIDE_PARAMS = False
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     hip = indelope_amd.api()
     hip.init(0)
-    for kv in sys.argv[3:]:                                      # library switches: key=value (ihp_debug_set)
+    global WIDE_PARAMS
+    for kv in sys.argv[3:]:                                      # library switches: key=value (ihp_debug_set); "params" = randomise ihp_params too
+        if kv == "params":
+            WIDE_PARAMS = True
+            continue
         k, v = kv.split("=")
         hip.debug_set(**{k: int(v)})
     orc = oracle.get()
@@ -39,6 +46,18 @@ def main():
         kw = dict(K=K)
         if rng.random() < 0.5:
             kw.update(min_reads=3, min_ctg_len=73)
+        if WIDE_PARAMS and rng.random() < 0.7:                     # the parameters the CLI leaves at their defaults, too
+            if rng.random() < 0.4: kw.update(bw=int(rng.choice([0, 8, 20, 47, 48, 49, 62, 70, -1])))
+            if rng.random() < 0.3: kw.update(zdrop=int(rng.choice([-1, 20, 100, 1000])))
+            if rng.random() < 0.3: kw.update(min_overlap_pct=float(rng.choice([0.4, 0.5, 0.8, 1.0])))
+            if rng.random() < 0.2: kw.update(max_mismatch=int(rng.choice([1, 2])))
+            if rng.random() < 0.3: kw.update(combine_min_support=int(rng.choice([1, 2, 4])))
+            if rng.random() < 0.3: kw.update(combine_min_overlap=int(rng.choice([10, 17, 30, 80])))
+            if rng.random() < 0.2: kw.update(gap_open=int(rng.choice([2, 6])), gap_ext=int(rng.choice([1, 2])), mismatch=int(rng.choice([-1, -4])))
+            if rng.random() < 0.2: kw.update(ref_pad=int(rng.choice([0, 10, 60])))
+            if rng.random() < 0.2: kw.update(max_pre_contigs=int(rng.choice([2, 5, 50])), max_events=int(rng.choice([1, 3])))
+            if rng.random() < 0.2: kw.update(fallback=0)
+            if rng.random() < 0.2: kw.update(ksw_flag=2)
         if rng.random() < 0.3:
             b.mapq = rng.choice(np.array([0, 5, 9, 10, 19, 20, 60], np.uint8), b.n_reads)
         if rng.random() < 0.4:
@@ -61,6 +80,8 @@ def main():
         ok = d is None and np.allclose(got.events["gl"], exp.events["gl"], rtol=1e-12)
         vg, ve = hip.call_variants(b, got, hip.params(**kw)), orc.call_variants(b, exp, orc.params(**kw))
         okv = [(x["filter"], x["start"], x["ref"], x["alt"], x["line"]) for x in vg] == [(x["filter"], x["start"], x["ref"], x["alt"], x["line"]) for x in ve]
+        if WIDE_PARAMS:
+            print("    params", {k: v for k, v in kw.items() if k != "K"})
         print("%3d %s rl=%d K=%d reads=%s err=%g dup=%g regions=%d contigs=%d events=%d fallback=%d variants=%d"
               % (it, "ok " if ok and okv else "DIFF", rl, K, cfg["n_reads"], cfg["err_rate"], cfg["dup_frac"], b.n_regions,
                  got.n_contigs, got.n_events, int((got.events["aligned"] == 1).sum()), sum(x["filter"] == 0 for x in vg)), d or "", flush=True)
