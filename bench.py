@@ -644,7 +644,7 @@ def main():
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
                                     "records per step" + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
-            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine3 + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_stale": stale,
                          "algorithmic_bytes_per_launch": int(by_kernel[KERNELS[dom]]),

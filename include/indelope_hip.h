@@ -494,7 +494,7 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *                   the others take shares of its best_match calls
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
- *   "lpt" 0         k_asm_combine in input order: no cost classes, no second arena tier
+ *   "lpt" 0         k_asm_combine3 in input order: no cost classes, no arena tiers
  *   "asm_waves", "asmr_waves", "comb_occ", "ksw_waves", "tally_waves"   waves per CU of a kernel (0 = library sizing)
  *   "v2_arena", "v2_pdw"   LDS bytes / dwords per wave of the packed assembly (0 = library sizing)
  *   "profile" 1     per-phase cycle counters (ihp_batch_profile)

@@ -232,7 +232,7 @@ __device__ __forceinline__ long long bcast64(long long v, int src)
 
 // Cost class of a region for the combine kernel (0 = most work): combine compares every contig with a growing list
 // (contig.nim:254-281), so its time grows with the square of the contigs the read phase leaves.  k_asm_reads files every
-// region under its class and k_asm_combine takes the classes in order -- the longest chains start first and the short ones
+// region under its class and k_asm_combine3 takes the classes in order -- the longest chains start first and the short ones
 // fill the end of the launch instead of the other way round.
 constexpr int LPT_CLASSES = 16, LPT_TIERS = 3;     // three combine launches: arenas of growing size at falling occupancy
 // (16 classes: two contigs apart over the range of 150 bp pile-ups, wider above.  The contig count is the best predictor the
@@ -264,7 +264,7 @@ struct ReadArgs {
 	const uint32_t *v2_pk;
 	uint32_t *v2_hand; const long long *v2_hoff;
 	int *n_final;                                             // per region: 0 for a region handed to out_list (nobody may take that list in this run)
-	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine by arena tier and cost class, longest first (see lpt_class)
+	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine3 by arena tier and cost class, longest first (see lpt_class)
 	int *n_tier_b;                                            // counts the regions filed under the second and third tier (diagnostics)
 	int tier_a_cap, tier_b_cap;                               // arena capacities of the first two combine launches: a region is filed under the first that holds it
 	int hist_cap[7]; int *hist;                               // hist[k] counts the regions whose need fits hist_cap[k] (ascending) and no smaller one: what the
@@ -275,7 +275,7 @@ struct ReadArgs {
 	long long *prof; unsigned long long *t_start;
 };
 
-// Hand-over record of one region in HBM (a.v2_hand + a.v2_hoff[r], dwords), written by k_asm_reads, read by k_asm_combine:
+// Hand-over record of one region in HBM (a.v2_hand + a.v2_hoff[r], dwords), written by k_asm_reads, read by k_asm_combine3:
 //   [0] contigs n (-1: the region was not taken), [1] reads of the region, [2..7] unused
 //   n x V2_DIRW: { packed data offset (dwords from the record's start), length, nreads, start lo, start hi, anchor, 0, 0 }
 //   one record dword per read of the region (see below), then the contigs' packed bases (ceil(len / 16) dwords each)

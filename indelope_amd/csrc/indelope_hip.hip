@@ -72,7 +72,7 @@ struct Knobs {
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
-	int lpt = 1;           // 0: k_asm_combine takes its regions in input order (no cost classes, no second arena tier)
+	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
 	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
 	int profile = 0;       // 1: kernels sum shader-clock cycles per phase (ihp_batch_profile)

@@ -41,8 +41,8 @@ struct AsmArgs {
 	// packed read phase (asm2_dev.h): what k_prepack left -- 2-bit bases, the kept range of every read, "not ACGT" flags
 	const uint32_t *v2_pk; const int *v2_trim_lo, *v2_trim_hi; const uint8_t *v2_read_bad;
 	int v2_pdw;                                        // dwords of the per-wave packed area in LDS (k_asm_reads)
-	int v2_pm_dw;                                      // dwords of the packed mirror behind the byte arena (k_asm_combine)
-	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine: region r at v2_hand + v2_hoff[r]
+	int v2_pm_dw;                                      // dwords of the packed mirror behind the byte arena (k_asm_combine3)
+	uint32_t *v2_hand; const long long *v2_hoff;       // hand-over records k_asm_reads -> k_asm_combine3: region r at v2_hand + v2_hoff[r]
 	const int *lpt_cnt, *lpt_seg; int lpt_stride;      // k_asm_combine3: its regions by cost class (asm2_dev.h lpt_class; the counters and list
 	int lpt_nclass;                                    // segments of this launch's tier -- or tiers: lpt_nclass of them, laid end to end), or null
 };
