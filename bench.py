@@ -203,7 +203,9 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
             gate = threading.Barrier(threads + 1)
 
             def worker(k, nb=nb):
-                finish(start(slabs[k][0], nb), nb)                   # untimed: this thread's buffers come out of the pools from here on
+                warm = [start(slabs[k][j], nb) for j in range(depth)]    # untimed, with as many batches in flight as the timed loop keeps:
+                for h in warm:                                           # this thread's buffers come out of the pools from here on
+                    finish(h, nb)
                 gate.wait()
                 q = []
                 for i in range(n_each):
