@@ -29,6 +29,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# hardware queues for the streams of the batches in flight (read when the HIP runtime starts: before torch or the library
+# make their first call; see ihp_init in indelope_hip.hip); never overrides the caller's setting
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)

@@ -8,6 +8,11 @@ GPU is usable the calls fail loudly.
 import ctypes as C
 import os
 
+# hardware queues for the streams of the batches in flight (two per batch; the HIP runtime's default of 4 makes launch chains
+# that should overlap share a queue every few runs).  Read when the runtime starts, so it is set before anything here touches
+# HIP; the caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 from . import _abi
 from .host import Api, BatchResult, Contig, IhpError, Match, RegionBatch, unaligned  # noqa: F401
 

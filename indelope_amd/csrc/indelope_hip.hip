@@ -151,7 +151,15 @@ struct StreamCache {
 		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
 		return s;
 	}
-	void put(hipStream_t s) { std::lock_guard<std::mutex> l(mu); free_list.push_back(s); }
+	// Only a few are kept: the runtime spreads the streams that EXIST over its hardware queues (the least used queue gets
+	// the next stream), so a pile of idle cached streams makes two live ones share a queue sooner.
+	void put(hipStream_t s) {
+		{
+			std::lock_guard<std::mutex> l(mu);
+			if (free_list.size() < 4) { free_list.push_back(s); return; }
+		}
+		(void)hipStreamDestroy(s);
+	}
 	void clear() {
 		std::lock_guard<std::mutex> l(mu);
 		for (auto s : free_list) (void)hipStreamDestroy(s);
@@ -196,16 +204,20 @@ struct SlabHdr { uint64_t magic; size_t cap; uint64_t pad[6]; };
 static_assert(sizeof(SlabHdr) == 64, "slab header");
 constexpr uint64_t SLAB_MAGIC = 0x49485053'4c414231ull;
 struct SlabCache {
+	struct Ent { void *base; size_t cap; unsigned long long tick; };
 	std::mutex mu;
-	std::vector<std::pair<void *, size_t>> free_list;      // (base, capacity)
+	std::vector<Ent> free_list;
+	unsigned long long clock = 0;
+	size_t bytes_kept = 0;
 	void *get(size_t bytes) {
 		{
 			std::lock_guard<std::mutex> l(mu);
 			int best = -1;
 			for (int i = 0; i < (int)free_list.size(); ++i)
-				if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = i;
-			if (best >= 0 && free_list[best].second <= 4 * bytes + (1u << 20)) {
-				void *p = free_list[best].first;
+				if (free_list[i].cap >= bytes && (best < 0 || free_list[i].cap < free_list[best].cap)) best = i;
+			if (best >= 0 && free_list[best].cap <= 4 * bytes + (1u << 20)) {
+				void *p = free_list[best].base;
+				bytes_kept -= free_list[best].cap;
 				free_list.erase(free_list.begin() + best);
 				return p;
 			}
@@ -217,20 +229,30 @@ struct SlabCache {
 		h->magic = SLAB_MAGIC; h->cap = cap;
 		return p;
 	}
+	// Freed blocks are kept -- result slabs and staging blocks of every batch in flight, of a few sizes -- up to 64 blocks and
+	// 4 GB; beyond that the one that has been lying here longest goes (hipHostFree waits for the device: an eviction policy
+	// that threw out the smallest block first made every batch of a sweep allocate and free its staging block again).
 	void put(void *base) {
-		std::lock_guard<std::mutex> l(mu);
-		free_list.push_back({base, ((SlabHdr *)base)->cap});
-		while (free_list.size() > 24) {                      // keep some (result slabs and staging blocks of the batches in flight); drop the smallest
-			int w = 0;
-			for (int i = 1; i < (int)free_list.size(); ++i) if (free_list[i].second < free_list[w].second) w = i;
-			(void)hipHostFree(free_list[w].first);
-			free_list.erase(free_list.begin() + w);
+		std::vector<void *> drop;
+		{
+			std::lock_guard<std::mutex> l(mu);
+			free_list.push_back({base, ((SlabHdr *)base)->cap, ++clock});
+			bytes_kept += free_list.back().cap;
+			while (free_list.size() > 64 || (bytes_kept > ((size_t)4 << 30) && free_list.size() > 1)) {
+				int w = 0;
+				for (int i = 1; i < (int)free_list.size(); ++i) if (free_list[i].tick < free_list[w].tick) w = i;
+				drop.push_back(free_list[w].base);
+				bytes_kept -= free_list[w].cap;
+				free_list.erase(free_list.begin() + w);
+			}
 		}
+		for (void *p : drop) (void)hipHostFree(p);
 	}
 	void clear() {
 		std::lock_guard<std::mutex> l(mu);
-		for (auto &e : free_list) (void)hipHostFree(e.first);
+		for (auto &e : free_list) (void)hipHostFree(e.base);
 		free_list.clear();
+		bytes_kept = 0;
 	}
 };
 SlabCache g_slabs;
@@ -334,6 +356,12 @@ static void report_pool_clear();
 extern "C" int ihp_init(int device)
 {
 	if (g.ready && g.device == device) { tl_device = -1; return ensure_init(); }
+	// Every batch in flight has two streams of its own, and the HIP runtime multiplexes all streams of a process onto
+	// GPU_MAX_HW_QUEUES hardware queues (default 4): with more than two batches about, two launch chains that should
+	// overlap land on one queue every few runs and run one after the other (C3 / C5 behind the e2e leg of bench.py: 4.4 ->
+	// 3.8 M and 2.6 -> 2.1 M regions/s in two runs of five; none in five with 16 queues).  The variable is read when the
+	// runtime starts: this helps when this call is the process's first HIP call and never overrides the user's setting.
+	(void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g.err, sizeof(g.err), "no HIP device"); return IHP_E_NODEVICE; }
 	if (device < 0 || device >= n) return IHP_E_ARG;
