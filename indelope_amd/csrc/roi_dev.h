@@ -107,7 +107,13 @@ __global__ __launch_bounds__(ROI_BLOCK) void k_roi_pmax_apply(const RoiArgs a)
 	const long long excl = ll_max(before, t ? sc[t - 1] : ROI_NONE);
 	a.pmax_incl[i] = ll_max(before, sc[t]);
 	const long long s = a.start[i];
-	if (excl != ROI_NONE && s > excl && s >= 0 && s <= a.len) a.cut[s] = 1;
+	// (:529 also asks for a non-empty cache: behind a skippable read that flushed it, the next reads -- skippable or not --
+	// flush nothing until a non-skippable one has been added, and the window keeps starting at that first read's start.
+	// In a run of skippable reads the stops seen so far do not change and the starts ascend, so it is enough to look at the
+	// read before.  Only min_event_support = 0 can tell: otherwise no evidence lies between the two starts.)
+	bool first = true;
+	if (i > 0 && a.skip && a.skip[i - 1]) first = !(a.start[i - 1] > excl);
+	if (excl != ROI_NONE && s > excl && first && s >= 0 && s <= a.len) a.cut[s] = 1;
 }
 
 // event_locations (:430-445) of one read per thread, evidence[i] += 1 over every event (:539-543)

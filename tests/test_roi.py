@@ -92,7 +92,10 @@ def test_oracle_windows_are_cut_where_the_cache_is_flushed(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,n,span,gap,minev,minr,maxr", [
     (1, 3000, 20_000, 0, 4, 4, 600), (2, 5000, 60_000, 40, 3, 3, 600), (3, 800, 3_000, 0, 4, 4, 30),
-    (4, 20_000, 400_000, 500, 4, 4, 600), (5, 2000, 5_000, 7, 2, 1, 600), (6, 300, 100_000, 3, 1, 1, 600)])
+    (4, 20_000, 400_000, 500, 4, 4, 600), (5, 2000, 5_000, 7, 2, 1, 600), (6, 300, 100_000, 3, 1, 1, 600),
+    # min_event_support = 0: every position counts, so a window starts exactly where the cache was flushed -- at the start of the
+    # FIRST read beyond every cached stop, skippable or not (tools/roi_stress.py found the device cutting again at the next read)
+    (7, 400, 20_000, 3, 0, 1, 30), (8, 12_000, 150_000, 0, 0, 2, 100_000), (9, 60, 20_000, 3, 0, 1, 100_000)])
 def test_device_scan_equals_oracle(hip, oracle, seed, n, span, gap, minev, minr, maxr):
     rng = np.random.default_rng(seed)
     hot = sorted(rng.integers(500, span - 500, max(3, span // 3000)).tolist())
@@ -134,3 +137,17 @@ def test_device_scan_edges(hip, oracle):
     # more reads than max_read_coverage: the region is dropped (:483-485)
     kw["max_read_coverage"] = 299
     assert hip.gen_roi(st, en, cg, **kw) == oracle.gen_roi(st, en, cg, **kw) == []
+
+
+@pytest.mark.gpu
+def test_a_skippable_read_flushes_the_cache_once(hip, oracle):
+    """indelope.nim:529-537 with min_event_support = 0: read B (skippable) lies beyond the cached read A and flushes the window;
+    C, behind it, finds the cache empty and flushes nothing -- the next window starts at B's start, not at C's."""
+    st = np.array([0, 200, 250], np.int64)
+    en = np.array([100, 300, 350], np.int64)
+    cg = [cig("100M"), cig("100M"), cig("100M")]
+    skip = np.array([0, 1, 0], np.uint8)
+    kw = dict(read_skip=skip, origin=0, span=400, min_event_support=0, min_read_coverage=1, max_read_coverage=10)
+    exp = oracle.gen_roi(st, en, cg, **kw)
+    assert [(a, b) for a, b, _ in exp] == [(0, 199), (200, 400)]
+    assert hip.gen_roi(st, en, cg, **kw) == exp
