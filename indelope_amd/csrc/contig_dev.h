@@ -133,7 +133,9 @@ __device__ inline void slide_scan(const ST &S, const Arena &A, int qs, int ts, i
 	const long long qreads = S.nreads[qs], treads = S.nreads[ts];
 	const uint32_t *a32 = (const uint32_t *)A.seq;
 	const int qb = S.off[qs], tb = S.off[ts];
-	const int qlo3 = S.lo3[qs], qhi3 = S.hi3[qs], tlo3 = S.lo3[ts], thi3 = S.hi3[ts];
+	// (kept inside [0, 2^30]: the differences below then cannot wrap, whatever a slot holds)
+	auto zone = [](int v) { return v < 0 ? 0 : v > 0x3fffffff ? 0x3fffffff : v; };
+	const int qlo3 = zone(S.lo3[qs]), qhi3 = zone(S.hi3[qs]), tlo3 = zone(S.lo3[ts]), thi3 = zone(S.hi3[ts]);
 	const int omax = tlen - min_overlap;                       // :79
 	int omin_abs = qlen - min_overlap;                         // :78, :114 abs(omin)
 	if (omin_abs < 0) omin_abs = -omin_abs;

@@ -263,6 +263,9 @@ __device__ inline int assemble_region(const AsmArgs &a, ST &S, Arena &A, int r, 
 					if (lane == 0) {
 						S.off[slot] = noff; S.len[slot] = tl; S.cap[slot] = need; S.nreads[slot] = 1;
 						S.start[slot] = S.start[QSLOT]; S.alive[slot] = 1; S.bump = noff + need + SLOT_PAD;
+						// support 1 everywhere, no ">= 3" run: slide_scan reads these of every target (a slot's old values, or
+						// whatever the LDS held, sent its 8-base window anywhere -- a memory fault in the HBM-arena pass)
+						S.smin[slot] = 1; S.smax[slot] = 1; S.lo3[slot] = 0x3fffffff; S.hi3[slot] = 0;
 						S.listA[n] = (short)slot;
 					}
 					n++;

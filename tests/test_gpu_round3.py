@@ -314,3 +314,17 @@ def test_ksw_band_widths_at_the_edges_of_the_sweeps(hip, oracle):
                 ez2, cg2 = oracle.align_batch(qs, ts, **kw)
                 for i in range(len(qs)):
                     assert ez[i].tolist() == ez2[i].tolist() and cg[i].tolist() == cg2[i].tolist(), (kw, len(qs[i]), len(ts[i]), ez[i], ez2[i])
+
+
+def test_many_contigs_with_mismatches_allowed_in_the_catch_all_pass(hip, oracle):
+    """min_overlap_pct = 1.0 with max_mismatch = 1: hardly any read merges, a region of 223 reads leaves 204 contigs and ends up in
+    the HBM-arena pass through the general (mismatch-tolerant) insert path.  tools/stress_parity.py with randomised parameters
+    found a memory fault there: a new contig's slot kept the ">= 3 supports" run of whatever the slot held before."""
+    b, _ = synth.generate(n_regions=93, read_len=151, n_reads=(25, 251), err_rate=0.01, config_id=1102, dup_frac=0.2, seed=2144126653)
+    kw = dict(min_ctg_len=73, min_overlap_pct=1.0, max_mismatch=1)
+    exp = oracle.run_regions_mt(b, oracle.params(**kw), 16)
+    assert int(exp.n_contigs_pre.max()) > 128
+    for _ in range(3):
+        assert_same(hip.run_regions(b, hip.params(**kw)), exp)
+    one = b.slice(3, 4)
+    assert_same(hip.run_regions(one, hip.params(**kw)), oracle.run_regions(one, oracle.params(**kw)))

@@ -16,6 +16,7 @@ from indelope_amd.host import BatchResult  # noqa: E402
 
 
 WIDE_PARAMS = False
+ONLY = None
 
 
 def main():
@@ -27,6 +28,10 @@ def main():
     for kv in sys.argv[3:]:                                      # library switches: key=value (ihp_debug_set); "params" = randomise ihp_params too
         if kv == "params":
             WIDE_PARAMS = True
+            continue
+        if kv.startswith("only="):
+            global ONLY
+            ONLY = int(kv[5:])
             continue
         k, v = kv.split("=")
         hip.debug_set(**{k: int(v)})
@@ -58,6 +63,10 @@ def main():
             if rng.random() < 0.2: kw.update(max_pre_contigs=int(rng.choice([2, 5, 50])), max_events=int(rng.choice([1, 3])))
             if rng.random() < 0.2: kw.update(fallback=0)
             if rng.random() < 0.2: kw.update(ksw_flag=2)
+            if rng.random() < 0.2: kw.update(min_mapq_assemble=int(rng.choice([0, 10, 30])), min_mapq_stop=int(rng.choice([0, 20])), min_mapq_tally=int(rng.choice([0, 10, 30])))
+            if rng.random() < 0.2: kw.update(trim_min_qual=int(rng.choice([0, 3, 20])))
+            if rng.random() < 0.2: kw.update(min_event_len=int(rng.choice([1, 3, 10])))
+            if rng.random() < 0.2: kw.update(K=int(rng.choice([9, 13, 17, 31])))
         if rng.random() < 0.3:
             b.mapq = rng.choice(np.array([0, 5, 9, 10, 19, 20, 60], np.uint8), b.n_reads)
         if rng.random() < 0.4:
@@ -74,6 +83,10 @@ def main():
             hit = rng.random(len(bases)) < 0.003
             bases[hit] = rng.choice(np.frombuffer(b"Nacgt", np.uint8), int(hit.sum()))
             b.bases = bases
+        if ONLY is not None and it != ONLY:
+            continue
+        if WIDE_PARAMS:
+            print("    next", it, cfg, {k: v for k, v in kw.items()}, flush=True)
         got = hip.run_regions(b, hip.params(**kw))
         exp = orc.run_regions(b, orc.params(**kw))
         d = BatchResult.first_difference(got, exp)
