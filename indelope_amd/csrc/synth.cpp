@@ -126,12 +126,15 @@ static void fill_range(const ihp_synth_cfg *c, int r_lo, int r_hi, int64_t ri, i
 		if (c->n_events >= 2) { slo = p0 - (RL - 15); shi = p0 + 235; }
 		else { slo = p0 - RL + 15; shi = p0 - 15; }
 		if (slo < 0) slo = 0;
+		if (shi < slo) shi = slo;                                  // reads shorter than 30 bases: all start at the same place
+		if (shi > L - RL) shi = L - RL > slo ? L - RL : slo;
 		rds.resize(n);
 		for (int i = 0; i < n; ++i) {
 			rds[i].hap = (int)g.below(2);
 			int hl = rds[i].hap ? (int)alt.size() : L;
 			int s = slo + (int)g.below((uint32_t)(shi - slo + 1));
 			if (s + RL > hl) s = hl - RL;
+			if (s < 0) s = 0;
 			rds[i].s = s; rds[i].order = i;
 		}
 		// error draws happen in generation order so that sorting does not change the stream

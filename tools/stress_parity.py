@@ -16,6 +16,7 @@ from indelope_amd.host import BatchResult  # noqa: E402
 
 
 WIDE_PARAMS = False
+LONG_SHORT = None
 ONLY = None
 
 
@@ -29,6 +30,10 @@ def main():
         if kv == "params":
             WIDE_PARAMS = True
             continue
+        if kv == "lengths":                                      # very short and very long reads (the packed path takes 20 .. 960 bases)
+            global LONG_SHORT
+            LONG_SHORT = [20, 25, 36, 50, 400, 700, 959, 960, 961, 1200, 1500]
+            continue
         if kv.startswith("only="):
             global ONLY
             ONLY = int(kv[5:])
@@ -39,7 +44,7 @@ def main():
     bad = 0
     t0 = time.time()
     for it in range(n):
-        rl = int(rng.choice([75, 100, 125, 150, 151, 200, 250, 300]))
+        rl = int(rng.choice(LONG_SHORT if LONG_SHORT else [75, 100, 125, 150, 151, 200, 250, 300]))
         K = int(rng.choice([21, 25, 27, 31])) if rl >= 100 else 21
         lo = int(rng.integers(2, 40))
         hi = int(rng.integers(lo, min(300, lo + rng.choice([10, 60, 250]))))
