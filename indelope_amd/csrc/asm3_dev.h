@@ -724,7 +724,10 @@ __device__ inline void v3_compact(V3State &S, V3Ctx &C)
 		const int c = ctz64(ballot(key == k));
 		key = lane == c ? 0x7fffffff : key;
 		const int so = uni(S.so[c]), dw = uni(S.dw[c]), sh = uni((int)S.sh[c]), len = uni(S.len[c]);
-		const int nd = ((sh + len + 15) >> 4) + 1;                   // dwords incl. the pad
+		// dwords: the bases from `sh` on, room for the rest of the capacity the contig keeps (an insert in place may grow it to
+		// cap bases without asking -- with sh > 0 that can be a dword more than the bases it has now), and the pad
+		const int capn = align4(len);
+		const int nsrc = (sh + len + 15) >> 4, nd = ((sh + capn + 15) >> 4) + 1;
 		if (so >= 0 && so != nsup) {
 			for (int i0 = 0; i0 < len; i0 += 64) {
 				const int i = i0 + lane;
@@ -737,13 +740,13 @@ __device__ inline void v3_compact(V3State &S, V3Ctx &C)
 		if (dw != npm) {
 			for (int i0 = 0; i0 < nd; i0 += 64) {
 				const int i = i0 + lane;
-				const unsigned v = i < nd - 1 ? C.PM[dw + i] : 0u;
+				const unsigned v = i < nsrc ? C.PM[dw + i] : 0u;
 				LDS_ORDER();
 				if (i < nd) C.PM[npm + i] = v;
 				LDS_ORDER();
 			}
 		}
-		if (lane == 0) { S.so[c] = so >= 0 ? nsup : -1; S.dw[c] = npm; S.cap[c] = align4(len); }
+		if (lane == 0) { S.so[c] = so >= 0 ? nsup : -1; S.dw[c] = npm; S.cap[c] = capn; }
 		if (so >= 0) nsup += align4(len) + SLOT_PAD;
 		npm += nd;
 	}

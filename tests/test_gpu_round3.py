@@ -328,3 +328,15 @@ def test_many_contigs_with_mismatches_allowed_in_the_catch_all_pass(hip, oracle)
         assert_same(hip.run_regions(b, hip.params(**kw)), exp)
     one = b.slice(3, 4)
     assert_same(hip.run_regions(one, hip.params(**kw)), oracle.run_regions(one, oracle.params(**kw)))
+
+
+def test_compaction_keeps_room_for_a_trimmed_contig_to_grow_in_place(hip, oracle):
+    """A contig whose start a trim moved into the middle of a dword keeps, after a compaction of the packed area, the dwords
+    its capacity needs from THAT start: one base added in place later crossed into the next contig's first dword otherwise
+    (its first 16 bases read 'AAAA...' and a merge was missed; tools/thread_stress.py, one region in ~100 000)."""
+    b, _ = synth.generate(n_regions=340, read_len=150, n_reads=(51, 53), err_rate=0.01, config_id=5618, dup_frac=0.0, seed=1031199230)
+    b = b.with_trim_bounds()
+    kw = dict(K=27, min_overlap_pct=1.0)
+    assert_same(hip.run_regions(b, hip.params(**kw)), oracle.run_regions_mt(b, oracle.params(**kw), 16))
+    one = b.slice(102, 103)
+    assert_same(hip.run_regions(one, hip.params(**kw)), oracle.run_regions(one, oracle.params(**kw)))

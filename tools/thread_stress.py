@@ -24,6 +24,9 @@ bad = []
 lock = threading.Lock()
 
 
+ONLY = tuple(int(x) for x in sys.argv[4].split(":")) if len(sys.argv) > 4 else None     # "thread:config": replay that one alone
+
+
 def worker(k):
     rng = np.random.default_rng(seed * 100 + k)
     for it in range(N):
@@ -41,16 +44,21 @@ def worker(k):
         if rng.random() < 0.5:
             b = b.with_trim_bounds()
         mode = int(rng.integers(0, 3))
+        plan = (bool(rng.integers(0, 2)), int(rng.integers(1, 4)), [bool(rng.random() < 0.5) for _ in range(3)])
+        if ONLY and (k, it) != ONLY:
+            continue
+        if ONLY:
+            print("replay", k, it, cfg, kw, "mode", mode, plan, "trim", b.trim_lo is not None, flush=True)
         if mode == 0:
             got = hip.run_regions(b, hip.params(**kw))
         else:                                                   # the batch API: several runs, eager fetch, a slab now and then
             slab = hip.make_slab(b.with_trim_bounds()) if mode == 2 and not (b.bases >= 97).any() else None
             h = hip.batch_upload_slab(slab, hip.params(**kw)) if slab else hip.batch_upload(b, hip.params(**kw))
             try:
-                hip.batch_set_fetch(h, eager=bool(rng.integers(0, 2)))
-                for _ in range(int(rng.integers(1, 4))):
+                hip.batch_set_fetch(h, eager=plan[0])
+                for j in range(plan[1]):
                     hip.batch_run(h)
-                    if rng.random() < 0.5:
+                    if plan[2][j]:
                         hip.batch_sync(h)
                 got = hip.batch_fetch(h)
             finally:
@@ -65,6 +73,11 @@ def worker(k):
                 print("DIFF thread", k, it, cfg, kw, d, flush=True)
 
 
+if ONLY:
+    for rep in range(5):
+        worker(ONLY[0])
+    print("replayed 5 times, %d differences" % len(bad))
+    sys.exit(1 if bad else 0)
 th = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
 for x in th:
     x.start()
