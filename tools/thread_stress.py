@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host threads running different batches with different parameters at the same time (the hints one batch leaves for the next,
 the pools and the stream cache are process-wide), every result compared with the oracle.
-usage: tools/thread_stress.py [threads] [configs per thread] [seed]"""
+usage: tools/thread_stress.py [threads] [configs per thread] [seed] [thread:config | -] [key=value ...]"""
 import os
 import sys
 import threading
@@ -19,12 +19,15 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 hip = indelope_amd.api()
 hip.init(0)
+for kv in sys.argv[5:]:                                      # library switches: key=value (ihp_debug_set)
+    k_, v_ = kv.split("=")
+    hip.debug_set(**{k_: int(v_)})
 orc = oracle.get()
 bad = []
 lock = threading.Lock()
 
 
-ONLY = tuple(int(x) for x in sys.argv[4].split(":")) if len(sys.argv) > 4 else None     # "thread:config": replay that one alone
+ONLY = tuple(int(x) for x in sys.argv[4].split(":")) if len(sys.argv) > 4 and sys.argv[4] != "-" else None     # "thread:config": replay that one alone
 
 
 def worker(k):
@@ -41,6 +44,10 @@ def worker(k):
             kw.update(max_mismatch=1)
         if rng.random() < 0.3:
             kw.update(min_overlap_pct=float(rng.choice([0.5, 1.0])))
+        if rng.random() < 0.3:
+            kw.update(bw=int(rng.choice([20, 48, 62, -1])), zdrop=int(rng.choice([-1, 50, 1000])))
+        if rng.random() < 0.3:
+            kw.update(combine_min_support=int(rng.choice([1, 2, 4])), combine_min_overlap=int(rng.choice([17, 30, 80])))
         if rng.random() < 0.5:
             b = b.with_trim_bounds()
         mode = int(rng.integers(0, 3))
