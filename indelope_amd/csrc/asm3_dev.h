@@ -726,7 +726,11 @@ __device__ inline void v3_compact(V3State &S, V3Ctx &C)
 		const int so = uni(S.so[c]), dw = uni(S.dw[c]), sh = uni((int)S.sh[c]), len = uni(S.len[c]);
 		// dwords: the bases from `sh` on, room for the rest of the capacity the contig keeps (an insert in place may grow it to
 		// cap bases without asking -- with sh > 0 that can be a dword more than the bases it has now), and the pad
-		const int capn = align4(len);
+		// -- never more than the capacity it has (a trim at the front leaves cap = old cap - a, which need not be a multiple of
+		// four: rounding len up past it would ask for a dword the slot never had, and the contigs behind it would have to move
+		// UP through each other).  So every contig moves down or stays.
+		const int cap0 = uni(S.cap[c]);
+		const int capn = align4(len) < cap0 ? align4(len) : cap0;
 		const int nsrc = (sh + len + 15) >> 4, nd = ((sh + capn + 15) >> 4) + 1;
 		if (so >= 0 && so != nsup) {
 			for (int i0 = 0; i0 < len; i0 += 64) {

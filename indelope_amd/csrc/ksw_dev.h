@@ -348,7 +348,7 @@ __device__ inline void ksw_wave(const uint8_t *query, int qlen, const uint8_t *t
 		last_st = st; last_en = en;
 	}
 	out.max = ez_max; out.zdropped = zdropped; out.max_q = ez_max_q; out.max_t = ez_max_t;
-	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = score;
+	out.mqe = mqe; out.mqe_t = mqe_t; out.mte = mte; out.mte_q = mte_q; out.score = zdropped ? KSW_NEG_INF : score;   // (the reference tests the z-drop before it takes the score of the last diagonal, :355-357: a sweep that stopped has none)
 	WSYNC();
 	const long long tc2 = pacc ? (long long)clock64() : 0;
 	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }

@@ -289,7 +289,7 @@ __device__ inline void ksw_wave_fast(const uint8_t *query, int qlen, const uint8
 	if (w >= 49) for (; r < r_hi && !stop; ++r) stop = fast_diag<RIGHT, true>(F, E, C, r);   // w >= 49: a steady band spans blocks 0..3
 	for (; r < total && !stop; ++r) stop = fast_diag<RIGHT, false>(F, E, C, r);
 	out.max = F.ez_max; out.zdropped = F.zdropped; out.max_q = F.ez_max_q; out.max_t = F.ez_max_t;
-	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.score;
+	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.zdropped ? KSW_NEG_INF : F.score;   // (the reference tests the z-drop before it takes the score of the last diagonal, :355-357: a sweep that stopped has none)
 	WSYNC();
 	const long long tc2 = pacc ? (long long)clock64() : 0;
 	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }

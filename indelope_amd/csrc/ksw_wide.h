@@ -275,7 +275,7 @@ __device__ inline bool ksw_wave_wide(const uint8_t *query, int qlen, const uint8
 	for (int r = 0; r < total; ++r) if (wide_diag<NS, RIGHT>(F, E, r)) { stop = true; break; }
 	WSYNC();
 	out.max = F.ez_max; out.zdropped = stop ? 1 : 0; out.max_q = F.ez_max_q; out.max_t = F.ez_max_t;
-	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = F.score;
+	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = stop ? KSW_NEG_INF : F.score;   // (the reference tests the z-drop before it takes the score of the last diagonal, :355-357: a sweep that stopped has none)
 	ksw_backtrack_wave(p, ncol, qlen, tlen, w, flag, stop ? 1 : 0, F.ez_max_t, F.ez_max_q, cig_tmp, cig_cap, out);
 	return true;
 }

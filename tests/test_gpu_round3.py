@@ -340,3 +340,34 @@ def test_compaction_keeps_room_for_a_trimmed_contig_to_grow_in_place(hip, oracle
     assert_same(hip.run_regions(b, hip.params(**kw)), oracle.run_regions_mt(b, oracle.params(**kw), 16))
     one = b.slice(102, 103)
     assert_same(hip.run_regions(one, hip.params(**kw)), oracle.run_regions(one, oracle.params(**kw)))
+
+
+def test_a_z_drop_on_the_last_diagonal_leaves_no_score(hip, oracle):
+    """ksw2_extz2_sse.c:355-357: the z-drop test comes before `ez->score = H[tlen-1]`, so a sweep that drops on its very last
+    diagonal reports no score.  Identical sequences but for the last base, z-drop below the mismatch penalty (found by
+    stress_parity with randomised parameters: bw 20, z-drop 100, once in 3 000 configurations)."""
+    rng = np.random.default_rng(12)
+    qs, ts = [], []
+    for n in (40, 97, 150, 203, 333):
+        t = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+        q = t.copy()
+        q[-1] = ord("A") if t[-1] != ord("A") else ord("C")
+        qs.append(q)
+        ts.append(t)
+    for bw in (8, 20, 50, 62, -1):
+        for flag in (0, A.KSW_EZ_RIGHT):
+            kw = dict(match=1, mismatch=-5, gap_open=5, gap_ext=1, bw=bw, z=4, flag=flag)
+            ez, cg = hip.align_batch(qs, ts, **kw)
+            ez2, cg2 = oracle.align_batch(qs, ts, **kw)
+            assert any(e["zdropped"] == 1 and e["score"] < -(1 << 29) for e in ez2), "the construction no longer drops on the last diagonal"
+            for i in range(len(qs)):
+                assert ez[i].tolist() == ez2[i].tolist() and cg[i].tolist() == cg2[i].tolist(), (kw, len(qs[i]), ez[i], ez2[i])
+
+
+def test_compaction_never_moves_a_contig_up(hip, oracle):
+    """The second half of the compaction fix: a trimmed contig keeps at most the capacity it has (old cap - trimmed bases, not a
+    multiple of four); rounding its length up past that asked for a dword its slot never had, the contigs behind it moved up
+    through each other and one lost its first dword (stress_parity seed 90001, configuration 2661: a read-rich region in the
+    arena of a batch of smaller ones)."""
+    b, _ = synth.generate(n_regions=108, read_len=200, n_reads=(35, 249), err_rate=0.001, config_id=3661, dup_frac=0.6, seed=2102651584)
+    assert_same(hip.run_regions(b, hip.params(K=21)), oracle.run_regions_mt(b, oracle.params(K=21), 16))

@@ -109,6 +109,8 @@ def main():
         print("%3d %s rl=%d K=%d reads=%s err=%g dup=%g regions=%d contigs=%d events=%d fallback=%d variants=%d"
               % (it, "ok " if ok and okv else "DIFF", rl, K, cfg["n_reads"], cfg["err_rate"], cfg["dup_frac"], b.n_regions,
                  got.n_contigs, got.n_events, int((got.events["aligned"] == 1).sum()), sum(x["filter"] == 0 for x in vg)), d or "", flush=True)
+        if not (ok and okv):
+            print("    cfg", cfg, kw, flush=True)
         bad += not (ok and okv)
     print("done: %d configs, %d differences, %d refused, %.1f s" % (n, bad, errs, time.time() - t0))
     sys.exit(1 if bad else 0)
