@@ -490,6 +490,8 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *                   run when the previous batch needed none of them; whoever waits for the run checks, and repeats it in full)
  *   "spec_fail" 1   test hook: such a run is treated as if a region had needed them
  *   "verbose" 1     a line on stderr per run: the combine tiers (waves per CU, arenas, grids) it was launched with
+ *   "ksw_p_cap" n   bytes of traceback scratch per wave of the main ksw2 launch (0 = library sizing): jobs that need more take the
+ *                   roomy launch behind it
  *   "comb_waves" n  waves per workgroup of the combine kernel, 1 / 2 / 4 (0 = by the tier's occupancy): wave 0 runs the region,
  *                   the others take shares of its best_match calls
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path

@@ -68,6 +68,7 @@ struct Knobs {
 	int no_rich = 0;       // 1: read-rich regions (classes 2-4) stay with the byte-based passes
 	int no_hint = 0;       // 1: every combine launch with its full grid whatever the last batch needed
 	int no_spec = 0;       // 1: the retry launches are always enqueued (default: left out when the last batch needed none, checked at the wait)
+	int ksw_p_cap = 0;     // bytes: caps the traceback scratch per wave of the MAIN ksw2 launch (its jobs that need more go to the roomy launch)
 	int comb_waves = 0;    // waves per workgroup of k_asm_combine3 (1, 2, 4; 0 = by the tier's occupancy): wave 0 runs the region, the others share its best_match calls
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
@@ -89,7 +90,7 @@ Knobs g_knob;
 // shape does not use the histogram.
 constexpr int HIST_N = 7;
 constexpr int HIST_OCC[HIST_N] = {16, 14, 12, 10, 9, 8, 6};
-struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}, regions{0}, sig{0}; std::atomic<int> hist[HIST_N]; };
+struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}, n_kovf{0}, regions{0}, sig{0}; std::atomic<int> hist[HIST_N]; };
 TierHint g_hint;
 std::atomic<int> g_live_batches{0};
 
@@ -439,7 +440,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -577,6 +578,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
 	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
 	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr; a.t_start = nullptr;
+	a.in_list = nullptr; a.ovf_list = nullptr; a.ovf_n = nullptr;          // (this entry point sizes LDS and scratch for its longest pair)
 	a.gm = 0; memset(a.gmat, 0, sizeof(a.gmat));
 	if ((P.flag & KSW_EZ_GENERIC_SC) && mat && P.m <= 8) { a.gm = P.m; for (int i = 0; i < P.m * P.m; ++i) a.gmat[i] = mat[i]; }
 	g_last_ksw_mode = mode;
@@ -822,8 +824,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 17 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_CNT_KSW = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32 };
+enum { WQ_SETS = 18 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32 };
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -880,6 +882,9 @@ struct ihp_batch {
 	bool acc_pending = false;                              // the last run's stamps have not been added yet
 	bool spec_skipped = false;                             // the run left out the retry launches (nobody needed them in the last batch): checked when it is waited for
 	bool force_full = false;
+	bool ksw_skipped = false;                              // the run left out the roomy ksw2 launch (no job needed it in the last batch): checked at the wait
+	DBuf ksw_ovf, p_scratch_big, cig_tmp_big;              // jobs the main ksw2 launch could not hold, and the roomy launch's scratch
+	size_t p_cap_big = 0; int cig_cap_big = 0, grid_kovf = 0;
 	long long v2_nb1 = 0; int tier_occ = 0, tier_occ_default = 0, tier_sig = 0;   // first-tier sizing of the combine launches (size_combine_tiers)
 	bool counted = false;                                  // k_pack_count / k_pack_scan of the last run are enqueued (or done)
 	long long n_reruns = 0;
@@ -932,6 +937,9 @@ static int alloc_work(ihp_batch *b)
 	AL(corr, sizeof(Corr) * (size_t)b->corr_cap * std::max(std::max(std::max(b->grid_asm, std::max(std::max(b->grid_v2, b->grid_v2b), b->grid_v2big)), b->grid_asm2), std::max(b->grid_asm3, b->grid_retry)));
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
+	AL(ksw_ovf, sizeof(int) * (size_t)std::max<long long>(1, b->njobs_cap));
+	AL(p_scratch_big, b->p_cap_big * b->grid_kovf);
+	AL(cig_tmp_big, sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf);
 	if (p->fallback) {
 		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
@@ -958,7 +966,7 @@ static int alloc_work(ihp_batch *b)
 static void release_work(ihp_batch *b)
 {
 	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
-	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
+	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->ksw_ovf, &b->p_scratch_big, &b->cig_tmp_big, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
 	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab};
@@ -1283,6 +1291,12 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		const int qeff = std::min(qmax, tmax + 2 * std::max(w, 64));
 		b->p_cap = std::max(((size_t)(qeff + tmax) * nc + 1) * 16, ksw_narrow_p_bytes(qeff, tmax)) + 64;
 		b->cig_cap = qeff + tmax + 8;
+		// the roomy launch for the jobs that do not fit that (a contig much longer than its window): a few workgroups, all the LDS,
+		// scratch for the longest contig the assembly can leave (up to 256 MB each; what still does not fit is IHP_E_CAPACITY)
+		const int ncq = (std::min(std::min(qmax, tmax), w + 1) + 15) / 16 + 1;
+		b->p_cap_big = std::min<size_t>(std::max(((size_t)(qmax + tmax) * ncq + 1) * 16, ksw_narrow_p_bytes(qmax, tmax)) + 64, (size_t)256 << 20);
+		b->cig_cap_big = qmax + tmax + 8;
+		b->grid_kovf = (int)std::max<size_t>(1, std::min<size_t>(16, ((size_t)512 << 20) / b->p_cap_big));
 	}
 	b->grid_ksw = grid_for((int)std::min<long long>(slots, 1 << 30), g_knob.ksw_waves ? g_knob.ksw_waves : 32);
 	b->grid_tally = grid_for((int)std::min<long long>(slots, 1 << 30), g_knob.tally_waves ? g_knob.tally_waves : 32);
@@ -1293,7 +1307,8 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	b->ev_pool_cap = (long long)std::max(1, p->max_events) * njobs_cap + 16;
 	if (g_limits[0] > 0) { b->cig_bump_cap = std::min(b->cig_bump_cap, g_limits[0]); b->cig_pool_cap = b->cig_bump_cap + (long long)CIG_SLOT * njobs_cap; }
 	if (g_limits[1] > 0) b->ev_pool_cap = std::min(b->ev_pool_cap, g_limits[1]);
-	if (g_limits[3] > 0) b->p_cap = std::min(b->p_cap, (size_t)g_limits[3]);
+	if (g_limits[3] > 0) { b->p_cap = std::min(b->p_cap, (size_t)g_limits[3]); b->p_cap_big = std::min(b->p_cap_big, (size_t)g_limits[3]); }
+	if (g_knob.ksw_p_cap > 0) b->p_cap = std::min(b->p_cap, (size_t)g_knob.ksw_p_cap);
 	if (p->fallback) {
 		// a read against the rest of the reference window / of the contig from the read's start.  Contigs are rarely
 		// longer than the window; the scratch is sized for that and the kernel flags anything larger (IHP_E_CAPACITY).
@@ -1375,7 +1390,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	int *misc = b->misc.as<int>();
 	unsigned long long *tm = b->timing ? b->times_dev() : nullptr;
 	HIPC(hipEventRecord(b->ev[0], s));
-	bool spec_skipped_run = false;
+	bool spec_skipped_run = false, ksw_skipped_run = false;
 	if (b->R > 0) {
 		AsmArgs a;
 		a.n_regions = b->R;
@@ -1626,8 +1641,24 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.gm = 0; memset(a.gmat, 0, sizeof(a.gmat));
 		g_last_ksw_mode = ksw_mode(a.P);
+		a.in_list = nullptr; a.ovf_list = b->ksw_ovf.as<int>(); a.ovf_n = misc + M_KSW_OVF;
 		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
+		// the roomy launch: left out when the last batch had no such job (a few workgroups that ask for all the LDS of a CU wait for
+		// one to drain); the wait checks the count and repeats the run with it otherwise (see the retry launches above)
+		const bool hintk = g_hint.valid.load() != 0 && !g_knob.no_hint;
+		ksw_skipped_run = hintk && !g_knob.no_spec && !b->force_full && g_hint.n_kovf.load() == 0;
+		if (g_knob.verbose) fprintf(stderr, "[ihp] ksw2: grid %d lds %d p_cap %zu; roomy launch %s: grid %d p_cap %zu cig %d\n", b->grid_ksw, b->lds_ksw, b->p_cap, ksw_skipped_run ? "left out" : "enqueued", b->grid_kovf, b->p_cap_big, b->cig_cap_big);
+		if (!ksw_skipped_run) {
+			KswArgs r2 = a;
+			r2.t_start = nullptr; r2.in_list = b->ksw_ovf.as<int>(); r2.n_jobs = misc + M_KSW_OVF; r2.ovf_list = nullptr; r2.ovf_n = nullptr;
+			r2.lds_budget = g.max_lds - 2048 - 64;
+			r2.p_scratch = b->p_scratch_big.as<uint8_t>(); r2.p_cap = b->p_cap_big;
+			r2.cig_tmp = b->cig_tmp_big.as<uint32_t>(); r2.cig_cap = b->cig_cap_big;
+			r2.work_counter = wq + 17 * WQ_WORDS;
+			launch_ksw(g_last_ksw_mode, dim3(b->grid_kovf), (size_t)g.max_lds - 2048, s, r2);
+			HIPC(hipGetLastError());
+		}
 	}
 	HIPC(hipEventRecord(b->ev[2], s));
 	if (b->R > 0 && b->n_reads > 0) {
@@ -1701,6 +1732,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	b->counted = false;
 	if (b->fetch_flags & IHP_FETCH_EAGER) { const int rcp = pack_counts_enqueue(b); if (rcp) return rcp; }
 	b->spec_skipped = spec_skipped_run;
+	b->ksw_skipped = ksw_skipped_run;
 	b->acc_pending = b->timing;
 	b->dirty = false;                                      // k_summary is in the stream: it leaves `misc` clear for the next run
 	return 0;
@@ -1721,7 +1753,9 @@ static int report_overflow(const ihp_batch *b)
 // turned out to need them: the counters in the report say so.
 static bool spec_failed(const ihp_batch *b)
 {
-	return b->ran && b->spec_skipped && (b->report[M_NRETRYC] > 0 || b->report[M_NRETRY0] > 0 || g_knob.spec_fail);
+	if (!b->ran) return false;
+	if (b->spec_skipped && (b->report[M_NRETRYC] > 0 || b->report[M_NRETRY0] > 0 || g_knob.spec_fail)) return true;
+	return b->ksw_skipped && (b->report[M_KSW_OVF] > 0 || g_knob.spec_fail);
 }
 static int run_again_in_full(ihp_batch *b)
 {
@@ -1773,7 +1807,8 @@ extern "C" int ihp_batch_sync(ihp_batch *b)
 	}
 	if (b->ran && b->R > 0 && b->v2 && g_knob.lpt) {
 		g_hint.n_b = b->report[M_NTIERB]; g_hint.n_c = b->report[M_NTIERC]; g_hint.n_big = b->report[M_NRETRYC];
-		g_hint.n_back = b->report[M_NRETRY0];
+		g_hint.n_back = b->report[M_NRETRY0]; g_hint.n_kovf = b->report[M_KSW_OVF];
+		if (g_knob.verbose) fprintf(stderr, "[ihp] sync: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);
 		if (b->v2) {
 			for (int k = 0; k < HIST_N; ++k) g_hint.hist[k] = b->report[M_HIST + k];
 			g_hint.regions = b->n_cls[0] - b->report[M_NRETRY0]; g_hint.sig = b->tier_sig;
@@ -1822,7 +1857,7 @@ extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64])
 	out[29] = b->report[M_NTIERB];                    // regions the read phase filed under the second (larger-arena) combine launch
 	out[30] = b->report[M_NTIERC];                    // ... and under the third
 	out[31] = b->n_reruns;                            // runs of this batch repeated in full because a run without the retry launches met a region that needed them
-	out[21] = b->spec_skipped ? 1 : 0;                // the last run left the retry launches out
+	out[21] = (b->spec_skipped ? 1 : 0) | (b->ksw_skipped ? 2 : 0);   // the last run left out: 1 the assembly retry launches, 2 the roomy ksw2 launch
 	return 0;
 }
 

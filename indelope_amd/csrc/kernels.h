@@ -627,6 +627,11 @@ struct KswArgs {
 	long long cig_bump_cap;                    // then one CIG_SLOT-word slot per job
 	int *overflow;                             // [0] cigar pool, [1] LDS/p budget
 	int *work_counter;
+	// A job whose sequences need more LDS or traceback scratch than this launch gives every wave is put on ovf_list (when there
+	// is one) and gets an empty record for now; a second launch of the same kernel -- in_list = that list, a few workgroups with
+	// all the LDS and a large scratch each -- aligns it.  Without ovf_list such a job raises overflow[1] (IHP_E_CAPACITY).
+	const int *in_list;                        // work item -> job (null: item j is job j)
+	int *ovf_list, *ovf_n;
 	long long *prof;                           // optional cycle counters (diagnostics)
 	unsigned long long *t_start;               // optional: see mark_start()
 	signed char gmat[64]; int gm;              // KSW_EZ_GENERIC_SC: the m x m score matrix (gm = m <= 8, else 0); MODE 2 only
@@ -666,7 +671,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 			const int j = __builtin_amdgcn_readfirstlane(s_item);   // wave-uniform by construction; tells the compiler so
 			WSYNC();
 			if (j < 0) break;
-			const AlnJob jb = a->jobs[j];
+			const int jj = a->in_list ? a->in_list[j] : j;
+			const AlnJob jb = a->jobs[jj];
 			KswOut out;
 			{
 				uint8_t *p = a->p_scratch + (size_t)blockIdx.x * a->p_cap;
@@ -690,6 +696,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 				if (jb.qlen > 0 && jb.tlen > 0 && (lneed > (size_t)a->lds_budget || pneed > a->p_cap)) {
 					out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
 					out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
+					if (a->ovf_list) {                                     // the roomy launch takes it; an empty record until then
+						if (lane == 0) a->ovf_list[atomicAdd(a->ovf_n, 1)] = jj;
+						out.n_cigar = 0;
+					}
 				} else if (MODE == 3 || MODE == 4) {
 					if (!ksw_wave_narrow<MODE == 4>(qy, jb.qlen, tg, jb.tlen, P, lds, p, ct, cig_cap, out, pacc))
 						out.n_cigar = -1;                                  // a code outside the alphabet: the host never sends those here
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 			const uint32_t *ct = a->cig_tmp + (size_t)blockIdx.x * a->cig_cap;
 			long long off = -1;
 			if (out.n_cigar > 0) {
-				if (out.n_cigar <= CIG_SLOT) off = a->cig_bump_cap + (long long)j * CIG_SLOT;   // the job's own slot: no atomic
+				if (out.n_cigar <= CIG_SLOT) off = a->cig_bump_cap + (long long)jj * CIG_SLOT;  // the job's own slot: no atomic
 				else {
 					if (lane == 0) s_off = (long long)atomicAdd(a->cig_cursor, (unsigned long long)out.n_cigar);
 					WSYNC();

@@ -371,3 +371,28 @@ def test_compaction_never_moves_a_contig_up(hip, oracle):
     arena of a batch of smaller ones)."""
     b, _ = synth.generate(n_regions=108, read_len=200, n_reads=(35, 249), err_rate=0.001, config_id=3661, dup_frac=0.6, seed=2102651584)
     assert_same(hip.run_regions(b, hip.params(K=21)), oracle.run_regions_mt(b, oracle.params(K=21), 16))
+
+
+def test_alignments_too_large_for_the_main_ksw_launch_take_the_roomy_one(hip, oracle):
+    """A contig much longer than its reference window needs more LDS / traceback scratch than the main ksw2 launch gives a wave:
+    such jobs go to a second, roomy launch of the same kernel instead of failing the batch (IHP_E_CAPACITY before).  Here the
+    `ksw_p_cap` switch sends every job there; with the hint that the last batch needed none the launch is left out and the
+    wait repeats the run."""
+    b, _ = synth.generate(64, n_reads=(32, 48), err_rate=1e-3, config_id=73)
+    exp = oracle.run_regions(b)
+    clean, _ = synth.generate(16, n_reads=(20, 30), err_rate=0.0, config_id=5)
+    try:
+        h = hip.batch_upload(clean)                            # leaves "no job needed the roomy launch"
+        hip.batch_run(h); hip.batch_sync(h); hip.batch_free(h)
+        hip.debug_set(ksw_p_cap=4096)
+        for _ in range(3):
+            h = hip.batch_upload(b)
+            hip.batch_run(h)
+            hip.batch_sync(h)
+            assert_same(hip.batch_fetch(h), exp)
+            hip.batch_free(h)
+    finally:
+        hip.debug_set()
+    # reads of 1 500 bases: contigs longer than window + 64 (refused until round 3)
+    long_, _ = synth.generate(12, read_len=1500, n_reads=(20, 30), err_rate=1e-3, config_id=11, seed=5)
+    assert_same(hip.run_regions(long_), oracle.run_regions(long_))

@@ -111,6 +111,15 @@ def main():
                  got.n_contigs, got.n_events, int((got.events["aligned"] == 1).sum()), sum(x["filter"] == 0 for x in vg)), d or "", flush=True)
         if not (ok and okv):
             print("    cfg", cfg, kw, flush=True)
+            if ONLY is not None:                                  # once more through the batch calls, with the library's own account of the run
+                hip.debug_set(verbose=1)
+                h = hip.batch_upload(b, hip.params(**kw))
+                hip.batch_run(h)
+                hip.batch_sync(h)
+                g2 = hip.batch_fetch(h)
+                print("    again:", BatchResult.first_difference(g2, exp), "profile", hip.batch_profile(h)[[21, 23, 24, 25, 26, 28, 31]].tolist(), flush=True)
+                hip.batch_free(h)
+                hip.debug_set(verbose=0)
         bad += not (ok and okv)
     print("done: %d configs, %d differences, %d refused, %.1f s" % (n, bad, errs, time.time() - t0))
     sys.exit(1 if bad else 0)
