@@ -479,6 +479,9 @@ int  ihp_batch_profile(ihp_batch *b, int64_t out[64]);
  * not cover), 5 = ring sweep for bands > 62 or unbanded (ksw_wide.h; per job the LDS sweep
  * where the ring does not fit), 2 = LDS sweep.  Results are identical in every mode.       */
 int  ihp_debug_last_ksw_mode(void);
+/* How many PAIRS of alignments the last ihp_ksw_extz2_batch call ran two to a wavefront (ksw_pair.h; 0 when the
+ * parameters or the jobs did not allow it, or after ihp_debug_set("ksw_pair", 0)).                             */
+int  ihp_debug_last_ksw_pairs(void);
 /* Test hook: upper limits for the device pools of batches uploaded from now on -- {CIGAR bump-pool words,
  * event-pool entries, hit-pool ints, ksw2 traceback bytes per wave}; 0 = the library's own sizing.  NULL resets.
  * Lets the overflow paths (IHP_E_CAPACITY from ihp_batch_sync / fetch) be driven by small inputs.               */
@@ -497,6 +500,8 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
  *   "lpt" 0         k_asm_combine3 in input order: no cost classes, no arena tiers
+ *   "ksw_pair" 0    every ksw2 alignment through the single sweep (default: jobs of equal contig length share a wavefront where
+ *                   their windows allow it, ksw_pair.h)
  *   "asm_waves", "asmr_waves", "comb_occ", "ksw_waves", "tally_waves"   waves per CU of a kernel (0 = library sizing)
  *   "v2_arena", "v2_pdw"   LDS bytes / dwords per wave of the packed assembly (0 = library sizing)
  *   "profile" 1     per-phase cycle counters (ihp_batch_profile)

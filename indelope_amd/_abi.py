@@ -233,6 +233,7 @@ _PRODUCT_ONLY = {
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
     "batch_summary_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "debug_last_ksw_mode": (C.c_int, []),
+    "debug_last_ksw_pairs": (C.c_int, []),
     "debug_limits": (C.c_int, [i64p]),
     "debug_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "ksw_last_status": (C.c_int, []),

@@ -132,7 +132,10 @@ struct AlnJob {
 	int qlen, tlen;
 	int out;             // result slot
 	int region;          // -1 for the plain batch API
+	int flags;           // ALN_Q_ACGT: the producer vouches that every query base encodes to A C G T and every target base to A C G T N
+	int pad_;
 };
+constexpr int ALN_Q_ACGT = 1;
 
 // Device-side event record (host converts to ihp_event and adds the genotype).
 struct DevEvent {

@@ -74,6 +74,7 @@ struct Knobs {
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
+	int ksw_pair = 1;      // 0: every alignment through the single sweep (no k_ksw_plan / k_ksw_pair launches)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
 	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
 	int profile = 0;       // 1: kernels sum shader-clock cycles per phase (ihp_batch_profile)
@@ -322,6 +323,30 @@ template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStr
 	else hipLaunchKernelGGL(k_ksw<2>, grid, dim3(64), lds, s, a);
 }
 
+// The production ksw2 stage as three launches: k_ksw_plan pairs the jobs of equal contig length the pair sweep can take
+// (ksw_pair.h), the single sweep walks the rest through in_list, k_ksw_pair takes the pairs.  `a` is the single launch's
+// argument block (in_list null); the plan's lists live in `plan` (ints: order[n] | singles[n] | pairs[2n]), its two counts
+// at `cnt`, the pair launch's work queue at `wq_pair`; p_pair / ct_pair: traceback and CIGAR scratch of the pair launch
+// (p_cap_pair, a.cig_cap per workgroup).  Returns false when these parameters are not the pair sweep's (nothing launched).
+static bool ksw_pair_wanted(const KswParams &P, int mode) { return g_knob.ksw_pair && mode == 3 && ksw_pair_ok(P); }
+static void launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hipStream_t s, const KswArgs &a, int *plan, int n_cap, int *cnt,
+                               int *wq_pair, uint8_t *p_pair, size_t p_cap_pair, uint32_t *ct_pair)
+{
+	KswPlanArgs pl;
+	pl.jobs = a.jobs; pl.n_jobs = a.n_jobs; pl.n_jobs_host = a.n_jobs_host; pl.P = a.P; pl.pair_on = 1;
+	pl.lds_budget = (int)lds_pair - 64; pl.p_cap = p_cap_pair;
+	pl.order = plan; pl.singles = plan + n_cap; pl.pairs = (int2 *)(plan + 2 * (size_t)n_cap);
+	pl.n_pairs = cnt; pl.n_singles = cnt + 1;
+	hipLaunchKernelGGL(k_ksw_plan, dim3(1), dim3(1024), 0, s, pl);
+	KswArgs x = a;
+	x.in_list = pl.singles; x.n_jobs = pl.n_singles;
+	launch_ksw(3, grid, lds_single, s, x);
+	KswArgs y = a;
+	y.t_start = nullptr; y.in_list = nullptr; y.pairs = pl.pairs; y.n_jobs = pl.n_pairs; y.ovf_list = nullptr; y.ovf_n = nullptr;
+	y.lds_budget = (int)lds_pair - 64; y.p_scratch = p_pair; y.p_cap = p_cap_pair; y.cig_tmp = ct_pair; y.work_counter = wq_pair;
+	hipLaunchKernelGGL(k_ksw_pair, grid, dim3(64), lds_pair, s, y);
+}
+
 KswParams make_ksw_params(int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag, int ascii)
 {
 	KswParams P;
@@ -440,7 +465,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -513,6 +538,9 @@ extern "C" double ihp_genotype_qual(const ihp_genotype_t *g_)
 // ----------------------------------------------------------------- ksw2 batch
 // diagnostics: which k_ksw<MODE> the last ksw_extz2_sse / ihp_ksw_extz2_batch / ihp_batch_run call used
 extern "C" int ihp_debug_last_ksw_mode(void) { return g_last_ksw_mode; }
+// diagnostics: how many PAIRS of alignments the last ihp_ksw_extz2_batch call ran two to a wavefront (ksw_pair.h)
+static std::atomic<int> g_last_ksw_pairs{0};
+extern "C" int ihp_debug_last_ksw_pairs(void) { return g_last_ksw_pairs.load(); }
 
 static int codes_below(const uint8_t *s, size_t n, int m)
 {
@@ -567,7 +595,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	if ((rc = d_coff.alloc(sizeof(long long) * n))) return rc;
 	const long long fixed_words = (long long)n * CIG_SLOT;
 	if ((rc = d_pool.alloc(sizeof(uint32_t) * (size_t)(cig_bound + 4 + fixed_words)))) return rc;
-	if ((rc = d_misc.alloc(64 + sizeof(int) * WQ_WORDS))) return rc;      // [0] cursor u64, [2..4] overflow, [16..] work queue
+	if ((rc = d_misc.alloc(64 + sizeof(int) * WQ_WORDS * 2))) return rc;  // [0] cursor u64, [2..4] overflow, [6..7] the plan's counts, [16..] two work queues
 	if ((rc = d_misc.zero(g.stream))) return rc;
 	KswArgs a;
 	a.jobs = d_jobs.as<AlnJob>(); a.n_jobs = nullptr; a.n_jobs_host = n;
@@ -578,11 +606,25 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	a.cig_pool = d_pool.as<uint32_t>(); a.cig_cursor = d_misc.as<unsigned long long>();
 	a.cig_bump_cap = cig_bound + 4; a.cig_pool_cap = cig_bound + 4 + fixed_words;
 	a.overflow = d_misc.as<int>() + 2; a.work_counter = d_misc.as<int>() + 16; a.prof = nullptr; a.t_start = nullptr;
-	a.in_list = nullptr; a.ovf_list = nullptr; a.ovf_n = nullptr;          // (this entry point sizes LDS and scratch for its longest pair)
+	a.in_list = nullptr; a.pairs = nullptr; a.ovf_list = nullptr; a.ovf_n = nullptr;   // (this entry point sizes LDS and scratch for its longest pair)
 	a.gm = 0; memset(a.gmat, 0, sizeof(a.gmat));
 	if ((P.flag & KSW_EZ_GENERIC_SC) && mat && P.m <= 8) { a.gm = P.m; for (int i = 0; i < P.m * P.m; ++i) a.gmat[i] = mat[i]; }
 	g_last_ksw_mode = mode;
-	launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
+	DBuf d_plan, d_pp, d_pct;
+	if (ksw_pair_wanted(P, mode) && n >= 2) {
+		// two alignments per wavefront where the jobs allow it (ksw_pair.h); the rest through the single sweep
+		size_t lds_pair = 0, p_pair = 0;
+		for (const AlnJob &j : jobs)
+			if ((j.flags & ALN_Q_ACGT) && ksw_pair_job_ok(P, j.qlen, j.tlen)) {
+				lds_pair = std::max(lds_pair, 2 * ksw_pair_lds_share(j.qlen, j.tlen)); p_pair = std::max(p_pair, ksw_pair_p_bytes(j.qlen, P.w));
+			}
+		lds_pair = std::min(lds_pair + 64, (size_t)g.max_lds - 2048);
+		if ((rc = d_plan.alloc(sizeof(int) * 4 * (size_t)n))) return rc;
+		if ((rc = d_pp.alloc((p_pair + 64) * grid))) return rc;
+		if ((rc = d_pct.alloc(sizeof(uint32_t) * (size_t)(cig_cap + 4) * grid))) return rc;
+		launch_ksw_planned(dim3(grid), lds_need + 64, lds_pair + 64, g.stream, a, d_plan.as<int>(), n, d_misc.as<int>() + 6,
+		                   d_misc.as<int>() + 16 + WQ_WORDS, d_pp.as<uint8_t>(), p_pair + 64, d_pct.as<uint32_t>());
+	} else launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
 	HIPC(hipMemcpyAsync(ez.data(), d_ez.p, sizeof(KswOut) * n, hipMemcpyDeviceToHost, g.stream));
@@ -591,6 +633,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	HIPC(hipStreamSynchronize(g.stream));
 	const long long used = misc[0];
 	const int *ov = (const int *)misc + 2;
+	g_last_ksw_pairs = d_plan.p ? ((const int *)misc)[6] : 0;
 	if (ov[0] || ov[1]) { snprintf(g.err, sizeof(g.err), "ksw2 kernel capacity overflow (%d,%d)", ov[0], ov[1]); return IHP_E_CAPACITY; }
 	(void)used;
 	pool.resize((size_t)a.cig_pool_cap);
@@ -614,7 +657,9 @@ extern "C" int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int6
 	for (int i = 0; i < n; ++i) {
 		jobs[i].q_off = q_off[i]; jobs[i].t_off = t_off[i];
 		jobs[i].qlen = (int)(q_off[i + 1] - q_off[i]); jobs[i].tlen = (int)(t_off[i + 1] - t_off[i]);
-		jobs[i].out = i; jobs[i].region = -1;
+		jobs[i].out = i; jobs[i].region = -1; jobs[i].pad_ = 0;
+		// what the pair sweep needs to know (ksw_pair.h): no wildcard in the query, nothing above the wildcard in the target
+		jobs[i].flags = (m == 5 && codes_below(queries + q_off[i], (size_t)jobs[i].qlen, 4) && codes_below(targets + t_off[i], (size_t)jobs[i].tlen, 5)) ? ALN_Q_ACGT : 0;
 	}
 	DBuf d_q, d_t;
 	if ((rc = d_q.upload(queries, (size_t)q_off[n], g.stream))) return rc;
@@ -824,7 +869,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 18 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch
+enum { WQ_SETS = 20 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19] the counts of k_ksw_plan (pairs, singles)
 enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32 };
 struct ihp_batch {
 	ihp_params P;
@@ -855,6 +900,9 @@ struct ihp_batch {
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
+	// two alignments per wavefront (ksw_pair.h): the plan's lists, the pair launch's LDS per wave and scratch per workgroup
+	DBuf ksw_plan, p_scratch_pair, cig_tmp_pair;
+	int lds_ksw_pair = 0; size_t p_cap_pair = 0;           // 0: no pair launch for this batch
 	long long cig_pool_cap = 0, cig_bump_cap = 0, ev_pool_cap = 0, njobs_cap = 0;
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
@@ -938,6 +986,11 @@ static int alloc_work(ihp_batch *b)
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(ksw_ovf, sizeof(int) * (size_t)std::max<long long>(1, b->njobs_cap));
+	if (b->p_cap_pair) {
+		AL(ksw_plan, sizeof(int) * 4 * (size_t)std::max<long long>(1, b->njobs_cap));
+		AL(p_scratch_pair, b->p_cap_pair * b->grid_ksw);
+		AL(cig_tmp_pair, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
+	}
 	AL(p_scratch_big, b->p_cap_big * b->grid_kovf);
 	AL(cig_tmp_big, sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf);
 	if (p->fallback) {
@@ -966,7 +1019,7 @@ static int alloc_work(ihp_batch *b)
 static void release_work(ihp_batch *b)
 {
 	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
-	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->ksw_ovf, &b->p_scratch_big, &b->cig_tmp_big, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
+	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->ksw_ovf, &b->ksw_plan, &b->p_scratch_pair, &b->cig_tmp_pair, &b->p_scratch_big, &b->cig_tmp_big, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
 	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab};
@@ -1291,6 +1344,13 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		const int qeff = std::min(qmax, tmax + 2 * std::max(w, 64));
 		b->p_cap = std::max(((size_t)(qeff + tmax) * nc + 1) * 16, ksw_narrow_p_bytes(qeff, tmax)) + 64;
 		b->cig_cap = qeff + tmax + 8;
+		// the pair launch (ksw_pair.h) takes contigs at least w + 1 bases shorter than their window
+		b->lds_ksw_pair = 0; b->p_cap_pair = 0;
+		const int qpair = std::min(qmax, tmax - p->bw - 1);
+		if (fastp && p->bw >= 49 && qpair >= p->bw + 32) {
+			b->lds_ksw_pair = (int)std::min(ksw_pair_lds_bytes(qpair, tmax, tmax) + 64, (size_t)g.max_lds - 2048);
+			b->p_cap_pair = ksw_pair_p_bytes(qpair, p->bw) + 64;
+		}
 		// the roomy launch for the jobs that do not fit that (a contig much longer than its window): a few workgroups, all the LDS,
 		// scratch for the longest contig the assembly can leave (up to 256 MB each; what still does not fit is IHP_E_CAPACITY)
 		const int ncq = (std::min(std::min(qmax, tmax), w + 1) + 15) / 16 + 1;
@@ -1309,6 +1369,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	if (g_limits[1] > 0) b->ev_pool_cap = std::min(b->ev_pool_cap, g_limits[1]);
 	if (g_limits[3] > 0) { b->p_cap = std::min(b->p_cap, (size_t)g_limits[3]); b->p_cap_big = std::min(b->p_cap_big, (size_t)g_limits[3]); }
 	if (g_knob.ksw_p_cap > 0) b->p_cap = std::min(b->p_cap, (size_t)g_knob.ksw_p_cap);
+	if (g_limits[3] > 0 || g_knob.ksw_p_cap > 0) b->p_cap_pair = std::min(b->p_cap_pair, 2 * b->p_cap);
 	if (p->fallback) {
 		// a read against the rest of the reference window / of the contig from the read's start.  Contigs are rarely
 		// longer than the window; the scratch is sized for that and the kernel flags anything larger (IHP_E_CAPACITY).
@@ -1641,8 +1702,11 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.prof = profiling ? b->prof.as<long long>() : nullptr;
 		a.gm = 0; memset(a.gmat, 0, sizeof(a.gmat));
 		g_last_ksw_mode = ksw_mode(a.P);
-		a.in_list = nullptr; a.ovf_list = b->ksw_ovf.as<int>(); a.ovf_n = misc + M_KSW_OVF;
-		launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
+		a.in_list = nullptr; a.pairs = nullptr; a.ovf_list = b->ksw_ovf.as<int>(); a.ovf_n = misc + M_KSW_OVF;
+		if (b->p_cap_pair && ksw_pair_wanted(a.P, g_last_ksw_mode))
+			launch_ksw_planned(dim3(b->grid_ksw), b->lds_ksw, b->lds_ksw_pair, s, a, b->ksw_plan.as<int>(), (int)std::max<long long>(1, b->njobs_cap),
+			                   wq + 19 * WQ_WORDS, wq + 18 * WQ_WORDS, b->p_scratch_pair.as<uint8_t>(), b->p_cap_pair, b->cig_tmp_pair.as<uint32_t>());
+		else launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 		// the roomy launch: left out when the last batch had no such job (a few workgroups that ask for all the LDS of a CU wait for
 		// one to drain); the wait checks the count and repeats the run with it otherwise (see the retry launches above)

@@ -4,6 +4,7 @@
 #include "contig_dev.h"
 #include "ksw_dev.h"
 #include "ksw_narrow.h"
+#include "ksw_pair.h"
 #include "ksw_wide.h"
 #include "tally_dev.h"
 #include "roi_dev.h"
@@ -339,7 +340,7 @@ __device__ inline void region_epilogue(const AsmArgs &a, ST &S, Arena &A, int r,
 				const int j = atomicAdd(a.n_jobs, 1);
 				AlnJob jb;
 				jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
-				jb.out = (int)slot; jb.region = r;
+				jb.out = (int)slot; jb.region = r; jb.flags = 0; jb.pad_ = 0;
 				a.jobs[j] = jb;
 			}
 			a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
@@ -514,7 +515,7 @@ __device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ct
 				const int j = atomicAdd(a.n_jobs, 1);
 				AlnJob jb;
 				jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
-				jb.out = (int)slot; jb.region = r;
+				jb.out = (int)slot; jb.region = r; jb.flags = ALN_Q_ACGT; jb.pad_ = 0;   // 2-bit packed contigs; enc_base() folds the window
 				a.jobs[j] = jb;
 			}
 			a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
@@ -631,6 +632,7 @@ struct KswArgs {
 	// is one) and gets an empty record for now; a second launch of the same kernel -- in_list = that list, a few workgroups with
 	// all the LDS and a large scratch each -- aligns it.  Without ovf_list such a job raises overflow[1] (IHP_E_CAPACITY).
 	const int *in_list;                        // work item -> job (null: item j is job j)
+	const int2 *pairs;                         // k_ksw_pair: work item -> two jobs of equal qlen (k_ksw_plan); n_jobs counts pairs
 	int *ovf_list, *ovf_n;
 	long long *prof;                           // optional cycle counters (diagnostics)
 	unsigned long long *t_start;               // optional: see mark_start()
@@ -751,6 +753,155 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 	{
 		const KswArgsK a = ksw_args_again(a0);
 		if (a->prof && lane < 6)      // [8..11] init, DP, traceback, alignments; [60], [61] early / tail diagonals of the narrow sweep
+			atomicAdd((unsigned long long *)&a->prof[lane < 4 ? 8 + lane : 56 + lane], (unsigned long long)((long long *)(lds + a->lds_budget + 16))[lane]);
+	}
+}
+
+// ------------------------------------------------------- ksw2, two alignments per wavefront (ksw_pair.h)
+// k_ksw_plan: which jobs share a wavefront.  The jobs the pair sweep can take (ksw_pair_job_ok, a producer that vouches
+// for the codes, room in the pair launch's LDS and traceback scratch) are counting-sorted by qlen, longest first, and
+// neighbours of equal qlen become a pair; everything else -- the odd one of a length included -- goes on the singles
+// list, which the single sweep's launch walks through in_list.  One workgroup: a batch has 10^4..10^5 jobs and the three
+// passes are a few microseconds each.  The order inside a length comes from atomics and differs from run to run;
+// results do not depend on who is paired with whom (tests/test_gpu_round4.py).
+struct KswPlanArgs {
+	const AlnJob *jobs; const int *n_jobs; int n_jobs_host;
+	KswParams P; int pair_on;
+	int lds_budget; size_t p_cap;              // of the pair launch
+	int *order;                                // scratch, one int per job
+	int2 *pairs; int *n_pairs; int *singles; int *n_singles;
+};
+constexpr int PLAN_KEYS = 4096;
+
+__device__ __forceinline__ int ksw_plan_key(const KswPlanArgs &a, int qlen, int tlen, int flags)
+{
+	if (!a.pair_on || !(flags & ALN_Q_ACGT) || qlen >= PLAN_KEYS || !ksw_pair_job_ok(a.P, qlen, tlen)) return -1;
+	if (2 * ksw_pair_lds_share(qlen, tlen) > (size_t)a.lds_budget || ksw_pair_p_bytes(qlen, a.P.w) > a.p_cap) return -1;
+	return PLAN_KEYS - 1 - qlen;
+}
+
+__global__ __launch_bounds__(1024) void k_ksw_plan(const KswPlanArgs a)
+{
+	__shared__ int cur[PLAN_KEYS], start[PLAN_KEYS + 1], pbase[PLAN_KEYS];
+	__shared__ int part[1024], part2[1024];
+	__shared__ int s_ns;
+	const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+	const int n = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
+	for (int i = tid; i < PLAN_KEYS; i += nt) cur[i] = 0;
+	if (tid == 0) s_ns = 0;
+	__syncthreads();
+	for (int j = tid; j < n; j += nt) {
+		const int k = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
+		if (k < 0) a.singles[atomicAdd(&s_ns, 1)] = j; else atomicAdd(&cur[k], 1);
+	}
+	__syncthreads();
+	// exclusive scans over the keys: positions of the jobs (start) and of the pairs (pbase); thread t owns keys 4t..4t+3
+	constexpr int PER = PLAN_KEYS / 1024;
+	int c[PER], sum = 0, psum = 0;
+	for (int i = 0; i < PER; ++i) { c[i] = cur[tid * PER + i]; sum += c[i]; psum += c[i] >> 1; }
+	part[tid] = sum; part2[tid] = psum;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {
+		const int v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
+		__syncthreads();
+		part[tid] += v; part2[tid] += v2;
+		__syncthreads();
+	}
+	int run = part[tid] - sum, prun = part2[tid] - psum;
+	for (int i = 0; i < PER; ++i) { start[tid * PER + i] = run; cur[tid * PER + i] = run; pbase[tid * PER + i] = prun; run += c[i]; prun += c[i] >> 1; }
+	if (tid == 1023) start[PLAN_KEYS] = run;
+	__syncthreads();
+	const int n_elig = start[PLAN_KEYS];
+	for (int j = tid; j < n; j += nt) {
+		const int k = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
+		if (k >= 0) a.order[atomicAdd(&cur[k], 1)] = j;
+	}
+	__threadfence_block();
+	__syncthreads();
+	for (int pos = tid; pos < n_elig; pos += nt) {
+		const int j = a.order[pos];
+		const int k = PLAN_KEYS - 1 - a.jobs[j].qlen;
+		const int rank = pos - start[k], cnt = start[k + 1] - start[k];
+		if (rank & 1) continue;
+		if (rank + 1 < cnt) a.pairs[pbase[k] + (rank >> 1)] = make_int2(j, a.order[pos + 1]);
+		else a.singles[atomicAdd(&s_ns, 1)] = j;
+	}
+	__syncthreads();
+	if (tid == 0) { *a.n_pairs = part2[1023]; *a.n_singles = s_ns; }
+}
+
+// k_ksw_pair: one wavefront per pair of the plan; the launch arguments are the single sweep's (KswArgs: jobs, sequences,
+// result slots, CIGAR pool), `pairs` / n_jobs the plan's list.  a->lds_budget and a->p_cap are the plan's limits.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_ksw_pair(const KswArgs)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	__shared__ int s_item;
+	__shared__ long long s_off;
+	const int lane = lane_id();
+	const KswArgsK a0 = (KswArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+	{
+		const KswArgsK a = a0;
+		mark_start(a->t_start);
+		if (a->prof && lane < 6) ((long long *)(lds + a->lds_budget + 16))[lane] = 0;
+	}
+	WSYNC();
+	unsigned wq_dead = 0;
+	for (;;) {
+		KswArgsK a = ksw_args_again(a0);
+		const int nitems = *a->n_jobs;
+		if (lane == 0) s_item = wq_next(a->work_counter, nitems, (int)blockIdx.x, wq_dead);
+		WSYNC();
+		const int it = __builtin_amdgcn_readfirstlane(s_item);
+		WSYNC();
+		if (it < 0) break;
+		const int2 pr = a->pairs[it];
+		const int j0 = __builtin_amdgcn_readfirstlane(pr.x), j1 = __builtin_amdgcn_readfirstlane(pr.y);
+		const AlnJob jb0 = a->jobs[j0], jb1 = a->jobs[j1];
+		uint8_t *p = a->p_scratch + (size_t)blockIdx.x * a->p_cap;
+		uint32_t *ct = a->cig_tmp + (size_t)blockIdx.x * a->cig_cap;
+		long long *pacc = a->prof ? (long long *)(lds + a->lds_budget + 16) : nullptr;
+		const KswParams P = {a->P.m, a->P.sc_mch, a->P.sc_mis, a->P.min_sc, a->P.q, a->P.e, a->P.w, a->P.zdrop, a->P.flag,
+		                     a->P.encode_ascii, a->P.codes_ok};
+		const int cig_cap = a->cig_cap;
+		const int slot0 = jb0.out, slot1 = jb1.out;
+		auto emit = [&](int k, const KswOut &out) {
+			const KswArgsK b = ksw_args_again(a0);
+			const int jj = k ? j1 : j0, slot = k ? slot1 : slot0;
+			long long off = -1;
+			if (out.n_cigar > 0) {
+				if (out.n_cigar <= CIG_SLOT) off = b->cig_bump_cap + (long long)jj * CIG_SLOT;   // the job's own slot: no atomic
+				else {
+					if (lane == 0) s_off = (long long)atomicAdd(b->cig_cursor, (unsigned long long)out.n_cigar);
+					WSYNC();
+					off = s_off;
+					if (off + out.n_cigar > b->cig_bump_cap) off = b->cig_pool_cap;        // bump region exhausted
+				}
+				if (off + out.n_cigar <= b->cig_pool_cap) {
+					uint32_t *pool = b->cig_pool;
+					for (int i = lane; i < out.n_cigar; i += 64) pool[off + i] = ct[i];
+				} else {
+					if (lane == 0) atomicExch(&b->overflow[0], 1);
+					off = -1;
+				}
+			} else if (out.n_cigar < 0) {
+				if (lane == 0) atomicExch(&b->overflow[1], 1);
+			}
+			if (lane == 0) { b->ez[slot] = out; b->cig_off[slot] = off; }
+			WSYNC();
+		};
+		const bool ok = ksw_wave_pair(a->qbase + jb0.q_off, a->tbase + jb0.t_off, jb0.tlen, a->qbase + jb1.q_off, a->tbase + jb1.t_off, jb1.tlen,
+		                              jb0.qlen, P, lds, p, ct, cig_cap, emit, pacc);
+		if (!ok) {                                                     // a code the producer vouched against: refuse loudly
+			KswOut out;
+			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
+			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
+			emit(0, out); emit(1, out);
+		}
+	}
+	WSYNC();
+	{
+		const KswArgsK a = ksw_args_again(a0);
+		if (a->prof && lane < 6)
 			atomicAdd((unsigned long long *)&a->prof[lane < 4 ? 8 + lane : 56 + lane], (unsigned long long)((long long *)(lds + a->lds_budget + 16))[lane]);
 	}
 }

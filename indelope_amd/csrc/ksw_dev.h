@@ -86,9 +86,10 @@ __device__ __forceinline__ int sext8(unsigned v) { return (int)(signed char)(v &
 // Wave-parallel walk back through p (:47-79, :380-385).  off[r]/off_end[r] are recomputed from r.
 // Lane k speculates on the cell reached after k moves in the direction of the current state; a
 // ballot gives the length of the run, so a CIGAR of n ops costs O(n + len/64) round trips to HBM.
-// PACKED: p is ksw_narrow.h's slot matrix (80 dwords per slot, a nibble of four compare bits per cell) instead of the
-// reference's n_col*16 bytes per diagonal.
-template <bool PACKED = false>
+// PACKED 1: p is ksw_narrow.h's slot matrix (80 dwords per slot, a nibble of four compare bits per cell, eight diagonals per
+// dword) instead of the reference's n_col*16 bytes per diagonal; 2: ksw_pair.h's (four diagonals per 16-bit half, HALF = this
+// alignment's half).
+template <int PACKED = 0, int HALF = 0>
 __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, int tlen, int w, int flag,
                                           int zdropped, int ez_max_t, int ez_max_q,
                                           uint32_t *cig_tmp, int cig_cap, KswOut &out)
@@ -120,7 +121,8 @@ __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, 
 			if (force_state < 0) {
 				if (!PACKED) tmp = p[(size_t)rr * ncol + ik - st];
 				else {
-					const unsigned nib = ((const unsigned *)p)[(size_t)((rr >> 3) + (st >> 4)) * 80 + (ik - st)] >> (4 * (7 - (rr & 7))) & 15u;
+					const unsigned nib = PACKED == 1 ? ((const unsigned *)p)[(size_t)((rr >> 3) + (st >> 4)) * 80 + (ik - st)] >> (4 * (7 - (rr & 7))) & 15u
+					                                 : ((const unsigned *)p)[(size_t)((rr >> 2) + (st >> 4)) * 80 + (ik - st)] >> (16 * HALF + 4 * (3 - (rr & 3))) & 15u;
 					tmp = ((nib & 4) ? 2u : (nib >> 3)) | ((nib & 2) << 2) | ((nib & 1) << 4);
 				}
 			}

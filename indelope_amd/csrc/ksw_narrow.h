@@ -911,7 +911,7 @@ __device__ inline bool ksw_wave_narrow(const uint8_t *query, int qlen, const uin
 	out.mqe = F.mqe; out.mqe_t = F.mqe_t; out.mte = F.mte; out.mte_q = F.mte_q; out.score = stop ? KSW_NEG_INF : F.score;   // (the reference tests the z-drop before it takes the score of the last diagonal, :355-357: a sweep that stopped has none)
 	const long long tc2 = pacc ? (long long)clock64() : 0;
 	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 1; }
-	ksw_backtrack_wave<true>(p, 0, qlen, tlen, w, flag, stop ? 1 : 0, F.ez_max_t, F.ez_max_q, cig_tmp, cig_cap, out);
+	ksw_backtrack_wave<1>(p, 0, qlen, tlen, w, flag, stop ? 1 : 0, F.ez_max_t, F.ez_max_q, cig_tmp, cig_cap, out);
 	if (pacc && lane == 0) pacc[2] += (long long)clock64() - tc2;
 	return true;
 }
