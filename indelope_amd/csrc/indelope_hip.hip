@@ -329,23 +329,39 @@ template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStr
 // at `cnt`, the pair launch's work queue at `wq_pair`; p_pair / ct_pair: traceback and CIGAR scratch of the pair launch
 // (p_cap_pair, a.cig_cap per workgroup).  Returns false when these parameters are not the pair sweep's (nothing launched).
 static bool ksw_pair_wanted(const KswParams &P, int mode) { return g_knob.ksw_pair && mode == 3 && ksw_pair_ok(P); }
-static void launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hipStream_t s, const KswArgs &a, int *plan, int n_cap, int *cnt,
-                               int *wq_pair, uint8_t *p_pair, size_t p_cap_pair, uint32_t *ct_pair)
+static int launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hipStream_t s, const KswArgs &a, int *plan, int n_cap, int *zero,
+                              int *wq_pair, uint8_t *p_pair, size_t p_cap_pair, uint32_t *ct_pair,
+                              hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr)
 {
+	// plan: ints [n_cap: ranks | n_cap: singles | 2 n_cap: pairs]; zero: ints that are zero when the run starts
+	// [PLAN_KEYS: jobs per contig length | pairs | singles]
 	KswPlanArgs pl;
 	pl.jobs = a.jobs; pl.n_jobs = a.n_jobs; pl.n_jobs_host = a.n_jobs_host; pl.P = a.P; pl.pair_on = 1;
 	pl.lds_budget = (int)lds_pair - 64; pl.p_cap = p_cap_pair;
-	pl.order = plan; pl.singles = plan + n_cap; pl.pairs = (int2 *)(plan + 2 * (size_t)n_cap);
-	pl.n_pairs = cnt; pl.n_singles = cnt + 1;
-	hipLaunchKernelGGL(k_ksw_plan, dim3(1), dim3(1024), 0, s, pl);
+	pl.count = zero; pl.n_pairs = zero + PLAN_KEYS; pl.n_singles = zero + PLAN_KEYS + 1;
+	pl.t_start = a.t_start;
+	pl.rank = plan; pl.singles = plan + n_cap; pl.pairs = (int2 *)(plan + 2 * (size_t)n_cap + (n_cap & 1));
+	const dim3 pg(std::max(1, std::min(2 * g.cus, (n_cap + 255) / 256)));
+	hipLaunchKernelGGL(k_ksw_plan_count, pg, dim3(256), 0, s, pl);
+	hipLaunchKernelGGL(k_ksw_plan_place, pg, dim3(256), 0, s, pl);
+	// the jobs without a partner: a few per cent, each a serial chain of ~0.1 ms -- beside the pairs, not in front of them
 	KswArgs x = a;
-	x.in_list = pl.singles; x.n_jobs = pl.n_singles;
-	launch_ksw(3, grid, lds_single, s, x);
+	x.t_start = nullptr; x.in_list = pl.singles; x.n_jobs = pl.n_singles;
+	if (side) {
+		HIPC(hipEventRecord(ev_fork, s));
+		HIPC(hipStreamWaitEvent(side, ev_fork, 0));
+		launch_ksw(3, grid, lds_single, side, x);
+		HIPC(hipEventRecord(ev_join, side));
+	} else launch_ksw(3, grid, lds_single, s, x);
 	KswArgs y = a;
 	y.t_start = nullptr; y.in_list = nullptr; y.pairs = pl.pairs; y.n_jobs = pl.n_pairs; y.ovf_list = nullptr; y.ovf_n = nullptr;
 	y.lds_budget = (int)lds_pair - 64; y.p_scratch = p_pair; y.p_cap = p_cap_pair; y.cig_tmp = ct_pair; y.work_counter = wq_pair;
 	hipLaunchKernelGGL(k_ksw_pair, grid, dim3(64), lds_pair, s, y);
+	if (side) HIPC(hipStreamWaitEvent(s, ev_join, 0));
+	return 0;
 }
+static size_t ksw_plan_ints(long long n_cap) { return 4 * (size_t)n_cap + 8; }
+constexpr int PLAN_ZERO_INTS = PLAN_KEYS + 16;
 
 KswParams make_ksw_params(int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag, int ascii)
 {
@@ -595,7 +611,7 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 	if ((rc = d_coff.alloc(sizeof(long long) * n))) return rc;
 	const long long fixed_words = (long long)n * CIG_SLOT;
 	if ((rc = d_pool.alloc(sizeof(uint32_t) * (size_t)(cig_bound + 4 + fixed_words)))) return rc;
-	if ((rc = d_misc.alloc(64 + sizeof(int) * WQ_WORDS * 2))) return rc;  // [0] cursor u64, [2..4] overflow, [6..7] the plan's counts, [16..] two work queues
+	if ((rc = d_misc.alloc(64 + sizeof(int) * (WQ_WORDS * 2 + PLAN_ZERO_INTS)))) return rc;  // [0] cursor u64, [2..4] overflow, [16..] two work queues, then the plan's zero block
 	if ((rc = d_misc.zero(g.stream))) return rc;
 	KswArgs a;
 	a.jobs = d_jobs.as<AlnJob>(); a.n_jobs = nullptr; a.n_jobs_host = n;
@@ -619,21 +635,23 @@ static int run_ksw_jobs(const std::vector<AlnJob> &jobs, const uint8_t *d_q, con
 				lds_pair = std::max(lds_pair, 2 * ksw_pair_lds_share(j.qlen, j.tlen)); p_pair = std::max(p_pair, ksw_pair_p_bytes(j.qlen, P.w));
 			}
 		lds_pair = std::min(lds_pair + 64, (size_t)g.max_lds - 2048);
-		if ((rc = d_plan.alloc(sizeof(int) * 4 * (size_t)n))) return rc;
+		if ((rc = d_plan.alloc(sizeof(int) * ksw_plan_ints(n)))) return rc;
 		if ((rc = d_pp.alloc((p_pair + 64) * grid))) return rc;
 		if ((rc = d_pct.alloc(sizeof(uint32_t) * (size_t)(cig_cap + 4) * grid))) return rc;
-		launch_ksw_planned(dim3(grid), lds_need + 64, lds_pair + 64, g.stream, a, d_plan.as<int>(), n, d_misc.as<int>() + 6,
+		launch_ksw_planned(dim3(grid), lds_need + 64, lds_pair + 64, g.stream, a, d_plan.as<int>(), n, d_misc.as<int>() + 16 + 2 * WQ_WORDS,
 		                   d_misc.as<int>() + 16 + WQ_WORDS, d_pp.as<uint8_t>(), p_pair + 64, d_pct.as<uint32_t>());
 	} else launch_ksw(g_last_ksw_mode, dim3(grid), lds_need + 64, g.stream, a);
 	HIPC(hipGetLastError());
 	long long misc[8];
+	int plan_counts[2] = {0, 0};
 	HIPC(hipMemcpyAsync(ez.data(), d_ez.p, sizeof(KswOut) * n, hipMemcpyDeviceToHost, g.stream));
 	HIPC(hipMemcpyAsync(coff.data(), d_coff.p, sizeof(long long) * n, hipMemcpyDeviceToHost, g.stream));
 	HIPC(hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, g.stream));
+	if (d_plan.p) HIPC(hipMemcpyAsync(plan_counts, d_misc.as<int>() + 16 + 2 * WQ_WORDS + PLAN_KEYS, 8, hipMemcpyDeviceToHost, g.stream));
 	HIPC(hipStreamSynchronize(g.stream));
 	const long long used = misc[0];
 	const int *ov = (const int *)misc + 2;
-	g_last_ksw_pairs = d_plan.p ? ((const int *)misc)[6] : 0;
+	g_last_ksw_pairs = plan_counts[0];
 	if (ov[0] || ov[1]) { snprintf(g.err, sizeof(g.err), "ksw2 kernel capacity overflow (%d,%d)", ov[0], ov[1]); return IHP_E_CAPACITY; }
 	(void)used;
 	pool.resize((size_t)a.cig_pool_cap);
@@ -869,7 +887,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 20 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19] the counts of k_ksw_plan (pairs, singles)
+enum { WQ_SETS = 24 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles)
 enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32 };
 struct ihp_batch {
 	ihp_params P;
@@ -896,7 +914,7 @@ struct ihp_batch {
 	int n_small = 0, n_rich = 0;                           // class 1 = the regions of the usual size + the read-rich ones the packed path takes (its own k_asm_reads launch)
 	int v2_pdw_rich = 0, grid_v2r_rich = 0;
 	hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr;
-	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bfork = nullptr, ev_bjoin = nullptr;
+	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bfork = nullptr, ev_bjoin = nullptr, ev_kfork = nullptr, ev_kjoin = nullptr;
 	int grid_asm = 0, grid_ksw = 0, grid_tally = 0;
 	int arena_cap = 0, stage_cap = 0, corr_cap = 0, lds_ksw = 0, cig_cap = 0;
 	size_t p_cap = 0;
@@ -952,6 +970,8 @@ struct ihp_batch {
 		if (ev_join) (void)hipEventDestroy(ev_join);
 		if (ev_bfork) (void)hipEventDestroy(ev_bfork);
 		if (ev_bjoin) (void)hipEventDestroy(ev_bjoin);
+		if (ev_kfork) (void)hipEventDestroy(ev_kfork);
+		if (ev_kjoin) (void)hipEventDestroy(ev_kjoin);
 		if (ev_rfork) (void)hipEventDestroy(ev_rfork);
 		if (ev_rjoin) (void)hipEventDestroy(ev_rjoin);
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -987,7 +1007,7 @@ static int alloc_work(ihp_batch *b)
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(ksw_ovf, sizeof(int) * (size_t)std::max<long long>(1, b->njobs_cap));
 	if (b->p_cap_pair) {
-		AL(ksw_plan, sizeof(int) * 4 * (size_t)std::max<long long>(1, b->njobs_cap));
+		AL(ksw_plan, sizeof(int) * ksw_plan_ints(std::max<long long>(1, b->njobs_cap)));
 		AL(p_scratch_pair, b->p_cap_pair * b->grid_ksw);
 		AL(cig_tmp_pair, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	}
@@ -1420,6 +1440,8 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	HIPB(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_bfork, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_bjoin, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_kfork, hipEventDisableTiming));
+	HIPB(hipEventCreateWithFlags(&b->ev_kjoin, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_rfork, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_rjoin, hipEventDisableTiming));
 	b->report = g_reports.get();
@@ -1704,9 +1726,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		g_last_ksw_mode = ksw_mode(a.P);
 		a.in_list = nullptr; a.pairs = nullptr; a.ovf_list = b->ksw_ovf.as<int>(); a.ovf_n = misc + M_KSW_OVF;
 		if (b->p_cap_pair && ksw_pair_wanted(a.P, g_last_ksw_mode))
-			launch_ksw_planned(dim3(b->grid_ksw), b->lds_ksw, b->lds_ksw_pair, s, a, b->ksw_plan.as<int>(), (int)std::max<long long>(1, b->njobs_cap),
-			                   wq + 19 * WQ_WORDS, wq + 18 * WQ_WORDS, b->p_scratch_pair.as<uint8_t>(), b->p_cap_pair, b->cig_tmp_pair.as<uint32_t>());
-		else launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
+		{
+			const int prc = launch_ksw_planned(dim3(b->grid_ksw), b->lds_ksw, b->lds_ksw_pair, s, a, b->ksw_plan.as<int>(), (int)std::max<long long>(1, b->njobs_cap),
+			                                   wq + 19 * WQ_WORDS, wq + 18 * WQ_WORDS, b->p_scratch_pair.as<uint8_t>(), b->p_cap_pair, b->cig_tmp_pair.as<uint32_t>(),   // (5 sets >= PLAN_ZERO_INTS)
+			                                   b->stream2, b->ev_kfork, b->ev_kjoin);
+			if (prc) return prc;
+		} else launch_ksw(g_last_ksw_mode, dim3(b->grid_ksw), b->lds_ksw, s, a);
 		HIPC(hipGetLastError());
 		// the roomy launch: left out when the last batch had no such job (a few workgroups that ask for all the LDS of a CU wait for
 		// one to drain); the wait checks the count and repeats the run with it otherwise (see the retry launches above)

@@ -758,18 +758,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ||
 }
 
 // ------------------------------------------------------- ksw2, two alignments per wavefront (ksw_pair.h)
-// k_ksw_plan: which jobs share a wavefront.  The jobs the pair sweep can take (ksw_pair_job_ok, a producer that vouches
-// for the codes, room in the pair launch's LDS and traceback scratch) are counting-sorted by qlen, longest first, and
-// neighbours of equal qlen become a pair; everything else -- the odd one of a length included -- goes on the singles
-// list, which the single sweep's launch walks through in_list.  One workgroup: a batch has 10^4..10^5 jobs and the three
-// passes are a few microseconds each.  The order inside a length comes from atomics and differs from run to run;
-// results do not depend on who is paired with whom (tests/test_gpu_round4.py).
+// The plan: which jobs share a wavefront.  A job the pair sweep can take (ksw_pair_job_ok, a producer that vouches for the
+// codes, room in the pair launch's LDS and traceback scratch) is counted under its contig length (k_ksw_plan_count: one
+// atomic per job, its rank among the jobs of that length kept in `rank`); k_ksw_plan_place turns the counts into positions
+// (every workgroup scans the 4096 counts in LDS: cheaper than a launch in between) and the jobs of rank 2i and 2i + 1 of a
+// length write the two halves of pair i of that length.  Everything else -- the odd one of a length included -- goes on the
+// singles list, which the single sweep's launch walks through in_list (positions from one atomic per wavefront: a ballot
+// ranks the lanes).  Two earlier versions: a counting sort in ONE workgroup (0.6 ms for 200 000 jobs) and pairing through a
+// compare-and-swap slot per length (retries grow with the jobs in flight: 190 ms for the same batch).  Who is paired with
+// whom differs from run to run; results do not depend on it (tests/test_gpu_round4.py).
 struct KswPlanArgs {
 	const AlnJob *jobs; const int *n_jobs; int n_jobs_host;
 	KswParams P; int pair_on;
 	int lds_budget; size_t p_cap;              // of the pair launch
-	int *order;                                // scratch, one int per job
+	int *count;                                // [PLAN_KEYS] jobs per contig length; zero when the run starts
+	int *rank;                                 // [jobs] scratch
 	int2 *pairs; int *n_pairs; int *singles; int *n_singles;
+	unsigned long long *t_start;               // optional: see mark_start() (the ksw2 stage begins with its plan)
 };
 constexpr int PLAN_KEYS = 4096;
 
@@ -777,57 +782,73 @@ __device__ __forceinline__ int ksw_plan_key(const KswPlanArgs &a, int qlen, int 
 {
 	if (!a.pair_on || !(flags & ALN_Q_ACGT) || qlen >= PLAN_KEYS || !ksw_pair_job_ok(a.P, qlen, tlen)) return -1;
 	if (2 * ksw_pair_lds_share(qlen, tlen) > (size_t)a.lds_budget || ksw_pair_p_bytes(qlen, a.P.w) > a.p_cap) return -1;
-	return PLAN_KEYS - 1 - qlen;
+	return qlen;
 }
 
-__global__ __launch_bounds__(1024) void k_ksw_plan(const KswPlanArgs a)
+// position of every lane with `take` in a list whose length is *cnt (one atomic per wavefront); -1 for the other lanes
+__device__ __forceinline__ int plan_append(int *cnt, bool take)
 {
-	__shared__ int cur[PLAN_KEYS], start[PLAN_KEYS + 1], pbase[PLAN_KEYS];
-	__shared__ int part[1024], part2[1024];
-	__shared__ int s_ns;
-	const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+	const unsigned long long m = ballot(take);
+	if (!m) return -1;
+	const int lane = lane_id();
+	int base = 0;
+	if (lane == ctz64(m)) base = atomicAdd(cnt, popc64(m));
+	base = __builtin_amdgcn_readlane(base, ctz64(m));
+	return take ? base + popc64(m & ((1ull << lane) - 1)) : -1;
+}
+
+__global__ __launch_bounds__(256) void k_ksw_plan_count(const KswPlanArgs a)
+{
+	const int tid = (int)threadIdx.x;
+	mark_start(a.t_start);
 	const int n = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
-	for (int i = tid; i < PLAN_KEYS; i += nt) cur[i] = 0;
-	if (tid == 0) s_ns = 0;
-	__syncthreads();
-	for (int j = tid; j < n; j += nt) {
-		const int k = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
-		if (k < 0) a.singles[atomicAdd(&s_ns, 1)] = j; else atomicAdd(&cur[k], 1);
+	const int step = (int)(gridDim.x * blockDim.x);
+	for (int j0 = (int)(blockIdx.x * blockDim.x); j0 < n; j0 += step) {      // (whole wavefronts stay together for the ballot)
+		const int j = j0 + tid;
+		int key = -1;
+		if (j < n) key = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
+		if (key >= 0) a.rank[j] = atomicAdd(a.count + key, 1);
+		const int ss = plan_append(a.n_singles, j < n && key < 0);
+		if (ss >= 0) a.singles[ss] = j;
 	}
+}
+
+__global__ __launch_bounds__(256) void k_ksw_plan_place(const KswPlanArgs a)
+{
+	__shared__ int pbase[PLAN_KEYS];
+	__shared__ int part[256];
+	const int tid = (int)threadIdx.x;
+	const int n = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
+	if (blockIdx.x && (long long)blockIdx.x * blockDim.x >= n) return;     // (the grid is sized for the job slots, not the jobs)
+	constexpr int PER = PLAN_KEYS / 256;
+	int c[PER], sum = 0;
+	for (int i = 0; i < PER; ++i) { c[i] = a.count[tid * PER + i] >> 1; sum += c[i]; }
+	part[tid] = sum;
 	__syncthreads();
-	// exclusive scans over the keys: positions of the jobs (start) and of the pairs (pbase); thread t owns keys 4t..4t+3
-	constexpr int PER = PLAN_KEYS / 1024;
-	int c[PER], sum = 0, psum = 0;
-	for (int i = 0; i < PER; ++i) { c[i] = cur[tid * PER + i]; sum += c[i]; psum += c[i] >> 1; }
-	part[tid] = sum; part2[tid] = psum;
-	__syncthreads();
-	for (int d = 1; d < 1024; d <<= 1) {
-		const int v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
+	for (int d = 1; d < 256; d <<= 1) {
+		const int v = tid >= d ? part[tid - d] : 0;
 		__syncthreads();
-		part[tid] += v; part2[tid] += v2;
+		part[tid] += v;
 		__syncthreads();
 	}
-	int run = part[tid] - sum, prun = part2[tid] - psum;
-	for (int i = 0; i < PER; ++i) { start[tid * PER + i] = run; cur[tid * PER + i] = run; pbase[tid * PER + i] = prun; run += c[i]; prun += c[i] >> 1; }
-	if (tid == 1023) start[PLAN_KEYS] = run;
+	int run = part[tid] - sum;
+	for (int i = 0; i < PER; ++i) { pbase[tid * PER + i] = run; run += c[i]; }
 	__syncthreads();
-	const int n_elig = start[PLAN_KEYS];
-	for (int j = tid; j < n; j += nt) {
-		const int k = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
-		if (k >= 0) a.order[atomicAdd(&cur[k], 1)] = j;
+	if (blockIdx.x == 0 && tid == 255) *a.n_pairs = part[255];
+	const int step = (int)(gridDim.x * blockDim.x);
+	for (int j0 = (int)(blockIdx.x * blockDim.x); j0 < n; j0 += step) {
+		const int j = j0 + tid;
+		int key = -1;
+		if (j < n) key = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
+		bool odd_one = false;
+		if (key >= 0) {
+			const int rk = a.rank[j], cnt = a.count[key];
+			odd_one = rk == cnt - 1 && (cnt & 1);
+			if (!odd_one) ((int *)(a.pairs + pbase[key] + (rk >> 1)))[rk & 1] = j;
+		}
+		const int ss = plan_append(a.n_singles, odd_one);
+		if (ss >= 0) a.singles[ss] = j;
 	}
-	__threadfence_block();
-	__syncthreads();
-	for (int pos = tid; pos < n_elig; pos += nt) {
-		const int j = a.order[pos];
-		const int k = PLAN_KEYS - 1 - a.jobs[j].qlen;
-		const int rank = pos - start[k], cnt = start[k + 1] - start[k];
-		if (rank & 1) continue;
-		if (rank + 1 < cnt) a.pairs[pbase[k] + (rank >> 1)] = make_int2(j, a.order[pos + 1]);
-		else a.singles[atomicAdd(&s_ns, 1)] = j;
-	}
-	__syncthreads();
-	if (tid == 0) { *a.n_pairs = part2[1023]; *a.n_singles = s_ns; }
 }
 
 // k_ksw_pair: one wavefront per pair of the plan; the launch arguments are the single sweep's (KswArgs: jobs, sequences,
@@ -854,19 +875,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
 		const int it = __builtin_amdgcn_readfirstlane(s_item);
 		WSYNC();
 		if (it < 0) break;
-		const int2 pr = a->pairs[it];
-		const int j0 = __builtin_amdgcn_readfirstlane(pr.x), j1 = __builtin_amdgcn_readfirstlane(pr.y);
-		const AlnJob jb0 = a->jobs[j0], jb1 = a->jobs[j1];
-		uint8_t *p = a->p_scratch + (size_t)blockIdx.x * a->p_cap;
-		uint32_t *ct = a->cig_tmp + (size_t)blockIdx.x * a->cig_cap;
-		long long *pacc = a->prof ? (long long *)(lds + a->lds_budget + 16) : nullptr;
-		const KswParams P = {a->P.m, a->P.sc_mch, a->P.sc_mis, a->P.min_sc, a->P.q, a->P.e, a->P.w, a->P.zdrop, a->P.flag,
-		                     a->P.encode_ascii, a->P.codes_ok};
-		const int cig_cap = a->cig_cap;
-		const int slot0 = jb0.out, slot1 = jb1.out;
-		auto emit = [&](int k, const KswOut &out) {
+		PairResult R;
+		bool ok;
+		{
+			const int2 pr = a->pairs[it];
+			const int j0 = __builtin_amdgcn_readfirstlane(pr.x), j1 = __builtin_amdgcn_readfirstlane(pr.y);
+			const AlnJob jb0 = a->jobs[j0], jb1 = a->jobs[j1];
+			uint8_t *p = a->p_scratch + (size_t)blockIdx.x * a->p_cap;
+			long long *pacc = a->prof ? (long long *)(lds + a->lds_budget + 16) : nullptr;
+			ok = ksw_pair_sweep(a->qbase + jb0.q_off, a->tbase + jb0.t_off, jb0.tlen, a->qbase + jb1.q_off, a->tbase + jb1.t_off, jb1.tlen, jb0.qlen,
+			                    a->P.w, a->P.q, a->P.e, a->P.sc_mch, a->P.sc_mis, a->P.zdrop, a->P.encode_ascii, lds, p, R, pacc);
+		}
+		// the tracebacks: the jobs are read again (nothing of them stayed in a register across the sweep)
+		for (int k = 0; k < 2; ++k) {
 			const KswArgsK b = ksw_args_again(a0);
-			const int jj = k ? j1 : j0, slot = k ? slot1 : slot0;
+			const int2 pr = b->pairs[it];
+			const int jj = __builtin_amdgcn_readfirstlane(k ? pr.y : pr.x);
+			const int qlen = uni(b->jobs[jj].qlen), tlen = uni(b->jobs[jj].tlen), slot = uni(b->jobs[jj].out);
+			const uint8_t *p = b->p_scratch + (size_t)blockIdx.x * b->p_cap;
+			uint32_t *ct = b->cig_tmp + (size_t)blockIdx.x * b->cig_cap;
+			long long *pacc = b->prof ? (long long *)(lds + b->lds_budget + 16) : nullptr;
+			KswOut out;
+			if (!ok) {                                                     // a code the producer vouched against: refuse loudly
+				out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
+				out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
+			} else if (k == 0) ksw_pair_finish<0>(R, p, qlen, tlen, b->P.w, b->P.flag, ct, b->cig_cap, out, pacc);
+			else ksw_pair_finish<1>(R, p, qlen, tlen, b->P.w, b->P.flag, ct, b->cig_cap, out, pacc);
 			long long off = -1;
 			if (out.n_cigar > 0) {
 				if (out.n_cigar <= CIG_SLOT) off = b->cig_bump_cap + (long long)jj * CIG_SLOT;   // the job's own slot: no atomic
@@ -888,14 +922,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
 			}
 			if (lane == 0) { b->ez[slot] = out; b->cig_off[slot] = off; }
 			WSYNC();
-		};
-		const bool ok = ksw_wave_pair(a->qbase + jb0.q_off, a->tbase + jb0.t_off, jb0.tlen, a->qbase + jb1.q_off, a->tbase + jb1.t_off, jb1.tlen,
-		                              jb0.qlen, P, lds, p, ct, cig_cap, emit, pacc);
-		if (!ok) {                                                     // a code the producer vouched against: refuse loudly
-			KswOut out;
-			out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = out.mte_q = -1;
-			out.mqe = out.mte = out.score = KSW_NEG_INF; out.n_cigar = -1;
-			emit(0, out); emit(1, out);
 		}
 	}
 	WSYNC();

@@ -123,7 +123,8 @@ __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, 
 				else {
 					const unsigned nib = PACKED == 1 ? ((const unsigned *)p)[(size_t)((rr >> 3) + (st >> 4)) * 80 + (ik - st)] >> (4 * (7 - (rr & 7))) & 15u
 					                                 : ((const unsigned *)p)[(size_t)((rr >> 2) + (st >> 4)) * 80 + (ik - st)] >> (16 * HALF + 4 * (3 - (rr & 3))) & 15u;
-					tmp = ((nib & 4) ? 2u : (nib >> 3)) | ((nib & 2) << 2) | ((nib & 1) << 4);
+					if (PACKED == 1) tmp = ((nib & 4) ? 2u : (nib >> 3)) | ((nib & 2) << 2) | ((nib & 1) << 4);
+					else tmp = ((nib & 1) ? 2u : ((nib >> 1) & 1u)) | ((nib & 12) << 1);   // ksw_pair.h: bit 1 = :265, bit 0 = :273, bits 2, 3
 				}
 			}
 			int s = state;

@@ -37,23 +37,31 @@
 
 namespace ihp {
 
-#define IHP_PK2(NAME, OP) __device__ __forceinline__ unsigned NAME(unsigned a, unsigned b) { unsigned r; asm(OP " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-IHP_PK2(pk_add, "v_pk_add_u16")
-IHP_PK2(pk_sub, "v_pk_sub_u16")
-IHP_PK2(pk_maxu, "v_pk_max_u16")
-IHP_PK2(pk_minu, "v_pk_min_u16")
-#undef IHP_PK2
-__device__ __forceinline__ unsigned pk_sub_sat(unsigned a, unsigned b) { unsigned r; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ unsigned pk_max0(unsigned a) { unsigned r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
-__device__ __forceinline__ unsigned pk_add_s(unsigned a, unsigned s) { unsigned r; asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
-__device__ __forceinline__ unsigned pk_sub_s(unsigned a, unsigned s) { unsigned r; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
-__device__ __forceinline__ unsigned pk_minu_s(unsigned a, unsigned s) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
-template <int N> __device__ __forceinline__ unsigned pk_shr(unsigned a) { unsigned r; asm("v_pk_lshrrev_b16 %0, %2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "n"(N)); return r; }
-template <int K> __device__ __forceinline__ unsigned pk_minc(unsigned a) { unsigned r; asm("v_pk_min_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "n"(K)); return r; }
+// Packed 16-bit arithmetic on two alignments at once.  Written on clang's vector types, not as inline assembly: the compiler
+// then knows the instructions (v_pk_add_u16, v_pk_sub_i16 clamp, v_pk_max_u16 ...), schedules them and needs no wait
+// state between two of them -- behind an asm statement whose result the next one reads it places an s_nop (nine per diagonal).
+typedef unsigned short pk_us2 __attribute__((ext_vector_type(2)));
+typedef short pk_ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_us2 pk_u(unsigned x) { return __builtin_bit_cast(pk_us2, x); }
+__device__ __forceinline__ pk_ss2 pk_s(unsigned x) { return __builtin_bit_cast(pk_ss2, x); }
+__device__ __forceinline__ unsigned pk_r(pk_us2 x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ unsigned pk_r(pk_ss2 x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) { return pk_r((pk_us2)(pk_u(a) + pk_u(b))); }
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) { return pk_r((pk_us2)(pk_u(a) - pk_u(b))); }
+__device__ __forceinline__ unsigned pk_maxu(unsigned a, unsigned b) { return pk_r(__builtin_elementwise_max(pk_u(a), pk_u(b))); }
+__device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) { return pk_r(__builtin_elementwise_min(pk_u(a), pk_u(b))); }
+// the saturating signed difference: negative <=> a < b as int16 (never wraps)
+__device__ __forceinline__ unsigned pk_sub_sat(unsigned a, unsigned b) { return pk_r(__builtin_elementwise_sub_sat(pk_s(a), pk_s(b))); }
+__device__ __forceinline__ unsigned pk_max0(unsigned a) { return pk_r(__builtin_elementwise_max(pk_s(a), (pk_ss2){0, 0})); }
+__device__ __forceinline__ unsigned pk_add_s(unsigned a, unsigned s) { return pk_add(a, s); }
+__device__ __forceinline__ unsigned pk_sub_s(unsigned a, unsigned s) { return pk_sub(a, s); }
+__device__ __forceinline__ unsigned pk_minu_s(unsigned a, unsigned s) { return pk_minu(a, s); }
+template <int N> __device__ __forceinline__ unsigned pk_shr(unsigned a) { return pk_r((pk_us2)(pk_u(a) >> (pk_us2){N, N})); }
+template <int K> __device__ __forceinline__ unsigned pk_minc(unsigned a) { return pk_r(__builtin_elementwise_min(pk_u(a), (pk_us2){K, K})); }
 // a * K + c per half
-template <int K> __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned c) { unsigned r; asm("v_pk_mad_u16 %0, %1, %3, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c), "n"(K)); return r; }
+template <int K> __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned c) { return pk_r((pk_us2)(pk_u(a) * (pk_us2){K, K} + pk_u(c))); }
 // both halves shifted left by the wave-uniform n (n in both halves of the scalar)
-__device__ __forceinline__ unsigned pk_shl_s(unsigned a, unsigned n2) { unsigned r; asm("v_pk_lshlrev_b16 %0, %2, %1" : "=v"(r) : "v"(a), "s"(n2)); return r; }
+__device__ __forceinline__ unsigned pk_shl_s(unsigned a, unsigned n2) { return pk_r((pk_us2)(pk_u(a) << pk_u(n2))); }
 
 // lanes whose half K of v is >  / >= the wave-uniform 16-bit t
 template <int K> __device__ __forceinline__ unsigned long long pk_gt(unsigned v, int t)
@@ -72,6 +80,9 @@ template <int K> __device__ __forceinline__ unsigned long long pk_ge(unsigned v,
 }
 // half K of a packed word, sign extended (scalar and per lane)
 template <int K> __device__ __forceinline__ int pk_half(int s) { return K == 0 ? (int)(short)(s & 0xffff) : s >> 16; }
+__device__ __forceinline__ int pos_pack(int r, int t) { return (int)(((unsigned)r << 16) | ((unsigned)t & 0xffffu)); }
+__device__ __forceinline__ int pos_t(int pos) { return (int)(short)(pos & 0xffff); }
+__device__ __forceinline__ int pos_q(int pos) { return (pos >> 16) - (int)(short)(pos & 0xffff); }
 
 // bytes of LDS / of traceback scratch a pair needs (qlen shared, the two window lengths)
 __host__ __device__ __forceinline__ size_t ksw_pair_lds_bytes(int qlen, int tlen0, int tlen1)
@@ -107,6 +118,7 @@ struct PairEnv {
 	unsigned *p;                                         // traceback slots of 80 dwords
 	int qlen, w, qe, e;
 	int zd;                                              // z-drop, or a value no score difference reaches
+	int qlm1;                                            // qlen - 1
 	unsigned Qp, Mp, ZWp, QE2p;                          // both halves: q << 8, max_sc << 8, z of a never-refreshed cell << 8; 2(q+e)
 	unsigned zx4, zdm;                                   // z(mismatch) in four bytes, z(match) - z(mismatch)
 	unsigned zw4;                                        // z(wildcard) in four bytes
@@ -121,9 +133,10 @@ struct PairState {
 	// wave-uniform
 	int st; int edge_g;
 	int thr0, thr1;                                      // ez.max + r (q+e) of the coming diagonal
-	int max_t0, max_t1, max_q0, max_q1, mqe0, mqe1, mqe_t0, mqe_t1;
-	int dead0, dead1;                                    // z-dropped: the values above are final, ez_max* holds ez.max
-	int ez_max0, ez_max1;
+	int pos0, pos1;                                      // where ez.max was found: the diagonal << 16 | max_t (max_q = diagonal - max_t)
+	int mqe0, mqe1, mqe_t0, mqe_t1;
+	int inc0, inc1;                                      // q+e while the alignment is live; 0 once it has z-dropped: the values above are final,
+	int fin0, fin1;                                      // fin* holds ez.max and thr* stands at 32767
 };
 
 // z by query code (bytes 0..3) for a target base
@@ -135,7 +148,7 @@ __device__ __forceinline__ unsigned pair_table(const PairEnv &E, unsigned code)
 __device__ __forceinline__ unsigned pair_z(unsigned T0, unsigned T1, unsigned sel) { return __builtin_amdgcn_perm(T1, T0, sel); }
 
 // One cell of both alignments (:116-137 + :262-284, left-aligned); every value is (int8 << 8) per half; z > 0 (ksw_narrow_ok).
-// nib: the four compare results of ksw_narrow.h's nibble, first compare highest, in bits 3..0 of each half.
+// nib: the four compare results behind the reference's traceback byte in bits 3..0 of each half (see below for the order).
 __device__ __forceinline__ void pair_cell(unsigned z, unsigned xp, unsigned vp, unsigned u, unsigned y, const PairEnv &E,
                                           unsigned &xn, unsigned &vn, unsigned &un, unsigned &yn, unsigned &nib)
 {
@@ -149,10 +162,10 @@ __device__ __forceinline__ void pair_cell(unsigned z, unsigned xp, unsigned vp, 
 	const unsigned zq = pk_sub_s(zz, E.Qp);
 	const unsigned a2 = pk_sub(a, zq), b2 = pk_sub(b, zq);
 	xn = pk_max0(a2); yn = pk_max0(b2);                                 // :277-280
-	// a2 > 0 <=> x' != 0 (then x' >= 0x100)
+	// a2 > 0 <=> x' != 0 (then x' >= 0x100): bit 1 = :265, bit 0 = :273, bit 2 = a2 > 0, bit 3 = b2 > 0
 	const unsigned c12 = pk_mad<2>(pk_shr<15>(s1), pk_shr<15>(s2));
-	const unsigned c34 = pk_add(pk_minc<2>(xn), pk_minc<1>(yn));
-	nib = pk_mad<4>(c12, c34);
+	const unsigned c34 = pk_add(pk_minc<4>(xn), pk_minc<8>(yn));
+	nib = pk_add(c12, c34);
 }
 
 // Close the traceback slot of diagonals ..r_last (band origin st): a full group when (r_last & 3) == 3.
@@ -162,7 +175,7 @@ __device__ __forceinline__ void pair_flush(PairState &S, const PairEnv &E, int r
 	unsigned *row = E.p + (size_t)((r_last >> 2) + (st >> 4)) * 80;
 	const unsigned sh = (unsigned)(4 * (3 - (r_last & 3))) * 0x00010001u;
 	row[lane] = pk_shl_s(S.accA, sh);
-	if (lane < 16) row[64 + lane] = pk_shl_s(S.accB, sh);
+	row[64 + lane] = pk_shl_s(S.accB, sh);              // (lanes 16..63 land in the next slot's first dwords, which its own store rewrites later)
 }
 
 // The exact maximum (:312-349) and ksw_apply_zdrop (:88-104) of alignment K on diagonal r, decided by lane compares where
@@ -174,8 +187,8 @@ __device__ __forceinline__ void pair_ez(PairState &S, const PairEnv &E, const in
 	const int INTMIN = -0x7fffffff - 1;
 	const int st = S.st, loA = st0 - st;
 	int &thr = K == 0 ? S.thr0 : S.thr1;
-	int &emt = K == 0 ? S.max_t0 : S.max_t1;
-	int &emq = K == 0 ? S.max_q0 : S.max_q1;
+	int &pos = K == 0 ? S.pos0 : S.pos1;
+	const int emt = pos_t(pos), emq = pos_q(pos);
 	const unsigned long long mA = pk_gt<K>(S.GA, thr) & inTA, mB = hasB ? pk_gt<K>(S.GB, thr) & mInB : 0ull;
 	if (mA | mB) {
 		int gmax, max_t;
@@ -189,7 +202,7 @@ __device__ __forceinline__ void pair_ez(PairState &S, const PairEnv &E, const in
 			if (hasB) { const int mb = wave_max_i32_keep(hBm); gmax = mb > gmax ? mb : gmax; }
 			max_t = narrow_max_t(hAm, hBm, gmax, hasB, mInB, loA, st, st0, en0);
 		}
-		thr = gmax; emt = max_t; emq = r - max_t;
+		thr = gmax; pos = pos_pack(r, max_t);
 		return;
 	}
 	int thz = thr - E.zd;
@@ -203,7 +216,8 @@ __device__ __forceinline__ void pair_ez(PairState &S, const PairEnv &E, const in
 	const int tl = t - emt, ql = dq - emq;
 	const int l = tl > ql ? tl - ql : ql - tl;
 	if (thr - gmax > E.zd + l * E.e) {                                  // z-drop: this alignment is done; its partner goes on
-		if (K == 0) { S.dead0 = 1; S.ez_max0 = thr - r * E.qe; } else { S.dead1 = 1; S.ez_max1 = thr - r * E.qe; }
+		if (K == 0) { S.inc0 = 0; S.fin0 = thr - r * E.qe; } else { S.inc1 = 0; S.fin1 = thr - r * E.qe; }
+		thr = 0x7fff - E.qe;                                                // (the caller adds q+e once more)
 	}
 }
 
@@ -216,7 +230,9 @@ __device__ __forceinline__ void pair_move(PairState &S, const PairEnv &E, const 
 	ex = (unsigned)__builtin_amdgcn_readlane((int)S.XA, 15);
 	ev = (unsigned)__builtin_amdgcn_readlane((int)S.VA, 15);
 	S.edge_g = __builtin_amdgcn_readlane((int)S.GA, 15);
-	const unsigned zB = S.rlB < 0 ? E.ZWp : pair_z(S.TB0, S.TB1, E.qs[E.qlen - 1 - S.rlB + S.st + 64 + (lane & 15)]);
+	// (the selector is read whether or not it is needed: a load behind a per-lane test is a divergent branch)
+	const unsigned zBf = pair_z(S.TB0, S.TB1, E.qs[E.qlen - 1 - (S.rlB < 0 ? 0 : S.rlB) + S.st + 64 + (lane & 15)]);
+	const unsigned zB = S.rlB < 0 ? E.ZWp : zBf;
 	S.XA = rot16(S.XA, S.XB, lane); S.VA = rot16(S.VA, S.VB, lane);
 	S.UA = rot16(S.UA, S.UB, lane); S.YA = rot16(S.YA, S.YB, lane);
 	S.ZA = rot16(S.ZA, zB, lane);
@@ -257,11 +273,12 @@ __device__ __forceinline__ void pair_diag(PairState &S, const PairEnv &E, const 
 		const int geB = __builtin_amdgcn_readlane((int)S.GA, 63);
 		const unsigned xpB = (unsigned)set_lane0((int)exB, 0, dppz_shr1((int)S.XB)), vpB = (unsigned)set_lane0((int)evB, 0, dppz_shr1((int)S.VB));
 		const unsigned GpB = (unsigned)set_lane0(geB, 0, dppz_shr1((int)S.GB));
-		const unsigned zB = S.rlB < 0 ? E.ZWp : pair_z(S.TB0, S.TB1, E.qs[E.qlen - 1 - S.rlB + st + 64 + (lane & 15)]);
+		const unsigned zBf = pair_z(S.TB0, S.TB1, E.qs[E.qlen - 1 - (S.rlB < 0 ? 0 : S.rlB) + st + 64 + (lane & 15)]);
+		const unsigned zB = S.rlB < 0 ? E.ZWp : zBf;
 		mInB = lane_range(0, hiT - 64 < 15 ? hiT - 64 : 15);
-		if (lane < 16) {
+		{   // (all 64 lanes; lanes 16..63 of the slot-B registers are never read)
 			unsigned ut = S.UB, yt = S.YB;
-			if (st + 64 + lane == r) { yt = 0; ut = r ? E.Qp : 0u; }     // :212
+			{ const bool tr = st + 64 + lane == r; yt = tr ? 0u : yt; ut = tr ? (r ? E.Qp : 0u) : ut; }   // :212
 			unsigned xn, vn, un, yn, nib;
 			pair_cell(zB, xpB, vpB, ut, yt, E, xn, vn, un, yn, nib);
 			S.XB = xn; S.VB = vn; S.UB = un; S.YB = yn;
@@ -294,37 +311,524 @@ __device__ __forceinline__ void pair_diag(PairState &S, const PairEnv &E, const 
 	if (r - st0 == E.qlen - 1) {
 		const int g = __builtin_amdgcn_readlane((int)S.GA, loA);
 		const int h0 = pk_half<0>(g) - r * E.qe, h1 = pk_half<1>(g) - r * E.qe;
-		if (!S.dead0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st0; }
-		if (!S.dead1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st0; }
+		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st0; }
+		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st0; }
 	}
-	if (!S.dead0) { pair_ez<0>(S, E, r, st0, en0, hasB, inTA, mInB); S.thr0 += E.qe; }
-	if (!S.dead1) { pair_ez<1>(S, E, r, st0, en0, hasB, inTA, mInB); S.thr1 += E.qe; }
+	if (S.inc0) { pair_ez<0>(S, E, r, st0, en0, hasB, inTA, mInB); S.thr0 += E.qe; }
+	if (S.inc1) { pair_ez<1>(S, E, r, st0, en0, hasB, inTA, mInB); S.thr1 += E.qe; }
 }
 
-// Two jobs with the same qlen and parameters, both ksw_pair_job_ok().  Returns false when a sequence holds a code the
-// pair sweep does not take (a wildcard or worse in a query, anything above the wildcard in a target): nothing useful in
-// the outputs then -- the plan kernel only pairs jobs whose producer vouches for the codes.  Otherwise both results
-// are final (fields and CIGAR of out0 first: cig_tmp is used twice, `emit(k, out)` is called behind each traceback).
-template <class Emit>
-__device__ inline bool ksw_wave_pair(const uint8_t *q0, const uint8_t *t0, int tlen0, const uint8_t *q1, const uint8_t *t1, int tlen1, int qlen,
-                                     const KswParams P, uint8_t *lds, uint8_t *p, uint32_t *cig_tmp, int cig_cap, Emit emit, long long *pacc = nullptr)
+// Tell the compiler again that the wave-uniform part of the state is uniform.  pair_diag has divergent branches (slot B's
+// sixteen lanes, a lazily formed score behind a per-lane test); behind a loop over it the compiler's uniformity analysis
+// gives up on the loop's exit and with it on every scalar that leaves the loop -- they would live in vector registers,
+// and every branch on them would be an exec-mask branch.
+__device__ __forceinline__ void pair_uniform(PairState &S)
+{
+	S.st = uni(S.st); S.edge_g = uni(S.edge_g); S.thr0 = uni(S.thr0); S.thr1 = uni(S.thr1); S.pos0 = uni(S.pos0); S.pos1 = uni(S.pos1);
+	S.mqe0 = uni(S.mqe0); S.mqe1 = uni(S.mqe1); S.mqe_t0 = uni(S.mqe_t0); S.mqe_t1 = uni(S.mqe_t1);
+	S.inc0 = uni(S.inc0); S.inc1 = uni(S.inc1); S.fin0 = uni(S.fin0); S.fin1 = uni(S.fin1);
+}
+
+// ---------------------------------------------------------------- the steady diagonals, laid out as ksw_narrow.h's
+// What the lean loops carry from diagonal to diagonal besides PairState (wave-uniform).
+struct PairCtl {
+	int r, st0, en0;                                     // the coming diagonal and its true band
+	int lim;                                             // the run's end; pulled below r once both alignments have z-dropped
+	unsigned long long geLoM, spM, hiM;                  // lanes >= st0 - st; the lane of en0 (slot A); lanes <= en0 - st
+	int zsafe0, zsafe1;                                  // the last diagonal on which the cell of the running maximum alone rules a z-drop out
+};
+
+// The exact maximum (:312-349) and ksw_apply_zdrop (:88-104) of alignment K on a diagonal of the lean loops, and the step of
+// its threshold to the next diagonal.  As pair_ez, with two differences that keep the scalar unit's share small (the kernel
+// is bound by SALU issue as much as by VALU issue: tools/r4 profiles):
+//  * a finished alignment needs no test of its own: its threshold stands at 32767, where no G reaches, its `inc` is 0 and
+//    its zsafe is INT_MAX;
+//  * a z-drop is ruled out without looking while the cell t* of the running maximum vouches for it.  t* held G = thr when
+//    it was found; while it stays inside the band below the top cell its G cannot fall (H[t] changes by v8 - (q+e), v8
+//    unsigned, :323-329), and the z-drop threshold is thr + (r - r*) (q+e) - zdrop: for (r - r*) <= zq = zdrop / (q+e)
+//    diagonals -- and while t* is in the band: r <= 2 t* + w and r <= t* + qlen - 1 -- that cell alone keeps max_H within
+//    zdrop of ez.max and :98 cannot hold.  (Not when t* was the top cell en0: H[en0] is formed anew from H[en0-1] + u8 on
+//    every diagonal, :318.)
+// inTA / mInB: the lanes of the true band in slot A / B; topA: the lane of en0 when it is in slot A, else 0.
+template <int K, bool HASB>
+__device__ __forceinline__ void pair_ez_lean(PairState &S, const PairEnv &E, PairCtl &C, const int r, const unsigned long long inTA, const unsigned long long mInB,
+                                             const unsigned long long topA, const int zq)
+{
+	const int INTMIN = -0x7fffffff - 1;
+	const int st = S.st;
+	int &thr = K == 0 ? S.thr0 : S.thr1;
+	int &pos = K == 0 ? S.pos0 : S.pos1;
+	int &zsafe = K == 0 ? C.zsafe0 : C.zsafe1;
+	const int inc = K == 0 ? S.inc0 : S.inc1;
+	const unsigned long long mA = pk_gt<K>(S.GA, thr) & inTA, mB = HASB ? pk_gt<K>(S.GB, thr) & mInB : 0ull;
+	if (mA | mB) {
+		int gmax, max_t; bool top;
+		if (!HASB ? !(mA & (mA - 1)) : popc64(mA) + popc64(mB) == 1) {
+			if (!HASB || mA) {
+				const int i = ctz64(mA);
+				gmax = pk_half<K>(__builtin_amdgcn_readlane((int)S.GA, i)); max_t = st + i; top = (mA & topA) != 0;
+			} else {
+				const int i = ctz64(mB);
+				gmax = pk_half<K>(__builtin_amdgcn_readlane((int)S.GB, i)); max_t = st + 64 + i; top = max_t == C.en0;
+			}
+		} else {
+			const int st0 = C.st0, en0 = C.en0;
+			const int hAm = lane_in(inTA) ? pk_half<K>((int)S.GA) : INTMIN, hBm = (HASB && lane_in(mInB)) ? pk_half<K>((int)S.GB) : INTMIN;
+			gmax = wave_max_i32_keep(hAm);
+			if (HASB) { const int mb = wave_max_i32_keep(hBm); gmax = mb > gmax ? mb : gmax; }
+			max_t = narrow_max_t(hAm, hBm, gmax, HASB, mInB, st0 - st, st, st0, en0);
+			top = max_t == en0;
+		}
+		pos = pos_pack(r, max_t);
+		int zs = r + zq;
+		const int b1 = 2 * max_t + E.w, b2 = max_t + E.qlen - 1;
+		zs = zs < b1 ? zs : b1; zs = zs < b2 ? zs : b2;
+		zsafe = uni(top ? r : zs);                                           // (or the compiler forms the minimum on the vector unit and keeps zsafe there)
+		thr = uni(gmax + inc); pos = uni(pos);
+		return;
+	}
+	if (r <= zsafe) { thr += inc; return; }
+	{
+		const int st0 = C.st0, en0 = C.en0;
+		int thz = thr - E.zd;
+		thz = thz < -32768 ? -32768 : thz;
+		if (!((pk_ge<K>(S.GA, thz) & inTA) | (HASB ? pk_ge<K>(S.GB, thz) & mInB : 0ull))) {   // else ez.max - max_H <= zdrop: :98 cannot hold
+			const int hAm = lane_in(inTA) ? pk_half<K>((int)S.GA) : INTMIN, hBm = (HASB && lane_in(mInB)) ? pk_half<K>((int)S.GB) : INTMIN;
+			int gmax = wave_max_i32_keep(hAm);
+			if (HASB) { const int mb = wave_max_i32_keep(hBm); gmax = mb > gmax ? mb : gmax; }
+			const int t = narrow_max_t(hAm, hBm, gmax, HASB, mInB, st0 - st, st, st0, en0), dq = r - t;
+			const int emt = pos_t(pos), emq = pos_q(pos);
+			if (t >= emt && dq >= emq) {
+				const int tl = t - emt, ql = dq - emq;
+				const int l = tl > ql ? tl - ql : ql - tl;
+				if (thr - gmax > E.zd + l * E.e) {                          // z-drop: this alignment is done; its partner goes on
+					const int fin = thr - r * E.qe;
+					thr = 0x7fff; zsafe = 0x7fffffff;
+					if (K == 0) { S.inc0 = 0; S.fin0 = fin; } else { S.inc1 = 0; S.fin1 = fin; }
+					if (!(S.inc0 | S.inc1)) C.lim = INTMIN;
+					return;
+				}
+			}
+		}
+	}
+	thr += inc;
+}
+
+// pair_ez_lean's everyday cases for a diagonal without block 4, on the scalar unit by hand: no lane of alignment K above its
+// threshold and the cell of the running maximum still vouching against a z-drop (seven instructions), or exactly one lane
+// above it (the new maximum: twenty).  Returns 0 when that was all; 1: several lanes improve, 2: the vouching has run out --
+// pair_ez_rest does those, nothing has been changed then.  Written as one asm statement because the compiler kept max_t /
+// max_q in spill lanes of a vector register (v_writelane / v_readlane around every new maximum) and formed the minimum of
+// three scalars on the vector unit; everything here stays in the SGPRs the operands name.
+#define IHP_PAIR_EZ_ASM(WORD, SEXT)                                                                                    \
+	asm("v_cmp_gt_i16_sdwa %[m], %[G], %[thr] src0_sel:" WORD " src1_sel:WORD_0\n\t"                               \
+	    "s_mov_b32 %[stat], 0\n\t"                                                                                 \
+	    "s_and_b64 %[m], %[m], %[inT]\n\t"                                                                         \
+	    "s_cbranch_scc1 1f\n\t"                                                                                    \
+	    "s_cmp_le_i32 %[r], %[zs]\n\t"                                                                             \
+	    "s_cbranch_scc1 2f\n\t"                                                                                    \
+	    "s_mov_b32 %[stat], 2\n\t"                                                                                 \
+	    "s_branch 9f\n"                                                                                            \
+	    "2:\n\t"                                                                                                   \
+	    "s_add_i32 %[thr], %[thr], %[inc]\n\t"                                                                     \
+	    "s_branch 9f\n"                                                                                            \
+	    "1:\n\t"                                                                                                   \
+	    "s_bcnt1_i32_b64 %[i], %[m]\n\t"                                                                           \
+	    "s_cmp_lg_u32 %[i], 1\n\t"                                                                                 \
+	    "s_cbranch_scc0 3f\n\t"                                                                                    \
+	    "s_mov_b32 %[stat], 1\n\t"                                                                                 \
+	    "s_branch 9f\n"                                                                                            \
+	    "3:\n\t"                                                                                                   \
+	    "s_ff1_i32_b64 %[i], %[m]\n\t"                                                                             \
+	    "v_readlane_b32 %[g], %[G], %[i]\n\t"                                                                      \
+	    "s_add_i32 %[i], %[i], %[st]\n\t"                                                                          \
+	    "s_add_i32 %[zs], %[r], %[zq]\n\t"                                                                         \
+	    "s_lshl1_add_u32 %[b], %[i], %[w]\n\t"                                                                     \
+	    "s_min_i32 %[zs], %[zs], %[b]\n\t"                                                                         \
+	    "s_add_i32 %[b], %[i], %[qlm1]\n\t"                                                                        \
+	    "s_min_i32 %[zs], %[zs], %[b]\n\t"                                                                         \
+	    "s_pack_ll_b32_b16 %[pos], %[i], %[r]\n\t"                                                                 \
+	    SEXT "\n\t"                                                                                                \
+	    "s_and_b64 %[m], %[m], %[sp]\n\t"                                                                          \
+	    "s_cselect_b32 %[zs], %[r], %[zs]\n\t"                                                                     \
+	    "s_add_i32 %[thr], %[g], %[inc]\n"                                                                         \
+	    "9:"                                                                                                       \
+	    : [m] "=&s"(m), [stat] "=&s"(stat), [i] "=&s"(i), [g] "=&s"(g), [b] "=&s"(b), [thr] "+s"(thr), [pos] "+s"(pos), [zs] "+s"(zsafe) \
+	    : [G] "v"(G), [inT] "s"(inT), [sp] "s"(spM), [r] "s"(r), [st] "s"(st), [zq] "s"(zq), [w] "s"(w), [qlm1] "s"(qlm1), [inc] "s"(inc) \
+	    : "scc")
+template <int K>
+__device__ __forceinline__ int pair_ez_asm(const unsigned G, int &thr, int &pos, int &zsafe, const unsigned long long inT_, const unsigned long long spM_,
+                                           const int r_, const int st_, const int zq_, const int w_, const int qlm1_, const int inc_)
+{
+	const unsigned long long inT = (unsigned long long)uni((long long)inT_), spM = (unsigned long long)uni((long long)spM_);
+	const int r = uni(r_), st = uni(st_), zq = uni(zq_), w = uni(w_), qlm1 = uni(qlm1_), inc = uni(inc_);
+	unsigned long long m; int stat, i, g, b;
+	if (K == 0) IHP_PAIR_EZ_ASM("WORD_0", "s_sext_i32_i16 %[g], %[g]");
+	else IHP_PAIR_EZ_ASM("WORD_1", "s_ashr_i32 %[g], %[g], 16");
+	return stat;
+}
+#undef IHP_PAIR_EZ_ASM
+
+// One steady diagonal of both alignments and the step to the next (narrow_steady_step of ksw_narrow.h on packed halves).
+// HASB = block 4 is computed (hiT >= 64); EDGE = 1: the band origin moved on this diagonal and lane 0 takes the block edge
+// ex, ev (:207-208); EDGE = 2: a diagonal 1 <= r <= w+30 -- the band still starts in block 0 (lane 0 takes x1 = 0, v1 = q,
+// :211), grows from the single cell t = r, computes blocks 0 .. en0/16 only and, while r <= en, holds the boundary cell
+// t = r (:212).  PAR = parity of r + w when the caller knows it (0: st0 grows on the step to r+1, 1: en0 does), -1 otherwise.
+// FLUSH: 0 = r & 3 is known not to be 3 (no traceback store on this diagonal), 1 = it is 3 when r & 2, -1 = look.
+template <bool HASB, int EDGE, int PAR, int FLUSH>
+__device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E, PairCtl &C, const int zq, const unsigned ex = 0, const unsigned ev = 0)
+{
+	const int lane = lane_id();
+	const int st = S.st, r = C.r;
+	if (PAR < 0) {
+		C.geLoM = ~0ull << (C.st0 - st);
+		C.spM = HASB ? 0ull : 1ull << (C.en0 - st); C.hiM = HASB ? ~0ull : C.spM | (C.spM - 1);
+	}
+	unsigned xpA = (unsigned)dppz_shr1((int)S.XA), vpA = (unsigned)dppz_shr1((int)S.VA);    // neighbours of r-1
+	if (EDGE == 1) { xpA = (unsigned)set_lane0((int)ex, 0, (int)xpA); vpA = (unsigned)set_lane0((int)ev, 0, (int)vpA); }
+	if (EDGE == 2) vpA = (unsigned)set_lane0((int)E.Qp, 0, (int)vpA);
+	const int en = C.en0 | 15;                           // EDGE == 2: last computed cell; t = r is computed while r <= en
+	const unsigned GpA = (unsigned)dppz_shr1((int)S.GA);                                   // en0 is never on lane 0 here
+	const unsigned long long geLoM = C.geLoM;
+	unsigned long long mInB = 0;
+	// ---- slot B (block 4) ------------------------------------------------------------
+	if (HASB) {
+		const unsigned exB = (unsigned)__builtin_amdgcn_readlane((int)S.XA, 63), evB = (unsigned)__builtin_amdgcn_readlane((int)S.VA, 63);
+		const int geB = __builtin_amdgcn_readlane((int)S.GA, 63);
+		const unsigned xpB = (unsigned)set_lane0((int)exB, 0, dppz_shr1((int)S.XB)), vpB = (unsigned)set_lane0((int)evB, 0, dppz_shr1((int)S.VB));
+		const unsigned GpB = (unsigned)set_lane0(geB, 0, dppz_shr1((int)S.GB));
+		const unsigned zf = pair_z(S.TB0, S.TB1, S.qptr[S.qoffB]);       // qs[qlen-1-r+st+64+lane]
+		const unsigned zB = lane_in(~geLoM) ? zf : E.ZWp;                  // refreshed up to lane loA + 63: lanes 0..loA-1 here
+		const int hiB = C.en0 - st - 64;
+		mInB = lane_range(0, hiB < 15 ? hiB : 15);
+		{   // (all 64 lanes: a wave instruction costs the same with 16 lanes active, and a divergent branch here costs the loop
+			// its scalar control; lanes 16..63 of the slot-B registers are never read)
+			unsigned ut = S.UB, yt = S.YB;
+			if (EDGE == 2) { const bool tr = 64 + lane == r; yt = tr ? 0u : yt; ut = tr ? E.Qp : ut; }   // :212
+			unsigned xn, vn, un, yn, nib;
+			pair_cell(zB, xpB, vpB, ut, yt, E, xn, vn, un, yn, nib);
+			S.XB = xn; S.VB = vn; S.UB = un; S.YB = yn;
+			S.accB = pk_mad<16>(S.accB, nib);                              // :283
+			const bool sp = lane == hiB;
+			S.GB = pk_add(sp ? GpB : S.GB, pk_shr<8>(sp ? un : vn));       // :318, :323-329
+		}
+	}
+	// ---- slot A (blocks 0..3) --------------------------------------------------------
+	// (EDGE == 2 commits under a lane mask instead of branching around the cell: a divergent branch in the loop body made
+	// the compiler treat the loop's whole control as divergent and keep every scalar of it in vector registers)
+	S.qptr -= 1;
+	{
+		const unsigned long long actM = EDGE == 2 ? ~0ull >> (63 - (en < 63 ? en : 63)) : ~0ull;
+		const unsigned znew = pair_z(S.TA0, S.TA1, S.qptr[1]);          // qs[qlen-1-r+st+lane]
+		S.ZA = lane_in(geLoM & actM) ? znew : S.ZA;                        // :214-228: refreshed from st0 to st0 + 63 (or to en)
+		if (EDGE == 2 && r <= en && r < 64) {                             // :212
+			const bool tr = lane_in(1ull << r);
+			S.YA = tr ? 0u : S.YA; S.UA = tr ? E.Qp : S.UA;
+		}
+		unsigned xn, vn, un, yn, nib;
+		pair_cell(S.ZA, xpA, vpA, S.UA, S.YA, E, xn, vn, un, yn, nib);
+		if (EDGE == 2) {
+			const bool act = lane_in(actM);
+			S.XA = act ? xn : S.XA; S.VA = act ? vn : S.VA; S.UA = act ? un : S.UA; S.YA = act ? yn : S.YA;
+		} else { S.XA = xn; S.VA = vn; S.UA = un; S.YA = yn; }
+		S.accA = pk_mad<16>(S.accA, nib);                                  // :283
+		if (!HASB) {
+			const bool sp = lane_in(C.spM);
+			S.GA = pk_add(sp ? GpA : S.GA, pk_shr<8>(sp ? un : vn));       // :318, :323-329
+		} else S.GA = pk_add(S.GA, pk_shr<8>(vn));                         // en0 is in block 4
+	}
+	if (FLUSH < 0 ? (r & 3) == 3 : FLUSH > 0 && (r & 2)) {                // pair_flush of a full group
+		unsigned *row = E.p + (size_t)((r >> 2) + (st >> 4)) * 80;
+		row[lane] = S.accA;
+		row[64 + lane] = S.accB;                        // (lanes 16..63 land in the next slot's first dwords, which its own store rewrites later)
+	}
+	// ---- exact max (:312-349) and ksw_apply_zdrop (:88-104) ----------------------------
+	const unsigned long long inTA = geLoM & C.hiM;
+	if (HASB) {
+		pair_ez_lean<0, true>(S, E, C, r, inTA, mInB, C.spM, zq);
+		pair_ez_lean<1, true>(S, E, C, r, inTA, mInB, C.spM, zq);
+	} else {
+		if (pair_ez_asm<0>(S.GA, S.thr0, S.pos0, C.zsafe0, inTA, C.spM, r, st, zq, E.w, E.qlm1, S.inc0)) pair_ez_lean<0, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+		if (pair_ez_asm<1>(S.GA, S.thr1, S.pos1, C.zsafe1, inTA, C.spM, r, st, zq, E.w, E.qlm1, S.inc1)) pair_ez_lean<1, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+	}
+	// ---- the step to r + 1: (r+w)>>1 grows from an odd r+w, (r-w+1)>>1 otherwise ----
+	if (EDGE == 2) {
+		const int s1 = (r + 2 - E.w) >> 1, e1 = (r + 1 + E.w) >> 1;
+		C.st0 = s1 > 0 ? s1 : 0; C.en0 = e1 < r + 1 ? e1 : r + 1;
+	} else if (PAR == 0) { C.st0 += 1; C.geLoM <<= 1; }
+	else if (PAR == 1) { C.en0 += 1; C.spM <<= 1; C.hiM = (C.hiM << 1) | 1ull; }
+	else { const int up = (r + E.w) & 1; C.en0 += up; C.st0 += 1 - up; }
+	C.r = r + 1;
+}
+
+// The diagonals C.r .. bound-1, all with or all without block 4: single steps until r + w is even, then pairs.  With an even
+// w the first diagonal of a pair is an even one: only the second can close a group of four (FLUSH).
+template <bool HASB>
+__device__ __forceinline__ void pair_steady_run(PairState &S, const PairEnv &E, PairCtl &C, const int zq, const int bound)
+{
+	C.lim = (S.inc0 | S.inc1) ? bound : -0x7fffffff - 1;
+	if (C.r < C.lim && ((C.r + E.w) & 1)) pair_steady_step<HASB, 0, -1, -1>(S, E, C, zq);
+	C.geLoM = ~0ull << (C.st0 - S.st);
+	C.spM = HASB ? 0ull : 1ull << ((C.en0 - S.st) & 63); C.hiM = HASB ? ~0ull : C.spM | (C.spM - 1);
+	if (!(E.w & 1)) {
+		while (C.r + 1 < C.lim) {
+			pair_steady_step<HASB, 0, 0, 0>(S, E, C, zq);
+			pair_steady_step<HASB, 0, 1, 1>(S, E, C, zq);
+		}
+	} else {
+		while (C.r + 1 < C.lim) {
+			pair_steady_step<HASB, 0, 0, -1>(S, E, C, zq);
+			pair_steady_step<HASB, 0, 1, -1>(S, E, C, zq);
+		}
+	}
+	if (C.r < C.lim) pair_steady_step<HASB, 0, -1, -1>(S, E, C, zq);
+}
+
+// The early and steady diagonals r .. r_hi-1 (see narrow_steady_loop): on return r is the next diagonal (or, when both
+// alignments have z-dropped, one behind the last computed).
+__device__ __forceinline__ void pair_steady_loop(PairState &S, const PairEnv &E, int &r, const int r_hi)
+{
+	const int lane = lane_id();
+	const int w = E.w;
+	const int zq = uni(E.zd >= 0x3fffffff ? 0x3fffffff : E.zd / E.qe);   // (the division runs on the vector unit)
+	PairCtl C;
+	C.r = r; C.st0 = (r - w + 1) >> 1; C.en0 = (r + w) >> 1;
+	C.geLoM = C.spM = C.hiM = 0; C.lim = r_hi;
+	C.zsafe0 = S.inc0 ? -1 : 0x7fffffff; C.zsafe1 = S.inc1 ? -1 : 0x7fffffff;
+	if (r < w + 31) {                                    // the band grows from one cell (EDGE = 2)
+		C.st0 = C.st0 > 0 ? C.st0 : 0; C.en0 = C.en0 < r ? C.en0 : r;
+		C.lim = r_hi < w + 31 ? r_hi : w + 31;
+		while (uni(C.r) < uni(C.lim)) {
+			if (uni(C.en0) < 64) pair_steady_step<false, 2, -1, -1>(S, E, C, zq);
+			else pair_steady_step<true, 2, -1, -1>(S, E, C, zq);
+		}
+		C.r = uni(C.r); C.st0 = uni(C.st0); C.en0 = uni(C.en0); C.zsafe0 = uni(C.zsafe0); C.zsafe1 = uni(C.zsafe1);
+		pair_uniform(S);
+	}
+	while (C.r < r_hi && (S.inc0 | S.inc1)) {
+		C.lim = r_hi;
+		const bool moved = (C.st0 & ~15) != S.st;
+		unsigned ex = 0, ev = 0;
+		if (moved) {
+			// the band origin moved one block right: close the traceback slot, rotate the registers 16 lanes, re-seed slot B
+			if (C.r & 3) pair_flush(S, E, C.r - 1, S.st);
+			ex = (unsigned)__builtin_amdgcn_readlane((int)S.XA, 15); ev = (unsigned)__builtin_amdgcn_readlane((int)S.VA, 15);
+			S.edge_g = __builtin_amdgcn_readlane((int)S.GA, 15);
+			const unsigned zf = pair_z(S.TB0, S.TB1, S.qptr[S.qoffB + 1]);  // qs[qlen-r+st+64+lane]: scores of diagonal r-1
+			const unsigned zB = lane_in(0x7fffull) ? zf : E.ZWp;            // st0 was 16k+15, so last_sc = 78
+			S.XA = rot16(S.XA, S.XB, lane); S.VA = rot16(S.VA, S.VB, lane);
+			S.UA = rot16(S.UA, S.UB, lane); S.YA = rot16(S.YA, S.YB, lane);
+			S.ZA = rot16(S.ZA, zB, lane);
+			S.GA = rot16(S.GA, S.GB, lane);
+			S.st = C.st0 & ~15;
+			S.qptr += 16;
+			S.XB = S.VB = S.UB = S.YB = 0; S.GB = 0;
+			S.TA0 = pair_table(E, E.tg0[S.st + lane]); S.TA1 = pair_table(E, E.tg1[S.st + lane]);
+			S.TB0 = pair_table(E, E.tg0[S.st + 64 + (lane & 15)]); S.TB1 = pair_table(E, E.tg1[S.st + 64 + (lane & 15)]);
+		}
+		int r_end = 2 * (S.st + 16) + w - 1;             // the next move
+		r_end = r_end < r_hi ? r_end : r_hi;
+		int r_b = 2 * (S.st + 64) - w;                   // block 4 from here on
+		r_b = r_b > C.r ? r_b : C.r; r_b = r_b < r_end ? r_b : r_end;
+		if (moved) {                                     // the diagonal of the move: lane 0 takes the block edge
+			if (C.r < r_b) pair_steady_step<false, 1, -1, -1>(S, E, C, zq, ex, ev);
+			else pair_steady_step<true, 1, -1, -1>(S, E, C, zq, ex, ev);
+		}
+		pair_steady_run<false>(S, E, C, zq, r_b);
+		pair_steady_run<true>(S, E, C, zq, r_end);
+	}
+	r = C.r;
+	// what these diagonals did not track: a slot-B lane was refreshed on the last one (st0 - st + 63 of diagonal r-1) or never
+	S.rlB = lane <= ((r - w) >> 1) - S.st + 63 - 64 ? r - 1 : -1;
+}
+
+// ---------------------------------------------------------------- the tail: the band cut by the end of the query
+// One diagonal behind the steady ones, once the band is narrower than 48 cells (narrow_tail_step of ksw_narrow.h on packed
+// halves): st0 = r - qlen + 1 grows on every diagonal (the window never cuts the band of a pair), the band shrinks, never
+// reaches block 4 (hiT <= 62) and refreshes no score past lane 62, so slot B only waits for the next move; only the computed
+// lanes (blocks 0 .. (en0|15)-st) are committed.  H[st0] is the end-of-query result of every diagonal (:353-354).
+// C.lim is pulled below r when the band leaves the matrix (:200-203) or both alignments have z-dropped.
+template <bool EDGE>
+__device__ __forceinline__ void pair_tail_step(PairState &S, const PairEnv &E, PairCtl &C, const int zq, const unsigned ex = 0, const unsigned ev = 0)
+{
+	const int INTMIN = -0x7fffffff - 1;
+	const int st = S.st, r = C.r, st0 = C.st0, en0 = C.en0;
+	const int loA = st0 - st, hiT = en0 - st;
+	const int sc = loA + (((en0 - st0) >> 4) + 1) * 16 - 1;      // last refreshed score lane (:215): <= 62
+	const int nTop = (en0 | 15) - st;                    // last computed lane: 15, 31, 47 or 63
+	unsigned xpA = (unsigned)dppz_shr1((int)S.XA), vpA = (unsigned)dppz_shr1((int)S.VA), GpA = (unsigned)dppz_shr1((int)S.GA);   // neighbours of r-1
+	if (EDGE) { xpA = (unsigned)set_lane0((int)ex, 0, (int)xpA); vpA = (unsigned)set_lane0((int)ev, 0, (int)vpA); }
+	if (hiT == 0) GpA = (unsigned)set_lane0(S.edge_g, 0, (int)GpA);      // en0 on lane 0: H[en0-1] is the block edge
+	const unsigned long long inTM = lane_span(loA, hiT);
+	S.qptr -= 1;
+	{
+		const unsigned znew = pair_z(S.TA0, S.TA1, S.qptr[1]);          // qs[qlen-1-r+st+lane]
+		S.ZA = lane_in(lane_span(loA, sc)) ? znew : S.ZA;                  // :214-228 (the 16-byte stores run past en)
+	}
+	{
+		unsigned xn, vn, un, yn, nib;
+		pair_cell(S.ZA, xpA, vpA, S.UA, S.YA, E, xn, vn, un, yn, nib);
+		const bool act = lane_in(lane_span(0, nTop));
+		S.XA = act ? xn : S.XA; S.VA = act ? vn : S.VA; S.UA = act ? un : S.UA; S.YA = act ? yn : S.YA;
+		S.accA = pk_mad<16>(S.accA, nib);                                  // :283
+		const bool sp = lane_in(1ull << hiT);
+		S.GA = pk_add(sp ? GpA : S.GA, pk_shr<8>(sp ? un : vn));           // :318, :323-329
+	}
+	if ((r & 3) == 3) pair_flush(S, E, r, st);
+	{                                                                    // :353-354 (r - st0 == qlen - 1 on every diagonal here)
+		const int g = __builtin_amdgcn_readlane((int)S.GA, loA);
+		const int h0 = pk_half<0>(g) - r * E.qe, h1 = pk_half<1>(g) - r * E.qe;
+		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st0; }
+		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st0; }
+	}
+	if (pair_ez_asm<0>(S.GA, S.thr0, S.pos0, C.zsafe0, inTM, 1ull << hiT, r, st, zq, E.w, E.qlm1, S.inc0)) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, 1ull << hiT, zq);
+	if (pair_ez_asm<1>(S.GA, S.thr1, S.pos1, C.zsafe1, inTM, 1ull << hiT, r, st, zq, E.w, E.qlm1, S.inc1)) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, 1ull << hiT, zq);
+	// ---- the band of r + 1 (:196-205) ----
+	{
+		const int a = r + 2 - E.qlen, b = (r + 2 - E.w) >> 1;
+		C.st0 = a > b ? a : b; C.en0 = (r + 1 + E.w) >> 1; C.r = r + 1;
+		if (C.st0 > C.en0) C.lim = INTMIN;                                 // :200-203
+	}
+}
+
+// A run of tail diagonals C.r .. C.lim-1 within which the band origin, the number of computed blocks and the number of
+// refreshed 16-byte score groups do not change (narrow_tail_qrun): every lane set moves by a bit or two per diagonal.
+// FULL: blocks 0..3 are all computed (nothing to hold back).  The caller has done the diagonal of a move.
+template <bool FULL>
+__device__ __forceinline__ void pair_tail_qrun(PairState &S, const PairEnv &E, PairCtl &C, const int zq)
+{
+	const int st = S.st;
+	int loA = C.st0 - st, hiT = C.en0 - st;
+	int sc = loA + (((hiT - loA) >> 4) + 1) * 16 - 1;    // last refreshed score lane (:215): <= 62
+	const int nTop = (C.en0 | 15) - st;                  // last computed lane
+	unsigned long long inTM = lane_span(loA, hiT), refM = lane_span(loA, sc), spM = 1ull << hiT;
+	const unsigned long long actM = ~0ull >> (63 - nTop);
+	do {
+		const int r = C.r;
+		const unsigned xpA = (unsigned)dppz_shr1((int)S.XA), vpA = (unsigned)dppz_shr1((int)S.VA), GpA = (unsigned)dppz_shr1((int)S.GA);   // (no move: edge 0, :210)
+		S.qptr -= 1;
+		{
+			const unsigned znew = pair_z(S.TA0, S.TA1, S.qptr[1]);      // qs[qlen-1-r+st+lane]
+			S.ZA = lane_in(refM) ? znew : S.ZA;                            // :214-228
+		}
+		{
+			unsigned xn, vn, un, yn, nib;
+			pair_cell(S.ZA, xpA, vpA, S.UA, S.YA, E, xn, vn, un, yn, nib);
+			if (FULL) { S.XA = xn; S.VA = vn; S.UA = un; S.YA = yn; }
+			else { const bool act = lane_in(actM); S.XA = act ? xn : S.XA; S.VA = act ? vn : S.VA; S.UA = act ? un : S.UA; S.YA = act ? yn : S.YA; }
+			S.accA = pk_mad<16>(S.accA, nib);                              // :283
+			const bool sp = lane_in(spM);
+			S.GA = pk_add(sp ? GpA : S.GA, pk_shr<8>(sp ? un : vn));       // :318, :323-329
+		}
+		if ((r & 3) == 3) pair_flush(S, E, r, st);
+		{                                                                // :353-354
+			const int g = __builtin_amdgcn_readlane((int)S.GA, loA);
+			const int h0 = pk_half<0>(g) - r * E.qe, h1 = pk_half<1>(g) - r * E.qe;
+			if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st + loA; }
+			if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st + loA; }
+		}
+		if (pair_ez_asm<0>(S.GA, S.thr0, S.pos0, C.zsafe0, inTM, spM, r, st, zq, E.w, E.qlm1, S.inc0)) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, spM, zq);
+		if (pair_ez_asm<1>(S.GA, S.thr1, S.pos1, C.zsafe1, inTM, spM, r, st, zq, E.w, E.qlm1, S.inc1)) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, spM, zq);
+		// ---- the band of r + 1: st0 + 1, en0 + 1 from an odd r + w ----
+		const int p = (r + E.w) & 1;
+		inTM = bit_clear(inTM, loA); refM = bit_clear(refM, loA);
+		loA += 1; sc += 1; refM = bit_set(refM, sc);
+		hiT += p; spM <<= p; inTM |= spM;
+		C.r = r + 1; C.st0 = st + loA; C.en0 = st + hiT;
+	} while (C.r < C.lim);
+}
+
+// The diagonals behind the steady ones, r .. r_end-1 (r_end: the first diagonal without a cell).  While the band is still 48
+// or more cells wide (a handful of diagonals) the general pair_diag does them; from then on pair_tail_step / pair_tail_qrun,
+// run by run between two moves of the band origin.  On return r is one behind the last diagonal computed.
+__device__ __forceinline__ void pair_tail_loop(PairState &S, const PairEnv &E, int &r, const int r_end)
+{
+	const int INTMIN = -0x7fffffff - 1;
+	const int qlen = E.qlen, w = E.w;
+	const int zq = uni(E.zd >= 0x3fffffff ? 0x3fffffff : E.zd / E.qe);   // (the division runs on the vector unit)
+	for (; r < r_end; ++r) {
+		int st0 = r - qlen + 1, en0 = (r + w) >> 1;
+		const int sw = (r - w + 1) >> 1;
+		st0 = st0 > sw ? st0 : sw; st0 = st0 > 0 ? st0 : 0;
+		en0 = en0 < r ? en0 : r;
+		// the lean steps need a band that is narrower than 48 cells and stays so: cut by the end of the query from here on
+		if (en0 - st0 < 48 && r > w + 32 && (st0 & ~15) > 0 && r - qlen + 1 >= sw) break;
+		pair_diag<false>(S, E, r, st0, en0);
+		if (!(S.inc0 | S.inc1)) { ++r; return; }
+	}
+	r = uni(r);
+	pair_uniform(S);
+	if (r >= r_end) return;
+	PairCtl C;
+	C.r = r; C.geLoM = C.spM = C.hiM = 0;
+	C.zsafe0 = S.inc0 ? -1 : 0x7fffffff; C.zsafe1 = S.inc1 ? -1 : 0x7fffffff;
+	{
+		const int a = r + 1 - qlen, b = (r + 1 - w) >> 1;
+		C.st0 = a > b ? a : b; C.en0 = (r + w) >> 1;
+	}
+	bool out = false;
+	while (C.r < r_end && !out) {
+		const bool moved = (C.st0 & ~15) != S.st;
+		unsigned ex = 0, ev = 0;
+		if (moved) pair_move(S, E, C.r, C.st0 & ~15, ex, ev);
+		// the next move: st0 = r - qlen + 1 reaches st + 16 (the other bound, (r-w+1)>>1, lags behind it in the tail)
+		const int m1 = S.st + 15 + qlen, m2 = 2 * (S.st + 16) + w - 1;
+		int r_move = m1 < m2 ? m1 : m2;
+		r_move = r_move < r_end ? r_move : r_end;
+		C.lim = r_move;
+		if (moved) pair_tail_step<true>(S, E, C, zq, ex, ev);
+		while (C.r < C.lim) {
+			// a run up to the next diagonal on which the band origin, the computed blocks (en0 crosses a multiple of 16) or the
+			// refreshed score groups ((en0-st0)>>4 drops) change
+			const int rr = C.r, wd = C.en0 - C.st0, p = (rr + w) & 1;
+			const int r_k = rr + 2 * ((wd & 15) + 1) - 1 + p;            // width falls to 16k - 1
+			const int r_e = rr + 2 * (16 - (C.en0 & 15)) - p;             // en0 reaches the next multiple of 16
+			int e = r_k < r_e ? r_k : r_e; e = e < C.lim ? e : C.lim;
+			if (e > rr) {
+				const int keep = C.lim;
+				C.lim = e;
+				if (((C.en0 | 15) - S.st) == 63) pair_tail_qrun<true>(S, E, C, zq); else pair_tail_qrun<false>(S, E, C, zq);
+				if (C.lim != INTMIN) C.lim = keep;
+				continue;
+			}
+			pair_tail_step<false>(S, E, C, zq);
+		}
+		if (C.lim == INTMIN) out = true;                 // both z-dropped, or the band has left the matrix
+	}
+	r = C.r;
+}
+
+// What the sweep of a pair leaves for the traceback (every field of ksw_extz_t the sweep decides, per alignment).
+struct PairResult { int max0, max1, pos0, pos1, mqe0, mqe1, mqe_t0, mqe_t1; };
+
+// The sweep of two jobs with the same qlen and parameters, both ksw_pair_job_ok(): the traceback slots in p, the results
+// in R.  Returns false when a sequence holds a code the pair sweep does not take (a wildcard or worse in a query, anything
+// above the wildcard in a target): the plan kernel only pairs jobs whose producer vouches for the codes.
+// Nothing but (lds, p) and what is in R is needed afterwards: the caller reads the jobs again for the tracebacks, so that
+// none of their fields occupies a scalar register across the sweep (the kernel is short of them: 100 per wavefront).
+__device__ inline bool ksw_pair_sweep(const uint8_t *q0, const uint8_t *t0, int tlen0, const uint8_t *q1, const uint8_t *t1, int tlen1, int qlen,
+                                      int w, int q, int e, int sc_mch, int sc_mis, int zdrop, int encode_ascii, uint8_t *lds, uint8_t *p, PairResult &R, long long *pacc = nullptr)
 {
 	const long long tc0 = pacc ? (long long)clock64() : 0;
 	const int lane = lane_id();
-	const int w = P.w, q = P.q, e = P.e, qe = q + e;
+	// every scalar a register of its own: the launch arguments arrive four to a load, and a register tuple is kept -- and
+	// spilled, and reloaded inside the loops -- as long as any part of it is needed
+	w = uni(w); q = uni(q); e = uni(e); sc_mch = uni(sc_mch); sc_mis = uni(sc_mis); zdrop = uni(zdrop); qlen = uni(qlen); tlen0 = uni(tlen0); tlen1 = uni(tlen1);
+	asm volatile("" : "+s"(w), "+s"(q), "+s"(e), "+s"(sc_mch), "+s"(sc_mis), "+s"(zdrop), "+s"(qlen), "+s"(tlen0), "+s"(tlen1));
+	const int qe = q + e;
 	const int TP0 = (tlen0 + 15) / 16 * 16 + 96, TP1 = (tlen1 + 15) / 16 * 16 + 96, QR = (qlen + 15) / 16 * 16 + 96;
 	uint8_t *tg0 = lds + 64, *tg1 = tg0 + TP0;
 	unsigned *qs = (unsigned *)(tg1 + TP1) + 16;
 	bool bad = false;
 	for (int i = lane; i < TP0; i += 64) {
 		uint8_t b = 0;
-		if (i < tlen0) { b = t0[i]; if (P.encode_ascii) b = enc_base(b); }
+		if (i < tlen0) { b = t0[i]; if (encode_ascii) b = enc_base(b); }
 		bad |= b > 4;
 		tg0[i] = b;
 	}
 	for (int i = lane; i < TP1; i += 64) {
 		uint8_t b = 0;
-		if (i < tlen1) { b = t1[i]; if (P.encode_ascii) b = enc_base(b); }
+		if (i < tlen1) { b = t1[i]; if (encode_ascii) b = enc_base(b); }
 		bad |= b > 4;
 		tg1[i] = b;
 	}
@@ -333,19 +837,19 @@ __device__ inline bool ksw_wave_pair(const uint8_t *q0, const uint8_t *t0, int t
 		unsigned c0 = 0, c1 = 0;
 		if (i < qlen) {
 			c0 = q0[qlen - 1 - i]; c1 = q1[qlen - 1 - i];
-			if (P.encode_ascii) { c0 = enc_base((uint8_t)c0); c1 = enc_base((uint8_t)c1); }
+			if (encode_ascii) { c0 = enc_base((uint8_t)c0); c1 = enc_base((uint8_t)c1); }
 		}
 		bad |= c0 > 3 || c1 > 3;
 		qs[i] = 0x000c000cu | c0 << 8 | (4 + c1) << 24;
 	}
 	if (ballot(bad)) return false;
 	WSYNC();
-	const long long tc1 = pacc ? (long long)clock64() : 0;
+	if (pacc && lane == 0) { const long long tc1 = (long long)clock64(); pacc[0] += tc1 - tc0; pacc[1] -= tc1; }
 
-	const unsigned ZW = (unsigned)(2 * qe) & 0xff, ZM = (unsigned)(2 * qe + P.sc_mch) & 0xff, ZX = (unsigned)(2 * qe + P.sc_mis) & 0xff;
+	const unsigned ZW = (unsigned)(2 * qe) & 0xff, ZM = (unsigned)(2 * qe + sc_mch) & 0xff, ZX = (unsigned)(2 * qe + sc_mis) & 0xff;
 	PairEnv E;
-	E.tg0 = tg0; E.tg1 = tg1; E.qs = qs; E.p = (unsigned *)p; E.qlen = qlen; E.w = w; E.qe = qe; E.e = e;
-	E.zd = P.zdrop < 0 ? 0x3fffffff : P.zdrop;
+	E.tg0 = tg0; E.tg1 = tg1; E.qs = qs; E.p = (unsigned *)p; E.qlen = qlen; E.qlm1 = qlen - 1; E.w = w; E.qe = qe; E.e = e;
+	E.zd = zdrop < 0 ? 0x3fffffff : zdrop;
 	E.Qp = ((unsigned)q & 0xff) * 0x01000100u; E.Mp = ZM * 0x01000100u; E.ZWp = ZW * 0x01000100u; E.QE2p = (unsigned)(2 * qe) * 0x00010001u;
 	E.zx4 = ZX * 0x01010101u; E.zdm = ZM - ZX; E.zw4 = ZW * 0x01010101u;
 	PairState S;
@@ -355,39 +859,39 @@ __device__ inline bool ksw_wave_pair(const uint8_t *q0, const uint8_t *t0, int t
 	S.TB0 = pair_table(E, tg0[64 + (lane & 15)]); S.TB1 = pair_table(E, tg1[64 + (lane & 15)]);
 	S.qptr = qs + (qlen - 1 + lane); S.qoffB = 64 + (lane & 15) - lane; S.rlB = -1;
 	S.accA = S.accB = 0; S.st = 0; S.edge_g = 0;
-	S.thr0 = S.thr1 = 0; S.max_t0 = S.max_t1 = S.max_q0 = S.max_q1 = -1;
+	S.thr0 = S.thr1 = 0; S.pos0 = S.pos1 = pos_pack(-2, -1);             // max_t = max_q = -1 (:81-86)
 	S.mqe0 = S.mqe1 = KSW_NEG_INF; S.mqe_t0 = S.mqe_t1 = -1;
-	S.dead0 = S.dead1 = 0; S.ez_max0 = S.ez_max1 = 0;
+	S.inc0 = S.inc1 = qe; S.fin0 = S.fin1 = 0;
 	// the band leaves the matrix on diagonal 2 qlen + w - 1 (:200-203): r_end is the first diagonal without a cell
 	const int r_end = 2 * qlen + w - 1;
 	pair_diag<true>(S, E, 0, 0, 0);
+	pair_uniform(S);
 	int r = 1;
-	for (; r < r_end; ++r) {
-		int st0 = r - qlen + 1, en0 = (r + w) >> 1;
-		const int sw = (r - w + 1) >> 1;
-		st0 = st0 > sw ? st0 : sw; st0 = st0 > 0 ? st0 : 0;
-		en0 = en0 < r ? en0 : r;
-		pair_diag<false>(S, E, r, st0, en0);
-		if (S.dead0 & S.dead1) { ++r; break; }
-	}
+	// steady diagonals: st0 = (r-w+1)>>1 > r-qlen+1 (the window never cuts the band): up to 2 qlen - w - 3
+	pair_steady_loop(S, E, r, 2 * qlen - w - 2);
+	if (S.inc0 | S.inc1) pair_tail_loop(S, E, r, r_end);
 	// r - 1 is the last diagonal whose cells were computed; thr* stand at diagonal r
 	if (((r - 1) & 3) != 3) pair_flush(S, E, r - 1, S.st);
 	WSYNC();
-	const long long tc2 = pacc ? (long long)clock64() : 0;
-	if (pacc && lane == 0) { pacc[0] += tc1 - tc0; pacc[1] += tc2 - tc1; pacc[3] += 2; }
-	for (int k = 0; k < 2; ++k) {
-		KswOut out;
-		// every exit is a z-drop for the caller (:98-101, :200-203); a sweep that stopped has no score (:355-357) and the window's end is never reached
-		out.zdropped = 1; out.mte = out.score = KSW_NEG_INF; out.mte_q = -1; out.n_cigar = 0;
-		if (k == 0) { out.max = S.dead0 ? S.ez_max0 : S.thr0 - r * qe; out.max_t = S.max_t0; out.max_q = S.max_q0; out.mqe = S.mqe0; out.mqe_t = S.mqe_t0; }
-		else { out.max = S.dead1 ? S.ez_max1 : S.thr1 - r * qe; out.max_t = S.max_t1; out.max_q = S.max_q1; out.mqe = S.mqe1; out.mqe_t = S.mqe_t1; }
-		const long long tb0 = pacc ? (long long)clock64() : 0;
-		if (k == 0) ksw_backtrack_wave<2, 0>(p, 0, qlen, tlen0, w, P.flag, 1, out.max_t, out.max_q, cig_tmp, cig_cap, out);
-		else ksw_backtrack_wave<2, 1>(p, 0, qlen, tlen1, w, P.flag, 1, out.max_t, out.max_q, cig_tmp, cig_cap, out);
-		if (pacc && lane == 0) pacc[2] += (long long)clock64() - tb0;
-		emit(k, out);
-	}
+	if (pacc && lane == 0) { pacc[1] += (long long)clock64(); pacc[3] += 2; }
+	R.max0 = S.inc0 ? S.thr0 - r * qe : S.fin0; R.max1 = S.inc1 ? S.thr1 - r * qe : S.fin1;
+	R.pos0 = S.pos0; R.pos1 = S.pos1; R.mqe0 = S.mqe0; R.mqe1 = S.mqe1; R.mqe_t0 = S.mqe_t0; R.mqe_t1 = S.mqe_t1;
 	return true;
+}
+
+// The record and the CIGAR of alignment K of a pair from its sweep's results (ksw_backtrack_wave on the shared slots).
+template <int K>
+__device__ __forceinline__ void ksw_pair_finish(const PairResult &R, const uint8_t *p, int qlen, int tlen, int w, int flag, uint32_t *cig_tmp, int cig_cap, KswOut &out, long long *pacc = nullptr)
+{
+	// every exit is a z-drop for the caller (:98-101, :200-203); a sweep that stopped has no score (:355-357) and the window's end is never reached
+	out.zdropped = 1; out.mte = out.score = KSW_NEG_INF; out.mte_q = -1; out.n_cigar = 0;
+	out.max = K == 0 ? R.max0 : R.max1;
+	const int pos = K == 0 ? R.pos0 : R.pos1;
+	out.max_t = pos_t(pos); out.max_q = pos_q(pos);
+	out.mqe = K == 0 ? R.mqe0 : R.mqe1; out.mqe_t = K == 0 ? R.mqe_t0 : R.mqe_t1;
+	const long long tb0 = pacc ? (long long)clock64() : 0;
+	ksw_backtrack_wave<2, K>(p, 0, qlen, tlen, w, flag, 1, out.max_t, out.max_q, cig_tmp, cig_cap, out);
+	if (pacc && lane_id() == 0) pacc[2] += (long long)clock64() - tb0;
 }
 
 }  // namespace ihp
