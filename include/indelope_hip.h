@@ -33,7 +33,11 @@ const char *ihp_strerror(int code);
 const char *ihp_last_hip_error(void);   /* text of the last failing HIP call    */
 const char *ihp_version(void);
 
-/* Bind the calling process to one GPU (one process per GPU).  Idempotent.     */
+/* Bind the calling process to one GPU (one process per GPU).  Idempotent.
+ * Environment (the caller's to set, before the process's first HIP call): GPU_MAX_HW_QUEUES=16.  Every batch in flight
+ * drives two streams, and the HIP runtime folds all streams of a process onto that many hardware queues (default 4): with
+ * more than two batches about, launch chains that should overlap share a queue every few runs and run one after the other
+ * (-15 % measured).  The library does not set it itself (setenv is not thread safe and comes too late once HIP is up). */
 int ihp_init(int device);
 int ihp_device_info(int *cu_count, int *wave_size, int64_t *hbm_bytes);
 void ihp_shutdown(void);
@@ -433,7 +437,9 @@ int  ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_rea
 #define IHP_FETCH_EAGER 2
 int  ihp_batch_set_fetch(ihp_batch *b, int32_t flags);
 /* Hand the batch's scratch and result buffers back to the device pool; its inputs and the per-region summary
- * records (ihp_batch_summary_dev) stay.  For callers that walk through more regions than one GPU holds results for
+ * records (ihp_batch_summary_dev) stay.  Waits for the run and confirms it first (a run that left launches out is
+ * repeated here when a region needed them, exactly as ihp_batch_sync would): the records that stay are final, and a
+ * pool overflow of the run is reported as IHP_E_CAPACITY (the buffers are released either way).  For callers that walk through more regions than one GPU holds results for
  * (C4 on fewer than 8 GPUs): every chunk's inputs stay resident, one chunk's results at a time.  The next
  * ihp_batch_run takes buffers again; fetch / pack need that run first.                                           */
 int  ihp_batch_release_outputs(ihp_batch *b);
@@ -473,6 +479,9 @@ int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
  * launches out, [31] runs of this batch repeated in full because of that, [22] ksw2 kernel mode; [32..39] event counts of the combine kernel
  * (best_match calls, exact candidates, verification passes, vote scans, merges, filter passes, query-phase target looks, trims that read supports). */
 int  ihp_batch_profile(ihp_batch *b, int64_t out[64]);
+/* The same with the caller's capacity: the first min(cap, 64) counters.  (ihp_batch_profile writes 64 int64 since round 3;
+ * a caller with a smaller buffer uses this one.)                                                                   */
+int  ihp_batch_profile_n(ihp_batch *b, int64_t *out, int32_t cap);
 /* Diagnostics: which ksw2 kernel the most recent ksw_extz2_sse / ihp_ksw_extz2_batch /
  * ihp_batch_run used: 3/4 = top-byte register sweep (left/right gaps; the production
  * kernels), 0/1 = masked register sweep (scoring schemes or base codes the former does
@@ -515,8 +524,8 @@ typedef struct {
 	int32_t status, n_contigs_pre, n_contigs, n_aligned, n_events, n_tallied;
 	int32_t ref_support, alt_support;     /* of the first tallied event, else -1 */
 } ihp_region_summary;
-/* Device pointer (valid until the next run/free) + count of the summaries.  Read the records after ihp_batch_sync
- * has returned for the run: it is the wait that confirms the run (a run may be repeated there, see "no_spec").        */
+/* Device pointer (valid until the next run/free) + count of the summaries.  The call waits for the batch's run and
+ * confirms it (a run may be repeated at that point, see "no_spec"): the records behind the pointer are final.         */
 int  ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n);
 /* The same records copied to the host (cap >= n_regions entries).             */
 int  ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int64_t cap);

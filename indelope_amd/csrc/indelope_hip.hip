@@ -91,8 +91,38 @@ Knobs g_knob;
 // shape does not use the histogram.
 constexpr int HIST_N = 7;
 constexpr int HIST_OCC[HIST_N] = {16, 14, 12, 10, 9, 8, 6};
-struct TierHint { std::atomic<int> valid{0}, n_b{0}, n_c{0}, n_big{0}, n_back{0}, n_kovf{0}, regions{0}, sig{0}; std::atomic<int> hist[HIST_N]; };
-TierHint g_hint;
+struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0}; };
+// One hint per batch SHAPE (hint_key: read length, read bases per region, the packed / byte-based path, the parameters that
+// decide which launches a run needs), sixteen shapes remembered: a sweep that interleaves batches of different shapes, or
+// several host threads with different workloads, keep their plans apart (round 3 had one process-wide hint; only the tier
+// histogram was keyed, so a batch that needed the retry route made every other shape re-run, and the other way round).
+// Refreshed by whoever confirms a run (sync, fetch, pack, summary, release): after a run that had to be repeated the
+// counters are those of the full run, so the next batch of that shape enqueues the launches it needs.
+struct HintTable {
+	std::mutex mu;
+	struct Slot { unsigned long long key = 0; unsigned long long age = 0; TierHint h; } slot[16];
+	unsigned long long clock = 0;
+	bool get(unsigned long long key, TierHint &out)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		for (Slot &s : slot) if (s.h.valid && s.key == key) { s.age = ++clock; out = s.h; return true; }
+		out = TierHint();
+		return false;
+	}
+	void put(unsigned long long key, const TierHint &h)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		Slot *best = &slot[0];
+		for (Slot &s : slot) {
+			if (s.h.valid && s.key == key) { best = &s; break; }
+			if (!s.h.valid) { if (best->h.valid) best = &s; }
+			else if (best->h.valid && s.age < best->age) best = &s;
+		}
+		best->key = key; best->h = h; best->h.valid = 1; best->age = ++clock;
+	}
+	void clear() { std::lock_guard<std::mutex> lk(mu); for (Slot &s : slot) s = Slot(); }
+};
+HintTable g_hints;
 std::atomic<int> g_live_batches{0};
 
 // Device memory comes from a caching pool: a BAM sweep uploads batch after batch of similar shape, and hipMalloc /
@@ -402,8 +432,10 @@ extern "C" int ihp_init(int device)
 	// GPU_MAX_HW_QUEUES hardware queues (default 4): with more than two batches about, two launch chains that should
 	// overlap land on one queue every few runs and run one after the other (C3 / C5 behind the e2e leg of bench.py: 4.4 ->
 	// 3.8 M and 2.6 -> 2.1 M regions/s in two runs of five; none in five with 16 queues).  The variable is read when the
-	// runtime starts: this helps when this call is the process's first HIP call and never overrides the user's setting.
-	(void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+	// runtime starts, so it is the CALLER's to set before its first HIP call (include/indelope_hip.h says so; the Python
+	// package does it at import).  The library no longer calls setenv(): that is not safe beside a getenv() in another host
+	// thread, and it has no effect once the runtime is up.  A process that did not set it gets a one-line note under "verbose".
+	if (g_knob.verbose && !getenv("GPU_MAX_HW_QUEUES")) fprintf(stderr, "[ihp] GPU_MAX_HW_QUEUES is not set: the runtime's default of 4 hardware queues lets launch chains of different batches share a queue\n");
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g.err, sizeof(g.err), "no HIP device"); return IHP_E_NODEVICE; }
 	if (device < 0 || device >= n) return IHP_E_ARG;
@@ -479,7 +511,7 @@ extern "C" int ihp_debug_limits(const int64_t limits[4])
 
 extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
-	if (!key) { g_knob = Knobs(); return 0; }
+	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
 		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
@@ -921,6 +953,7 @@ struct ihp_batch {
 	// two alignments per wavefront (ksw_pair.h): the plan's lists, the pair launch's LDS per wave and scratch per workgroup
 	DBuf ksw_plan, p_scratch_pair, cig_tmp_pair;
 	int lds_ksw_pair = 0; size_t p_cap_pair = 0;           // 0: no pair launch for this batch
+	unsigned long long hint_key = 0;                       // the batch's shape (HintTable)
 	long long cig_pool_cap = 0, cig_bump_cap = 0, ev_pool_cap = 0, njobs_cap = 0;
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
@@ -1011,8 +1044,7 @@ static int alloc_work(ihp_batch *b)
 		AL(p_scratch_pair, b->p_cap_pair * b->grid_ksw);
 		AL(cig_tmp_pair, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	}
-	AL(p_scratch_big, b->p_cap_big * b->grid_kovf);
-	AL(cig_tmp_big, sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf);
+	// (the roomy ksw2 launch's scratch -- up to 512 MB -- is taken when that launch is enqueued: most runs leave it out)
 	if (p->fallback) {
 		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
@@ -1125,8 +1157,21 @@ extern "C" int ihp_slab_layout_for(int32_t n_regions, int64_t n_reads, int64_t n
 extern "C" int ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab, const ihp_slab_layout *L,
                                      int32_t flags, ihp_batch **bout)
 {
-	if (!slab || !L || n_regions < 0 || n_reads < 0) return IHP_E_ARG;
+	if (!slab || !L || n_regions < 0 || n_reads < 0 || (flags & ~IHP_SLAB_HAS_SKIP)) return IHP_E_ARG;
 	const char *h = (const char *)slab;
+	{
+		// the layout is the caller's word for where everything is: checked against ihp_slab_layout_for before any offset is
+		// followed -- first the sections whose places depend on the counts alone (the offset arrays among them), then, with
+		// the base and window totals read from those, the whole of it
+		ihp_slab_layout X;
+		if (ihp_slab_layout_for(n_regions, n_reads, 0, 0, &X)) return IHP_E_ARG;
+		if (L->region_read_off != X.region_read_off || L->read_off != X.read_off || L->read_start != X.read_start || L->read_stop != X.read_stop ||
+		    L->ref_off != X.ref_off || L->ref_origin != X.ref_origin || L->trim_lo != X.trim_lo || L->trim_hi != X.trim_hi || L->mapq != X.mapq ||
+		    L->read_skip != X.read_skip || L->ref_bases != X.ref_bases || L->bytes < X.bytes) return IHP_E_ARG;
+		const int64_t n_bases = n_reads ? ((const int64_t *)(h + L->read_off))[n_reads] : 0, n_ref = n_regions ? ((const int64_t *)(h + L->ref_off))[n_regions] : 0;
+		if (n_bases < 0 || n_ref < 0 || ihp_slab_layout_for(n_regions, n_reads, n_bases, n_ref, &X)) return IHP_E_ARG;
+		if (L->bases4 != X.bases4 || L->bytes != X.bytes) return IHP_E_ARG;
+	}
 	ihp_batch_in in;
 	memset(&in, 0, sizeof(in));
 	in.n_regions = n_regions; in.n_reads = n_reads;
@@ -1464,6 +1509,16 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	hipStream_t s = b->stream;
 	const ihp_params &p = b->P;
 	{ int rc1 = alloc_work(b); if (rc1) return rc1; }
+	// the shape of the batch: what its plan is remembered under
+	{
+		const long long per_region = b->R > 0 ? b->n_bases / b->R : 0;
+		unsigned long long k = (unsigned long long)(b->max_read_len / 32) | (unsigned long long)std::min<long long>(per_region / 2048, 0xffff) << 12;
+		k |= (unsigned long long)(b->v2 ? 1 : 0) << 28 | (unsigned long long)(b->tier_occ_default & 63) << 29 | (unsigned long long)(p.max_mismatch & 15) << 35;
+		k |= (unsigned long long)(p.bw & 0xff) << 39 | (unsigned long long)(p.fallback ? 1 : 0) << 47 | (unsigned long long)(b->max_ref_len / 64 & 0xfff) << 48;
+		b->hint_key = k | 1ull << 63;
+	}
+	TierHint H;
+	const bool have_hint = g_hints.get(b->hint_key, H) && !g_knob.no_hint;
 	// counters, stamps, work queues and per-region hit counts are zero: cleared at upload and by the previous run's k_summary
 	int *wq = b->queues_dev();
 	const bool profiling = g_knob.profile != 0;
@@ -1513,15 +1568,15 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		const bool side = n2 + n3 + n4 > 0;
 		// The first combine tier is sized from the read bases of the usual region (size_combine_tiers); when the last batch of
 		// this shape filed most of its regions above that, the tiers are cut again so that the first one holds 85 % of them.
-		if (b->v2 && !g_knob.no_hint && !g_knob.comb_occ && !g_knob.v2_arena && g_hint.valid.load() && g_hint.sig.load() == b->tier_sig && g_hint.regions.load() > 0) {
-			const long long tot = g_hint.regions.load();
+		if (b->v2 && have_hint && !g_knob.comb_occ && !g_knob.v2_arena && H.sig == b->tier_sig && H.regions > 0) {
+			const long long tot = H.regions;
 			// a tier of its own for a few percent of the regions costs a round of the heaviest ones at the end: when a first tier
 			// of not much lower occupancy holds (nearly) all regions -- a narrow distribution just above the predicted arena --
 			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest
 			int want = 0, want_all = 0;
 			long long cum = 0;
 			for (int k = 0; k < HIST_N; ++k) {
-				cum += g_hint.hist[k].load();
+				cum += H.hist[k];
 				if (HIST_OCC[k] > b->tier_occ_default) continue;
 				if (!want && cum * 100 >= 85 * tot) want = HIST_OCC[k];
 				if (!want_all && cum * 200 >= 199 * tot) want_all = HIST_OCC[k];
@@ -1534,7 +1589,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		if (g_knob.verbose && b->v2)
 			fprintf(stderr, "[ihp] run: %d regions, first tier %d waves/CU (default %d): arenas %d / %d / %d / %d, grids %d / %d / %d / %d; hint valid %d b %d c %d big %d back %d\n",
 			        b->R, b->tier_occ, b->tier_occ_default, b->v2_arena, b->v2_arena_b, b->v2_arena_c, b->v2_arena_big, b->grid_v2, b->grid_v2b, b->grid_v2c, b->grid_v2big,
-			        g_hint.valid.load(), g_hint.n_b.load(), g_hint.n_c.load(), g_hint.n_big.load(), g_hint.n_back.load());
+			        (int)have_hint, H.n_b, H.n_c, H.n_big, H.n_back);
 		auto pass2 = [&](AsmArgs x, hipStream_t st, const int *in, const int *n_in, int set, Corr *corr, int grid) {
 			x.arena_seq = nullptr; x.arena_sup = b->lds_sup2.as<uint32_t>(); x.arena_cap = b->lds_arena2; x.lds_arena = b->lds_arena2;
 			x.in_list = in; x.n_in = n_in; x.out_list = o3; x.n_out = misc + M_NRETRY2; x.work_counter = wq + set * WQ_WORDS; x.corr = corr;
@@ -1615,8 +1670,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// own -- an empty launch of workgroups that each ask for 25-60 KB of LDS still has to get every one of them
 			// scheduled, 0.05-0.3 ms on the critical path in front of k_ksw while another batch's kernels fill the CUs: the first
 			// tier's launch walks its lists behind its own instead (a straggler does not fit there and takes the retry route).
-			const bool hint = g_hint.valid.load() != 0 && !g_knob.no_hint;
-			const bool fold_c = hint && g_hint.n_c.load() == 0, fold_b = fold_c && g_hint.n_b.load() == 0;
+			const bool hint = have_hint;
+			const bool fold_c = hint && H.n_c == 0, fold_b = fold_c && H.n_b == 0;
 			HIPC(hipEventRecord(b->ev_bfork, s));
 			// The second tier runs beside the first on the other stream -- if its workgroups find LDS: the first tier's persistent
 			// grid fills every CU and keeps it until its queue is dry, so a second tier launched next to it in fact ran behind it
@@ -1633,7 +1688,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			const int tm_a = team(b->tier_occ), tm_b = team(std::max(1, (b->tier_occ * 2 + 1) / 3)), tm_c = team(std::max(1, b->tier_occ / 3)), tm_big = team(2);
 			int ga = b->grid_v2, gb = b->grid_v2b;
 			if (hint && ra.lpt_cnt && !fold_b) {
-				const long long nb_hint = g_hint.n_b.load(), reg = std::max(1, g_hint.regions.load());
+				const long long nb_hint = H.n_b, reg = std::max(1, H.regions);
 				if (nb_hint == 0) gb = std::min(gb, 128);
 				else {
 					const long long nb = nb_hint * std::max(1, b->n_cls[0]) / reg + 1;
@@ -1675,9 +1730,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// launches that are empty for batch after batch, each waiting for wave slots while another batch's persistent grids
 			// fill the chip (0.2-0.4 ms in front of k_ksw).  When the last batch needed none of them they are left out, and
 			// whoever waits for this run checks the counters: a region that did need the route makes the run repeat in full.
-			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && g_hint.n_big.load() == 0 && g_hint.n_back.load() == 0;
+			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && H.n_big == 0 && H.n_back == 0;
 			if (!spec_skip) {
-			if (hint && g_hint.n_big.load() == 0) {
+			if (hint && H.n_big == 0) {
 				launch_comb(std::min(b->grid_v2big, 64), tm_a, b->v2_arena + 4 * b->v2_pm, s, x);
 			} else {
 				x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
@@ -1735,10 +1790,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		HIPC(hipGetLastError());
 		// the roomy launch: left out when the last batch had no such job (a few workgroups that ask for all the LDS of a CU wait for
 		// one to drain); the wait checks the count and repeats the run with it otherwise (see the retry launches above)
-		const bool hintk = g_hint.valid.load() != 0 && !g_knob.no_hint;
-		ksw_skipped_run = hintk && !g_knob.no_spec && !b->force_full && g_hint.n_kovf.load() == 0;
+		const bool hintk = have_hint;
+		ksw_skipped_run = hintk && !g_knob.no_spec && !b->force_full && H.n_kovf == 0;
 		if (g_knob.verbose) fprintf(stderr, "[ihp] ksw2: grid %d lds %d p_cap %zu; roomy launch %s: grid %d p_cap %zu cig %d\n", b->grid_ksw, b->lds_ksw, b->p_cap, ksw_skipped_run ? "left out" : "enqueued", b->grid_kovf, b->p_cap_big, b->cig_cap_big);
 		if (!ksw_skipped_run) {
+			if (!b->p_scratch_big.p) { int rcb = b->p_scratch_big.alloc(b->p_cap_big * b->grid_kovf); if (rcb) return rcb; }
+			if (!b->cig_tmp_big.p) { int rcb = b->cig_tmp_big.alloc(sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf); if (rcb) return rcb; }
 			KswArgs r2 = a;
 			r2.t_start = nullptr; r2.in_list = b->ksw_ovf.as<int>(); r2.n_jobs = misc + M_KSW_OVF; r2.ovf_list = nullptr; r2.ovf_n = nullptr;
 			r2.lds_budget = g.max_lds - 2048 - 64;
@@ -1854,6 +1911,20 @@ static int run_again_in_full(ihp_batch *b)
 	b->n_reruns++;
 	return rc;
 }
+// What the confirmed run needed goes into the hint of the batch's shape (HintTable): every wait that confirms a run calls this.
+static void hint_refresh(const ihp_batch *b)
+{
+	if (!b->ran || b->R <= 0 || !b->hint_key) return;
+	TierHint h;
+	h.n_b = b->report[M_NTIERB]; h.n_c = b->report[M_NTIERC]; h.n_big = b->report[M_NRETRYC];
+	h.n_back = b->report[M_NRETRY0]; h.n_kovf = b->report[M_KSW_OVF];
+	if (b->v2 && g_knob.lpt) {
+		for (int k = 0; k < HIST_N; ++k) h.hist[k] = b->report[M_HIST + k];
+		h.regions = b->n_cls[0] - b->report[M_NRETRY0]; h.sig = b->tier_sig;
+	}
+	if (g_knob.verbose) fprintf(stderr, "[ihp] confirmed: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);
+	g_hints.put(b->hint_key, h);
+}
 static int finish_run(ihp_batch *b)
 {
 	HIPC(hipStreamSynchronize(b->stream));
@@ -1862,6 +1933,7 @@ static int finish_run(ihp_batch *b)
 		if (rc) return rc;
 		HIPC(hipStreamSynchronize(b->stream));
 	}
+	hint_refresh(b);
 	return 0;
 }
 
@@ -1894,16 +1966,6 @@ extern "C" int ihp_batch_sync(ihp_batch *b)
 		b->acc_n++;
 		b->acc_pending = false;
 	}
-	if (b->ran && b->R > 0 && b->v2 && g_knob.lpt) {
-		g_hint.n_b = b->report[M_NTIERB]; g_hint.n_c = b->report[M_NTIERC]; g_hint.n_big = b->report[M_NRETRYC];
-		g_hint.n_back = b->report[M_NRETRY0]; g_hint.n_kovf = b->report[M_KSW_OVF];
-		if (g_knob.verbose) fprintf(stderr, "[ihp] sync: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);
-		if (b->v2) {
-			for (int k = 0; k < HIST_N; ++k) g_hint.hist[k] = b->report[M_HIST + k];
-			g_hint.regions = b->n_cls[0] - b->report[M_NRETRY0]; g_hint.sig = b->tier_sig;
-		}
-		g_hint.valid = 1;
-	}
 	if (b->ran && b->R > 0) return report_overflow(b);
 	return 0;
 }
@@ -1930,7 +1992,19 @@ extern "C" int ihp_batch_stage_ms(ihp_batch *b, float ms[4])
 
 // Diagnostics (IHP_PROFILE=1): shader-clock cycles summed over waves.
 // [0] assemble total, [1] combine, [2] assemble+output, [3] regions; [8] ksw init, [9] ksw DP, [10] ksw traceback, [11] jobs
-extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64])
+static int batch_profile64(ihp_batch *b, int64_t out[64]);
+// the first `cap` of the 64 counters (a caller built against the 32-entry form of an earlier round passes 32)
+extern "C" int ihp_batch_profile_n(ihp_batch *b, int64_t *out, int32_t cap)
+{
+	if (!b || !out || cap < 0) return IHP_E_ARG;
+	int64_t all[64];
+	const int rc = batch_profile64(b, all);
+	if (rc) return rc;
+	memcpy(out, all, sizeof(int64_t) * (size_t)std::min(cap, 64));
+	return 0;
+}
+extern "C" int ihp_batch_profile(ihp_batch *b, int64_t out[64]) { return b && out ? batch_profile64(b, out) : IHP_E_ARG; }
+static int batch_profile64(ihp_batch *b, int64_t out[64])
 {
 	if (!b || !out) return IHP_E_ARG;
 	if (!b->ran || !b->work_live) return IHP_E_ARG;           // no run yet, or its scratch went back to the pool (ihp_batch_release_outputs)
@@ -1980,6 +2054,8 @@ extern "C" int ihp_batch_fallback_ms(ihp_batch *b, float *ms)
 extern "C" int ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n)
 {
 	if (!b || !dev_ptr || !n) return IHP_E_ARG;
+	// the records of a run are final once the run is confirmed (it may be repeated at the wait): wait here
+	if (b->ran && b->work_live) { int rc0 = ensure_init(); if (rc0) return rc0; int rc1 = finish_run(b); if (rc1) return rc1; }
 	*dev_ptr = b->summary.p; *n = b->R;
 	return 0;
 }
@@ -2010,11 +2086,17 @@ extern "C" int ihp_batch_release_outputs(ihp_batch *b)
 {
 	if (!b) return IHP_E_ARG;
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
-	HIPC(hipStreamSynchronize(b->stream));
+	// the run is confirmed first: one that left launches out and met a region that needed them is repeated here, so that the
+	// summary records that stay behind are final (after the release nothing could tell any more)
+	int rc = 0;
+	if (b->ran && b->work_live) {
+		rc = finish_run(b);
+		if (!rc && b->R > 0) rc = report_overflow(b);
+	} else HIPC(hipStreamSynchronize(b->stream));
 	if (b->stream2) HIPC(hipStreamSynchronize(b->stream2));
 	release_work(b);
 	b->ran = false;
-	return 0;
+	return rc;
 }
 
 // ---- host result slabs ---------------------------------------------------------------
@@ -2114,6 +2196,7 @@ static int pack_enqueue(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t co
 		const int rc = run_again_in_full(b);
 		if (rc) return rc;
 	}
+	hint_refresh(b);
 	const volatile long long *tot_h = (const volatile long long *)(b->report + REPORT_INTS);
 	long long tot[5];
 	for (int k = 0; k < 5; ++k) tot[k] = tot_h[k];

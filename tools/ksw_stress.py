@@ -23,3 +23,4 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
             if bad<5: print('DIFF',kw,len(qs[i]),len(ts[i]),ez[i],ez2[i])
     print(it, kw, 'mode', hip.b.debug_last_ksw_mode(), 'bad', bad, flush=True)
 print('done', n, 'pairs', bad, 'differences')
+sys.exit(1 if bad else 0)
