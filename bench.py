@@ -39,8 +39,13 @@ ISSUE_PEAK = 1.0               # wave64 instructions per cycle per CU and per un
                                # the scalar unit serves one SIMD per cycle, so a CU retires at most 1 VALU + 1 SALU per cycle (rocprofv3's
                                # VALUBusy / SALUBusy definitions; tools/ubench_issue.hip reaches 0.93 / 0.96 by wall clock)
 KERNELS = ["k_assemble", "k_ksw", "k_tally"]
-PMC_FILE = os.path.join("profiles", "r03_c2_pmc.json")
-MIX_FILE = os.path.join("profiles", "r03_c2_pmc_mix.json")
+ISSUE_PEAK_ARCH = 2.0          # MI355X_MICROARCH.md: a SIMD-32 issues a wave64 VALU instruction over 2 cycles -- reached only by pure streams of
+                               # mov / and / xor / add (1.5-1.8 measured); in a mixed stream every VALU instruction costs the half-rate slot
+                               # (tools/ubench_ksw.hip: v_sub / v_max alternating 0.93 per cycle and CU)
+PMC_FILE = os.path.join("profiles", "r04_c2_pmc.json")
+MIX_FILE = os.path.join("profiles", "r04_c2_pmc_mix.json")
+STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_asm_reads", "k_asm_combine3", "k_assemble"),
+                 "k_ksw": ("k_ksw", "k_ksw_pair", "k_ksw_plan_count", "k_ksw_plan_place"), "k_tally": ("k_tally",)}
 
 
 def src_sha16():
@@ -273,7 +278,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
 
 
 # ------------------------------------------------------------------------------------------ other configs
-def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2):
+def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2, dup_frac=0.0):
     """A short run of another BASELINE config on this GPU (the same step as the headline: `sub_batches` chains in flight,
     resident inputs): value, per-launch stage times, the HBM-roofline fraction of its dominant stage, oracle check."""
     from indelope_amd import synth
@@ -287,7 +292,7 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2):
     for i in range(sub_batches):
         g = dict(cfg)
         g["n_regions"] = cuts[i + 1] - cuts[i]
-        sb, _ = synth.generate(first_region=cuts[i], **g)
+        sb, _ = synth.generate(first_region=cuts[i], dup_frac=dup_frac, **g)
         sb = sb.with_trim_bounds()
         subs.append(sb)
         hs.append(api.batch_upload(sb, params))
@@ -320,8 +325,9 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2):
     dom = int(np.argmax(km[:3]))
     achieved = by_kernel[KERNELS[dom]] / (km[dom] * 1e-3) / 1e9
     whole = (sum(sb.algorithmic_input_bytes() for sb in subs) + res.algorithmic_output_bytes(K)) / (dt / steps) / 1e9
-    out = {"workload": "%s: %d regions x %s reads x %d bp, K=%d" % (name, regions, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
-                                                                       else str(cfg["n_reads"][0]), cfg["read_len"], K),
+    out = {"workload": "%s: %d regions x %s reads x %d bp, K=%d%s" % (name, regions, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
+                                                                         else str(cfg["n_reads"][0]), cfg["read_len"], K,
+                                                                         ", %g of the events tandem duplications (alignment fallback, indelope.nim:312-372)" % dup_frac if dup_frac else ""),
            "value": round(regions * steps / dt, 1), "unit": "regions/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
            "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS, km[:3])}, k_fallback=round(float(km[3]), 4)),
            "roofline": {"kernel": KERNELS[dom], "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -342,6 +348,170 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2):
         out["oracle_check"] = {"regions": n, "identical": bad is None, "first_difference": bad, "seconds": round(time.perf_counter() - t1, 2)}
         assert bad is None, "%s: device results differ from the oracle: %s" % (name, bad)
     return out
+
+
+# ----------------------------------------------------------------------------------- BASELINE configs[0] (C1)
+def c1_leg(api, K=27, reps=7):
+    """BASELINE configs[0]: ONE synthetic region, 48 x 150 bp reads, end to end.  `cpu_us_per_region`: the CPU path (C oracle with
+    the compiled reference ksw2 where built; the Nim binary cannot be built here), median of `reps`; `gpu_us_per_region`: the same
+    region through ihp_run_regions (host arrays in, host results out, one region: pure latency), median of `reps`."""
+    import oracle
+    from indelope_amd import synth
+    from indelope_amd.host import BatchResult
+    o = oracle.get()
+    b, _ = synth.config("C1")
+    used_ref = o.use_reference_ksw(True)
+    try:
+        exp = o.run_regions(b, o.params(K=K))
+        cpu = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            o.run_regions(b, o.params(K=K))
+            cpu.append(time.perf_counter() - t0)
+    finally:
+        o.use_reference_ksw(False)
+    got = api.run_regions(b, api.params(K=K))
+    gpu = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        api.run_regions(b, api.params(K=K))
+        gpu.append(time.perf_counter() - t0)
+    d = BatchResult.first_difference(got, exp)
+    return {"workload": "C1: 1 region x 48 reads x 150 bp, end to end (BASELINE configs[0])",
+            "cpu_us_per_region": round(float(np.median(cpu)) * 1e6, 1), "cpu_min_us": round(min(cpu) * 1e6, 1),
+            "cpu_kind": "C oracle (oracle/), ksw2 = %s; one thread" % ("reference ksw2_extz2_sse.c compiled (oracle/_ref)" if used_ref else "scalar restatement"),
+            "gpu_us_per_region": round(float(np.median(gpu)) * 1e6, 1), "gpu_min_us": round(min(gpu) * 1e6, 1),
+            "gpu_kind": "ihp_run_regions: upload + run + fetch of the one region (launch latency, not throughput)",
+            "reps": reps, "identical": d is None, "first_difference": d}
+
+
+# ------------------------------------------------------------------------------------------ mixed stream
+def mixed_stream(api, n_batches=48, in_flight=2):
+    """What a sweep hands over is whatever gen_roi yields (indelope.nim:515-545, 601-603): batches of different shapes, one after
+    the other.  C2-, C3-, C5- and dup-shaped batches (different seeds) are pushed through ONE process in rotation, `in_flight`
+    at a time; reported: regions/s, runs repeated because a launch plan was wrong (`n_reruns`), the same stream with the plans
+    switched off (no_hint=1, no_spec=1), and the rate the single-shape timings predict for this sequence (time-weighted)."""
+    from indelope_amd import synth
+    shapes = [("C2", dict(synth.CONFIGS["C2"], n_regions=5000), 0.0), ("C3", dict(synth.CONFIGS["C3"], n_regions=5000), 0.0),
+              ("C5", dict(synth.CONFIGS["C5"], n_regions=2500), 0.0), ("dup10", dict(synth.CONFIGS["C2"], n_regions=5000, config_id=12), 0.1)]
+    hs, meta = [], []
+    try:
+        for name, cfg, dup in shapes:
+            pair = []
+            for k in range(2):                                   # two batches of every shape (different regions): the single-shape timing keeps two in flight
+                b, _ = synth.generate(first_region=k * cfg["n_regions"], dup_frac=dup, **cfg)
+                pair.append(api.batch_upload(b.with_trim_bounds(), api.params(K=cfg["K"])))
+            hs.append(pair)
+            meta.append((name, cfg["n_regions"]))
+
+        def stream(seq, which=lambda i: 0):
+            q = []
+            for i, s in enumerate(seq):
+                h = hs[s][which(i)]
+                api.batch_run(h)
+                q.append(h)
+                if len(q) == in_flight:
+                    api.batch_sync(q.pop(0))
+            for h in q:
+                api.batch_sync(h)
+
+        def reruns():
+            return int(sum(api.batch_profile(h)[31] for pair in hs for h in pair))
+        seq = [i % len(shapes) for i in range(n_batches)]
+        regions = sum(meta[s][1] for s in seq)
+        # single-shape rates, two batches of the shape in flight
+        single = {}
+        for s, (name, n) in enumerate(meta):
+            stream([s] * 4, which=lambda i: i & 1)
+            t0 = time.perf_counter()
+            stream([s] * 8, which=lambda i: i & 1)
+            single[name] = (time.perf_counter() - t0) / 8
+        predicted = sum(single[meta[s][0]] for s in seq)
+        out = {}
+        for label, knobs in (("plans_per_shape", {}), ("no_plans", dict(no_hint=1, no_spec=1))):
+            api.debug_set(**knobs)
+            stream(seq[:len(shapes) * 2])                        # every shape seen twice
+            r0 = reruns()
+            t0 = time.perf_counter()
+            stream(seq)
+            dt = time.perf_counter() - t0
+            out[label] = {"regions_per_s": round(regions / dt, 1), "ms_per_batch": round(dt / len(seq) * 1e3, 3), "n_reruns": reruns() - r0}
+            api.debug_set()
+        out.update({"batches": len(seq), "in_flight": in_flight, "shapes": ["%s x %d regions" % m for m in meta],
+                    "single_shape_ms_per_batch": {k: round(v * 1e3, 3) for k, v in single.items()},
+                    "predicted_regions_per_s": round(regions / predicted, 1),
+                    "mixed_over_predicted": round(predicted / (regions / out["plans_per_shape"]["regions_per_s"]), 3),
+                    "rerun_share": round(out["plans_per_shape"]["n_reruns"] / len(seq), 4),
+                    "note": "one process, one device; batches resident (inputs uploaded once), run + sync per batch; never `value`"})
+        return out
+    finally:
+        for pair in hs:
+            for h in pair:
+                api.batch_free(h)
+
+
+# ------------------------------------------------------------------------- the attached strong-scaling leg
+def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps=2, warmup=1):
+    """north_star's strong-scaling number in the same invocation as the weak one (`--gpus N`, no --config): the C4 generator's
+    first `regions_total` regions split over the ranks (dist.shard_bounds), every rank's share resident in chunks, a step = one pass
+    over all of them + THE gather of the per-region records to rank 0.  Every rank calls this; rank 0 gets the record."""
+    from indelope_amd import synth
+    cfg = dict(synth.CONFIGS["C4"])
+    params = api.params(K=cfg["K"])
+    bounds = idist.shard_bounds(np.ones(regions_total), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    cuts = list(range(lo, hi, max(1, chunk))) + [hi]
+    hs = []
+    try:
+        for i in range(len(cuts) - 1):
+            g = dict(cfg, n_regions=cuts[i + 1] - cuts[i])
+            sb, _ = synth.generate(first_region=cuts[i], **g)
+            hs.append(api.batch_upload(sb.with_trim_bounds(), params))
+        views = []
+        for h in hs:
+            sptr, sn = api.batch_summary_dev(h)
+            views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda"))
+        summary = views[0] if len(views) == 1 else torch.cat(views)
+        sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+        m_pad = max(sizes)
+        send = summary if hi - lo == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
+        gl = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+
+        def step():
+            for i, h in enumerate(hs):
+                api.batch_run(h)
+                if i >= 1:
+                    api.batch_sync(hs[i - 1])
+            api.batch_sync(hs[-1])
+            if len(views) > 1:
+                torch.cat(views, out=summary)
+            if send is not summary:
+                send[:summary.numel()] = summary
+            dist.gather(send, gl, dst=0)
+        for _ in range(warmup):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ok = None
+        if rank == 0:
+            got = torch.cat([g[:n * idist.SUMMARY_WORDS] for g, n in zip(gl, sizes)])
+            ok = bool((got.view(-1, idist.SUMMARY_WORDS)[:, 0] == 0).all().item())       # every region's status
+        return {"config": "C4 (BASELINE configs[3] generator), first %d of its 5 000 000 regions" % regions_total, "scaling": "strong",
+                "value": round(regions_total * steps / dt, 1), "unit": "regions/s", "ms_per_step": round(dt / steps * 1e3, 3),
+                "regions_total": regions_total, "regions_per_gpu": sizes, "steps": steps, "warmup": warmup,
+                "chunks_per_rank": len(hs), "all_regions_ok": ok,
+                "sharding": "contiguous region ranges (dist.shard_bounds), one RCCL gather of the per-region records per step"}
+    finally:
+        for h in hs:
+            api.batch_free(h)
 
 
 # ----------------------------------------------------------------------------------------------- launching
@@ -375,7 +545,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2", help="BASELINE config id (C2, C3, C4, C5)")
+    ap.add_argument("--config", default=None, help="BASELINE config id (C2, C3, C4, C5); default C2 -- and, with more than one GPU, "
+                                                     "a strong-scaling C4 leg attached as `strong`")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank holds --regions regions of the config (default: the config's own count, at most "
                          "200 000); strong: --regions is the TOTAL (default: the config's own count, e.g. 5 000 000 for C4), split "
@@ -409,11 +580,16 @@ def main():
                          "path on a single GPU (tests/test_gpu_round3.py)")
     ap.add_argument("--verify-gather", action="store_true",
                     help="rank 0 checks the gathered per-region records (and payload slabs) against its own fetched results")
-    ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 legs (`other_configs`) of the default run")
+    ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 / dup10 legs (`other_configs`), `mixed_stream` and `c1` of the default run")
+    ap.add_argument("--strong-regions", type=int, default=1_250_000,
+                    help="regions of the attached strong-scaling leg (C4 generator; 5 000 000 = all of BASELINE configs[3])")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counters of the kernels (ihp_debug_set profile) in `profile_cycles`")
     ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
                     help="library path / occupancy switches (ihp_debug_set), e.g. --knob asm_v1=1; results do not depend on them")
     args = ap.parse_args()
+    config_given = args.config is not None
+    if not config_given:
+        args.config = "C2"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the parent starts the ranks and exits with their code: nothing below (torch, HIP) runs in it
@@ -435,10 +611,19 @@ def main():
         n = int(bounds[rank + 1] - bounds[rank])
         local = torch.full((n, idist.SUMMARY_WORDS), rank, dtype=torch.int32)
         got = idist.gather_summaries(local, rank, world, dst=0)
+        strong_rec = None
+        if world > 1 and not config_given and not strong:
+            # the attached strong-scaling leg (C4 generator, --strong-regions in total): its shard bounds and its one gather
+            sb_ = idist.shard_bounds(np.ones(args.strong_regions), world)
+            n2 = int(sb_[rank + 1] - sb_[rank])
+            got2 = idist.gather_summaries(torch.full((n2, idist.SUMMARY_WORDS), rank, dtype=torch.int32), rank, world, dst=0)
+            if rank == 0:
+                assert got2.shape[0] == args.strong_regions
+                strong_rec = {"config": "C4", "scaling": "strong", "regions_total": int(sb_[-1]), "dry_run": True}
         if rank == 0:
             assert got.shape[0] == int(bounds[-1]) and [int(got[int(bounds[r])][0]) for r in range(world)] == list(range(world))
             print(json.dumps({"metric": "dry run (launcher check, no GPU work)", "value": 0.0, "n_gpus": world, "dry_run": True,
-                              "scaling": args.scaling, "regions_total": int(bounds[-1]), "launched_by": "bench.py --gpus" if
+                              "scaling": args.scaling, "regions_total": int(bounds[-1]), "strong": strong_rec, "launched_by": "bench.py --gpus" if
                               os.environ.get("IHP_BENCH_SPAWNED") else "external launcher"}))
         if world > 1:
             dist.barrier()
@@ -532,28 +717,38 @@ def main():
                 api.batch_run(h)                             # asynchronous: the sub-batches' launch chains overlap
             for h in hs:
                 api.batch_sync(h)
-        if use_dist:
-            if S > 1:
-                torch.cat(views, out=summary)
-            if send is not summary:
-                send[:summary.numel()] = summary
-            dist.gather(send, gather_list, dst=0)            # THE per-step collective: fixed-size per-region records to rank 0
-            if args.payload and not stream_outputs:
-                for h in hs:
-                    ptr, nbytes, counts = api.batch_pack_dev(h)
-                    slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
-                    last_payload[0] = idist.gather_payload(slab, counts, rank, world, dst=0, force=True)
+        if use_dist and strong:
+            gather()                                         # strong scaling: the job IS one pass, its gather belongs to the step
 
-    for _ in range(args.warmup):
-        step()
+    def gather():
+        # THE collective of the path: the fixed-size per-region records of every rank to rank 0 (+ the result slabs with --payload)
+        if S > 1:
+            torch.cat(views, out=summary)
+        if send is not summary:
+            send[:summary.numel()] = summary
+        dist.gather(send, gather_list, dst=0)
+        if args.payload and not stream_outputs:
+            for h in hs:
+                ptr, nbytes, counts = api.batch_pack_dev(h)
+                slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
+                last_payload[0] = idist.gather_payload(slab, counts, rank, world, dst=0, force=True)
+
+    def block(n):
+        # weak scaling: every rank walks through its own batches; the real job gathers ONCE at its end, so a timed
+        # block ends with one gather, not one per step (round 3 synchronised all ranks after every 1.8 ms step for no reason)
+        for _ in range(n):
+            step()
+        if use_dist and not strong:
+            gather()
+
+    block(args.warmup)
     for h in hs:
         api.batch_kernel_ms_mean(h, reset=True)              # the warm-up runs do not count
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    block(args.steps)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -562,10 +757,32 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # two more blocks of the same K steps, bracketed the same way: `value` is the first block (the contract's K steps), `blocks`
+    # says how far a single 40 ms block is from the median
+    block_ms = [dt / args.steps * 1e3]
+    if not strong:
+        for _ in range(2):
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            block(args.steps)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            if use_dist:
+                t = torch.tensor([d1], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d1 = float(t.item())
+            block_ms.append(d1 / args.steps * 1e3)
     # per LAUNCH (a launch processes one sub-batch / chunk): the mean over the timed steps' launches
     km = np.array([api.batch_kernel_ms_mean(h)[0] for h in hs]).mean(axis=0)
     stage = np.array([km[0], km[1], km[2], km[:4].sum()])
     fb_ms = float(km[3])
+    strong_rec = None
+    if use_dist and world > 1 and not config_given and not strong:
+        strong_rec = strong_leg(api, torch, dist, idist, rank, world, args.strong_regions, args.chunk)
 
     if rank == 0:
         from indelope_amd.host import concat_results
@@ -595,9 +812,9 @@ def main():
         pmc, mix = os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, MIX_FILE)
         same = args.config == "C2" and R == 10_000 and S == 2 and not strong
         # the launches a stage consists of (the assembly stage is the packed read phase, the combine phase and the byte-based
-        # passes behind them; the empty ones count too)
-        members = {"k_assemble": ("k_prepack", "k_asm_reads", "k_asm_combine3", "k_assemble"), "k_ksw": ("k_ksw",), "k_tally": ("k_tally",)}[KERNELS[dom]]
-        base = lambda n: n.split("<")[0].split("::")[-1].strip()
+        # passes behind them; the ksw2 stage is its plan, the pair sweep and the single sweep; the empty ones count too)
+        members = STAGE_MEMBERS[KERNELS[dom]]
+        base = lambda n: n.split("<")[0].split("(")[0].split("::")[-1].strip()
         sha = src_sha16()
         stale = None
         if same and os.path.exists(pmc):
@@ -609,25 +826,33 @@ def main():
                 traffic, traffic_source = int(sum(t)), PMC_FILE + (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload; "
                                                                    "2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; sum over the stage's launches; "
                                                                    + ("TAKEN FROM ANOTHER BUILD of the library (src_sha16 differs): stale)" if stale else "same sources as this run)"))
+        issue_by_stage = None
         if same and os.path.exists(mix):
             try:
-                k = json.load(open(mix))
-                va = sa = vb = sb = cyc = 0.0
-                for n, v in k.items():
-                    if not isinstance(v, dict):
-                        continue
-                    if base(n) in members and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
-                        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: CU-cycles of a launch = (GUI / 8) x 256 CUs.  The SQ_ACTIVE_INST_*
-                        # / SQ_INST_CYCLES_* counters are in quad-cycles per SIMD, i.e. in CU-cycles once summed over a CU's 4 SIMDs
-                        va += float(v["SQ_INSTS_VALU"]); sa += float(v.get("SQ_INSTS_SALU", 0)); cyc += float(v["GRBM_GUI_ACTIVE"]) * 32
-                        vb += float(v.get("SQ_ACTIVE_INST_VALU", 0)); sb += float(v.get("SQ_INST_CYCLES_SALU", 0))
-                if cyc:
-                    issue = {"stale": json.load(open(mix)).get("_src_sha16") != sha, "valu_per_cycle_per_cu": round(va / cyc, 3), "salu_per_cycle_per_cu": round(sa / cyc, 3),
-                             "valu_busy": round(vb / cyc, 3), "salu_busy": round(sb / cyc, 3),
-                             "issue_frac": round(max(va, sa) / cyc / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
-                             "source": MIX_FILE + " (SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_ACTIVE_INST_VALU, SQ_INST_CYCLES_SALU over GRBM_GUI_ACTIVE/8 x 256 "
-                                       "CU-cycles, summed over the stage's kernels); peak = 1 VALU + 1 SALU wave-instruction per cycle per CU; "
-                                       "issue_frac is the busier of the two units"}
+                mj = json.load(open(mix))
+                issue_by_stage = {}
+                for stage_name in KERNELS:
+                    va = sa = vb = sb = cyc = 0.0
+                    for n, v in mj.items():
+                        if not isinstance(v, dict):
+                            continue
+                        if base(n) in STAGE_MEMBERS[stage_name] and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: CU-cycles of a launch = (GUI / 8) x 256 CUs.  The SQ_ACTIVE_INST_*
+                            # / SQ_INST_CYCLES_* counters are in quad-cycles per SIMD, i.e. in CU-cycles once summed over a CU's 4 SIMDs
+                            va += float(v["SQ_INSTS_VALU"]); sa += float(v.get("SQ_INSTS_SALU", 0)); cyc += float(v["GRBM_GUI_ACTIVE"]) * 32
+                            vb += float(v.get("SQ_ACTIVE_INST_VALU", 0)); sb += float(v.get("SQ_INST_CYCLES_SALU", 0))
+                    if cyc:
+                        issue_by_stage[stage_name] = {
+                            "valu_per_cycle_per_cu": round(va / cyc, 3), "salu_per_cycle_per_cu": round(sa / cyc, 3),
+                            "valu_busy": round(vb / cyc, 3), "salu_busy": round(sb / cyc, 3),
+                            "issue_frac": round(max(va, sa) / cyc / ISSUE_PEAK, 3), "peak": ISSUE_PEAK,
+                            "issue_frac_arch": round(va / cyc / ISSUE_PEAK_ARCH, 3), "peak_arch": ISSUE_PEAK_ARCH}
+                issue = dict(issue_by_stage.get(KERNELS[dom], {}), stale=mj.get("_src_sha16") != sha, by_stage=issue_by_stage,
+                             source=MIX_FILE + " (SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_ACTIVE_INST_VALU, SQ_INST_CYCLES_SALU over GRBM_GUI_ACTIVE/8 x 256 "
+                                    "CU-cycles, summed over each stage's kernels); `peak` = 1 VALU + 1 SALU wave-instruction per cycle per CU (what a mixed "
+                                    "stream reaches: every VALU instruction then costs the half-rate slot), `issue_frac` the busier of the two units "
+                                    "against it; `peak_arch` = 2 VALU per cycle per CU (MI355X_MICROARCH.md, pure full-rate streams only), "
+                                    "`issue_frac_arch` the VALU rate against that")
             except Exception:
                 pass
         out = {
@@ -635,6 +860,10 @@ def main():
             "value": round(total * args.steps / dt, 1), "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "blocks": {"ms_per_step": [round(x, 4) for x in block_ms], "median_ms_per_step": round(float(np.median(block_ms)), 4),
+                       "min_ms_per_step": round(min(block_ms), 4), "value_median": round(total / (float(np.median(block_ms)) * 1e-3), 1),
+                       "value_best": round(total / (min(block_ms) * 1e-3), 1),
+                       "note": "`value` is the first block (exactly --steps steps, barrier + synchronize on both sides); the other blocks are bracketed the same way"},
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s x %s reads x %d bp, K=%d, err %g (SURVEY 8d generator, seed 0x1DE10BE^%d)"
                                    % (args.config, ("%d regions in total" % total) if strong else ("%d regions/GPU" % R),
@@ -647,7 +876,7 @@ def main():
                        if strong else "%d sub-batch%s of consecutive regions per step, each on its own stream" % (S, "es" if S > 1 else ""),
                        "regions_per_gpu": R, "regions_total": total,
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
-                                    "records per step" + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},
+                                    "records per %s" % ("step" if strong else "timed block (the job's one gather at its end)") + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine3 + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
@@ -660,6 +889,7 @@ def main():
                          "whole_path": {"algorithmic_bytes_per_step": int(alg_bytes * world),
                                         "achieved": round(alg_bytes * world / (dt / args.steps) / 1e9, 2),
                                         "frac": round(alg_bytes * world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}},
+            "strong": strong_rec,
             "build": {"src_sha16": sha},
             "results": {"contigs": int(res.n_contigs), "events": int(res.n_events),
                         "tallied": int((res.events["status"] == 0).sum()),
@@ -725,7 +955,10 @@ def main():
         if not args.no_other and args.config == "C2" and not strong and world == 1 and not args.dup_frac and R == 10_000:
             # the other single-GPU configs of BASELINE.json, a few steps each, in the same record (never `value`)
             out["other_configs"] = {"C3": quick_config(api, "C3", 50_000, steps=4, warmup=1, check=not args.no_check),
-                                    "C5": quick_config(api, "C5", 10_000, steps=6, warmup=2, check=not args.no_check)}
+                                    "C5": quick_config(api, "C5", 10_000, steps=6, warmup=2, check=not args.no_check),
+                                    "dup10": quick_config(api, "C2", 10_000, steps=4, warmup=1, check=not args.no_check, dup_frac=0.1)}
+            out["mixed_stream"] = mixed_stream(api)
+            out["c1"] = c1_leg(api)
         if not args.no_cpu and world == 1:
             full = batch0
             out["cpu_baseline"] = cpu_baseline(full, K)

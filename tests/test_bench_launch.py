@@ -27,6 +27,17 @@ def test_gpus_flag_spawns_the_ranks():
     assert out["n_gpus"] == 3 and out["scaling"] == "strong" and out["regions_total"] == 1000
 
 
+def test_more_than_one_gpu_and_no_config_attaches_the_strong_scaling_leg():
+    """VERDICT r3 6(e): one `--gpus N` invocation yields the weak C2 line AND north_star's strong-scaling number (C4 generator);
+    naming a config keeps it to that config.  The dry run walks through the shard bounds and the gather of both."""
+    out = _run(["--gpus", "2", "--dry-run", "--strong-regions", "5000"])
+    assert out["scaling"] == "weak" and out["strong"] == {"config": "C4", "scaling": "strong", "regions_total": 5000, "dry_run": True}
+    out = _run(["--gpus", "2", "--dry-run", "--config", "C2"])
+    assert out["strong"] is None
+    out = _run(["--dry-run"])
+    assert out["strong"] is None
+
+
 def test_single_rank_needs_no_launcher():
     out = _run(["--dry-run"])
     assert out["n_gpus"] == 1 and out["launched_by"] == "external launcher"
