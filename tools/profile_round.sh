@@ -35,6 +35,29 @@ python3 bench.py --knob asm_v1=1 --no-cpu --no-e2e --no-check --no-other >> $OUT
 python3 bench.py --config C3 --knob no_rich=1 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --scaling strong --config C4 --regions 1250000 --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/c4_strong_1gpu.json 2>> $OUT/err
 timeout 120 tools/ubench_issue.bin > $OUT/ubench_issue.txt 2>&1
+timeout 120 tools/ubench_ksw.bin > $OUT/ubench_ksw.txt 2>&1
+# what the compiler gave every kernel (registers, spills, scratch, LDS) -- from THESE sources, with their hash in the first line
+python3 - <<'PY' > $OUT/resource_usage.txt 2> $OUT/resource_usage.err
+import os, re, subprocess, sys
+sys.path.insert(0, ".")
+import bench
+inc, src = "include", "indelope_amd/csrc"
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", inc, "-I", src, "-Wno-unused-function",
+                    "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/ihp_ru.so", src + "/indelope_hip.hip"], capture_output=True, text=True)
+print("src_sha16 %s  (hipcc -O3 -Rpass-analysis=kernel-resource-usage over indelope_amd/csrc/indelope_hip.hip)" % bench.src_sha16())
+cur = None
+for ln in r.stderr.splitlines():
+    m = re.search(r"remark: [^:]+:\d+:\d+: (.*) \[-Rpass-analysis", ln)
+    if not m:
+        continue
+    t = m.group(1).strip()
+    if t.startswith("Function Name:"):
+        cur = t.split(":", 1)[1].strip()
+        p = subprocess.run(["c++filt", cur], capture_output=True, text=True) if os.path.exists("/usr/bin/c++filt") else None
+        print("\n" + (p.stdout.strip() if p and p.stdout.strip() else cur))
+    elif cur:
+        print("    " + t)
+PY
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --no-cpu --no-e2e --no-other --no-check --profile --sub-batches 1 > $OUT/c2_phase_cycles.json 2>> $OUT/err
 python3 bench.py --config C5 --no-cpu --no-e2e --no-other --no-check --profile --sub-batches 1 > $OUT/c5_phase_cycles.json 2>> $OUT/err
