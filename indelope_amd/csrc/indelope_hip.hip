@@ -75,6 +75,7 @@ struct Knobs {
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
 	int ksw_pair = 1;      // 0: every alignment through the single sweep (no k_ksw_plan / k_ksw_pair launches)
+	int fb_duo = 1;        // 0: the alignment fallback runs its two alignments one after the other (ksw_wide.h) instead of in one sweep (ksw_duo.h)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
 	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
 	int profile = 0;       // 1: kernels sum shader-clock cycles per phase (ihp_batch_profile)
@@ -513,7 +514,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -1451,6 +1452,10 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		size_t lneed = ksw_lds_bytes(ql, tt);                        // the generic LDS sweep always fits this
 		if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<3>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<3>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
 		else if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<6>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<6>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
+		if (ksw_duo_ok(FP, std::min(ql, 64 * DUO_NS), tt, tt)) {        // both alignments of an item in one sweep (ksw_duo.h)
+			lneed = std::max(lneed, ksw_duo_lds_bytes(tt));
+			b->fb_p_cap = std::max(b->fb_p_cap, ksw_duo_p_bytes(std::min(ql, 64 * DUO_NS), tt));
+		}
 		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
 		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(16, g.max_lds / (b->lds_fb + 256))));
 	}
@@ -1857,6 +1862,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.p_scratch = b->fb_p_scratch.as<uint8_t>(); a.p_cap = b->fb_p_cap;
 		a.cig_tmp = b->fb_cig_tmp.as<uint32_t>(); a.cig_cap = b->fb_cig_cap;
 		a.overflow = misc + M_OVF; a.work_counter = wq + 9 * WQ_WORDS;
+		a.duo = g_knob.fb_duo;
 		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
 		HIPC(hipGetLastError());
 	}

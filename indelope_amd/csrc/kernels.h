@@ -5,6 +5,7 @@
 #include "ksw_dev.h"
 #include "ksw_narrow.h"
 #include "ksw_pair.h"
+#include "ksw_duo.h"
 #include "ksw_wide.h"
 #include "tally_dev.h"
 #include "roi_dev.h"
@@ -1033,6 +1034,7 @@ struct FbArgs {
 	int *overflow;                             // [1] LDS / traceback scratch budget
 	int *work_counter;
 	unsigned long long *t_start;               // optional: see mark_start()
+	int duo;                                   // 1: items that fit it take the two-target sweep (ksw_duo.h)
 };
 
 // count_flanked_cigar (indelope.nim:185-199) over Ez.cigar (ksw2.nim:22-33); wave-uniform
@@ -1119,7 +1121,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		const bool wide_ok = !(a.P.flag & KSW_EZ_RIGHT);
 		int cnt[2];
 		bool over = false;
-		for (int side = 0; side < 2; ++side) {
+		// both alignments in one sweep (ksw_duo.h) when the item is the usual kind: a read of at most 192 bases, both strings non-empty
+		bool duo = false;
+		if (a.duo && rl > 0 && rsub > 0 && csub > 0 && ksw_duo_ok(a.P, rl, rsub, csub) &&
+		    ksw_duo_lds_bytes(tmax) <= (size_t)a.lds_budget && ksw_duo_p_bytes(rl, tmax) <= a.p_cap) {
+			DuoResult R;
+			duo = ksw_duo_sweep(qy, rl, a.ref_bases + uni(jb.t_off) + start, rsub, a.out_seq + uni(jb.q_off) + start, csub, a.P, lds, p, R);
+			if (duo) {
+				KswOut o;
+				ksw_duo_cigar<0>(R, p, rl, rsub, a.P.w, a.P.flag, ct, a.cig_cap, o);
+				WSYNC();
+				cnt[0] = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;
+				WSYNC();
+				ksw_duo_cigar<1>(R, p, rl, csub, a.P.w, a.P.flag, ct, a.cig_cap, o);
+				WSYNC();
+				cnt[1] = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;
+				WSYNC();
+			}
+		}
+		for (int side = 0; side < 2 && !duo; ++side) {
 			const int tl = side ? csub : rsub;
 			const uint8_t *tg = side ? a.out_seq + uni(jb.q_off) + (csub ? start : 0) : a.ref_bases + uni(jb.t_off) + (rsub ? start : 0);
 			KswOut o;

@@ -88,7 +88,7 @@ __device__ __forceinline__ int sext8(unsigned v) { return (int)(signed char)(v &
 // ballot gives the length of the run, so a CIGAR of n ops costs O(n + len/64) round trips to HBM.
 // PACKED 1: p is ksw_narrow.h's slot matrix (80 dwords per slot, a nibble of four compare bits per cell, eight diagonals per
 // dword) instead of the reference's n_col*16 bytes per diagonal; 2: ksw_pair.h's (four diagonals per 16-bit half, HALF = this
-// alignment's half).
+// alignment's half); 3: ksw_duo.h's (one byte per (diagonal, QUERY position): a nibble per alignment, ncol = bytes per diagonal).
 template <int PACKED = 0, int HALF = 0>
 __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, int tlen, int w, int flag,
                                           int zdropped, int ez_max_t, int ez_max_q,
@@ -120,7 +120,10 @@ __device__ inline void ksw_backtrack_wave(const uint8_t *p, int ncol, int qlen, 
 			unsigned tmp = 0;
 			if (force_state < 0) {
 				if (!PACKED) tmp = p[(size_t)rr * ncol + ik - st];
-				else {
+				else if (PACKED == 3) {
+					const unsigned nib = (unsigned)p[(size_t)rr * ncol + jk] >> (4 * HALF) & 15u;
+					tmp = ((nib & 1) ? 2u : ((nib >> 1) & 1u)) | ((nib & 12) << 1);
+				} else {
 					const unsigned nib = PACKED == 1 ? ((const unsigned *)p)[(size_t)((rr >> 3) + (st >> 4)) * 80 + (ik - st)] >> (4 * (7 - (rr & 7))) & 15u
 					                                 : ((const unsigned *)p)[(size_t)((rr >> 2) + (st >> 4)) * 80 + (ik - st)] >> (16 * HALF + 4 * (3 - (rr & 3))) & 15u;
 					if (PACKED == 1) tmp = ((nib & 4) ? 2u : (nib >> 3)) | ((nib & 2) << 2) | ((nib & 1) << 4);

@@ -199,6 +199,30 @@ def test_a_slab_layout_that_is_not_the_librarys_is_refused(hip, oracle):
         slab.free()
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(n_regions=60, n_reads=(24, 64), err_rate=1e-3, config_id=141, dup_frac=0.6),
+    dict(n_regions=40, read_len=100, n_reads=(20, 60), err_rate=2e-3, config_id=142, K=21, dup_frac=0.8),
+    dict(n_regions=40, read_len=192, n_reads=(16, 48), err_rate=5e-3, config_id=143, K=31, dup_frac=0.7, window_len=590),   # the longest read the sweep takes
+    dict(n_regions=40, read_len=193, n_reads=(16, 48), err_rate=1e-3, config_id=144, K=31, dup_frac=0.7, window_len=590),   # one more: ksw_wide.h
+    dict(n_regions=50, n_reads=(8, 40), err_rate=2e-2, config_id=145, dup_frac=0.9),
+])
+@pytest.mark.parametrize("scoring", [dict(), dict(fb_match=2, fb_mismatch=-4, fb_gap_open=7, fb_gap_ext=2), dict(fb_flag=0xc0)])
+def test_fallback_two_target_sweep_matches_oracle_and_single_sweeps(hip, oracle, cfg, scoring):
+    """the two alignments of a fallback item (read vs window, read vs contig; indelope.nim:336-344) share one
+    sweep (ksw_duo.h).  Same votes as the oracle and as the one-at-a-time sweeps, whatever the read length and the scoring."""
+    b, _ = synth.generate(**cfg)
+    K = cfg.get("K", 27)
+    want = oracle.run_regions(b, oracle.params(K=K, **scoring))
+    try:
+        for duo in (1, 0):
+            hip.debug_set(fb_duo=duo)
+            assert_same(hip.run_regions(b, hip.params(K=K, **scoring)), want)
+    finally:
+        hip.debug_set()
+    if cfg["config_id"] in (141, 143):
+        assert np.count_nonzero(want.events["fallback_needed"]) > 0           # the case exists in what was compared
+
+
 def test_stress_tools_with_todays_seeds():
     """The randomised harnesses under tools/ found every device bug of round 3 and none of the fixed-seed tests did: a bounded
     pass of each (fresh seed from the date, a few seconds apiece) runs where the driver can see it.  The seed is printed on
@@ -207,7 +231,7 @@ def test_stress_tools_with_todays_seeds():
     seed = day.year * 10000 + day.month * 100 + day.day
     env = dict(os.environ, PYTHONPATH=ROOT)
     jobs = [("ksw_pair_stress.py", [str(seed), "12"]), ("ksw_stress.py", [str(seed), "4"]), ("stress_parity.py", ["16", str(seed), "params"]),
-            ("thread_stress.py", ["3", "6", str(seed)]), ("sweep_stress.py", ["3", str(seed)])]
+            ("thread_stress.py", ["3", "6", str(seed)]), ("sweep_stress.py", ["3", str(seed)]), ("fb_stress.py", [str(seed), "8"])]
     t0 = time.time()
     for tool, args in jobs:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
