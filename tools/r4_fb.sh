@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 ARGS="--no-cpu --no-e2e --no-check --no-other --dup-frac 0.1 --steps 3 --warmup 1"
 O=gpurun_out/fb; rm -rf $O; mkdir -p $O
-python3 bench.py $ARGS > $O/plain.log 2>&1; tail -1 $O/plain.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["kernel_ms"])"
+python3 bench.py $ARGS > $O/plain.log 2>&1; tail -1 $O/plain.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_ms'])"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS > $O/kt.log 2>&1
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats.csv; head -8 $O/kernel_stats.csv | cut -c1-150
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $O/g1 -- python3 bench.py $ARGS > $O/g1.log 2>&1
