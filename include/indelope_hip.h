@@ -509,6 +509,8 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path
  *   "tally_pk" 0    k_tally on the ASCII bases even when the 2-bit reads are at hand
  *   "lpt" 0         k_asm_combine3 in input order: no cost classes, no arena tiers
+ *   "prepack_fast" n  0: the plain k_prepack for every batch; 1..4: reads per 16-lane group the pipelined k_prepack_fast keeps in
+ *                   flight (default 2; taken when the bases are ASCII and the batch brought its trim bounds)
  *   "fb_duo" 0      the alignment fallback runs the two alignments of an item one after the other (ksw_wide.h) instead of in one
  *                   sweep (ksw_duo.h); same votes
  *   "ksw_pair" 0    every ksw2 alignment through the single sweep (default: jobs of equal contig length share a wavefront where

@@ -147,6 +147,105 @@ __global__ __launch_bounds__(64) void k_prepack(const PrepackArgs a)
 	}
 }
 
+// The same for the usual batch -- ASCII bases, trim bounds from the stager -- as a software pipeline.  k_prepack's iteration is
+// two dependent round trips to HBM (a read's offsets, then its bases) with four reads of 150 bytes in flight per wave: at
+// 32 waves per CU and ~3 us per iteration that is the 1.5 TB/s it ran at, whatever the grid.  Here a wave has the bases of
+// iteration i+1 and the offsets and bounds of iteration i+2 in flight while it packs iteration i.
+// Every load of the loop is unconditional (indices clamped into the arrays) and nothing is computed from a loaded value before
+// the top of the next iteration: the loop has ONE wait, and what it waits for has had a whole iteration to arrive.
+struct PrepackRaw { long long off0, off1; };
+__device__ __forceinline__ PrepackRaw prepack_raw(const PrepackArgs &a, long long ri)
+{
+	const long long rc = ri < a.n_reads ? ri : a.n_reads - 1;
+	PrepackRaw m;
+	m.off0 = a.read_off[rc]; m.off1 = a.read_off[rc + 1];
+	return m;
+}
+struct PrepackRead { long long off; int len; };
+__device__ __forceinline__ PrepackRead prepack_read(const PrepackRaw &m) { PrepackRead r; r.off = m.off0; r.len = (int)(m.off1 - m.off0); return r; }
+struct PrepackData { unsigned w[4]; };
+__device__ __forceinline__ PrepackData prepack_data(const PrepackArgs &a, const PrepackRead &m, int sub)
+{   // dwords [4 sub, 4 sub + 4) of the read's bytes (lanes past the read load its first ones; like k_prepack, the last group may
+	// reach up to 15 bytes past the read: masked when it is packed)
+	const uint8_t *p = a.bases + m.off + (16 * sub < m.len ? 16 * sub : 0);
+	PrepackData d;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) d.w[k] = *(const u32_unaligned_t *)(p + 4 * k);
+	return d;
+}
+__device__ __forceinline__ unsigned prepack_words(const unsigned (&w)[4], int rem, unsigned &diff)
+{   // sixteen ASCII bases -> one dword; rem: how many of them belong to the read (>= 1)
+	unsigned out = 0, df = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		unsigned dk = 0;
+		const unsigned y = pack4(w[k], dk);
+		const int v = rem - 4 * k;
+		if (v < 4) dk &= v <= 0 ? 0u : (1u << (8 * v)) - 1u;
+		df |= dk;
+		out |= y << (8 * k);
+	}
+	if (rem < 16) out &= (1u << (2 * rem)) - 1u;
+	diff |= df;
+	return out;
+}
+
+// U reads per 16-lane group and iteration (4 U per wave).  The kept ranges are a map over the reads of their own (lane <-> read,
+// coalesced) in front of the pipeline, which then carries a read's offset and length and nothing else.
+template <int U>
+__global__ __launch_bounds__(64) void k_prepack_fast(const PrepackArgs a)
+{
+	const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+	if (a.t_start && blockIdx.x == 0 && threadIdx.x == 0) *a.t_start = (unsigned long long)wall_clock64();
+	for (long long ri = (long long)blockIdx.x * 64 + lane; ri < a.n_reads; ri += (long long)gridDim.x * 64) {
+		const int len = (int)(a.read_off[ri + 1] - a.read_off[ri]);
+		int lo = a.trim_lo_in[ri], hi = a.trim_hi_in[ri];
+		lo = lo < 0 ? 0 : lo > len ? len : lo;
+		hi = hi > len ? len : hi; hi = hi < lo ? lo : hi;
+		a.trim_lo[ri] = lo; a.trim_hi[ri] = hi;
+	}
+	const long long stride = (long long)gridDim.x * 4 * U;
+	long long i0 = (long long)blockIdx.x * 4 * U;
+	if (i0 >= a.n_reads) return;
+	PrepackRead cur[U], nxt[U];
+	PrepackRaw nn[U];
+	PrepackData dcur[U];
+#pragma unroll
+	for (int u = 0; u < U; ++u) cur[u] = prepack_read(prepack_raw(a, i0 + 4 * u + grp));
+#pragma unroll
+	for (int u = 0; u < U; ++u) { nn[u] = prepack_raw(a, i0 + stride + 4 * u + grp); dcur[u] = prepack_data(a, cur[u], sub); }
+	for (; i0 < a.n_reads; i0 += stride) {
+		PrepackData dnxt[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) { nxt[u] = prepack_read(nn[u]); dnxt[u] = prepack_data(a, nxt[u], sub); }
+#pragma unroll
+		for (int u = 0; u < U; ++u) nn[u] = prepack_raw(a, i0 + 2 * stride + 4 * u + grp);
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const long long ri = i0 + 4 * u + grp;
+			const bool live = ri < a.n_reads;
+			const int len = live ? cur[u].len : 0;
+			unsigned diff = 0;
+			const long long pkb = (cur[u].off >> 4) + ri;
+			const int nd = (len + 15) >> 4;
+			if (sub < nd) a.pk[pkb + sub] = prepack_words(dcur[u].w, len - 16 * sub, diff);
+			if (nd > 16) {                                       // reads longer than 256 bases: the rest as it comes
+				for (int d = sub + 16; d < nd; d += 16) {
+					unsigned w[4];
+					const uint8_t *p = a.bases + cur[u].off + 16 * d;
+#pragma unroll
+					for (int k = 0; k < 4; ++k) w[k] = *(const u32_unaligned_t *)(p + 4 * k);
+					a.pk[pkb + d] = prepack_words(w, len - 16 * d, diff);
+				}
+			}
+			const unsigned long long bm = ballot(diff != 0);
+			if (live && sub == 0) a.read_bad[ri] = (uint8_t)(((bm >> (16 * grp)) & 0xffffull) != 0);
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) { cur[u] = nxt[u]; dcur[u] = dnxt[u]; }
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ bit helpers
 // bits [sh, sh + 32) of the 64-bit value hi:lo (sh in 0..31)
 __device__ __forceinline__ unsigned fsh(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }

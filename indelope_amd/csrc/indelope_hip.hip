@@ -75,6 +75,7 @@ struct Knobs {
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
 	int ksw_pair = 1;      // 0: every alignment through the single sweep (no k_ksw_plan / k_ksw_pair launches)
+	int prepack_fast = 2;  // 0: k_prepack for every batch; 1..4: k_prepack_fast<n> (n reads per 16-lane group in flight) when the bases are ASCII and the trim bounds came with the batch
 	int fb_duo = 1;        // 0: the alignment fallback runs its two alignments one after the other (ksw_wide.h) instead of in one sweep (ksw_duo.h)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
 	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
@@ -514,7 +515,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -1623,7 +1624,11 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			pa.trim_min_qual = p.trim_min_qual; pa.pk = b->v2_pk.as<uint32_t>(); pa.trim_lo = b->v2_trim_lo.as<int>();
 			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
 			pa.t_start = tm;                                       // the first launch of the stage
-			hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			if (g_knob.prepack_fast == 1 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<1>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else if (g_knob.prepack_fast == 2 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<2>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else if (g_knob.prepack_fast == 3 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<3>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else if (g_knob.prepack_fast == 4 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<4>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			HIPC(hipGetLastError());
 		}
 		if (side) {
