@@ -361,18 +361,27 @@ template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStr
 // at `cnt`, the pair launch's work queue at `wq_pair`; p_pair / ct_pair: traceback and CIGAR scratch of the pair launch
 // (p_cap_pair, a.cig_cap per workgroup).  Returns false when these parameters are not the pair sweep's (nothing launched).
 static bool ksw_pair_wanted(const KswParams &P, int mode) { return g_knob.ksw_pair && mode == 3 && ksw_pair_ok(P); }
+// plan: ints [n_cap: ranks | n_cap: singles | 2 n_cap: pairs]; zero: ints that are zero when the run starts
+// [PLAN_KEYS: jobs per contig length (or the job waiting at that length) | pairs | singles]
+struct PlanLists { int *count, *n_pairs, *n_singles, *rank, *singles; int2 *pairs; };
+static PlanLists plan_lists(int *plan, int n_cap, int *zero)
+{
+	PlanLists L;
+	L.count = zero; L.n_pairs = zero + PLAN_KEYS; L.n_singles = zero + PLAN_KEYS + 1;
+	L.rank = plan; L.singles = plan + n_cap; L.pairs = (int2 *)(plan + 2 * (size_t)n_cap + (n_cap & 1));
+	return L;
+}
 static int launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hipStream_t s, const KswArgs &a, int *plan, int n_cap, int *zero,
                               int *wq_pair, uint8_t *p_pair, size_t p_cap_pair, uint32_t *ct_pair,
                               hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr)
 {
-	// plan: ints [n_cap: ranks | n_cap: singles | 2 n_cap: pairs]; zero: ints that are zero when the run starts
-	// [PLAN_KEYS: jobs per contig length | pairs | singles]
+	const PlanLists L = plan_lists(plan, n_cap, zero);
 	KswPlanArgs pl;
 	pl.jobs = a.jobs; pl.n_jobs = a.n_jobs; pl.n_jobs_host = a.n_jobs_host; pl.P = a.P; pl.pair_on = 1;
 	pl.lds_budget = (int)lds_pair - 64; pl.p_cap = p_cap_pair;
-	pl.count = zero; pl.n_pairs = zero + PLAN_KEYS; pl.n_singles = zero + PLAN_KEYS + 1;
+	pl.count = L.count; pl.n_pairs = L.n_pairs; pl.n_singles = L.n_singles;
 	pl.t_start = a.t_start;
-	pl.rank = plan; pl.singles = plan + n_cap; pl.pairs = (int2 *)(plan + 2 * (size_t)n_cap + (n_cap & 1));
+	pl.rank = L.rank; pl.singles = L.singles; pl.pairs = L.pairs;
 	const dim3 pg(std::max(1, std::min(2 * g.cus, (n_cap + 255) / 256)));
 	hipLaunchKernelGGL(k_ksw_plan_count, pg, dim3(256), 0, s, pl);
 	hipLaunchKernelGGL(k_ksw_plan_place, pg, dim3(256), 0, s, pl);

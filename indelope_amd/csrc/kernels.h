@@ -12,6 +12,28 @@
 
 namespace ihp {
 
+// ------------------------------------------------------------------ helpers of the ksw2 plan (k_ksw_plan_*, below)
+constexpr int PLAN_KEYS = 4096;
+// the contig length under which a job may be paired (ksw_pair.h), or -1; lds_budget / p_cap: of the pair launch
+__device__ __forceinline__ int plan_key(const KswParams &P, int lds_budget, size_t p_cap, int qlen, int tlen, int flags)
+{
+	if (!(flags & ALN_Q_ACGT) || qlen >= PLAN_KEYS || !ksw_pair_job_ok(P, qlen, tlen)) return -1;
+	if (2 * ksw_pair_lds_share(qlen, tlen) > (size_t)lds_budget || ksw_pair_p_bytes(qlen, P.w) > p_cap) return -1;
+	return qlen;
+}
+// position of every lane with `take` in a list whose length is *cnt (one atomic per wavefront); -1 for the other lanes
+__device__ __forceinline__ int plan_append(int *cnt, bool take)
+{
+	const unsigned long long m = ballot(take);
+	if (!m) return -1;
+	const int lane = lane_id();
+	int base = 0;
+	if (lane == ctz64(m)) base = atomicAdd(cnt, popc64(m));
+	base = __builtin_amdgcn_readlane(base, ctz64(m));
+	return take ? base + popc64(m & ((1ull << lane) - 1)) : -1;
+}
+
+
 // ------------------------------------------------------------------ assemble
 struct AsmArgs {
 	int n_regions;
@@ -497,31 +519,48 @@ __device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ct
 				for (int j = 0; j < 3; ++j) if (i + j < len) { oseq[i + j] = (uint8_t)(w >> (8 * j)); osup[i + j] = (sv >> (8 * j)) & 0xffu; }
 			}
 		}
-		if (lane == 0) {
+		cursor += len;
+	}
+	// The contigs' records and alignment jobs, lane k <-> final contig k (at most 64): one atomic per region for the job slots
+	// (per job it was a dependent round trip to L2 in the one lane that did this, and 200 000 requests to one address).
+	long long carry = 0;                                                // bases of the contigs before k0
+	for (int k0 = 0; k0 < n_final; k0 += 64) {
+		const int k = k0 + lane;
+		const bool mine = k < n_final;
+		const int c = mine ? (int)S.listA[k] : 0;
+		const int len = mine ? S.len[c] : 0;
+		const long long mycur = carry + (long long)(wave_scan_add((unsigned)len) - (unsigned)len);
+		carry += wave_sum_i(len);
+		const long long slot = r0 + k;
+		int flags = 0; long long rs = 0, beg = 0; int rl = 0;
+		bool job = false;
+		if (mine) {
 			const long long cstart = S.start[c], cn = S.nreads[c];
 			a.ctg_start[slot] = cstart; a.ctg_nreads[slot] = cn; a.ctg_len[slot] = len;
-			a.ctg_seq_off[slot] = seq_base + cursor;
-			int flags = 0; long long rs = 0; int rl = 0;
+			a.ctg_seq_off[slot] = seq_base + mycur;
 			if (n_pre <= a.max_pre_contigs && cn >= a.min_reads && len >= a.min_ctg_len) {   // :209-211
 				const long long max_stop = cstart > mstop ? cstart : mstop;
-				long long beg = cstart - origin, end = max_stop + width + a.ref_pad - origin;   // :220, faidx clamping
+				long long end = max_stop + width + a.ref_pad - origin;      // :220, faidx clamping
+				beg = cstart - origin;
 				int clamped = 0;
 				if (end < beg) { beg = end; clamped = 1; }
 				if (beg < 0) { beg = 0; clamped = 1; } else if (L <= beg) { beg = L - 1; clamped = 1; }
 				if (end < 0) { end = 0; clamped = 1; } else if (L <= end) { end = L - 1; clamped = 1; }
-				long long reflen = L > 0 ? end - beg + 1 : 0;
+				const long long reflen = L > 0 ? end - beg + 1 : 0;
 				if (L <= 0) { beg = 0; clamped = 1; }
 				flags = IHP_ALN_DONE | (clamped ? IHP_ALN_REF_CLAMPED : 0);
 				rs = origin + beg; rl = (int)reflen;
-				const int j = atomicAdd(a.n_jobs, 1);
-				AlnJob jb;
-				jb.q_off = seq_base + cursor; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
-				jb.out = (int)slot; jb.region = r; jb.flags = ALN_Q_ACGT; jb.pad_ = 0;   // 2-bit packed contigs; enc_base() folds the window
-				a.jobs[j] = jb;
+				job = true;
 			}
 			a.aln_flags[slot] = flags; a.aln_ref_start[slot] = rs; a.aln_ref_len[slot] = rl;
 		}
-		cursor += len;
+		const int j = plan_append(a.n_jobs, job);
+		if (job) {
+			AlnJob jb;
+			jb.q_off = seq_base + mycur; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
+			jb.out = (int)slot; jb.region = r; jb.flags = ALN_Q_ACGT; jb.pad_ = 0;   // 2-bit packed contigs; enc_base() folds the window
+			a.jobs[j] = jb;
+		}
 	}
 	if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
 }
@@ -777,25 +816,10 @@ struct KswPlanArgs {
 	int2 *pairs; int *n_pairs; int *singles; int *n_singles;
 	unsigned long long *t_start;               // optional: see mark_start() (the ksw2 stage begins with its plan)
 };
-constexpr int PLAN_KEYS = 4096;
 
 __device__ __forceinline__ int ksw_plan_key(const KswPlanArgs &a, int qlen, int tlen, int flags)
 {
-	if (!a.pair_on || !(flags & ALN_Q_ACGT) || qlen >= PLAN_KEYS || !ksw_pair_job_ok(a.P, qlen, tlen)) return -1;
-	if (2 * ksw_pair_lds_share(qlen, tlen) > (size_t)a.lds_budget || ksw_pair_p_bytes(qlen, a.P.w) > a.p_cap) return -1;
-	return qlen;
-}
-
-// position of every lane with `take` in a list whose length is *cnt (one atomic per wavefront); -1 for the other lanes
-__device__ __forceinline__ int plan_append(int *cnt, bool take)
-{
-	const unsigned long long m = ballot(take);
-	if (!m) return -1;
-	const int lane = lane_id();
-	int base = 0;
-	if (lane == ctz64(m)) base = atomicAdd(cnt, popc64(m));
-	base = __builtin_amdgcn_readlane(base, ctz64(m));
-	return take ? base + popc64(m & ((1ull << lane) - 1)) : -1;
+	return a.pair_on ? plan_key(a.P, a.lds_budget, a.p_cap, qlen, tlen, flags) : -1;
 }
 
 __global__ __launch_bounds__(256) void k_ksw_plan_count(const KswPlanArgs a)
@@ -808,7 +832,23 @@ __global__ __launch_bounds__(256) void k_ksw_plan_count(const KswPlanArgs a)
 		const int j = j0 + tid;
 		int key = -1;
 		if (j < n) key = ksw_plan_key(a, a.jobs[j].qlen, a.jobs[j].tlen, a.jobs[j].flags);
-		if (key >= 0) a.rank[j] = atomicAdd(a.count + key, 1);
+		// one atomic per (wavefront, contig length), all of a wavefront's side by side: the lanes of a length rank themselves
+		// behind their first lane's result (a length that a fifth of the batch shares is otherwise one address taking 40 000 requests)
+		{
+			const int lane = (int)(threadIdx.x & 63);
+			bool todo = key >= 0;
+			int leader = lane, rk = 0, cnt = 0;
+			while (const unsigned long long t = ballot(todo)) {
+				const int lead = ctz64(t);
+				const int k = __builtin_amdgcn_readlane(key, lead);
+				const unsigned long long m = ballot(todo && key == k);
+				if (todo && key == k) { leader = lead; rk = popc64(m & ((1ull << lane) - 1)); cnt = popc64(m); todo = false; }
+			}
+			int base = 0;
+			if (key >= 0 && leader == lane) base = atomicAdd(a.count + key, cnt);
+			base = __builtin_amdgcn_ds_bpermute(leader << 2, base);
+			if (key >= 0) a.rank[j] = base + rk;
+		}
 		const int ss = plan_append(a.n_singles, j < n && key < 0);
 		if (ss >= 0) a.singles[ss] = j;
 	}
