@@ -37,7 +37,8 @@ names = {"c2_kernel_stats.csv": "c2_kernel_stats.csv", "c2_pmc.json": "c2_pmc.js
          "other_workloads.jsonl": "other_workloads.jsonl", "c4_strong_1gpu.json": "c4_strong_1gpu.json",
          "ubench_issue.txt": "ubench_issue.txt", "c2_phase_cycles.json": "c2_phase_cycles.json",
          "c5_phase_cycles.json": "c5_phase_cycles.json", "resource_usage.txt": "resource_usage.txt", "ubench_ksw.txt": "ubench_ksw.txt",
-         "ksw_pair_pmc.json": "ksw_pair_pmc.json"}
+         "ksw_pair_pmc.json": "ksw_pair_pmc.json", "ksw_pair_pmc.txt": "ksw_pair_pmc.txt", "dup10_kernel_stats.csv": "dup10_kernel_stats.csv",
+         "dup10_pmc_mix.json": "dup10_pmc_mix.json", "dup10_summary.txt": "dup10_summary.txt", "prepack_compare.txt": "prepack_compare.txt"}
 refused = 0
 for a, b in names.items():
     p = os.path.join(src, a)

@@ -87,6 +87,28 @@ for k, v in raw.items():
                          "launches_averaged": v.get("_launches")}
 json.dump(out, open("gpurun_out/prof/c2_pmc.json", "w"), indent=1)
 PY
+# round 4: the alignment fallback under load (C2 with 10 % duplications), k_prepack vs k_prepack_fast, the pair sweep's instruction mix
+bash tools/r4_fb.sh > $OUT/dup10_summary.txt 2>&1
+cp gpurun_out/fb/kernel_stats.csv $OUT/dup10_kernel_stats.csv; cp gpurun_out/fb/mix.json $OUT/dup10_pmc_mix.json
+KS="0 2" bash tools/r4_prepack.sh > $OUT/prepack_compare.txt 2>&1
+bash tools/r4_kpmc.sh > $OUT/ksw_pair_pmc.txt 2>&1
+cp gpurun_out/kp/mix.json $OUT/ksw_pair_pmc.json
+python3 - <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import bench
+sha = bench.src_sha16()
+for f in ("gpurun_out/prof/dup10_pmc_mix.json", "gpurun_out/prof/ksw_pair_pmc.json"):
+    try:
+        m = json.load(open(f)); m["_src_sha16"] = sha; json.dump(m, open(f, "w"), indent=1)
+    except Exception as e:
+        print("stamp", f, e)
+for f in ("gpurun_out/prof/dup10_summary.txt", "gpurun_out/prof/prepack_compare.txt", "gpurun_out/prof/ksw_pair_pmc.txt"):
+    try:
+        t = open(f).read(); open(f, "w").write("src_sha16 %s\n" % sha + t)
+    except Exception as e:
+        print("stamp", f, e)
+PY
 # the raw rocprofv3 output directories are large (gpurun merges at most 64 MiB back): keep the summaries only
 rm -rf $OUT/c2 $OUT/steady100k $OUT/c3 $OUT/c5 $OUT/fetch $OUT/write gpurun_out/pmc_mix/g1 gpurun_out/pmc_mix/g2 gpurun_out/pmc_mix/g3
 du -sh gpurun_out
