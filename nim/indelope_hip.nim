@@ -171,6 +171,22 @@ proc ihp_batch_pack_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, bytes: ptr int64
 proc ihp_unpack_slab*(slab: pointer, bytes: int64, counts: ptr int64, error: float64, outp: ptr IhpBatchOut): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_summary_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_summary_host*(b: ptr IhpBatch, outp: ptr IhpRegionSummary, cap: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+# one page-locked slab per batch (4-bit bases as BAM stores them, trim bounds): the sections' offsets, the upload, what a fetch returns
+type IhpSlabLayout* {.importc: "ihp_slab_layout", header: "indelope_hip.h", bycopy.} = object
+  region_read_off*, read_off*, read_start*, read_stop*, ref_off*, ref_origin*: int64
+  trim_lo*, trim_hi*, mapq*, read_skip*, ref_bases*, bases4*, bytes*: int64
+proc ihp_slab_layout_for*(n_regions: int32, n_reads, n_bases, n_ref: int64, outp: ptr IhpSlabLayout): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_upload_slab*(p: ptr IhpParams, n_regions: int32, n_reads: int64, slab: pointer, layout: ptr IhpSlabLayout,
+                            flags: int32, b: ptr ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_set_fetch*(b: ptr IhpBatch, flags: int32): cint {.importc, cdecl, header: "indelope_hip.h".}
+# timing and diagnostics (what bench.py and the tests read; a caller needs none of them)
+proc ihp_batch_set_timing*(b: ptr IhpBatch, on: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_kernel_ms*(b: ptr IhpBatch, ms: ptr cfloat): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_kernel_ms_mean*(b: ptr IhpBatch, ms: ptr cfloat, n_runs: ptr int64, reset: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_profile_n*(b: ptr IhpBatch, outp: ptr int64, cap: int32): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_debug_set*(key: cstring, value: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_debug_last_ksw_mode*(): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_debug_last_ksw_pairs*(): cint {.importc, cdecl, header: "indelope_hip.h".}
 
 proc ihp_init*(device: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_strerror*(code: cint): cstring {.importc, cdecl, header: "indelope_hip.h".}
