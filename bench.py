@@ -583,6 +583,8 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 / dup10 legs (`other_configs`), `mixed_stream` and `c1` of the default run")
     ap.add_argument("--strong-regions", type=int, default=1_250_000,
                     help="regions of the attached strong-scaling leg (C4 generator; 5 000 000 = all of BASELINE configs[3])")
+    ap.add_argument("--lockstep", action="store_true", help="weak mode: wait for every sub-batch of a step before the next step starts (rounds 1-3); default: a sub-batch "
+                    "is run again as soon as its own last run is done")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counters of the kernels (ihp_debug_set profile) in `profile_cycles`")
     ap.add_argument("--knob", action="append", default=[], metavar="KEY=VALUE",
                     help="library path / occupancy switches (ihp_debug_set), e.g. --knob asm_v1=1; results do not depend on them")
@@ -712,11 +714,20 @@ def main():
             api.batch_sync(hs[-1])
             if stream_outputs:
                 api.batch_release_outputs(hs[-1])
-        else:
+        elif args.lockstep:
             for h in hs:
                 api.batch_run(h)                             # asynchronous: the sub-batches' launch chains overlap
             for h in hs:
                 api.batch_sync(h)
+        else:
+            # every sub-batch is run again as soon as ITS last run is done (run -> sync -> run per batch, the others in flight
+            # meanwhile): no step waits for the slowest chain of the step before it, and the chains drift apart so that one's
+            # assembly overlaps the other's alignments.  block() waits for everything before the clock stops.
+            for i, h in enumerate(hs):
+                if pending.get(i):
+                    api.batch_sync(h)
+                api.batch_run(h)
+                pending[i] = True
         if use_dist and strong:
             gather()                                         # strong scaling: the job IS one pass, its gather belongs to the step
 
@@ -733,11 +744,17 @@ def main():
                 slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
                 last_payload[0] = idist.gather_payload(slab, counts, rank, world, dst=0, force=True)
 
+    pending = {}
+
     def block(n):
         # weak scaling: every rank walks through its own batches; the real job gathers ONCE at its end, so a timed
         # block ends with one gather, not one per step (round 3 synchronised all ranks after every 1.8 ms step for no reason)
         for _ in range(n):
             step()
+        for i, h in enumerate(hs):                           # (pipelined steps: the last runs of the block)
+            if pending.get(i):
+                api.batch_sync(h)
+                pending[i] = False
         if use_dist and not strong:
             gather()
 
@@ -873,7 +890,9 @@ def main():
                        "read_trim": "device, from base qualities" if args.quals else "stager (trim bounds in the batch)",
                        "submission": ("%d resident chunk%s of <= %d regions per rank, one after the other%s"
                                       % (S, "s" if S > 1 else "", args.chunk, "; one chunk's results kept at a time" if stream_outputs else ""))
-                       if strong else "%d sub-batch%s of consecutive regions per step, each on its own stream" % (S, "es" if S > 1 else ""),
+                       if strong else "%d sub-batch%s of consecutive regions per step, each on its own stream; %s"
+                                      % (S, "es" if S > 1 else "", "a step waits for all of them (--lockstep)" if args.lockstep else
+                                         "a sub-batch is run again as soon as its own last run is done (run, sync, run per batch), every run waited for before the clock stops"),
                        "regions_per_gpu": R, "regions_total": total,
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
                                     "records per %s" % ("step" if strong else "timed block (the job's one gather at its end)") + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},

@@ -361,14 +361,15 @@ template <class... Args> void launch_ksw(int mode, dim3 grid, size_t lds, hipStr
 // at `cnt`, the pair launch's work queue at `wq_pair`; p_pair / ct_pair: traceback and CIGAR scratch of the pair launch
 // (p_cap_pair, a.cig_cap per workgroup).  Returns false when these parameters are not the pair sweep's (nothing launched).
 static bool ksw_pair_wanted(const KswParams &P, int mode) { return g_knob.ksw_pair && mode == 3 && ksw_pair_ok(P); }
-// plan: ints [n_cap: ranks | n_cap: singles | 2 n_cap: pairs]; zero: ints that are zero when the run starts
-// [PLAN_KEYS: jobs per contig length (or the job waiting at that length) | pairs | singles]
-struct PlanLists { int *count, *n_pairs, *n_singles, *rank, *singles; int2 *pairs; };
+// plan: ints [n_cap: ranks | n_cap: singles | 2 n_cap: pairs | PLAN_KEYS: first pair of a length]; zero: ints that are zero when the run starts
+// [PLAN_KEYS: jobs per contig length | pairs | singles | finished workgroups of the count]
+struct PlanLists { int *count, *n_pairs, *n_singles, *done, *rank, *singles, *pbase; int2 *pairs; };
 static PlanLists plan_lists(int *plan, int n_cap, int *zero)
 {
 	PlanLists L;
-	L.count = zero; L.n_pairs = zero + PLAN_KEYS; L.n_singles = zero + PLAN_KEYS + 1;
+	L.count = zero; L.n_pairs = zero + PLAN_KEYS; L.n_singles = zero + PLAN_KEYS + 1; L.done = zero + PLAN_KEYS + 2;
 	L.rank = plan; L.singles = plan + n_cap; L.pairs = (int2 *)(plan + 2 * (size_t)n_cap + (n_cap & 1));
+	L.pbase = plan + 4 * (size_t)n_cap + 8;
 	return L;
 }
 static int launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hipStream_t s, const KswArgs &a, int *plan, int n_cap, int *zero,
@@ -381,7 +382,7 @@ static int launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hip
 	pl.lds_budget = (int)lds_pair - 64; pl.p_cap = p_cap_pair;
 	pl.count = L.count; pl.n_pairs = L.n_pairs; pl.n_singles = L.n_singles;
 	pl.t_start = a.t_start;
-	pl.rank = L.rank; pl.singles = L.singles; pl.pairs = L.pairs;
+	pl.rank = L.rank; pl.singles = L.singles; pl.pairs = L.pairs; pl.done = L.done; pl.pbase = L.pbase;
 	const dim3 pg(std::max(1, std::min(2 * g.cus, (n_cap + 255) / 256)));
 	hipLaunchKernelGGL(k_ksw_plan_count, pg, dim3(256), 0, s, pl);
 	hipLaunchKernelGGL(k_ksw_plan_place, pg, dim3(256), 0, s, pl);
@@ -401,7 +402,7 @@ static int launch_ksw_planned(dim3 grid, size_t lds_single, size_t lds_pair, hip
 	if (side) HIPC(hipStreamWaitEvent(s, ev_join, 0));
 	return 0;
 }
-static size_t ksw_plan_ints(long long n_cap) { return 4 * (size_t)n_cap + 8; }
+static size_t ksw_plan_ints(long long n_cap) { return 4 * (size_t)n_cap + 8 + PLAN_KEYS; }
 constexpr int PLAN_ZERO_INTS = PLAN_KEYS + 16;
 
 KswParams make_ksw_params(int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag, int ascii)

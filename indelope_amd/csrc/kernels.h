@@ -814,6 +814,8 @@ struct KswPlanArgs {
 	int *count;                                // [PLAN_KEYS] jobs per contig length; zero when the run starts
 	int *rank;                                 // [jobs] scratch
 	int2 *pairs; int *n_pairs; int *singles; int *n_singles;
+	int *done;                                 // workgroups of k_ksw_plan_count that have finished; zero when the run starts
+	int *pbase;                                // [PLAN_KEYS] first pair of every contig length (the last workgroup of the count writes it)
 	unsigned long long *t_start;               // optional: see mark_start() (the ksw2 stage begins with its plan)
 };
 
@@ -852,18 +854,20 @@ __global__ __launch_bounds__(256) void k_ksw_plan_count(const KswPlanArgs a)
 		const int ss = plan_append(a.n_singles, j < n && key < 0);
 		if (ss >= 0) a.singles[ss] = j;
 	}
-}
-
-__global__ __launch_bounds__(256) void k_ksw_plan_place(const KswPlanArgs a)
-{
-	__shared__ int pbase[PLAN_KEYS];
+	// The workgroup that finishes last turns the counts into the first pair of every length (a.pbase) and the number of pairs:
+	// the placing launch then needs no LDS -- it used to hold the 16 KB scan in every workgroup, and its workgroups waited for
+	// that LDS behind the other chain's assembly (70 us on the critical path of a 5 000-region launch for 10 us of work).
 	__shared__ int part[256];
-	const int tid = (int)threadIdx.x;
-	const int n = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
-	if (blockIdx.x && (long long)blockIdx.x * blockDim.x >= n) return;     // (the grid is sized for the job slots, not the jobs)
+	__shared__ int s_last;
+	__threadfence();
+	__syncthreads();
+	if (tid == 0) s_last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
+	__syncthreads();
+	if (!s_last) return;
+	__threadfence();
 	constexpr int PER = PLAN_KEYS / 256;
 	int c[PER], sum = 0;
-	for (int i = 0; i < PER; ++i) { c[i] = a.count[tid * PER + i] >> 1; sum += c[i]; }
+	for (int i = 0; i < PER; ++i) { c[i] = atomicAdd(a.count + tid * PER + i, 0) >> 1; sum += c[i]; }   // (the other workgroups' atomics: read where they landed)
 	part[tid] = sum;
 	__syncthreads();
 	for (int d = 1; d < 256; d <<= 1) {
@@ -873,9 +877,16 @@ __global__ __launch_bounds__(256) void k_ksw_plan_place(const KswPlanArgs a)
 		__syncthreads();
 	}
 	int run = part[tid] - sum;
-	for (int i = 0; i < PER; ++i) { pbase[tid * PER + i] = run; run += c[i]; }
-	__syncthreads();
-	if (blockIdx.x == 0 && tid == 255) *a.n_pairs = part[255];
+	for (int i = 0; i < PER; ++i) { a.pbase[tid * PER + i] = run; run += c[i]; }
+	if (tid == 255) *a.n_pairs = part[255];
+}
+
+__global__ __launch_bounds__(256) void k_ksw_plan_place(const KswPlanArgs a)
+{
+	const int tid = (int)threadIdx.x;
+	const int n = a.n_jobs ? *a.n_jobs : a.n_jobs_host;
+	if ((long long)blockIdx.x * blockDim.x >= n) return;                   // (the grid is sized for the job slots, not the jobs)
+	const int *pbase = a.pbase;
 	const int step = (int)(gridDim.x * blockDim.x);
 	for (int j0 = (int)(blockIdx.x * blockDim.x); j0 < n; j0 += step) {
 		const int j = j0 + tid;
