@@ -298,19 +298,26 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2, d
         hs.append(api.batch_upload(sb, params))
         api.batch_set_timing(hs[-1], True)
 
-    def step():
-        for h in hs:
-            api.batch_run(h)
-        for h in hs:
-            api.batch_sync(h)
+    pending = [False] * len(hs)
+
+    def run_steps(n):
+        # as the headline: a sub-batch is run again as soon as its own last run is done; everything waited for at the end
+        for _ in range(n):
+            for i, h in enumerate(hs):
+                if pending[i]:
+                    api.batch_sync(h)
+                api.batch_run(h)
+                pending[i] = True
+        for i, h in enumerate(hs):
+            if pending[i]:
+                api.batch_sync(h)
+                pending[i] = False
     try:
-        for _ in range(warmup):
-            step()
+        run_steps(warmup)
         for h in hs:
             api.batch_kernel_ms_mean(h, reset=True)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run_steps(steps)
         dt = time.perf_counter() - t0
         km = np.array([api.batch_kernel_ms_mean(h)[0] for h in hs]).mean(axis=0)
         parts = [api.batch_fetch(h) for h in hs]

@@ -1107,10 +1107,11 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 	const int R = b->R;
 	const long long nb1 = b->v2_nb1, stat = comb_stat();
 	auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + stat; };
-	// 16 waves per CU when the launch is long enough to be bound by throughput; a launch of about one round of regions per
-	// wave slot lasts as long as its heaviest regions, and those run faster with fewer waves beside them on their SIMD
-	// (C2, 5 000 regions per launch: 14 waves per CU 5.33 M regions/s, 16: 4.98 M, 12: 5.22 M)
-	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : (b->n_cls[0] >= 40 * g.cus ? 16 : 14);
+	// 16 waves per CU.  (Round 3 took 14 for launches of about one round of regions per wave slot: such a launch lasts as long
+	// as its heaviest regions, and a caller that waited for every batch before starting the next saw those run faster with
+	// fewer waves beside them.  A caller that keeps batches in flight -- a sweep, bench.py since round 4 -- has another
+	// chain's kernels in those tails: C2, 5 000 regions per launch, 14: 1.74 ms per step, 16: 1.70, 18: 1.72.)
+	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 16;
 	long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
 	int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes(need_C)));
 	if (occ_first > 0) occ_c = std::max(1, std::min(occ_c, occ_first));
