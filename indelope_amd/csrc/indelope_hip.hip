@@ -1464,9 +1464,9 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		size_t lneed = ksw_lds_bytes(ql, tt);                        // the generic LDS sweep always fits this
 		if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<3>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<3>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
 		else if (!(p->fb_flag & KSW_EZ_RIGHT) && ksw_wide_ok<6>(FP, ql, tt)) lneed = std::max(ksw_wide_lds_bytes<6>(ql, tt), ksw_lds_bytes(std::min(ql, 32), tt));
-		if (ksw_duo_ok(FP, std::min(ql, 64 * DUO_NS), tt, tt)) {        // both alignments of an item in one sweep (ksw_duo.h)
+		if (ksw_duo_ok(FP, std::min(ql, 64 * DUO_NS_MAX), tt, tt)) {    // both alignments of an item in one sweep (ksw_duo.h)
 			lneed = std::max(lneed, ksw_duo_lds_bytes(tt));
-			b->fb_p_cap = std::max(b->fb_p_cap, ksw_duo_p_bytes(std::min(ql, 64 * DUO_NS), tt));
+			b->fb_p_cap = std::max(b->fb_p_cap, ksw_duo_p_bytes(std::min(ql, 64 * DUO_NS_MAX), tt));
 		}
 		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
 		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(16, g.max_lds / (b->lds_fb + 256))));

@@ -1172,12 +1172,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		const bool wide_ok = !(a.P.flag & KSW_EZ_RIGHT);
 		int cnt[2];
 		bool over = false;
-		// both alignments in one sweep (ksw_duo.h) when the item is the usual kind: a read of at most 192 bases, both strings non-empty
+		// both alignments in one sweep (ksw_duo.h) when the item is the usual kind: a read of at most 320 bases, both strings non-empty
 		bool duo = false;
 		if (a.duo && rl > 0 && rsub > 0 && csub > 0 && ksw_duo_ok(a.P, rl, rsub, csub) &&
 		    ksw_duo_lds_bytes(tmax) <= (size_t)a.lds_budget && ksw_duo_p_bytes(rl, tmax) <= a.p_cap) {
 			DuoResult R;
-			duo = ksw_duo_sweep(qy, rl, a.ref_bases + uni(jb.t_off) + start, rsub, a.out_seq + uni(jb.q_off) + start, csub, a.P, lds, p, R);
+			const uint8_t *tr = a.ref_bases + uni(jb.t_off) + start, *tc = a.out_seq + uni(jb.q_off) + start;
+			duo = rl <= 192 ? ksw_duo_sweep<3>(qy, rl, tr, rsub, tc, csub, a.P, lds, p, R) : ksw_duo_sweep<5>(qy, rl, tr, rsub, tc, csub, a.P, lds, p, R);
 			if (duo) {
 				KswOut o;
 				ksw_duo_cigar<0>(R, p, rl, rsub, a.P.w, a.P.flag, ct, a.cig_cap, o);

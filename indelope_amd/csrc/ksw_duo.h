@@ -9,7 +9,7 @@
 // one or the explicit boundaries (:207-212) -- the 16-rounded margins feed margins --, the exact maximum is only the FIRST
 // diagonal that reaches the final maximum, and no diagonal can stop the sweep.  So this sweep is the plain recurrence,
 // laid out for the two things the item's alignments share:
-//   * lanes <-> QUERY positions (lane i of slot k holds read base 64 k + i; up to 192).  Nothing moves: on diagonal r a
+//   * lanes <-> QUERY positions (lane i of slot k holds read base 64 k + i; three slots for reads up to 192, five up to 320).  Nothing moves: on diagonal r a
 //     lane works on target position t = r - i, its x / v of the previous diagonal are its own (cell (t-1, i)), its u / y
 //     come from the lane below (cell (t, i-1): one DPP rotation each), its score row is a constant of the lane and the
 //     target base arrives as a selector word read from LDS at r - i.
@@ -32,8 +32,8 @@
 
 namespace ihp {
 
-constexpr int DUO_NS = 3;                         // slots of 64 query positions
-constexpr int DUO_PAD = 64 * DUO_NS;
+constexpr int DUO_NS_MAX = 5;                     // slots of 64 query positions: the sweep is built for 3 (reads up to 192) and 5 (up to 320)
+constexpr int DUO_PAD = 64 * DUO_NS_MAX;
 
 __host__ __device__ __forceinline__ int duo_slots(int qlen) { return (qlen + 63) >> 6; }
 // selector words for t in [-DUO_PAD, tmax + DUO_PAD)
@@ -50,7 +50,7 @@ __host__ __device__ __forceinline__ bool ksw_duo_ok(const KswParams &P, int qlen
 	if (!(P.m == 5 && zm > 0 && zx > 0 && zw > 0 && P.sc_mch > 0 && P.sc_mis <= 0 && qe > 0 && qe < 64)) return false;
 	if (P.flag & (KSW_EZ_SCORE_ONLY | KSW_EZ_RIGHT | KSW_EZ_GENERIC_SC | KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP)) return false;
 	if (P.zdrop >= 0 || -P.min_sc > qe2) return false;
-	if (qlen < 1 || qlen > 64 * DUO_NS || tl0 < 1 || tl1 < 1 || qlen + tmax > 0xffff) return false;
+	if (qlen < 1 || qlen > 64 * DUO_NS_MAX || tl0 < 1 || tl1 < 1 || qlen + tmax > 0xffff) return false;
 	if (P.w >= 0 && P.w < (qlen > tmax ? qlen : tmax)) return false;       // the band must never cut the matrix
 	int big = qe > P.sc_mch ? qe : P.sc_mch;
 	big = big > -P.sc_mis ? big : -P.sc_mis;
@@ -62,16 +62,17 @@ struct DuoResult { int max[2], max_t[2], max_q[2]; };
 // lane l gets v[l-1], lane 0 gets v[63] (every lane is written: no value to start from, no v_mov in front of it)
 __device__ __forceinline__ unsigned duo_ror1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x13C, 0xf, 0xf, false); }
 
+template <int NS>
 struct DuoState {
-	unsigned X[DUO_NS], V[DUO_NS], U[DUO_NS], Y[DUO_NS], H[DUO_NS];
-	int B0[DUO_NS], B1[DUO_NS];                                                 // per alignment: the lane's maximum of H so far << 16 | 0xffff - the diagonal it was first reached on
-	unsigned T0[DUO_NS];                                                        // z by target code 0..3 for the lane's read base
+	unsigned X[NS], V[NS], U[NS], Y[NS], H[NS];
+	int B0[NS], B1[NS];                                                 // per alignment: the lane's maximum of H so far << 16 | 0xffff - the diagonal it was first reached on
+	unsigned T0[NS];                                                        // z by target code 0..3 for the lane's read base
 };
 
 // Slot K of diagonal r.  MASKED: the slot is still filling up -- lanes above `started` keep x, v, H at their boundary values.
 // tag: 0xffff - r in every lane (a register: with the mask of the select it would be a second scalar operand).
-template <int K, bool MASKED>
-__device__ __forceinline__ void duo_slot(DuoState &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned sel,
+template <int NS, int K, bool MASKED>
+__device__ __forceinline__ void duo_slot(DuoState<NS> &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned sel,
                                          const unsigned uin, const unsigned yin, const unsigned tag, const unsigned long long started, uint8_t *prow)
 {
 	const unsigned z = pair_z(S.T0[K], T1, sel);
@@ -91,15 +92,15 @@ __device__ __forceinline__ void duo_slot(DuoState &S, const PairEnv &E, const un
 }
 
 // ez.max / max_t / max_q of alignment K from the lanes' maxima (:88-104 with zdrop < 0; tie order of :320-348)
-template <int K>
-__device__ inline void duo_resolve(const DuoState &S, int qlen, int tlen, DuoResult &R)
+template <int NS, int K>
+__device__ inline void duo_resolve(const DuoState<NS> &S, int qlen, int tlen, DuoResult &R)
 {
 	const int lane = lane_id();
 	const int INTMIN = -0x7fffffff - 1;
-	int bv[DUO_NS], br[DUO_NS];
+	int bv[NS], br[NS];
 	int m = INTMIN;
 #pragma unroll
-	for (int k = 0; k < DUO_NS; ++k) {
+	for (int k = 0; k < NS; ++k) {
 		const int key = K == 0 ? S.B0[k] : S.B1[k];
 		bv[k] = 64 * k + lane < qlen ? key >> 16 : INTMIN;
 		br[k] = 0xffff - (key & 0xffff);
@@ -110,13 +111,13 @@ __device__ inline void duo_resolve(const DuoState &S, int qlen, int tlen, DuoRes
 	if (M <= 0) return;
 	unsigned rm = 0xffffffffu;
 #pragma unroll
-	for (int k = 0; k < DUO_NS; ++k) rm = (bv[k] == M && (unsigned)br[k] < rm) ? (unsigned)br[k] : rm;
+	for (int k = 0; k < NS; ++k) rm = (bv[k] == M && (unsigned)br[k] < rm) ? (unsigned)br[k] : rm;
 	const int rs = (int)wave_min_u32(rm);
 	const int st0 = rs - qlen + 1 > 0 ? rs - qlen + 1 : 0, en0 = rs < tlen - 1 ? rs : tlen - 1;
 	const int nv = (en0 - st0) / 4 * 4;
 	unsigned key = 0xffffffffu;
 #pragma unroll
-	for (int k = 0; k < DUO_NS; ++k) {
+	for (int k = 0; k < NS; ++k) {
 		const int t = rs - (64 * k + lane), i = t - st0;
 		const bool cand = bv[k] == M && br[k] == rs && t >= st0 && t <= en0;
 		const unsigned kk = t == en0 ? 0u : i < nv ? ((unsigned)((i & 3) + 1) << 16 | (unsigned)(i >> 2)) : (5u << 16 | (unsigned)(i - nv));
@@ -131,8 +132,34 @@ __device__ inline void duo_resolve(const DuoState &S, int qlen, int tlen, DuoRes
 	R.max[K] = M; R.max_t[K] = max_t; R.max_q[K] = rs - max_t;
 }
 
-// Returns false when the item is not for this sweep (a code outside the 5-letter alphabet).  Precondition: ksw_duo_ok().
-// lds: ksw_duo_lds_bytes(max(tl0, tl1)); p: ksw_duo_p_bytes(qlen, max(tl0, tl1)).
+// The slots of one diagonal, lowest first: slot K takes u / y of the lane below -- lane 0 from the slot below's lane 63
+// (`ru`, `ry`: the rotations of the PREVIOUS diagonal's values, all taken before any slot is overwritten), slot 0's lane 0 the
+// boundary.  Slots above `hi` have not started; slot `hi` is the one filling up.
+template <int NS, int K>
+struct DuoSlots {
+	static __device__ __forceinline__ void run(DuoState<NS> &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned *sp, const int r,
+	                                           const unsigned (&ru)[NS], const unsigned (&ry)[NS], const unsigned ub, const bool l0, const int hi,
+	                                           const unsigned tag, const unsigned long long started, uint8_t *prow)
+	{
+		if (K <= hi) {
+			const unsigned uin = l0 ? (K ? ru[K ? K - 1 : 0] : ub) : ru[K], yin = l0 ? (K ? ry[K ? K - 1 : 0] : 0u) : ry[K];
+			const unsigned sel = sp[r + 64 * (NS - 1 - K)];
+			if (K < NS - 1 && K < hi) duo_slot<NS, K, false>(S, E, T1, QEp, sel, uin, yin, tag, started, prow);
+			else duo_slot<NS, K, true>(S, E, T1, QEp, sel, uin, yin, tag, started, prow);
+			DuoSlots<NS, K + 1>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow);
+		}
+	}
+};
+template <int NS>
+struct DuoSlots<NS, NS> {
+	static __device__ __forceinline__ void run(DuoState<NS> &, const PairEnv &, const unsigned, const unsigned, const unsigned *, const int,
+	                                           const unsigned (&)[NS], const unsigned (&)[NS], const unsigned, const bool, const int,
+	                                           const unsigned, const unsigned long long, uint8_t *) {}
+};
+
+// Returns false when the item is not for this sweep (a code outside the 5-letter alphabet).  Preconditions: ksw_duo_ok(),
+// qlen <= 64 NS.  lds: ksw_duo_lds_bytes(max(tl0, tl1)); p: ksw_duo_p_bytes(qlen, max(tl0, tl1)).
+template <int NS>
 __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8_t *t0, int tl0, const uint8_t *t1, int tl1,
                                      const KswParams &P, uint8_t *lds, uint8_t *p, DuoResult &R)
 {
@@ -158,9 +185,9 @@ __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8
 	E.Qp = ((unsigned)q & 0xff) * 0x01000100u; E.Mp = ZM * 0x01000100u;
 	E.zx4 = ZX * 0x01010101u; E.zdm = ZM - ZX; E.zw4 = ZW * 0x01010101u;
 	const unsigned T1 = E.zw4, QEp = (unsigned)qe * 0x00010001u;
-	DuoState S;
+	DuoState<NS> S;
 #pragma unroll
-	for (int k = 0; k < DUO_NS; ++k) {
+	for (int k = 0; k < NS; ++k) {
 		const int i = 64 * k + lane;
 		unsigned c = 4;
 		if (i < qlen) { c = query[i]; if (P.encode_ascii) c = enc_base((uint8_t)c); }
@@ -175,7 +202,7 @@ __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8
 	WSYNC();
 	const int total = qlen + tmax - 1;
 	// lane's selector word of diagonal r: selw[DUO_PAD + r - i]; slot k at a fixed offset below slot 0
-	const unsigned *sp = selw + DUO_PAD - 64 * (DUO_NS - 1) - lane;
+	const unsigned *sp = selw + DUO_PAD - 64 * (NS - 1) - lane;
 	uint8_t *prow = p + lane;
 	unsigned ub = 0;                                                            // u of the cell entering at the top: r ? q : 0 (:212), lane 0 only
 	const unsigned ub1 = lane == 0 ? E.Qp : 0u;
@@ -185,31 +212,17 @@ __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8
 		const int hi = (r >> 6) < nsl - 1 ? (r >> 6) : nsl - 1;
 		const int fill = r - 64 * hi;
 		const unsigned long long started = fill >= 63 ? ~0ull : ~0ull >> (63 - fill);
-		// u, y of the previous diagonal one lane up (all slots before any is overwritten)
-		unsigned ru[DUO_NS], ry[DUO_NS];
+		unsigned ru[NS], ry[NS];
 #pragma unroll
-		for (int k = 0; k < DUO_NS; ++k) { ru[k] = duo_ror1(S.U[k]); ry[k] = duo_ror1(S.Y[k]); }
-		{
-			const unsigned uin = l0 ? ub : ru[0], yin = l0 ? 0u : ry[0];
-			if (hi > 0) duo_slot<0, false>(S, E, T1, QEp, sp[r + 64 * (DUO_NS - 1)], uin, yin, tag, started, prow);
-			else duo_slot<0, true>(S, E, T1, QEp, sp[r + 64 * (DUO_NS - 1)], uin, yin, tag, started, prow);
-		}
-		if (hi >= 1) {
-			const unsigned uin = l0 ? ru[0] : ru[1], yin = l0 ? ry[0] : ry[1];
-			if (hi > 1) duo_slot<1, false>(S, E, T1, QEp, sp[r + 64 * (DUO_NS - 2)], uin, yin, tag, started, prow);
-			else duo_slot<1, true>(S, E, T1, QEp, sp[r + 64 * (DUO_NS - 2)], uin, yin, tag, started, prow);
-		}
-		if (hi >= 2) {
-			const unsigned uin = l0 ? ru[1] : ru[2], yin = l0 ? ry[1] : ry[2];
-			duo_slot<2, true>(S, E, T1, QEp, sp[r], uin, yin, tag, started, prow);
-		}
+		for (int k = 0; k < NS; ++k) { ru[k] = duo_ror1(S.U[k]); ry[k] = duo_ror1(S.Y[k]); }
+		DuoSlots<NS, 0>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow);
 		ub = ub1;
 		tag -= 1;
 		prow += ncol;
 	}
 	WSYNC();
-	duo_resolve<0>(S, qlen, tl0, R);
-	duo_resolve<1>(S, qlen, tl1, R);
+	duo_resolve<NS, 0>(S, qlen, tl0, R);
+	duo_resolve<NS, 1>(S, qlen, tl1, R);
 	return true;
 }
 

@@ -202,8 +202,10 @@ def test_a_slab_layout_that_is_not_the_librarys_is_refused(hip, oracle):
 @pytest.mark.parametrize("cfg", [
     dict(n_regions=60, n_reads=(24, 64), err_rate=1e-3, config_id=141, dup_frac=0.6),
     dict(n_regions=40, read_len=100, n_reads=(20, 60), err_rate=2e-3, config_id=142, K=21, dup_frac=0.8),
-    dict(n_regions=40, read_len=192, n_reads=(16, 48), err_rate=5e-3, config_id=143, K=31, dup_frac=0.7, window_len=590),   # the longest read the sweep takes
-    dict(n_regions=40, read_len=193, n_reads=(16, 48), err_rate=1e-3, config_id=144, K=31, dup_frac=0.7, window_len=590),   # one more: ksw_wide.h
+    dict(n_regions=40, read_len=192, n_reads=(16, 48), err_rate=5e-3, config_id=143, K=31, dup_frac=0.7, window_len=590),   # the longest read of the three-slot build
+    dict(n_regions=40, read_len=193, n_reads=(16, 48), err_rate=1e-3, config_id=144, K=31, dup_frac=0.7, window_len=590),   # one more: five slots
+    dict(n_regions=30, read_len=320, n_reads=(16, 40), err_rate=2e-3, config_id=146, K=31, dup_frac=0.7, window_len=980),   # the longest read the sweep takes
+    dict(n_regions=30, read_len=321, n_reads=(16, 40), err_rate=1e-3, config_id=147, K=31, dup_frac=0.7, window_len=980),   # one more: ksw_wide.h
     dict(n_regions=50, n_reads=(8, 40), err_rate=2e-2, config_id=145, dup_frac=0.9),
 ])
 @pytest.mark.parametrize("scoring", [dict(), dict(fb_match=2, fb_mismatch=-4, fb_gap_open=7, fb_gap_ext=2), dict(fb_flag=0xc0)])

@@ -1,6 +1,7 @@
 """The alignment fallback's two-target sweep (ksw_duo.h) against the oracle and against the one-at-a-time sweep (ksw_wide.h).
 
-Batches with tandem duplications send events to k_fallback; read lengths, read counts, error rates, K and the fallback's
+Batches with tandem duplications send events to k_fallback; read lengths (60-321: three slots up to 192, five up to 320, the ring
+sweep beyond), read counts, error rates, K and the fallback's
 scoring vary per batch (inside and outside what ksw_duo_ok() takes).  Every field of every region is compared three ways:
 duo sweep vs oracle, ihp_debug_set("fb_duo", 0) vs oracle.
     python tools/fb_stress.py [seed] [batches]
@@ -24,7 +25,7 @@ def main():
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     bad = 0
     for it in range(nb):
-        rl = int(rng.choice([60, 100, 150, 150, 150, 180, 192, 193, 250]))
+        rl = int(rng.choice([60, 100, 150, 150, 150, 180, 192, 193, 250, 300, 320, 321]))
         K = int(rng.choice([21, 27, 31]))
         kw = dict(n_regions=int(rng.integers(20, 60)), read_len=rl, n_reads=(int(rng.integers(4, 24)), int(rng.integers(24, 80))),
                   err_rate=float(rng.choice([0, 1e-3, 5e-3, 2e-2])), config_id=int(rng.integers(100, 1 << 20)), K=K, dup_frac=float(rng.choice([0.3, 0.6, 0.9])))
