@@ -8,8 +8,12 @@ synthetic candidate regions that is already resident in HBM.  Default workload =
   python bench.py                       one GPU, C2
   python bench.py --gpus N              starts N ranks itself (one process per GPU over RCCL; the parent never touches
                                         the GPU) -- or run it under `python -m torch.distributed.run --nproc-per-node N`
-  --scaling weak   (default)            every rank holds its own C2-sized shard (N x the same per-GPU batch); each step
-                                        ends with ONE RCCL gather of the fixed-size per-region records to rank 0
+  --scaling weak   (default)            every rank holds `--in-flight` (2) resident C2-sized batches of its own that take turns:
+                                        a step is one pass over one of them, and a batch is run again as soon as its own last run
+                                        is done, so two steps are in flight (the path's callers stream independent batches; rounds
+                                        1-3 ran ONE batch as two sub-batches and waited for every step: `--in-flight 1 --lockstep`,
+                                        also measured in `other_configs`); a timed block ends with ONE RCCL gather of the fixed-size
+                                        per-region records to rank 0
   --scaling strong --config C4          the 5 M regions of BASELINE configs[3] split over the ranks by
                                         indelope_amd.dist.shard_bounds, each rank generating its shard from the seed
                                         (first_region), walked in resident chunks; one gather per step; `--payload`
@@ -44,7 +48,7 @@ ISSUE_PEAK_ARCH = 2.0          # MI355X_MICROARCH.md: a SIMD-32 issues a wave64 
                                # (tools/ubench_ksw.hip: v_sub / v_max alternating 0.93 per cycle and CU)
 PMC_FILE = os.path.join("profiles", "r04_c2_pmc.json")
 MIX_FILE = os.path.join("profiles", "r04_c2_pmc_mix.json")
-STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_asm_reads", "k_asm_combine3", "k_assemble"),
+STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_prepack_fast", "k_asm_reads", "k_asm_combine3", "k_assemble"),
                  "k_ksw": ("k_ksw", "k_ksw_pair", "k_ksw_plan_count", "k_ksw_plan_place"), "k_tally": ("k_tally",)}
 
 
@@ -278,18 +282,20 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
 
 
 # ------------------------------------------------------------------------------------------ other configs
-def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2, dup_frac=0.0):
-    """A short run of another BASELINE config on this GPU (the same step as the headline: `sub_batches` chains in flight,
-    resident inputs): value, per-launch stage times, the HBM-roofline fraction of its dominant stage, oracle check."""
+def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=1, dup_frac=0.0, in_flight=2, lockstep=False):
+    """A short run of another BASELINE config on this GPU, submitted like the headline (`in_flight` resident batches of `regions`
+    regions take turns, a step is one pass over one of them as `sub_batches` launch chains; `lockstep`: every step waited for):
+    value, per-launch stage times, the HBM-roofline fraction of its dominant stage, oracle check."""
     from indelope_amd import synth
     from indelope_amd.host import BatchResult, concat_results
     cfg = dict(synth.CONFIGS[name])
     K = cfg["K"]
     params = api.params(K=K)
     cfg["n_regions"] = regions
-    cuts = [regions * i // sub_batches for i in range(sub_batches + 1)]
+    B, S = max(1, in_flight), max(1, sub_batches)
+    cuts = [b * regions + regions * i // S for b in range(B) for i in range(S)] + [B * regions]
     subs, hs = [], []
-    for i in range(sub_batches):
+    for i in range(B * S):
         g = dict(cfg)
         g["n_regions"] = cuts[i + 1] - cuts[i]
         sb, _ = synth.generate(first_region=cuts[i], dup_frac=dup_frac, **g)
@@ -297,23 +303,28 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2, d
         subs.append(sb)
         hs.append(api.batch_upload(sb, params))
         api.batch_set_timing(hs[-1], True)
-
     pending = [False] * len(hs)
+    step_no = [0]
 
     def run_steps(n):
-        # as the headline: a sub-batch is run again as soon as its own last run is done; everything waited for at the end
         for _ in range(n):
-            for i, h in enumerate(hs):
+            b0 = (step_no[0] % B) * S
+            step_no[0] += 1
+            for i in range(b0, b0 + S):
                 if pending[i]:
-                    api.batch_sync(h)
-                api.batch_run(h)
+                    api.batch_sync(hs[i])
+                api.batch_run(hs[i])
                 pending[i] = True
+            if lockstep:
+                for i in range(b0, b0 + S):
+                    api.batch_sync(hs[i])
+                    pending[i] = False
         for i, h in enumerate(hs):
             if pending[i]:
                 api.batch_sync(h)
                 pending[i] = False
     try:
-        run_steps(warmup)
+        run_steps(max(warmup, B))
         for h in hs:
             api.batch_kernel_ms_mean(h, reset=True)
         t0 = time.perf_counter()
@@ -331,11 +342,12 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2, d
             by_kernel[k] += v / len(parts)
     dom = int(np.argmax(km[:3]))
     achieved = by_kernel[KERNELS[dom]] / (km[dom] * 1e-3) / 1e9
-    whole = (sum(sb.algorithmic_input_bytes() for sb in subs) + res.algorithmic_output_bytes(K)) / (dt / steps) / 1e9
+    whole = (sum(sb.algorithmic_input_bytes() for sb in subs) + res.algorithmic_output_bytes(K)) / B / (dt / steps) / 1e9
     out = {"workload": "%s: %d regions x %s reads x %d bp, K=%d%s" % (name, regions, "%d-%d" % cfg["n_reads"] if cfg["n_reads"][0] != cfg["n_reads"][1]
                                                                          else str(cfg["n_reads"][0]), cfg["read_len"], K,
                                                                          ", %g of the events tandem duplications (alignment fallback, indelope.nim:312-372)" % dup_frac if dup_frac else ""),
            "value": round(regions * steps / dt, 1), "unit": "regions/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+           "submission": "%d resident batch%s take turns%s%s" % (B, "es" if B > 1 else "", ", %d sub-batches per step" % S if S > 1 else "", ", every step waited for" if lockstep else ""),
            "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS, km[:3])}, k_fallback=round(float(km[3]), 4)),
            "roofline": {"kernel": KERNELS[dom], "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "whole_path_frac": round(whole / HBM_PEAK_GBS, 5)},
@@ -347,7 +359,9 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=2, d
         t1 = time.perf_counter()
         bad, n = None, 0
         for sb, pr in zip(subs, parts):
-            lim = min(sb.n_regions, 10_000)
+            lim = min(sb.n_regions, 10_000, max(0, 20_000 - n))
+            if lim == 0:
+                break
             exp = o.run_regions_mt(sb.slice(0, lim), o.params(K=K), usable)
             got = pr if lim == sb.n_regions else api.run_regions(sb.slice(0, lim), params)
             bad = bad or BatchResult.first_difference(got, exp)
@@ -568,8 +582,8 @@ def main():
     ap.add_argument("--quals", action="store_true",
                     help="hand the base qualities to the device and trim there (indelope.nim:23-38) instead of the "
                          "stager-side trim bounds that SURVEY.md 8b/8d specify as the batch input")
-    ap.add_argument("--sub-batches", type=int, default=2,
-                    help="weak scaling: the step submits the batch as this many sub-batches of consecutive regions, each an "
+    ap.add_argument("--sub-batches", type=int, default=None,
+                    help="(default 1; 2 with --in-flight 1) weak scaling: the step submits the batch as this many sub-batches of consecutive regions, each an "
                          "ihp_batch on its own stream: while one sub-batch's last regions drain a kernel, the other's next kernel "
                          "fills the chip.  With more than one chain the per-launch kernel_ms come from device wall-clock stamps "
                          "(ihp_batch_kernel_ms), not from event intervals.  1 = one launch chain, timed with HIP events")
@@ -590,6 +604,8 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 / dup10 legs (`other_configs`), `mixed_stream` and `c1` of the default run")
     ap.add_argument("--strong-regions", type=int, default=1_250_000,
                     help="regions of the attached strong-scaling leg (C4 generator; 5 000 000 = all of BASELINE configs[3])")
+    ap.add_argument("--in-flight", type=int, default=2, help="weak mode: resident batches of the configured size the stream alternates between -- a step is one pass "
+                    "over ONE of them, so this many steps are in flight (default 2; 1 = rounds 1-3: one batch, split by --sub-batches)")
     ap.add_argument("--lockstep", action="store_true", help="weak mode: wait for every sub-batch of a step before the next step starts (rounds 1-3); default: a sub-batch "
                     "is run again as soon as its own last run is done")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counters of the kernels (ihp_debug_set profile) in `profile_cycles`")
@@ -670,9 +686,14 @@ def main():
     else:
         R = args.regions or min(cfg["n_regions"], 200_000)
         total = R * world
-        lo = rank * R
+        B = max(1, args.in_flight)                           # resident batches of R regions; a step is one pass over one of them
+        if args.sub_batches is None:
+            args.sub_batches = 2 if B == 1 else 1
+        lo = rank * B * R
         S = max(1, min(args.sub_batches, R))
-        cuts = [lo + R * i // S for i in range(S + 1)]
+        cuts = [lo + b * R + R * i // S for b in range(B) for i in range(S)] + [lo + B * R]
+    if strong:
+        B = 1
     gen = dict(cfg)
     subs, hs = [], []
     # strong scaling on few GPUs: the results of a whole shard may not fit beside its inputs -> one chunk's results at a time
@@ -682,7 +703,8 @@ def main():
     api.b.device_info(ctypes.byref(cu_), ctypes.byref(ws_), ctypes.byref(hbm_))
     hbm = hbm_.value
     stream_outputs = strong and R * 64 * cfg["read_len"] * 9.0 > 0.7 * hbm
-    for i in range(S):
+    NH = B * S if not strong else S                      # launch chains (ihp_batch handles): handle b * S + i = sub-batch i of batch b
+    for i in range(NH):
         gen["n_regions"] = cuts[i + 1] - cuts[i]
         sb, _ = synth.generate(first_region=cuts[i], dup_frac=args.dup_frac, **gen)
         if not args.quals:
@@ -697,7 +719,7 @@ def main():
     for h in hs:
         api.batch_set_timing(h, True)
     views = []
-    for h in hs:
+    for h in hs[:S]:                                         # (weak mode: the records of the first resident batch stand for the rank's regions)
         sptr, sn = api.batch_summary_dev(h)
         views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda") if sn else torch.zeros(0, dtype=torch.int32, device="cuda"))
     summary = views[0] if S == 1 else torch.cat(views)       # per-region records of the rank's regions, region order
@@ -721,20 +743,22 @@ def main():
             api.batch_sync(hs[-1])
             if stream_outputs:
                 api.batch_release_outputs(hs[-1])
-        elif args.lockstep:
-            for h in hs:
-                api.batch_run(h)                             # asynchronous: the sub-batches' launch chains overlap
-            for h in hs:
-                api.batch_sync(h)
         else:
-            # every sub-batch is run again as soon as ITS last run is done (run -> sync -> run per batch, the others in flight
-            # meanwhile): no step waits for the slowest chain of the step before it, and the chains drift apart so that one's
-            # assembly overlaps the other's alignments.  block() waits for everything before the clock stops.
-            for i, h in enumerate(hs):
+            # a step is one pass over ONE of the B resident batches (its S sub-batches, each a launch chain on its own stream); the
+            # batches take turns.  A batch is run again as soon as ITS last run is done (run -> sync -> run per batch), so B steps
+            # are in flight and no step waits for the one before it; block() waits for everything before the clock stops.
+            # --lockstep: every step is waited for before the next one starts (rounds 1-3).
+            b0 = (step_no[0] % B) * S
+            step_no[0] += 1
+            for i in range(b0, b0 + S):
                 if pending.get(i):
-                    api.batch_sync(h)
-                api.batch_run(h)
+                    api.batch_sync(hs[i])
+                api.batch_run(hs[i])
                 pending[i] = True
+            if args.lockstep:
+                for i in range(b0, b0 + S):
+                    api.batch_sync(hs[i])
+                    pending[i] = False
         if use_dist and strong:
             gather()                                         # strong scaling: the job IS one pass, its gather belongs to the step
 
@@ -746,12 +770,13 @@ def main():
             send[:summary.numel()] = summary
         dist.gather(send, gather_list, dst=0)
         if args.payload and not stream_outputs:
-            for h in hs:
+            for h in (hs if strong else hs[:S]):
                 ptr, nbytes, counts = api.batch_pack_dev(h)
                 slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
                 last_payload[0] = idist.gather_payload(slab, counts, rank, world, dst=0, force=True)
 
     pending = {}
+    step_no = [0]
 
     def block(n):
         # weak scaling: every rank walks through its own batches; the real job gathers ONCE at its end, so a timed
@@ -765,6 +790,9 @@ def main():
         if use_dist and not strong:
             gather()
 
+    if not strong and B > 1:
+        block(2 * B)                                         # (every resident batch twice before the W warm-up steps: a batch's launch plan
+                                                             # comes from the last finished run of its shape)
     block(args.warmup)
     for h in hs:
         api.batch_kernel_ms_mean(h, reset=True)              # the warm-up runs do not count
@@ -813,9 +841,10 @@ def main():
         if stream_outputs:                                   # results were released chunk by chunk: rerun the first chunk for the report
             api.batch_run(hs[0])
             api.batch_sync(hs[0])
-        keep = [i for i in range(S) if subs[i] is not None]
+        keep = [i for i in range(NH) if subs[i] is not None]
         parts = [api.batch_fetch(hs[i]) for i in keep]
         res = concat_results(parts)
+        res_first = res if (strong or B == 1) else concat_results(parts[:S])   # what the gathered records describe
         assert (res.status == 0).all(), "regions failed on the device"
         # B = sum_reads(len+9) + len_refwindow + sum_contigs(5 len+16) + sum_aln(44+4 n_cigar) + sum_events(2K+12)
         n_kept = sum(subs[i].n_regions for i in keep)
@@ -834,7 +863,7 @@ def main():
         # own, tools/profile_round.sh); the figure of the committed passes over the same workload is quoted with its source
         traffic, traffic_source, issue = None, None, None
         pmc, mix = os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, MIX_FILE)
-        same = args.config == "C2" and R == 10_000 and S == 2 and not strong
+        same = args.config == "C2" and R == 10_000 and S == 1 and B == 2 and not strong
         # the launches a stage consists of (the assembly stage is the packed read phase, the combine phase and the byte-based
         # passes behind them; the ksw2 stage is its plan, the pair sweep and the single sweep; the empty ones count too)
         members = STAGE_MEMBERS[KERNELS[dom]]
@@ -897,9 +926,11 @@ def main():
                        "read_trim": "device, from base qualities" if args.quals else "stager (trim bounds in the batch)",
                        "submission": ("%d resident chunk%s of <= %d regions per rank, one after the other%s"
                                       % (S, "s" if S > 1 else "", args.chunk, "; one chunk's results kept at a time" if stream_outputs else ""))
-                       if strong else "%d sub-batch%s of consecutive regions per step, each on its own stream; %s"
-                                      % (S, "es" if S > 1 else "", "a step waits for all of them (--lockstep)" if args.lockstep else
-                                         "a sub-batch is run again as soon as its own last run is done (run, sync, run per batch), every run waited for before the clock stops"),
+                       if strong else "%d resident batch%s of %d regions take turns, a step is one pass over one of them%s; %s"
+                                      % (B, "es" if B > 1 else "", R, (" as %d sub-batches of consecutive regions, each on its own stream" % S) if S > 1 else "",
+                                         "every step is waited for before the next starts (--lockstep)" if args.lockstep else
+                                         "a batch is run again as soon as its own last run is done (run, sync, run per batch: %d step%s in flight), every run waited for before the clock stops"
+                                         % (B, "s" if B > 1 else "")),
                        "regions_per_gpu": R, "regions_total": total,
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
                                     "records per %s" % ("step" if strong else "timed block (the job's one gather at its end)") + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},
@@ -925,7 +956,7 @@ def main():
             # what rank 0 received in the last step against its own results: the records of the RCCL gather are the per-region
             # summaries of the fetched results, the payload slab unpacks to the same results
             got = torch.cat([g[:n * idist.SUMMARY_WORDS] for g, n in zip(gather_list, shard_sizes)]).cpu().numpy()
-            mine = idist.summaries_from_result(res).view(np.int32).reshape(-1)
+            mine = idist.summaries_from_result(res_first).view(np.int32).reshape(-1)
             # (strong scaling keeps only the first chunk's results on the host: its records are the head of the gathered ones)
             ok = bool(np.array_equal(got[:len(mine)], mine)) and (len(got) == len(mine) if (world == 1 and not strong) else len(got) >= len(mine))
             chk = {"records": int(len(got) // idist.SUMMARY_WORDS), "records_identical_to_own_results": ok, "backend": dist.get_backend()}
@@ -933,7 +964,7 @@ def main():
                 from indelope_amd.host import BatchResult
                 slab, counts = last_payload[0][0]
                 back = api.unpack_slab(slab.cpu().numpy(), counts)
-                d = BatchResult.first_difference(back, parts[-1])
+                d = BatchResult.first_difference(back, parts[S - 1] if not strong else parts[-1])
                 chk["payload_bytes"] = int(slab.numel())
                 chk["payload_identical_to_own_results"] = d is None
                 ok = ok and d is None
@@ -942,7 +973,7 @@ def main():
         if args.profile and not stream_outputs:
             out["profile_cycles"] = [int(x) for x in sum(np.array(api.batch_profile(h)) for h in hs)]
         batch0 = subs[keep[0]]
-        if not strong and len(keep) > 1:                     # the host-side legs work on the rank's whole batch
+        if not strong and S > 1:                             # the host-side legs work on a whole batch
             g2 = dict(cfg)
             g2["n_regions"] = R
             batch0, _ = synth.generate(first_region=lo, dup_frac=args.dup_frac, **g2)
@@ -980,9 +1011,13 @@ def main():
             assert bad is None, "device results differ from the oracle: " + str(bad)
         if not args.no_other and args.config == "C2" and not strong and world == 1 and not args.dup_frac and R == 10_000:
             # the other single-GPU configs of BASELINE.json, a few steps each, in the same record (never `value`)
-            out["other_configs"] = {"C3": quick_config(api, "C3", 50_000, steps=4, warmup=1, check=not args.no_check),
-                                    "C5": quick_config(api, "C5", 10_000, steps=6, warmup=2, check=not args.no_check),
-                                    "dup10": quick_config(api, "C2", 10_000, steps=4, warmup=1, check=not args.no_check, dup_frac=0.1)}
+            # (two launch chains in flight either way: two resident batches where a batch is one chain's worth of work -- C2's 10 000
+            # regions --, one batch as two sub-batches where half a batch already is -- measured both ways, tools/README.md)
+            out["other_configs"] = {"C3": quick_config(api, "C3", 50_000, steps=4, warmup=2, check=not args.no_check, in_flight=1, sub_batches=2),
+                                    "C5": quick_config(api, "C5", 10_000, steps=8, warmup=4, check=not args.no_check, in_flight=1, sub_batches=2),
+                                    "dup10": quick_config(api, "C2", 10_000, steps=6, warmup=4, check=not args.no_check, dup_frac=0.1),
+                                    # the headline workload submitted as in rounds 1-3: ONE resident batch, two sub-batches, every step waited for
+                                    "C2_one_batch_lockstep": quick_config(api, "C2", 10_000, steps=20, warmup=3, check=False, sub_batches=2, in_flight=1, lockstep=True)}
             out["mixed_stream"] = mixed_stream(api)
             out["c1"] = c1_leg(api)
         if not args.no_cpu and world == 1:
