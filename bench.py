@@ -606,6 +606,7 @@ def main():
                     help="regions of the attached strong-scaling leg (C4 generator; 5 000 000 = all of BASELINE configs[3])")
     ap.add_argument("--in-flight", type=int, default=2, help="weak mode: resident batches of the configured size the stream alternates between -- a step is one pass "
                     "over ONE of them, so this many steps are in flight (default 2; 1 = rounds 1-3: one batch, split by --sub-batches)")
+    ap.add_argument("--settle-s", type=float, default=0.1, help="weak mode: seconds of untimed steps in front of the W warm-up steps (clocks, launch plans)")
     ap.add_argument("--lockstep", action="store_true", help="weak mode: wait for every sub-batch of a step before the next step starts (rounds 1-3); default: a sub-batch "
                     "is run again as soon as its own last run is done")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counters of the kernels (ihp_debug_set profile) in `profile_cycles`")
@@ -790,9 +791,18 @@ def main():
         if use_dist and not strong:
             gather()
 
-    if not strong and B > 1:
-        block(2 * B)                                         # (every resident batch twice before the W warm-up steps: a batch's launch plan
-                                                             # comes from the last finished run of its shape)
+    if not strong:
+        # Before the W warm-up steps: every resident batch twice (a batch's launch plan comes from the last finished run of its
+        # shape), then ~0.1 s of steps -- a first timed block right behind a few milliseconds of warm-up ran 10 %
+        # slower than the two behind it in one run of three (clocks still ramping); untimed, reported as `settle_steps`.
+        t_s = time.perf_counter()
+        block(2 * B)
+        torch.cuda.synchronize()
+        est = max((time.perf_counter() - t_s) / (2 * B), 1e-5)
+        settle_steps = 2 * B + min(400, int(args.settle_s / est))
+        block(settle_steps - 2 * B)
+    else:
+        settle_steps = 0
     block(args.warmup)
     for h in hs:
         api.batch_kernel_ms_mean(h, reset=True)              # the warm-up runs do not count
@@ -911,7 +921,7 @@ def main():
         out = {
             "metric": "candidate regions/sec (assemble+ksw2+kmer-genotype), 150bp x 64-read batches",
             "value": round(total * args.steps / dt, 1), "unit": "regions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "blocks": {"ms_per_step": [round(x, 4) for x in block_ms], "median_ms_per_step": round(float(np.median(block_ms)), 4),
                        "min_ms_per_step": round(min(block_ms), 4), "value_median": round(total / (float(np.median(block_ms)) * 1e-3), 1),
