@@ -604,8 +604,10 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 / dup10 legs (`other_configs`), `mixed_stream` and `c1` of the default run")
     ap.add_argument("--strong-regions", type=int, default=1_250_000,
                     help="regions of the attached strong-scaling leg (C4 generator; 5 000 000 = all of BASELINE configs[3])")
-    ap.add_argument("--in-flight", type=int, default=2, help="weak mode: resident batches of the configured size the stream alternates between -- a step is one pass "
-                    "over ONE of them, so this many steps are in flight (default 2; 1 = rounds 1-3: one batch, split by --sub-batches)")
+    ap.add_argument("--in-flight", type=int, default=None, help="weak mode: resident batches of the configured size the stream alternates between -- a step is one pass "
+                    "over ONE of them, so this many steps are in flight (1 = rounds 1-3: one batch, split by --sub-batches).  Default: 2 when a "
+                    "batch is one launch chain's worth of work (up to ~120 MB of read bases: C2), otherwise 1 with two sub-batches -- two chains "
+                    "in flight either way (measured both ways for C3 and C5: DESIGN.md 5)")
     ap.add_argument("--settle-s", type=float, default=0.1, help="weak mode: seconds of untimed steps in front of the W warm-up steps (clocks, launch plans)")
     ap.add_argument("--lockstep", action="store_true", help="weak mode: wait for every sub-batch of a step before the next step starts (rounds 1-3); default: a sub-batch "
                     "is run again as soon as its own last run is done")
@@ -687,6 +689,8 @@ def main():
     else:
         R = args.regions or min(cfg["n_regions"], 200_000)
         total = R * world
+        if args.in_flight is None:
+            args.in_flight = 2 if R * 0.5 * (cfg["n_reads"][0] + cfg["n_reads"][1]) * cfg["read_len"] <= 1.2e8 else 1
         B = max(1, args.in_flight)                           # resident batches of R regions; a step is one pass over one of them
         if args.sub_batches is None:
             args.sub_batches = 2 if B == 1 else 1

@@ -18,9 +18,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py
 python3 tools/pmc_sum.py $OUT/fetch $OUT/write --last 10 --json $OUT/pmc_raw.json > $OUT/pmc_raw.txt 2>&1
 bash tools/pmc_mix.sh > /dev/null 2>&1
 cp gpurun_out/pmc_mix/mix.json $OUT/c2_pmc_mix.json
-STEADY="--no-cpu --no-e2e --no-check --no-other --regions 100000 --steps 3 --warmup 1 --sub-batches 1"
+STEADY="--no-cpu --no-e2e --no-check --no-other --regions 100000 --steps 3 --warmup 1 --in-flight 1 --sub-batches 1"
 stats steady100k $STEADY
-PMC_LAST=3 bash tools/pmc_mix.sh --regions 100000 --sub-batches 1 > /dev/null 2>&1
+PMC_LAST=3 bash tools/pmc_mix.sh --regions 100000 --in-flight 1 --sub-batches 1 > /dev/null 2>&1
 cp gpurun_out/pmc_mix/mix.json $OUT/steady100k_pmc_mix.json
 python3 bench.py $STEADY > $OUT/steady100k_bench.json 2>> $OUT/err
 stats c3 --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check
@@ -30,7 +30,8 @@ python3 bench.py --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e >> $OUT/othe
 python3 bench.py --config C5 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --no-cpu --no-e2e --no-check --no-other --quals >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --no-cpu --no-e2e --no-check --no-other --dup-frac 0.1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
-python3 bench.py --no-cpu --no-e2e --no-check --no-other --sub-batches 1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --no-other --in-flight 1 --sub-batches 1 >> $OUT/other_workloads.jsonl 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-check --no-other --in-flight 1 --lockstep >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --knob asm_v1=1 --no-cpu --no-e2e --no-check --no-other >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --config C3 --knob no_rich=1 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --scaling strong --config C4 --regions 1250000 --steps 2 --warmup 1 --no-cpu --no-e2e > $OUT/c4_strong_1gpu.json 2>> $OUT/err
@@ -59,8 +60,8 @@ for ln in r.stderr.splitlines():
         print("    " + t)
 PY
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 bench.py --no-cpu --no-e2e --no-other --no-check --profile --sub-batches 1 > $OUT/c2_phase_cycles.json 2>> $OUT/err
-python3 bench.py --config C5 --no-cpu --no-e2e --no-other --no-check --profile --sub-batches 1 > $OUT/c5_phase_cycles.json 2>> $OUT/err
+python3 bench.py --no-cpu --no-e2e --no-other --no-check --profile --in-flight 1 --sub-batches 1 > $OUT/c2_phase_cycles.json 2>> $OUT/err
+python3 bench.py --config C5 --no-cpu --no-e2e --no-other --no-check --profile --in-flight 1 --sub-batches 1 > $OUT/c5_phase_cycles.json 2>> $OUT/err
 python3 - <<'PY'
 import json, sys
 sys.path.insert(0, ".")

@@ -8,8 +8,8 @@ grep DIFF -A4 gpurun_out/pair_stress.txt | head -60; tail -2 gpurun_out/pair_str
 : > gpurun_out/b.err
 python bench.py --no-cpu --no-e2e --no-other > gpurun_out/b_pair.json 2>> gpurun_out/b.err
 python bench.py --no-cpu --no-e2e --no-other --no-check --knob ksw_pair=0 > gpurun_out/b_single.json 2>> gpurun_out/b.err
-python bench.py --no-cpu --no-e2e --no-other --no-check --regions 100000 --sub-batches 1 --steps 5 > gpurun_out/b_pair100k.json 2>> gpurun_out/b.err
-python bench.py --no-cpu --no-e2e --no-other --no-check --regions 100000 --sub-batches 1 --steps 5 --knob ksw_pair=0 > gpurun_out/b_single100k.json 2>> gpurun_out/b.err
+python bench.py --no-cpu --no-e2e --no-other --no-check --regions 100000 --in-flight 1 --sub-batches 1 --steps 5 > gpurun_out/b_pair100k.json 2>> gpurun_out/b.err
+python bench.py --no-cpu --no-e2e --no-other --no-check --regions 100000 --in-flight 1 --sub-batches 1 --steps 5 --knob ksw_pair=0 > gpurun_out/b_single100k.json 2>> gpurun_out/b.err
 grep -v amdgpu.ids gpurun_out/b.err | tail -5
 for f in b_pair b_single b_pair100k b_single100k; do python - <<PY
 import json
