@@ -266,7 +266,9 @@ __device__ __forceinline__ bool window_any(unsigned w0, unsigned w1, unsigned qh
 __device__ __forceinline__ unsigned window_bits(unsigned w0, unsigned w1, unsigned qh)
 {
 	const int lane = lane_id();
-	return (unsigned)ballot(lane < 16 && fsh(w1, w0, 2u * (unsigned)(lane & 15)) == qh);
+	// (every lane compares, the mask picks the sixteen: `lane < 16 && ...` is a branch around the compare and a round trip of the
+	// result through a register)
+	return (unsigned)ballot(fsh(w1, w0, 2u * (unsigned)(lane & 15)) == qh) & 0xffffu;
 }
 
 // Are the n bases at bit offset xb of LDS dword array P (dword index xd) equal to those at (yd, yb)?  Lane l compares
@@ -274,13 +276,12 @@ __device__ __forceinline__ unsigned window_bits(unsigned w0, unsigned w1, unsign
 __device__ __forceinline__ bool bits_equal(const uint32_t *P, int xd, unsigned xb, int yd, unsigned yb, int n)
 {
 	const int lane = lane_id();
-	unsigned x = 0;
-	if (16 * lane < n) {
-		const unsigned a0 = P[xd + lane], a1 = P[xd + lane + 1], b0 = P[yd + lane], b1 = P[yd + lane + 1];
-		x = fsh(a1, a0, xb) ^ fsh(b1, b0, yb);
-		const int rem = n - 16 * lane;
-		if (rem < 16) x &= (1u << (2 * rem)) - 1u;
-	}
+	// every lane loads (the lanes past the end load the last pair again) and the mask decides: no branch around the loads
+	const int last = (n - 1) >> 4, l = lane < last ? lane : last;
+	const unsigned a0 = P[xd + l], a1 = P[xd + l + 1], b0 = P[yd + l], b1 = P[yd + l + 1];
+	unsigned x = fsh(a1, a0, xb) ^ fsh(b1, b0, yb);
+	const int rem = n - 16 * lane;
+	x = rem >= 16 ? x : rem <= 0 ? 0u : x & ((1u << (2 * rem)) - 1u);
 	return ballot(x != 0) == 0;
 }
 
@@ -344,15 +345,14 @@ __device__ __forceinline__ int lpt_class(int n)
 
 // Candidate ranking of best_match (contig.nim:32-36, :107, :239) for exact matches: more matches, then the earlier contig,
 // then the target-offset phase before the query-offset phase, then the smaller offset.
-struct Best2 { int found, ma, c, ph, o; };
-__device__ __forceinline__ bool beats(const Best2 &b, int cn, int c, int ph, int o)
+// One key carries the whole order: matches (10 bits: a read is at most V2_MAX_READ long) | 63 - contig | 1 - phase | 8191 - offset
+// (a contig is at most MAXLEN = 8192 long); a larger key beats a smaller one, 0 = nothing found yet.
+struct Best2 { int found, ma, c, ph, o; unsigned key; };
+__device__ __forceinline__ unsigned best_key(int cn, int c, int ph, int o)
 {
-	if (!b.found) return true;
-	if (cn != b.ma) return cn > b.ma;
-	if (c != b.c) return c < b.c;
-	if (ph != b.ph) return ph < b.ph;
-	return o < b.o;
+	return (unsigned)cn << 20 | (unsigned)(63 - c) << 14 | (unsigned)(1 - ph) << 13 | (unsigned)(8191 - o);
 }
+__device__ __forceinline__ bool beats(const Best2 &b, int cn, int c, int ph, int o) { return best_key(cn, c, ph, o) > b.key; }
 
 // What the read kernel needs of a batch (a small struct: the ~70 fields of AsmArgs do not fit the scalar registers and
 // were reloaded from spill lanes all through the read loop).
@@ -488,7 +488,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 				wq0 = fsh(P[dw + 1], P[dw], 2u * (unsigned)(lane & 15));
 				if (omin > 63) { const int d2 = dw + 4; wq1 = fsh(d2 + 1 < RECB ? P[d2 + 1] : 0u, d2 < RECB ? P[d2] : 0u, 2u * (unsigned)(lane & 15)); }
 			}
-			Best2 best = {0, 0, 0, 0, 0};
+			Best2 best = {0, 0, 0, 0, 0, 0u};
 			V2_LAP(12);
 			// ---- target offsets (contig.nim:81-111): one dword of one contig per lane
 			for (int h = 0; h * 64 < wl_n; ++h) {
@@ -515,7 +515,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 						if (o > tlen - mo) continue;                 // :79 offsets 0 .. len(t) - min_overlap
 						const int cn = tl < tlen - o ? tl : tlen - o;
 						if (!beats(best, cn, c, 0, o)) continue;
-						if (bits_equal(P, 1, 0u, woff + (o >> 4), 2u * (unsigned)(o & 15), cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 0; best.o = o; }
+						if (bits_equal(P, 1, 0u, woff + (o >> 4), 2u * (unsigned)(o & 15), cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 0; best.o = o; best.key = best_key(cn, c, 0, o); }
 					}
 				}
 			}
@@ -546,7 +546,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 								m &= m - 1;
 								const int cn = tl - o < tlen ? tl - o : tlen;
 								if (cn < mo - 1 || !beats(best, cn, c, 1, o)) continue;      // best_ma starts at min_overlap - 1 (:81, :107)
-								if (bits_equal(P, 1 + (o >> 4), 2u * (unsigned)(o & 15), woff, 0u, cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 1; best.o = o; }
+								if (bits_equal(P, 1 + (o >> 4), 2u * (unsigned)(o & 15), woff, 0u, cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 1; best.o = o; best.key = best_key(cn, c, 1, o); }
 							}
 						}
 					}

@@ -164,8 +164,7 @@ __device__ __forceinline__ void pair_cell(unsigned z, unsigned xp, unsigned vp, 
 	xn = pk_max0(a2); yn = pk_max0(b2);                                 // :277-280
 	// a2 > 0 <=> x' != 0 (then x' >= 0x100): bit 1 = :265, bit 0 = :273, bit 2 = a2 > 0, bit 3 = b2 > 0
 	const unsigned c12 = pk_mad<2>(pk_shr<15>(s1), pk_shr<15>(s2));
-	const unsigned c34 = pk_add(pk_minc<4>(xn), pk_minc<8>(yn));
-	nib = pk_add(c12, c34);
+	nib = c12 + pk_minc<4>(xn) + pk_minc<8>(yn);                        // (each half stays below 16: one 32-bit v_add3 adds both)
 }
 
 // Close the traceback slot of diagonals ..r_last (band origin st): a full group when (r_last & 3) == 3.
