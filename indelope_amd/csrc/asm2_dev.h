@@ -522,21 +522,40 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 			V2_LAP(13);
 			// ---- query offsets 1 .. omin (contig.nim:114-135): lane o holds the read's window, the contigs' heads come by.
 			// Hits are rare (the read would have to extend a contig to the left): first only whether there is one at all.
-			{
-				const unsigned long long v0 = lane_range64(1, omin < 63 ? omin : 63), v1 = omin > 63 ? lane_range64(0, omin - 64) : 0ull;
+			// A query offset o matches at most tl - o bases, so once the target offsets have found `best.ma` matches only
+			// o <= tl - best.ma can still win (more matches, or as many on an earlier contig) -- for a read that extends its contig
+			// by a few bases that is a few offsets, and walking THEM (the window of offset o against every contig's head at once,
+			// lane <-> contig) costs a handful of compares where walking the contigs costs one per contig.
+			const int kq = best.found ? (omin < tl - best.ma ? omin : tl - best.ma) : omin;
+			if (kq >= 1 && kq <= 12) {
+				const unsigned long long live = n >= 64 ? ~0ull : (1ull << n) - 1ull;
+				for (int o = 1; o <= kq; ++o) {
+					const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wq0, o);
+					unsigned long long m = ballot(d_head == w) & live;
+					while (m) {
+						const int c = ctz64(m);
+						m &= m - 1;
+						const int tlen = bcast(d_len, c), woff = bcast(d_woff, c);
+						const int cn = tl - o < tlen ? tl - o : tlen;
+						if (cn < mo - 1 || !beats(best, cn, c, 1, o)) continue;      // best_ma starts at min_overlap - 1 (:81, :107)
+						if (bits_equal(P, 1 + (o >> 4), 2u * (unsigned)(o & 15), woff, 0u, cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 1; best.o = o; best.key = best_key(cn, c, 1, o); }
+					}
+				}
+			} else if (kq >= 1) {
+				const unsigned long long v0 = lane_range64(1, kq < 63 ? kq : 63), v1 = kq > 63 ? lane_range64(0, kq - 64) : 0ull;
 				unsigned long long any0 = 0, any1 = 0;
 				for (int c = 0; c < n; c += 4) {                     // lanes >= n hold head 0: a false hit only costs the second look
 #pragma unroll
 					for (int u = 0; u < 4; ++u) {
 						const unsigned hd = (unsigned)__builtin_amdgcn_readlane((int)d_head, c + u);
 						any0 |= ballot(wq0 == hd);
-						if (omin > 63) any1 |= ballot(wq1 == hd);
+						if (kq > 63) any1 |= ballot(wq1 == hd);
 					}
 				}
 				if ((any0 & v0) | (any1 & v1)) {
 					for (int c = 0; c < n; ++c) {
 						const unsigned hd = (unsigned)__builtin_amdgcn_readlane((int)d_head, c);
-						const unsigned long long m0 = ballot(wq0 == hd) & v0, m1 = omin > 63 ? ballot(wq1 == hd) & v1 : 0ull;
+						const unsigned long long m0 = ballot(wq0 == hd) & v0, m1 = kq > 63 ? ballot(wq1 == hd) & v1 : 0ull;
 						if (!(m0 | m1)) continue;
 						const int tlen = bcast(d_len, c), woff = bcast(d_woff, c);
 						for (int half = 0; half < 2; ++half) {
