@@ -225,6 +225,48 @@ def test_fallback_two_target_sweep_matches_oracle_and_single_sweeps(hip, oracle,
         assert np.count_nonzero(want.events["fallback_needed"]) > 0           # the case exists in what was compared
 
 
+def _reorder_reads(b, mode, seed):
+    """The same regions with the reads of every region in another order (ragged arrays rebuilt read by read)."""
+    rng = np.random.default_rng(seed)
+    order = []
+    for r in range(b.n_regions):
+        i0, i1 = int(b.region_read_off[r]), int(b.region_read_off[r + 1])
+        idx = np.arange(i0, i1)
+        order.append(idx[::-1] if mode == "reverse" else rng.permutation(idx))
+    order = np.concatenate(order) if order else np.zeros(0, np.int64)
+    lens = np.diff(b.read_off)[order]
+    read_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pick = np.concatenate([np.arange(b.read_off[i], b.read_off[i + 1]) for i in order]) if len(order) else np.zeros(0, np.int64)
+    c = copy.copy(b)
+    c.read_off = read_off
+    c.bases = b.bases[pick]
+    c.quals = b.quals[pick] if b.quals is not None and len(b.quals) == len(b.bases) else b.quals
+    c.read_start, c.read_stop = b.read_start[order], b.read_stop[order]
+    c.mapq, c.read_skip = b.mapq[order], b.read_skip[order]
+    if b.trim_lo is not None:
+        c.trim_lo, c.trim_hi = b.trim_lo[order], b.trim_hi[order]
+    return c
+
+
+@pytest.mark.parametrize("mode", ["reverse", "random"])
+@pytest.mark.parametrize("cfg", [
+    dict(n_regions=150, n_reads=(24, 64), err_rate=1e-3, config_id=151),
+    dict(n_regions=80, n_reads=(16, 200), err_rate=2e-3, config_id=152),
+    dict(n_regions=40, read_len=300, n_reads=(32, 64), err_rate=1e-3, n_events=2, window_len=1400, event_pos=500, config_id=153, K=31),
+])
+def test_reads_in_any_order_extend_contigs_on_either_side(hip, oracle, cfg, mode):
+    """The read phase's query offsets (contig.nim:114-135: the read reaches past a contig's START) are only looked at where they
+    can still beat what the target offsets found (round 4).  A position-sorted batch hardly uses them: the same regions with
+    their reads reversed -- every read then extends its contig to the left -- and in random order use both forms of that walk
+    (a few offsets against all contig heads; every contig against all offsets)."""
+    b, _ = synth.generate(**cfg)
+    b = _reorder_reads(b, mode, cfg["config_id"])
+    K = cfg.get("K", 27)
+    got = hip.run_regions(b, hip.params(K=K))
+    assert_same(got, oracle.run_regions(b, oracle.params(K=K)))
+    assert (got.status == 0).all()
+
+
 def test_stress_tools_with_todays_seeds():
     """The randomised harnesses under tools/ found every device bug of round 3 and none of the fixed-seed tests did: a bounded
     pass of each (fresh seed from the date, a few seconds apiece) runs where the driver can see it.  The seed is printed on
