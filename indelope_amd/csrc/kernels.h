@@ -502,7 +502,6 @@ __device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ct
 	long long cursor = 0;
 	for (int k = 0; k < n_final; ++k) {
 		const int c = uni((int)S.listA[k]);
-		const long long slot = r0 + k;
 		const int len = uni(S.len[c]), pb = uni(16 * S.dw[c] + S.sh[c]), so = uni(S.so[c]);
 		uint8_t *oseq = a.out_seq + seq_base + cursor; uint32_t *osup = a.out_sup + seq_base + cursor;
 		for (int i = 4 * lane; i < len; i += 256) {                  // four bases per lane: 2-bit codes -> "ACTG" bytes

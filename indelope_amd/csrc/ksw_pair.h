@@ -419,14 +419,14 @@ __device__ __forceinline__ void pair_ez_lean(PairState &S, const PairEnv &E, Pai
 // pair_ez_rest does those, nothing has been changed then.  Written as one asm statement because the compiler kept max_t /
 // max_q in spill lanes of a vector register (v_writelane / v_readlane around every new maximum) and formed the minimum of
 // three scalars on the vector unit; everything here stays in the SGPRs the operands name.
-#define IHP_PAIR_EZ_ASM(WORD, SEXT)                                                                                    \
+#define IHP_PAIR_EZ_ASM(WORD, SEXT, ENTRY, RARE2, RARE1, STATC)                                                                                    \
 	asm("v_cmp_gt_i16_sdwa %[m], %[G], %[thr] src0_sel:" WORD " src1_sel:WORD_0\n\t"                               \
-	    "s_mov_b32 %[stat], 0\n\t"                                                                                 \
+	    ENTRY                                                                                                      \
 	    "s_and_b64 %[m], %[m], %[inT]\n\t"                                                                         \
 	    "s_cbranch_scc1 1f\n\t"                                                                                    \
 	    "s_cmp_le_i32 %[r], %[zs]\n\t"                                                                             \
 	    "s_cbranch_scc1 2f\n\t"                                                                                    \
-	    "s_mov_b32 %[stat], 2\n\t"                                                                                 \
+	    RARE2 "\n\t"                                                                                 \
 	    "s_branch 9f\n"                                                                                            \
 	    "2:\n\t"                                                                                                   \
 	    "s_add_i32 %[thr], %[thr], %[inc]\n\t"                                                                     \
@@ -435,7 +435,7 @@ __device__ __forceinline__ void pair_ez_lean(PairState &S, const PairEnv &E, Pai
 	    "s_bcnt1_i32_b64 %[i], %[m]\n\t"                                                                           \
 	    "s_cmp_lg_u32 %[i], 1\n\t"                                                                                 \
 	    "s_cbranch_scc0 3f\n\t"                                                                                    \
-	    "s_mov_b32 %[stat], 1\n\t"                                                                                 \
+	    RARE1 "\n\t"                                                                                 \
 	    "s_branch 9f\n"                                                                                            \
 	    "3:\n\t"                                                                                                   \
 	    "s_ff1_i32_b64 %[i], %[m]\n\t"                                                                             \
@@ -452,19 +452,20 @@ __device__ __forceinline__ void pair_ez_lean(PairState &S, const PairEnv &E, Pai
 	    "s_cselect_b32 %[zs], %[r], %[zs]\n\t"                                                                     \
 	    "s_add_i32 %[thr], %[g], %[inc]\n"                                                                         \
 	    "9:"                                                                                                       \
-	    : [m] "=&s"(m), [stat] "=&s"(stat), [i] "=&s"(i), [g] "=&s"(g), [b] "=&s"(b), [thr] "+s"(thr), [pos] "+s"(pos), [zs] "+s"(zsafe) \
+	    : [m] "=&s"(m), [stat] STATC(stat), [i] "=&s"(i), [g] "=&s"(g), [b] "=&s"(b), [thr] "+s"(thr), [pos] "+s"(pos), [zs] "+s"(zsafe) \
 	    : [G] "v"(G), [inT] "s"(inT), [sp] "s"(spM), [r] "s"(r), [st] "s"(st), [zq] "s"(zq), [w] "s"(w), [qlm1] "s"(qlm1), [inc] "s"(inc) \
 	    : "scc")
+// `stat` is shared by the two alignments of a diagonal: alignment 0 clears it and reports in bits 1..0, alignment 1 in bits 3..2
+// (one test per diagonal instead of a clear and a test per alignment).
 template <int K>
-__device__ __forceinline__ int pair_ez_asm(const unsigned G, int &thr, int &pos, int &zsafe, const unsigned long long inT_, const unsigned long long spM_,
-                                           const int r_, const int st_, const int zq_, const int w_, const int qlm1_, const int inc_)
+__device__ __forceinline__ void pair_ez_asm(int &stat, const unsigned G, int &thr, int &pos, int &zsafe, const unsigned long long inT_, const unsigned long long spM_,
+                                            const int r_, const int st_, const int zq_, const int w_, const int qlm1_, const int inc_)
 {
 	const unsigned long long inT = (unsigned long long)uni((long long)inT_), spM = (unsigned long long)uni((long long)spM_);
 	const int r = uni(r_), st = uni(st_), zq = uni(zq_), w = uni(w_), qlm1 = uni(qlm1_), inc = uni(inc_);
-	unsigned long long m; int stat, i, g, b;
-	if (K == 0) IHP_PAIR_EZ_ASM("WORD_0", "s_sext_i32_i16 %[g], %[g]");
-	else IHP_PAIR_EZ_ASM("WORD_1", "s_ashr_i32 %[g], %[g], 16");
-	return stat;
+	unsigned long long m; int i, g, b;
+	if (K == 0) IHP_PAIR_EZ_ASM("WORD_0", "s_sext_i32_i16 %[g], %[g]", "s_mov_b32 %[stat], 0\n\t", "s_mov_b32 %[stat], 2", "s_mov_b32 %[stat], 1", "=&s");
+	else IHP_PAIR_EZ_ASM("WORD_1", "s_ashr_i32 %[g], %[g], 16", "", "s_or_b32 %[stat], %[stat], 8", "s_or_b32 %[stat], %[stat], 4", "+s");
 }
 #undef IHP_PAIR_EZ_ASM
 
@@ -547,8 +548,13 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 		pair_ez_lean<0, true>(S, E, C, r, inTA, mInB, C.spM, zq);
 		pair_ez_lean<1, true>(S, E, C, r, inTA, mInB, C.spM, zq);
 	} else {
-		if (pair_ez_asm<0>(S.GA, S.thr0, S.pos0, C.zsafe0, inTA, C.spM, r, st, zq, E.w, E.qlm1, S.inc0)) pair_ez_lean<0, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
-		if (pair_ez_asm<1>(S.GA, S.thr1, S.pos1, C.zsafe1, inTA, C.spM, r, st, zq, E.w, E.qlm1, S.inc1)) pair_ez_lean<1, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+		int stat;
+		pair_ez_asm<0>(stat, S.GA, S.thr0, S.pos0, C.zsafe0, inTA, C.spM, r, st, zq, E.w, E.qlm1, S.inc0);
+		pair_ez_asm<1>(stat, S.GA, S.thr1, S.pos1, C.zsafe1, inTA, C.spM, r, st, zq, E.w, E.qlm1, S.inc1);
+		if (stat) {                                                        // (an everyday diagonal: one test for both alignments)
+			if (stat & 3) pair_ez_lean<0, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+			if (stat >> 2) pair_ez_lean<1, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+		}
 	}
 	// ---- the step to r + 1: (r+w)>>1 grows from an odd r+w, (r-w+1)>>1 otherwise ----
 	if (EDGE == 2) {
@@ -680,8 +686,15 @@ __device__ __forceinline__ void pair_tail_step(PairState &S, const PairEnv &E, P
 		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st0; }
 		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st0; }
 	}
-	if (pair_ez_asm<0>(S.GA, S.thr0, S.pos0, C.zsafe0, inTM, 1ull << hiT, r, st, zq, E.w, E.qlm1, S.inc0)) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, 1ull << hiT, zq);
-	if (pair_ez_asm<1>(S.GA, S.thr1, S.pos1, C.zsafe1, inTM, 1ull << hiT, r, st, zq, E.w, E.qlm1, S.inc1)) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, 1ull << hiT, zq);
+	{
+		int stat;
+		pair_ez_asm<0>(stat, S.GA, S.thr0, S.pos0, C.zsafe0, inTM, 1ull << hiT, r, st, zq, E.w, E.qlm1, S.inc0);
+		pair_ez_asm<1>(stat, S.GA, S.thr1, S.pos1, C.zsafe1, inTM, 1ull << hiT, r, st, zq, E.w, E.qlm1, S.inc1);
+		if (stat) {
+			if (stat & 3) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, 1ull << hiT, zq);
+			if (stat >> 2) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, 1ull << hiT, zq);
+		}
+	}
 	// ---- the band of r + 1 (:196-205) ----
 	{
 		const int a = r + 2 - E.qlen, b = (r + 2 - E.w) >> 1;
@@ -726,8 +739,15 @@ __device__ __forceinline__ void pair_tail_qrun(PairState &S, const PairEnv &E, P
 			if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st + loA; }
 			if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st + loA; }
 		}
-		if (pair_ez_asm<0>(S.GA, S.thr0, S.pos0, C.zsafe0, inTM, spM, r, st, zq, E.w, E.qlm1, S.inc0)) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, spM, zq);
-		if (pair_ez_asm<1>(S.GA, S.thr1, S.pos1, C.zsafe1, inTM, spM, r, st, zq, E.w, E.qlm1, S.inc1)) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, spM, zq);
+		{
+			int stat;
+			pair_ez_asm<0>(stat, S.GA, S.thr0, S.pos0, C.zsafe0, inTM, spM, r, st, zq, E.w, E.qlm1, S.inc0);
+			pair_ez_asm<1>(stat, S.GA, S.thr1, S.pos1, C.zsafe1, inTM, spM, r, st, zq, E.w, E.qlm1, S.inc1);
+			if (stat) {
+				if (stat & 3) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, spM, zq);
+				if (stat >> 2) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, spM, zq);
+			}
+		}
 		// ---- the band of r + 1: st0 + 1, en0 + 1 from an odd r + w ----
 		const int p = (r + E.w) & 1;
 		inTM = bit_clear(inTM, loA); refM = bit_clear(refM, loA);
