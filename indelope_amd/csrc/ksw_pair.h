@@ -134,10 +134,17 @@ struct PairState {
 	int st; int edge_g;
 	int thr0, thr1;                                      // ez.max + r (q+e) of the coming diagonal
 	int pos0, pos1;                                      // where ez.max was found: the diagonal << 16 | max_t (max_q = diagonal - max_t)
-	int mqe0, mqe1, mqe_t0, mqe_t1;
+	int mqe0, mqe1;
+	int cold;                                            // lanes 0..3: mqe_t0, mqe_t1, fin0, fin1 -- written a few times per sweep and read at its end; in a
+	                                                     // register of their own they cost the loops four scalar registers and the compiler spilled hotter ones
 	int inc0, inc1;                                      // q+e while the alignment is live; 0 once it has z-dropped: the values above are final,
-	int fin0, fin1;                                      // fin* holds ez.max and thr* stands at 32767
+	                                                     // (fin* holds ez.max of an alignment that has z-dropped; thr* then stands at 32767)
 };
+
+extern "C" __device__ int ihp_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");   // (as in ksw_wide.h)
+constexpr int PC_MQE_T0 = 0, PC_MQE_T1 = 1, PC_FIN0 = 2, PC_FIN1 = 3;
+__device__ __forceinline__ void pair_cold_set(PairState &S, int k, int v) { S.cold = ihp_writelane_i32(v, k, S.cold); }
+__device__ __forceinline__ int pair_cold_get(const PairState &S, int k) { return __builtin_amdgcn_readlane(S.cold, k); }
 
 // z by query code (bytes 0..3) for a target base
 __device__ __forceinline__ unsigned pair_table(const PairEnv &E, unsigned code)
@@ -215,7 +222,8 @@ __device__ __forceinline__ void pair_ez(PairState &S, const PairEnv &E, const in
 	const int tl = t - emt, ql = dq - emq;
 	const int l = tl > ql ? tl - ql : ql - tl;
 	if (thr - gmax > E.zd + l * E.e) {                                  // z-drop: this alignment is done; its partner goes on
-		if (K == 0) { S.inc0 = 0; S.fin0 = thr - r * E.qe; } else { S.inc1 = 0; S.fin1 = thr - r * E.qe; }
+		if (K == 0) S.inc0 = 0; else S.inc1 = 0;
+		pair_cold_set(S, K == 0 ? PC_FIN0 : PC_FIN1, thr - r * E.qe);
 		thr = 0x7fff - E.qe;                                                // (the caller adds q+e once more)
 	}
 }
@@ -310,8 +318,8 @@ __device__ __forceinline__ void pair_diag(PairState &S, const PairEnv &E, const 
 	if (r - st0 == E.qlen - 1) {
 		const int g = __builtin_amdgcn_readlane((int)S.GA, loA);
 		const int h0 = pk_half<0>(g) - r * E.qe, h1 = pk_half<1>(g) - r * E.qe;
-		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st0; }
-		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st0; }
+		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; pair_cold_set(S, PC_MQE_T0, st0); }
+		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; pair_cold_set(S, PC_MQE_T1, st0); }
 	}
 	if (S.inc0) { pair_ez<0>(S, E, r, st0, en0, hasB, inTA, mInB); S.thr0 += E.qe; }
 	if (S.inc1) { pair_ez<1>(S, E, r, st0, en0, hasB, inTA, mInB); S.thr1 += E.qe; }
@@ -324,8 +332,8 @@ __device__ __forceinline__ void pair_diag(PairState &S, const PairEnv &E, const 
 __device__ __forceinline__ void pair_uniform(PairState &S)
 {
 	S.st = uni(S.st); S.edge_g = uni(S.edge_g); S.thr0 = uni(S.thr0); S.thr1 = uni(S.thr1); S.pos0 = uni(S.pos0); S.pos1 = uni(S.pos1);
-	S.mqe0 = uni(S.mqe0); S.mqe1 = uni(S.mqe1); S.mqe_t0 = uni(S.mqe_t0); S.mqe_t1 = uni(S.mqe_t1);
-	S.inc0 = uni(S.inc0); S.inc1 = uni(S.inc1); S.fin0 = uni(S.fin0); S.fin1 = uni(S.fin1);
+	S.mqe0 = uni(S.mqe0); S.mqe1 = uni(S.mqe1);
+	S.inc0 = uni(S.inc0); S.inc1 = uni(S.inc1);
 }
 
 // ---------------------------------------------------------------- the steady diagonals, laid out as ksw_narrow.h's
@@ -403,7 +411,8 @@ __device__ __forceinline__ void pair_ez_lean(PairState &S, const PairEnv &E, Pai
 				if (thr - gmax > E.zd + l * E.e) {                          // z-drop: this alignment is done; its partner goes on
 					const int fin = thr - r * E.qe;
 					thr = 0x7fff; zsafe = 0x7fffffff;
-					if (K == 0) { S.inc0 = 0; S.fin0 = fin; } else { S.inc1 = 0; S.fin1 = fin; }
+					if (K == 0) S.inc0 = 0; else S.inc1 = 0;
+					pair_cold_set(S, K == 0 ? PC_FIN0 : PC_FIN1, fin);
 					if (!(S.inc0 | S.inc1)) C.lim = INTMIN;
 					return;
 				}
@@ -683,8 +692,8 @@ __device__ __forceinline__ void pair_tail_step(PairState &S, const PairEnv &E, P
 	{                                                                    // :353-354 (r - st0 == qlen - 1 on every diagonal here)
 		const int g = __builtin_amdgcn_readlane((int)S.GA, loA);
 		const int h0 = pk_half<0>(g) - r * E.qe, h1 = pk_half<1>(g) - r * E.qe;
-		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st0; }
-		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st0; }
+		if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; pair_cold_set(S, PC_MQE_T0, st0); }
+		if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; pair_cold_set(S, PC_MQE_T1, st0); }
 	}
 	{
 		int stat;
@@ -736,8 +745,8 @@ __device__ __forceinline__ void pair_tail_qrun(PairState &S, const PairEnv &E, P
 		{                                                                // :353-354
 			const int g = __builtin_amdgcn_readlane((int)S.GA, loA);
 			const int h0 = pk_half<0>(g) - r * E.qe, h1 = pk_half<1>(g) - r * E.qe;
-			if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; S.mqe_t0 = st + loA; }
-			if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; S.mqe_t1 = st + loA; }
+			if (S.inc0 && h0 > S.mqe0) { S.mqe0 = h0; pair_cold_set(S, PC_MQE_T0, st + loA); }
+			if (S.inc1 && h1 > S.mqe1) { S.mqe1 = h1; pair_cold_set(S, PC_MQE_T1, st + loA); }
 		}
 		{
 			int stat;
@@ -879,8 +888,8 @@ __device__ inline bool ksw_pair_sweep(const uint8_t *q0, const uint8_t *t0, int 
 	S.qptr = qs + (qlen - 1 + lane); S.qoffB = 64 + (lane & 15) - lane; S.rlB = -1;
 	S.accA = S.accB = 0; S.st = 0; S.edge_g = 0;
 	S.thr0 = S.thr1 = 0; S.pos0 = S.pos1 = pos_pack(-2, -1);             // max_t = max_q = -1 (:81-86)
-	S.mqe0 = S.mqe1 = KSW_NEG_INF; S.mqe_t0 = S.mqe_t1 = -1;
-	S.inc0 = S.inc1 = qe; S.fin0 = S.fin1 = 0;
+	S.mqe0 = S.mqe1 = KSW_NEG_INF; S.cold = lane < 2 ? -1 : 0;           // mqe_t = -1, fin = 0
+	S.inc0 = S.inc1 = qe;
 	// the band leaves the matrix on diagonal 2 qlen + w - 1 (:200-203): r_end is the first diagonal without a cell
 	const int r_end = 2 * qlen + w - 1;
 	pair_diag<true>(S, E, 0, 0, 0);
@@ -893,8 +902,8 @@ __device__ inline bool ksw_pair_sweep(const uint8_t *q0, const uint8_t *t0, int 
 	if (((r - 1) & 3) != 3) pair_flush(S, E, r - 1, S.st);
 	WSYNC();
 	if (pacc && lane == 0) { pacc[1] += (long long)clock64(); pacc[3] += 2; }
-	R.max0 = S.inc0 ? S.thr0 - r * qe : S.fin0; R.max1 = S.inc1 ? S.thr1 - r * qe : S.fin1;
-	R.pos0 = S.pos0; R.pos1 = S.pos1; R.mqe0 = S.mqe0; R.mqe1 = S.mqe1; R.mqe_t0 = S.mqe_t0; R.mqe_t1 = S.mqe_t1;
+	R.max0 = S.inc0 ? S.thr0 - r * qe : pair_cold_get(S, PC_FIN0); R.max1 = S.inc1 ? S.thr1 - r * qe : pair_cold_get(S, PC_FIN1);
+	R.pos0 = S.pos0; R.pos1 = S.pos1; R.mqe0 = S.mqe0; R.mqe1 = S.mqe1; R.mqe_t0 = pair_cold_get(S, PC_MQE_T0); R.mqe_t1 = pair_cold_get(S, PC_MQE_T1);
 	return true;
 }
 
