@@ -491,9 +491,9 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 			Best2 best = {0, 0, 0, 0, 0, 0u};
 			V2_LAP(12);
 			// ---- target offsets (contig.nim:81-111): one dword of one contig per lane
-			for (int h = 0; h * 64 < wl_n; ++h) {
-				int ent = h ? wl1 : wl0;
-				if (h >= 2) ent = h * 64 + lane < wl_n ? (int)P[WLXB + (h - 2) * 64 + lane] : 0;
+			// (the two register chunks written out, the LDS chunks of long-read regions in a loop behind them: choosing the chunk's
+			// source inside one loop cost a dozen scalar instructions and three branches per chunk)
+			auto chunk = [&](const int h, const int ent) {
 				unsigned w0 = 0, w1 = 0;
 				bool any = false;
 				if (h * 64 + lane < wl_n) {
@@ -518,7 +518,10 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 						if (bits_equal(P, 1, 0u, woff + (o >> 4), 2u * (unsigned)(o & 15), cn)) { best.found = 1; best.ma = cn; best.c = c; best.ph = 0; best.o = o; best.key = best_key(cn, c, 0, o); }
 					}
 				}
-			}
+			};
+			if (wl_n > 0) chunk(0, wl0);
+			if (wl_n > 64) chunk(1, wl1);
+			for (int h = 2; h * 64 < wl_n; ++h) chunk(h, h * 64 + lane < wl_n ? (int)P[WLXB + (h - 2) * 64 + lane] : 0);
 			V2_LAP(13);
 			// ---- query offsets 1 .. omin (contig.nim:114-135): lane o holds the read's window, the contigs' heads come by.
 			// Hits are rare (the read would have to extend a contig to the left): first only whether there is one at all.
