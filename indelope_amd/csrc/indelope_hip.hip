@@ -1635,10 +1635,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			pa.trim_min_qual = p.trim_min_qual; pa.pk = b->v2_pk.as<uint32_t>(); pa.trim_lo = b->v2_trim_lo.as<int>();
 			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
 			pa.t_start = tm;                                       // the first launch of the stage
-			if (g_knob.prepack_fast == 1 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<1>, dim3(b->grid_pack), dim3(64), 0, s, pa);
-			else if (g_knob.prepack_fast == 2 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<2>, dim3(b->grid_pack), dim3(64), 0, s, pa);
-			else if (g_knob.prepack_fast == 3 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<3>, dim3(b->grid_pack), dim3(64), 0, s, pa);
-			else if (g_knob.prepack_fast == 4 && !pa.bases4 && pa.trim_lo_in && pa.n_reads > 0) hipLaunchKernelGGL(k_prepack_fast<4>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			// (the pipelined kernel loads without asking whether a read has bases: not for a batch without any)
+			const int pf = (!pa.bases4 && pa.trim_lo_in && pa.n_reads > 0 && b->n_bases >= 16) ? g_knob.prepack_fast : 0;
+			if (pf == 1) hipLaunchKernelGGL(k_prepack_fast<1>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else if (pf == 2) hipLaunchKernelGGL(k_prepack_fast<2>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else if (pf == 3) hipLaunchKernelGGL(k_prepack_fast<3>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			else if (pf == 4) hipLaunchKernelGGL(k_prepack_fast<4>, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			else hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			HIPC(hipGetLastError());
 		}

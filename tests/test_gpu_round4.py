@@ -267,6 +267,23 @@ def test_reads_in_any_order_extend_contigs_on_either_side(hip, oracle, cfg, mode
     assert (got.status == 0).all()
 
 
+def test_batches_with_hardly_any_bases(hip, oracle):
+    """The pipelined 2-bit packing loads without asking whether a read has bases: a batch whose reads are all trimmed away to
+    nothing / a few bases long takes the plain kernel or clamps, and gives what the oracle gives (no contigs)."""
+    b, _ = synth.generate(6, n_reads=(3, 5), err_rate=0.0, config_id=161)
+    b = b.with_trim_bounds()
+    for keep in (0, 3):
+        c = copy.copy(b)
+        nr = c.n_reads
+        c.read_off = (np.arange(nr + 1) * keep).astype(np.int64)
+        c.bases = np.frombuffer(b"ACG" * nr, np.uint8).copy()[:keep * nr] if keep else np.zeros(0, np.uint8)
+        c.quals = np.full(len(c.bases), 40, np.uint8)
+        c.read_stop = c.read_start + keep
+        c.trim_lo = np.zeros(nr, np.int32); c.trim_hi = np.full(nr, keep, np.int32)
+        got = hip.run_regions(c, hip.params(K=27))
+        assert_same(got, oracle.run_regions(c, oracle.params(K=27)))
+
+
 def test_stress_tools_with_todays_seeds():
     """The randomised harnesses under tools/ found every device bug of round 3 and none of the fixed-seed tests did: a bounded
     pass of each (fresh seed from the date, a few seconds apiece) runs where the driver can see it.  The seed is printed on
