@@ -491,6 +491,15 @@ int  ihp_debug_last_ksw_mode(void);
 /* How many PAIRS of alignments the last ihp_ksw_extz2_batch call ran two to a wavefront (ksw_pair.h; 0 when the
  * parameters or the jobs did not allow it, or after ihp_debug_set("ksw_pair", 0)).                             */
 int  ihp_debug_last_ksw_pairs(void);
+/* Diagnostics: n (read, target 0, target 1) items through the two-target sweep the alignment fallback runs per (event, read)
+ * (ksw_duo.h; indelope.nim:336-344 calls align_to twice, ksw2.nim:151-164, on the same read) -- on caller-made strings, so that
+ * a test can hold the sweep against the reference's ksw_extz2_sse (ksw2.h:54) directly.  Strings are base codes 0..4, q_off /
+ * t0_off / t1_off have n + 1 entries.  ez[2 i], ez[2 i + 1]: max, max_q, max_t and n_cigar of item i's two alignments (the
+ * fields the fallback reads, indelope.nim:343-344; the others stay reset); n_cigar = -2: the sweep does not take such an item
+ * (banded, z-drop, a read over 320 bases ...: k_fallback runs those one at a time).  cigar: 2 n slots of cig_slot words.      */
+int  ihp_debug_ksw_duo_batch(int32_t n, const uint8_t *reads, const int64_t *q_off, const uint8_t *t0, const int64_t *t0_off,
+                             const uint8_t *t1, const int64_t *t1_off, int8_t m, const int8_t *mat, int8_t q, int8_t e,
+                             int w, int zdrop, int flag, ihp_ez *ez, uint32_t *cigar, int32_t cig_slot);
 /* Test hook: upper limits for the device pools of batches uploaded from now on -- {CIGAR bump-pool words,
  * event-pool entries, hit-pool ints, ksw2 traceback bytes per wave}; 0 = the library's own sizing.  NULL resets.
  * Lets the overflow paths (IHP_E_CAPACITY from ihp_batch_sync / fetch) be driven by small inputs.               */

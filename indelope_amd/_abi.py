@@ -235,6 +235,8 @@ _PRODUCT_ONLY = {
     "batch_summary_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "debug_last_ksw_mode": (C.c_int, []),
     "debug_last_ksw_pairs": (C.c_int, []),
+    "debug_ksw_duo_batch": (C.c_int, [C.c_int32, u8p, i64p, u8p, i64p, u8p, i64p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, u32p, C.c_int32]),
     "debug_limits": (C.c_int, [i64p]),
     "debug_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "ksw_last_status": (C.c_int, []),

@@ -747,6 +747,52 @@ extern "C" int ihp_ksw_extz2_batch(int32_t n, const uint8_t *queries, const int6
 	return ret;
 }
 
+// Diagnostics: n (read, target 0, target 1) items through the alignment fallback's two-target sweep (ksw_duo.h) -- what
+// k_fallback runs per (event, read), here on caller-made strings so that a test can compare it with the compiled reference.
+// ez[2 i], ez[2 i + 1]: max / max_q / max_t / n_cigar of the item's alignments (the other fields stay reset: the fallback
+// reads none of them); n_cigar = -2 marks an item the sweep does not take (ksw_duo_ok).  cigar: 2 n slots of cig_slot words.
+extern "C" int ihp_debug_ksw_duo_batch(int32_t n, const uint8_t *reads, const int64_t *q_off, const uint8_t *t0, const int64_t *t0_off,
+                                       const uint8_t *t1, const int64_t *t1_off, int8_t m, const int8_t *mat, int8_t q, int8_t e,
+                                       int w, int zdrop, int flag, ihp_ez *ez, uint32_t *cigar, int32_t cig_slot)
+{
+	if (n < 0 || !q_off || !t0_off || !t1_off || !mat || !ez || !cigar || cig_slot < 1 || (n && (!reads || !t0 || !t1))) return IHP_E_ARG;
+	int rc = ensure_init();
+	if (rc) return rc;
+	if (n == 0) return 0;
+	const KswParams P = make_ksw_params(m, mat, q, e, w, zdrop, flag, 0);
+	int qmax = 1, tmax = 1;
+	for (int i = 0; i < n; ++i) {
+		qmax = std::max(qmax, (int)(q_off[i + 1] - q_off[i]));
+		tmax = std::max(tmax, (int)std::max(t0_off[i + 1] - t0_off[i], t1_off[i + 1] - t1_off[i]));
+	}
+	qmax = std::min(qmax, 64 * DUO_NS_MAX);
+	const size_t lds = std::min(ksw_duo_lds_bytes(tmax), (size_t)g.max_lds - 2048), p_cap = ksw_duo_p_bytes(qmax, tmax) + 64;
+	const int grid = std::min(n, 64), cig_cap = qmax + tmax + 16;
+	DBuf d_q, d_t0, d_t1, d_qo, d_t0o, d_t1o, d_p, d_ct, d_ez, d_cig;
+	if ((rc = d_q.upload(reads, (size_t)q_off[n], g.stream)) || (rc = d_t0.upload(t0, (size_t)t0_off[n], g.stream)) || (rc = d_t1.upload(t1, (size_t)t1_off[n], g.stream))) return rc;
+	if ((rc = d_qo.upload(q_off, sizeof(int64_t) * (n + 1), g.stream)) || (rc = d_t0o.upload(t0_off, sizeof(int64_t) * (n + 1), g.stream)) ||
+	    (rc = d_t1o.upload(t1_off, sizeof(int64_t) * (n + 1), g.stream))) return rc;
+	if ((rc = d_p.alloc(p_cap * grid)) || (rc = d_ct.alloc(sizeof(uint32_t) * (size_t)cig_cap * grid)) || (rc = d_ez.alloc(sizeof(KswOut) * 2 * n)) ||
+	    (rc = d_cig.alloc(sizeof(uint32_t) * (size_t)cig_slot * 2 * n))) return rc;
+	DuoTestArgs a;
+	a.n = n; a.q = d_q.as<uint8_t>(); a.t0 = d_t0.as<uint8_t>(); a.t1 = d_t1.as<uint8_t>();
+	a.q_off = d_qo.as<long long>(); a.t0_off = d_t0o.as<long long>(); a.t1_off = d_t1o.as<long long>();
+	a.P = P; a.lds_budget = (int)lds; a.p_scratch = d_p.as<uint8_t>(); a.p_cap = p_cap; a.cig_tmp = d_ct.as<uint32_t>(); a.cig_cap = cig_cap;
+	a.ez = d_ez.as<KswOut>(); a.cig = d_cig.as<uint32_t>(); a.cig_slot = cig_slot;
+	hipLaunchKernelGGL(k_ksw_duo_test, dim3(grid), dim3(64), lds + 64, g.stream, a);
+	HIPC(hipGetLastError());
+	std::vector<KswOut> out(2 * (size_t)n);
+	HIPC(hipMemcpyAsync(out.data(), d_ez.p, sizeof(KswOut) * out.size(), hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipMemcpyAsync(cigar, d_cig.p, sizeof(uint32_t) * (size_t)cig_slot * 2 * n, hipMemcpyDeviceToHost, g.stream));
+	HIPC(hipStreamSynchronize(g.stream));
+	for (size_t i = 0; i < out.size(); ++i) {
+		const KswOut &o = out[i];
+		ez[i].max = o.max; ez[i].zdropped = o.zdropped; ez[i].max_q = o.max_q; ez[i].max_t = o.max_t;
+		ez[i].mqe = o.mqe; ez[i].mqe_t = o.mqe_t; ez[i].mte = o.mte; ez[i].mte_q = o.mte_q; ez[i].score = o.score; ez[i].n_cigar = o.n_cigar;
+	}
+	return 0;
+}
+
 // Drop-in for the reference's FFI seam (ksw2.h:54).
 extern "C" void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                               int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag,

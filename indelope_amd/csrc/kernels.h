@@ -1217,6 +1217,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	}
 }
 
+// Diagnostics (ihp_debug_ksw_duo_batch): the two-target sweep of ksw_duo.h on caller-made (read, target 0, target 1) items, so
+// that tests can hold it against the compiled reference directly.  One wavefront per item; an item the sweep does not take
+// (ksw_duo_ok) gets n_cigar = -2 in both records.
+struct DuoTestArgs {
+	int n;
+	const uint8_t *q, *t0, *t1; const long long *q_off, *t0_off, *t1_off;
+	KswParams P; int lds_budget;
+	uint8_t *p_scratch; size_t p_cap;          // per workgroup
+	uint32_t *cig_tmp; int cig_cap;            // per workgroup
+	KswOut *ez;                                // [2 n]
+	uint32_t *cig; int cig_slot;               // [2 n][cig_slot]
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_ksw_duo_test(const DuoTestArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const int lane = lane_id();
+	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
+	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
+	for (int i = (int)blockIdx.x; i < a.n; i += (int)gridDim.x) {
+		const int ql = (int)uni(a.q_off[i + 1] - a.q_off[i]), tl0 = (int)uni(a.t0_off[i + 1] - a.t0_off[i]), tl1 = (int)uni(a.t1_off[i + 1] - a.t1_off[i]);
+		const int tmax = tl0 > tl1 ? tl0 : tl1;
+		KswOut o[2];
+		for (int k = 0; k < 2; ++k) {
+			o[k].max = 0; o[k].zdropped = 0; o[k].max_q = o[k].max_t = o[k].mqe_t = o[k].mte_q = -1;
+			o[k].mqe = o[k].mte = o[k].score = KSW_NEG_INF; o[k].n_cigar = -2;
+		}
+		bool done = false;
+		if (ql > 0 && tl0 > 0 && tl1 > 0 && ksw_duo_ok(a.P, ql, tl0, tl1) && ksw_duo_lds_bytes(tmax) <= (size_t)a.lds_budget &&
+		    ksw_duo_p_bytes(ql, tmax) <= a.p_cap && ql + tmax + 8 <= a.cig_cap && ql + tmax + 8 <= a.cig_slot) {
+			DuoResult R;
+			const uint8_t *qy = a.q + uni(a.q_off[i]), *tg0 = a.t0 + uni(a.t0_off[i]), *tg1 = a.t1 + uni(a.t1_off[i]);
+			done = ql <= 192 ? ksw_duo_sweep<3>(qy, ql, tg0, tl0, tg1, tl1, a.P, lds, p, R) : ksw_duo_sweep<5>(qy, ql, tg0, tl0, tg1, tl1, a.P, lds, p, R);
+			if (done) {
+				ksw_duo_cigar<0>(R, p, ql, tl0, a.P.w, a.P.flag, ct, a.cig_cap, o[0]);
+				WSYNC();
+				for (int j = lane; j < o[0].n_cigar; j += 64) a.cig[(size_t)(2 * i) * a.cig_slot + j] = ct[j];
+				WSYNC();
+				ksw_duo_cigar<1>(R, p, ql, tl1, a.P.w, a.P.flag, ct, a.cig_cap, o[1]);
+				WSYNC();
+				for (int j = lane; j < o[1].n_cigar; j += 64) a.cig[(size_t)(2 * i + 1) * a.cig_slot + j] = ct[j];
+				WSYNC();
+			}
+		}
+		if (lane == 0) { a.ez[2 * i] = o[0]; a.ez[2 * i + 1] = o[1]; }
+		WSYNC();
+	}
+}
+
 // ------------------------------------------------------------------- summary
 struct SummaryArgs {
 	int n_regions;

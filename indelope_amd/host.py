@@ -389,6 +389,27 @@ class Api:
             break
         return ez, [cig[coff[i]:coff[i + 1]].copy() for i in range(n)]
 
+    def duo_batch(self, reads, t0s, t1s, match=1, mismatch=-2, gap_open=5, gap_ext=1, bw=-1, z=-1, flag=0):
+        """Diagnostics: (read, target 0, target 1) items through the alignment fallback's two-target sweep (ksw_duo.h; the two
+        align_to calls of indelope.nim:340-341 in one pass).  Strings are base codes.  Returns (ez records [n, 2], CIGARs [n][2])."""
+        n = len(reads)
+
+        def cat(xs):
+            off = np.zeros(n + 1, np.int64)
+            off[1:] = np.cumsum([len(x) for x in xs])
+            c = np.concatenate([np.asarray(x, np.uint8) for x in xs]) if n else np.zeros(0, np.uint8)
+            return np.ascontiguousarray(c if len(c) else np.zeros(1, np.uint8)), off
+        (q, qo), (a, ao), (b, bo) = cat(reads), cat(t0s), cat(t1s)
+        slot = max([len(r) + max(len(x), len(y)) for r, x, y in zip(reads, t0s, t1s)] + [8]) + 16
+        ez = np.zeros(2 * n, A.EZ_DTYPE)
+        cig = np.zeros((2 * n, slot), np.uint32)
+        mat = self.matrix(match, mismatch)
+        self._chk(self.b.debug_ksw_duo_batch(n, A.ptr(q, A.u8p), A.ptr(qo, A.i64p), A.ptr(a, A.u8p), A.ptr(ao, A.i64p), A.ptr(b, A.u8p),
+                                             A.ptr(bo, A.i64p), 5, A.ptr(mat, A.i8p), abs(gap_open), abs(gap_ext), bw, z, flag,
+                                             ez.ctypes.data_as(C.c_void_p), A.ptr(cig, A.u32p), slot), "debug_ksw_duo_batch")
+        cigs = [[cig[2 * i + k, :max(0, int(ez[2 * i + k]["n_cigar"]))].copy() for k in range(2)] for i in range(n)]
+        return ez.reshape(n, 2), cigs
+
     # ---- tally / genotype ---------------------------------------------------
     def kmer_tally(self, reads, ref_kmer, alt_kmer, K=27, mapq=None, min_mapq=10):
         """The tally loop of indelope.nim:285-311 for one event."""

@@ -187,6 +187,9 @@ proc ihp_batch_profile_n*(b: ptr IhpBatch, outp: ptr int64, cap: int32): cint {.
 proc ihp_debug_set*(key: cstring, value: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_debug_last_ksw_mode*(): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_debug_last_ksw_pairs*(): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_debug_ksw_duo_batch*(n: int32, reads: ptr uint8, q_off: ptr int64, t0: ptr uint8, t0_off: ptr int64, t1: ptr uint8, t1_off: ptr int64,
+                              m: int8, mat: ptr int8, q: int8, e: int8, w: cint, zdrop: cint, flag: cint, ez: ptr IhpEz, cigar: ptr uint32,
+                              cig_slot: int32): cint {.importc, cdecl, header: "indelope_hip.h".}
 
 proc ihp_init*(device: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_strerror*(code: cint): cstring {.importc, cdecl, header: "indelope_hip.h".}

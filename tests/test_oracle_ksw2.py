@@ -115,3 +115,17 @@ def test_degenerate_inputs(oracle):
         assert got["n_cigar"] == 0 and got["score"] == A.KSW_NEG_INF and got["max"] == 0
     got, cig = oracle.ksw(one, one, mat=oracle.matrix(1, -20))      # -min_sc > 2(q+e)
     assert got["n_cigar"] == 0 and got["score"] == A.KSW_NEG_INF
+
+
+def test_restatement_equals_the_round5_reference_fixtures(oracle):
+    """tests/golden/ksw2_pair_golden.npz (compiled reference output, pair-shaped batches and fallback triples): the restated
+    ksw2 reproduces every field and CIGAR, so the GPU tests that compare with the oracle elsewhere stand on the same ground."""
+    import golden_util
+    z = golden_util.load_pair_golden()
+    n = len(z["params"])
+    assert n >= 600
+    for i in range(n):
+        q, t, ez, cig = golden_util._case(z, i)
+        ma, mi, go, ge, w, zd, flag = z["params"][i].tolist()
+        got, gc = oracle.ksw(q, t, mat=oracle.matrix(ma, mi), gapo=go, gape=ge, w=w, zdrop=zd, flag=flag)
+        assert [got[k] for k in FIELDS] == ez and gc.tolist() == cig, i
