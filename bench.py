@@ -272,6 +272,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
     dt = time.perf_counter() - t0
     ev = res["events_only"]
     return {"one_batch_ms": ev["one_batch_ms"], "one_batch_regions_per_s": ev["one_batch_regions_per_s"], "sustained": ev["sustained"],
+            "slab_MB": round(slab_bytes / 1e6, 2),
             "inputs": "one page-locked slab per batch (%d bytes: 4-bit bases, trim bounds), a single upload copy; results without contig "
                       "bases/supports (IHP_FETCH_NO_BASES)" % slab_bytes,
             "full_results": res["full"],
@@ -282,7 +283,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
 
 
 # ------------------------------------------------------------------------------------------ other configs
-def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=1, dup_frac=0.0, in_flight=2, lockstep=False):
+def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=1, dup_frac=0.0, in_flight=2, lockstep=False, check_regions=20_000):
     """A short run of another BASELINE config on this GPU, submitted like the headline (`in_flight` resident batches of `regions`
     regions take turns, a step is one pass over one of them as `sub_batches` launch chains; `lockstep`: every step waited for):
     value, per-launch stage times, the HBM-roofline fraction of its dominant stage, oracle check."""
@@ -359,7 +360,7 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=1, d
         t1 = time.perf_counter()
         bad, n = None, 0
         for sb, pr in zip(subs, parts):
-            lim = min(sb.n_regions, 10_000, max(0, 20_000 - n))
+            lim = min(sb.n_regions, max(10_000, check_regions // max(1, len(subs))), max(0, check_regions - n))
             if lim == 0:
                 break
             exp = o.run_regions_mt(sb.slice(0, lim), o.params(K=K), usable)
@@ -490,7 +491,7 @@ def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps
             hs.append(api.batch_upload(sb.with_trim_bounds(), params))
         views = []
         for h in hs:
-            sptr, sn = api.batch_summary_dev(h)
+            sptr, sn = api.batch_summary_ptr(h)                  # (the address only: no wait)
             views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda"))
         summary = views[0] if len(views) == 1 else torch.cat(views)
         sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
@@ -533,6 +534,37 @@ def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps
     finally:
         for h in hs:
             api.batch_free(h)
+
+
+def digest(out):
+    """The secondary legs in a few hundred characters, as the LAST key of the line: a record that keeps only the tail of the
+    line still carries them.  M = million regions/s; `ok` = bit-identical to the oracle."""
+    def m(v):
+        return None if v is None else round(v / 1e6, 3)
+    d = {"C2_M": m(out["value"]), "ms_per_step": out["ms_per_step"], "blocks_ms": out["blocks"]["ms_per_step"],
+         "kernel_ms": [out["kernel_ms"][k] for k in KERNELS], "frac": out["roofline"]["frac"], "traffic_stale": out["roofline"]["traffic_stale"],
+         "ok": (out.get("oracle_check") or {}).get("identical"), "ok_regions": (out.get("oracle_check") or {}).get("regions")}
+    oc = out.get("other_configs") or {}
+    for k, v in oc.items():
+        d[k] = [m(v["value"]), v.get("oracle_check", {}).get("identical"), v.get("oracle_check", {}).get("regions")]
+    ms = out.get("mixed_stream")
+    if ms:
+        d["mixed"] = [m(ms["plans_per_shape"]["regions_per_s"]), ms["plans_per_shape"]["n_reruns"], ms["mixed_over_predicted"]]
+    e = out.get("e2e")
+    if e:
+        d["e2e"] = {"one_M": m(e["one_batch_regions_per_s"]), "sus_M": m(e["sustained"]["regions_per_s"]),
+                    "full_one_M": m(e["full_results"]["one_batch_regions_per_s"]), "full_sus_M": m(e["full_results"]["sustained"]["regions_per_s"]),
+                    "slab_MB": e.get("slab_MB")}
+    c = out.get("c1")
+    if c:
+        d["c1_us"] = [c["cpu_us_per_region"], c["gpu_us_per_region"], c["identical"]]
+    cb = out.get("cpu_baseline")
+    if cb:
+        d["cpu"] = [cb["value"], cb["cores"], out.get("gpu_over_cpu")]
+    if out.get("strong"):
+        d["strong_M"] = m(out["strong"]["value"])
+    d["sha"] = out["build"]["src_sha16"]
+    return d
 
 
 # ----------------------------------------------------------------------------------------------- launching
@@ -602,6 +634,7 @@ def main():
     ap.add_argument("--verify-gather", action="store_true",
                     help="rank 0 checks the gathered per-region records (and payload slabs) against its own fetched results")
     ap.add_argument("--no-other", action="store_true", help="skip the short C3 / C5 / dup10 legs (`other_configs`), `mixed_stream` and `c1` of the default run")
+    ap.add_argument("--c3-regions", type=int, default=200_000, help="regions of the C3 leg in `other_configs` (BASELINE configs[2]: 200 000)")
     ap.add_argument("--strong-regions", type=int, default=1_250_000,
                     help="regions of the attached strong-scaling leg (C4 generator; 5 000 000 = all of BASELINE configs[3])")
     ap.add_argument("--in-flight", type=int, default=None, help="weak mode: resident batches of the configured size the stream alternates between -- a step is one pass "
@@ -609,6 +642,10 @@ def main():
                     "batch is one launch chain's worth of work (up to ~120 MB of read bases: C2), otherwise 1 with two sub-batches -- two chains "
                     "in flight either way (measured both ways for C3 and C5: DESIGN.md 5)")
     ap.add_argument("--settle-s", type=float, default=0.1, help="weak mode: seconds of untimed steps in front of the W warm-up steps (clocks, launch plans)")
+    ap.add_argument("--gather-per-step", action="store_true",
+                    help="weak mode with N > 1 ranks: one RCCL gather of the step's R per-region records after EVERY step (round 3's form, "
+                         "kept so that rounds can be compared); default: the records of every region a timed block processed "
+                         "(steps x R per rank) are kept on the device and gathered ONCE when the block ends")
     ap.add_argument("--lockstep", action="store_true", help="weak mode: wait for every sub-batch of a step before the next step starts (rounds 1-3); default: a sub-batch "
                     "is run again as soon as its own last run is done")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counters of the kernels (ihp_debug_set profile) in `profile_cycles`")
@@ -689,6 +726,8 @@ def main():
     else:
         R = args.regions or min(cfg["n_regions"], 200_000)
         total = R * world
+        if args.gather_per_step:
+            args.in_flight = 1                               # round 3's form: one resident batch, a gather behind every step
         if args.in_flight is None:
             args.in_flight = 2 if R * 0.5 * (cfg["n_reads"][0] + cfg["n_reads"][1]) * cfg["read_len"] <= 1.2e8 else 1
         B = max(1, args.in_flight)                           # resident batches of R regions; a step is one pass over one of them
@@ -723,17 +762,40 @@ def main():
     # the timed loop below reads nothing
     for h in hs:
         api.batch_set_timing(h, True)
-    views = []
-    for h in hs[:S]:                                         # (weak mode: the records of the first resident batch stand for the rank's regions)
-        sptr, sn = api.batch_summary_dev(h)
-        views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda") if sn else torch.zeros(0, dtype=torch.int32, device="cuda"))
-    summary = views[0] if S == 1 else torch.cat(views)       # per-region records of the rank's regions, region order
-    # shard sizes are known to every rank (bounds / equal shares): shards are padded to the longest, ONE gather per step
-    shard_sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)] if strong else [R] * world
+    views_all = []
+    for h in hs:
+        sptr, sn = api.batch_summary_ptr(h)                  # (the address only: no wait)
+        views_all.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda") if sn else torch.zeros(0, dtype=torch.int32, device="cuda"))
+    views = views_all if strong else views_all[:S]
+    summary = views[0] if S == 1 else torch.cat(views)       # per-region records of the rank's regions (strong) / of one step (weak), region order
+    # Weak mode gathers what a job of `steps` batches gathers at its end: the records of EVERY region the timed block processed
+    # (steps x R per rank).  A run's records are copied into the block's buffer when the run is waited for -- before the
+    # batch is run again and overwrites them -- and the buffer goes to rank 0 in ONE gather when the block ends.
+    per_block = use_dist and not strong and not args.gather_per_step
+    blockbuf = torch.empty(args.steps * R * idist.SUMMARY_WORDS, dtype=torch.int32, device="cuda") if per_block else None
+    block_cur, block_slots = [0], {}
+    # shard sizes are known to every rank (bounds / equal shares): shards are padded to the longest, ONE gather per step / block
+    shard_sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)] if strong else [R * (args.steps if per_block else 1)] * world
     m_pad = max(shard_sizes)
-    send = summary if R == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
+    if per_block:
+        send = blockbuf
+    else:
+        send = summary if R == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
     gather_list = [torch.empty_like(send) for _ in range(world)] if (use_dist and rank == 0) else None
     last_payload = [None]
+
+    def wait(i):
+        """Wait for handle i's run; in weak mode its records join the block's buffer (they are final now, and the next run of the
+        batch overwrites them)."""
+        api.batch_sync(hs[i])
+        pending[i] = False
+        if per_block:
+            v = views_all[i]
+            if block_cur[0] + v.numel() > blockbuf.numel():
+                block_cur[0] = 0                                 # (untimed blocks of another length wrap around)
+            blockbuf[block_cur[0]:block_cur[0] + v.numel()].copy_(v)
+            block_slots[i] = block_cur[0]
+            block_cur[0] += v.numel()
 
     def step():
         if strong:
@@ -757,22 +819,24 @@ def main():
             step_no[0] += 1
             for i in range(b0, b0 + S):
                 if pending.get(i):
-                    api.batch_sync(hs[i])
+                    wait(i)
                 api.batch_run(hs[i])
                 pending[i] = True
-            if args.lockstep:
+            if args.lockstep or (use_dist and args.gather_per_step):
                 for i in range(b0, b0 + S):
-                    api.batch_sync(hs[i])
-                    pending[i] = False
+                    wait(i)
+            if use_dist and args.gather_per_step:
+                gather()                                         # (one resident batch in this form: `summary` is its records)
         if use_dist and strong:
             gather()                                         # strong scaling: the job IS one pass, its gather belongs to the step
 
     def gather():
         # THE collective of the path: the fixed-size per-region records of every rank to rank 0 (+ the result slabs with --payload)
-        if S > 1:
-            torch.cat(views, out=summary)
-        if send is not summary:
-            send[:summary.numel()] = summary
+        if not per_block:
+            if S > 1:
+                torch.cat(views, out=summary)
+            if send is not summary:
+                send[:summary.numel()] = summary
         dist.gather(send, gather_list, dst=0)
         if args.payload and not stream_outputs:
             for h in (hs if strong else hs[:S]):
@@ -786,13 +850,13 @@ def main():
     def block(n):
         # weak scaling: every rank walks through its own batches; the real job gathers ONCE at its end, so a timed
         # block ends with one gather, not one per step (round 3 synchronised all ranks after every 1.8 ms step for no reason)
+        block_cur[0] = 0
         for _ in range(n):
             step()
         for i, h in enumerate(hs):                           # (pipelined steps: the last runs of the block)
             if pending.get(i):
-                api.batch_sync(h)
-                pending[i] = False
-        if use_dist and not strong:
+                wait(i)
+        if use_dist and not strong and not args.gather_per_step:
             gather()
 
     if not strong:
@@ -947,7 +1011,11 @@ def main():
                                          % (B, "s" if B > 1 else "")),
                        "regions_per_gpu": R, "regions_total": total,
                        "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
-                                    "records per %s" % ("step" if strong else "timed block (the job's one gather at its end)") + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU"},
+                                    "records per %s" % ("step" if (strong or args.gather_per_step) else "timed block (the job's one gather at its end: the records of every "
+                                                        "region the block processed)") + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU",
+                       "gather": ({"per": "step" if (strong or args.gather_per_step) else "block", "records_per_rank_per_gather": int(send.numel() // idist.SUMMARY_WORDS),
+                                   "regions_processed_per_rank_per_gather": int(R if (strong or args.gather_per_step) else R * args.steps),
+                                   "bytes_per_rank_per_gather": int(send.numel() * 4)} if use_dist else None)},
             "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS + ["total"], stage)}, k_fallback=round(fb_ms, 4)),
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + (" (k_prepack + k_asm_reads + k_asm_combine3 + byte-based overflow passes)" if dom == 0 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
@@ -971,9 +1039,19 @@ def main():
             # summaries of the fetched results, the payload slab unpacks to the same results
             got = torch.cat([g[:n * idist.SUMMARY_WORDS] for g, n in zip(gather_list, shard_sizes)]).cpu().numpy()
             mine = idist.summaries_from_result(res_first).view(np.int32).reshape(-1)
-            # (strong scaling keeps only the first chunk's results on the host: its records are the head of the gathered ones)
-            ok = bool(np.array_equal(got[:len(mine)], mine)) and (len(got) == len(mine) if (world == 1 and not strong) else len(got) >= len(mine))
-            chk = {"records": int(len(got) // idist.SUMMARY_WORDS), "records_identical_to_own_results": ok, "backend": dist.get_backend()}
+            if per_block:
+                # the block's buffer holds one set of records per step; every resident batch's LAST run landed at block_slots[handle]:
+                # rank 0's own part of the gather against the fetched results of each of its batches
+                ok = len(got) == args.steps * R * idist.SUMMARY_WORDS * world
+                for b_ in range(B):
+                    part = idist.summaries_from_result(concat_results(parts[b_ * S:(b_ + 1) * S])).view(np.int32).reshape(-1)
+                    at = block_slots.get(b_ * S)
+                    ok = ok and at is not None and bool(np.array_equal(got[at:at + len(part)], part))
+            else:
+                # (strong scaling keeps only the first chunk's results on the host: its records are the head of the gathered ones)
+                ok = bool(np.array_equal(got[:len(mine)], mine)) and (len(got) == len(mine) if (world == 1 and not strong) else len(got) >= len(mine))
+            chk = {"records": int(len(got) // idist.SUMMARY_WORDS), "regions_processed": int((R * args.steps if per_block else R if not strong else total) * (world if not strong else 1)),
+                   "records_identical_to_own_results": ok, "backend": dist.get_backend()}
             if args.payload and last_payload[0] is not None and not strong:
                 from indelope_amd.host import BatchResult
                 slab, counts = last_payload[0][0]
@@ -1027,7 +1105,9 @@ def main():
             # the other single-GPU configs of BASELINE.json, a few steps each, in the same record (never `value`)
             # (two launch chains in flight either way: two resident batches where a batch is one chain's worth of work -- C2's 10 000
             # regions --, one batch as two sub-batches where half a batch already is -- measured both ways, tools/README.md)
-            out["other_configs"] = {"C3": quick_config(api, "C3", 50_000, steps=4, warmup=2, check=not args.no_check, in_flight=1, sub_batches=2),
+            # C3 at BASELINE configs[2]'s own size, every one of its 200 000 regions through the oracle
+            out["other_configs"] = {"C3": quick_config(api, "C3", args.c3_regions, steps=4, warmup=2, check=not args.no_check, in_flight=1, sub_batches=2,
+                                                       check_regions=args.c3_regions),
                                     "C5": quick_config(api, "C5", 10_000, steps=8, warmup=4, check=not args.no_check, in_flight=1, sub_batches=2),
                                     "dup10": quick_config(api, "C2", 10_000, steps=6, warmup=4, check=not args.no_check, dup_frac=0.1),
                                     # the headline workload submitted as in rounds 1-3: ONE resident batch, two sub-batches, every step waited for
@@ -1046,6 +1126,7 @@ def main():
             out["work_rate"] = {"char_compares_per_s": round(w["char_compares"] * out["value"], -6),
                                 "ksw2_dp_cells_per_s": round(w["ksw2_dp_cells"] * out["value"], -6),
                                 "kmer_steps_per_s": round(w["kmer_steps"] * out["value"], -6)}
+        out["digest"] = digest(out)
         print(json.dumps(out))
         sys.stdout.flush()
     for h in hs:

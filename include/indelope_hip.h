@@ -540,6 +540,10 @@ typedef struct {
 /* Device pointer (valid until the next run/free) + count of the summaries.  The call waits for the batch's run and
  * confirms it (a run may be repeated at that point, see "no_spec"): the records behind the pointer are final.         */
 int  ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n);
+/* The same pointer WITHOUT the wait: the address is fixed from upload to ihp_batch_free, so a caller that orders its own work
+ * by stream (an RCCL gather enqueued on another stream behind an event, ...) takes it once and never stalls the host here.  The
+ * records behind it are final only after a call that waits for and confirms the run (ihp_batch_sync, fetch, summary_dev).      */
+int  ihp_batch_summary_ptr(ihp_batch *b, void **dev_ptr, int64_t *n);
 /* The same records copied to the host (cap >= n_regions entries).             */
 int  ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int64_t cap);
 

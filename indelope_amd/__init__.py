@@ -130,6 +130,12 @@ class HipApi(Api):
         self._chk_hip(self.b.batch_summary_dev(h, C.byref(p), C.byref(n)), "batch_summary_dev")
         return p.value, n.value
 
+    def batch_summary_ptr(self, h):
+        """The address of the per-region records without waiting for the run (fixed from upload to free)."""
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk_hip(self.b.batch_summary_ptr(h, C.byref(p), C.byref(n)), "batch_summary_ptr")
+        return p.value, n.value
+
     def batch_summary_host(self, h, n):
         """The per-region summary records of the last run as a numpy array of SUMMARY_DTYPE."""
         import numpy as np

@@ -230,6 +230,7 @@ _PRODUCT_ONLY = {
     "batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "batch_kernel_ms_mean": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), i64p, C.c_int]),
     "batch_summary_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
+    "batch_summary_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "batch_profile": (C.c_int, [C.c_void_p, i64p]),
     "batch_profile_n": (C.c_int, [C.c_void_p, i64p, C.c_int32]),
     "batch_summary_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -1048,7 +1048,15 @@ struct ihp_batch {
 	bool dirty = false;                                    // a run was cut short after some launches: `misc` is not known to be clear
 	int *report = nullptr;                                 // page-locked host block: the last run's counters, flags and stamps
 	int grid_ovf2 = 0, grid_ovf3 = 0, grid_ovf4 = 0;       // grids of the run-time overflow launches
-	ihp_batch() { g_live_batches.fetch_add(1); }
+	ihp_batch() {
+		// the second batch alive beside another: their launch chains only overlap reliably with more hardware queues than the
+		// runtime's default of four (see ihp_init) -- said once, unconditionally, because the loss (-15 %) is otherwise silent
+		static std::atomic<bool> told{false};
+		if (g_live_batches.fetch_add(1) >= 1 && !getenv("GPU_MAX_HW_QUEUES") && !told.exchange(true))
+			fprintf(stderr, "[ihp] note: GPU_MAX_HW_QUEUES is not set and more than one batch is alive: with the runtime's default of 4 hardware queues "
+			                "the launch chains of different batches can share a queue and run one after the other; export GPU_MAX_HW_QUEUES=16 before the "
+			                "process's first HIP call (include/indelope_hip.h)\n");
+	}
 	~ihp_batch() {
 		// the buffers go back to the pool (the members are released after this body): nothing of this batch may still be running
 		if (stream2) { (void)hipStreamSynchronize(stream2); g_streams.put(stream2); }
@@ -1582,6 +1590,14 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	}
 	TierHint H;
 	const bool have_hint = g_hints.get(b->hint_key, H) && !g_knob.no_hint;
+	// the roomy ksw2 launch (below) is left out when the last batch of this shape had no job for it; its scratch -- up to 512 MB,
+	// a pool miss is a hipMalloc, which synchronises the device -- is taken HERE, before anything of this run is enqueued: a
+	// failure returns with nothing in the stream
+	const bool ksw_roomy = b->R > 0 && b->n_reads > 0 && !(have_hint && !g_knob.no_spec && !b->force_full && H.n_kovf == 0);
+	if (ksw_roomy) {
+		if (!b->p_scratch_big.p) { int rcb = b->p_scratch_big.alloc(b->p_cap_big * b->grid_kovf); if (rcb) return rcb; }
+		if (!b->cig_tmp_big.p) { int rcb = b->cig_tmp_big.alloc(sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf); if (rcb) { b->p_scratch_big.release(); return rcb; } }
+	}
 	// counters, stamps, work queues and per-region hit counts are zero: cleared at upload and by the previous run's k_summary
 	int *wq = b->queues_dev();
 	const bool profiling = g_knob.profile != 0;
@@ -1859,12 +1875,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		HIPC(hipGetLastError());
 		// the roomy launch: left out when the last batch had no such job (a few workgroups that ask for all the LDS of a CU wait for
 		// one to drain); the wait checks the count and repeats the run with it otherwise (see the retry launches above)
-		const bool hintk = have_hint;
-		ksw_skipped_run = hintk && !g_knob.no_spec && !b->force_full && H.n_kovf == 0;
+		ksw_skipped_run = !ksw_roomy;
 		if (g_knob.verbose) fprintf(stderr, "[ihp] ksw2: grid %d lds %d p_cap %zu; roomy launch %s: grid %d p_cap %zu cig %d\n", b->grid_ksw, b->lds_ksw, b->p_cap, ksw_skipped_run ? "left out" : "enqueued", b->grid_kovf, b->p_cap_big, b->cig_cap_big);
 		if (!ksw_skipped_run) {
-			if (!b->p_scratch_big.p) { int rcb = b->p_scratch_big.alloc(b->p_cap_big * b->grid_kovf); if (rcb) return rcb; }
-			if (!b->cig_tmp_big.p) { int rcb = b->cig_tmp_big.alloc(sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf); if (rcb) return rcb; }
 			KswArgs r2 = a;
 			r2.t_start = nullptr; r2.in_list = b->ksw_ovf.as<int>(); r2.n_jobs = misc + M_KSW_OVF; r2.ovf_list = nullptr; r2.ovf_n = nullptr;
 			r2.lds_budget = g.max_lds - 2048 - 64;
@@ -2126,6 +2139,16 @@ extern "C" int ihp_batch_summary_dev(ihp_batch *b, void **dev_ptr, int64_t *n)
 	if (!b || !dev_ptr || !n) return IHP_E_ARG;
 	// the records of a run are final once the run is confirmed (it may be repeated at the wait): wait here
 	if (b->ran && b->work_live) { int rc0 = ensure_init(); if (rc0) return rc0; int rc1 = finish_run(b); if (rc1) return rc1; }
+	*dev_ptr = b->summary.p; *n = b->R;
+	return 0;
+}
+
+// The same address without the wait (it is fixed from upload to free): for a caller that orders its own work behind the run
+// by stream or by ihp_batch_sync -- e.g. to enqueue an RCCL gather on another stream -- and must not stall the host here.
+// What is behind the pointer is final only after a wait that confirms the run (ihp_batch_sync / fetch / ihp_batch_summary_dev).
+extern "C" int ihp_batch_summary_ptr(ihp_batch *b, void **dev_ptr, int64_t *n)
+{
+	if (!b || !dev_ptr || !n) return IHP_E_ARG;
 	*dev_ptr = b->summary.p; *n = b->R;
 	return 0;
 }

@@ -169,7 +169,10 @@ proc ihp_batch_release_outputs*(b: ptr IhpBatch): cint {.importc, cdecl, header:
 proc ihp_batch_free*(b: ptr IhpBatch) {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_pack_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, bytes: ptr int64, counts: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_unpack_slab*(slab: pointer, bytes: int64, counts: ptr int64, error: float64, outp: ptr IhpBatchOut): cint {.importc, cdecl, header: "indelope_hip.h".}
+# BLOCKING: waits for the batch's run and confirms it (the run may be repeated in full at this point); the records are final on return
 proc ihp_batch_summary_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+# the same address without the wait (fixed from upload to free): for callers that order by stream / call ihp_batch_sync themselves
+proc ihp_batch_summary_ptr*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_summary_host*(b: ptr IhpBatch, outp: ptr IhpRegionSummary, cap: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 # one page-locked slab per batch (4-bit bases as BAM stores them, trim bounds): the sections' offsets, the upload, what a fetch returns
 type IhpSlabLayout* {.importc: "ihp_slab_layout", header: "indelope_hip.h", bycopy.} = object

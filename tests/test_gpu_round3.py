@@ -152,9 +152,17 @@ def test_rccl_branch_on_one_gpu_weak():
     out = _bench(["--gpus", "1", "--force-dist", "--payload", "--verify-gather", "--regions", "3000", "--steps", "3", "--warmup", "1",
                   "--no-cpu", "--no-e2e", "--no-other"], launcher=True)
     g = out["gather_check"]
-    assert g["backend"] == "nccl" and g["records"] == 3000 and g["records_identical_to_own_results"]
+    # (round 5: the block's one gather carries the records of every region the block processed: steps x regions)
+    assert g["backend"] == "nccl" and g["records"] == 9000 == g["regions_processed"] and g["records_identical_to_own_results"]
     assert g["payload_identical_to_own_results"] and g["payload_bytes"] > 0
     assert out["oracle_check"]["identical"] and out["n_gpus"] == 1
+    assert out["config"]["gather"] == {"per": "block", "records_per_rank_per_gather": 9000, "regions_processed_per_rank_per_gather": 9000,
+                                       "bytes_per_rank_per_gather": 9000 * 32}
+    # round 3's form (one gather behind every step) is still there for comparison across rounds
+    out = _bench(["--gpus", "1", "--force-dist", "--gather-per-step", "--verify-gather", "--regions", "3000", "--steps", "3", "--warmup", "1",
+                  "--no-cpu", "--no-e2e", "--no-other", "--no-check"], launcher=True)
+    g = out["gather_check"]
+    assert g["records"] == 3000 and g["records_identical_to_own_results"] and out["config"]["gather"]["per"] == "step"
 
 
 def test_rccl_branch_on_one_gpu_strong():
