@@ -575,6 +575,188 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 	C.r = r + 1;
 }
 
+// ---------------------------------------------------------------- round 5: the everyday steady run as ONE asm loop
+// pair_steady_step<false, 0, 0, 0> + <false, 0, 1, 1> (no block 4, even w: a pair of diagonals starts on an even r, only the
+// second can close a traceback group) until C.lim or until a diagonal needs the general ez code, written out by hand:
+//  * the vector side is the 30 instructions of the cell + 2 compares (the compiler's: 37 + reloads of scalars it had spilled
+//    into lanes of a vector register -- a v_readlane and its wait states inside the loop);
+//  * the scalar side tests BOTH alignments with one branch: no lane of either above its threshold and both running maxima
+//    still vouching (r <= min(zsafe0, zsafe1)) is seven instructions for the two of them; an alignment with exactly one lane
+//    above its threshold (the new maximum) takes fourteen; one whose vouching has run out is cleared by a single compare
+//    against the z-drop threshold where that is enough.  Several lanes at once or a possible z-drop leave the loop: `stat`
+//    says which alignment needs pair_ez_lean (bits 1..0 / 3..2 as in pair_ez_asm) and whether the diagonal was the second of
+//    its pair (bit 4); everything else of that diagonal (cells, traceback store, the other alignment) is done.
+//  * inside the steady run t* leaves the band only through (r - w + 1) >> 1 (the end of the query is not in reach), so the
+//    vouching limit is min(r + zq, 2 t* + w): pair_ez_asm's third term is gone; the caller's tail loop starts afresh (-1).
+//  * nothing of the loop lives in a spilled scalar: what it needs are operands, the rest of the kernel's state is the
+//    compiler's to park where it likes across the statement.
+// Hazards (the assembler pads nothing inside an asm string): a DPP source is never written in the two instructions in front
+// of it (every one of XA / VA / GA is written a dozen instructions earlier; nine scalar / LDS instructions open the
+// statement), no VALU reads an SGPR that a VALU wrote (the compare masks go to the scalar unit, v_readlane's lane select
+// comes from s_ff1), lgkmcnt counts only this loop's two LDS reads (the statement opens with lgkmcnt(0)) and is 0 again at
+// every exit, the statement ends with two wait states before the compiler's code may read its outputs through DPP.
+#define IHP_PS_VEC(ZW, CNT)                                                                                     \
+	"v_mov_b32_dpp %[t0], %[XA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+	"v_mov_b32_dpp %[t1], %[VA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+	"v_mov_b32_dpp %[t2], %[GA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+	"s_waitcnt lgkmcnt(" CNT ")\n\t"                                                                               \
+	"v_perm_b32 %[t3], %[TA1], %[TA0], " ZW "\n\t"                                                                 \
+	"v_cndmask_b32_e64 %[ZA], %[ZA], %[t3], %[ge]\n\t"                                                             \
+	"v_pk_add_u16 %[t0], %[t0], %[t1]\n\t"               /* a = x' + v' */                                         \
+	"v_pk_add_u16 %[t3], %[YA], %[UA]\n\t"               /* b = y + u */                                           \
+	"v_pk_sub_i16 %[t4], %[ZA], %[t0] clamp\n\t"         /* s1: negative <=> a > z */                              \
+	"v_pk_max_u16 %[t5], %[ZA], %[t0]\n\t"                                                                         \
+	"v_pk_sub_i16 %[t8], %[t5], %[t3] clamp\n\t"         /* s2: negative <=> b > max(z, a) */                      \
+	"v_pk_max_u16 %[t5], %[t5], %[t3]\n\t"                                                                         \
+	"v_pk_min_u16 %[t5], %[t5], %[Mp]\n\t"               /* z */                                                   \
+	"v_pk_sub_i16 %[VA], %[t5], %[UA]\n\t"               /* v = z - u */                                           \
+	"v_pk_sub_i16 %[UA], %[t5], %[t1]\n\t"               /* u = z - v' */                                          \
+	"v_pk_sub_i16 %[t5], %[t5], %[Qp]\n\t"                                                                         \
+	"v_pk_sub_i16 %[t0], %[t0], %[t5]\n\t"                                                                         \
+	"v_pk_sub_i16 %[t3], %[t3], %[t5]\n\t"                                                                         \
+	"v_pk_max_i16 %[XA], %[t0], 0\n\t"                                                                             \
+	"v_pk_max_i16 %[YA], %[t3], 0\n\t"                                                                             \
+	"v_pk_lshrrev_b16 %[t1], 15, %[t8] op_sel_hi:[0,1]\n\t"                                                        \
+	"v_pk_lshrrev_b16 %[t4], 14, %[t4] op_sel_hi:[0,1]\n\t"                                                        \
+	"v_and_or_b32 %[t1], %[t4], %[k22], %[t1]\n\t"                                                                 \
+	"v_pk_min_i16 %[t4], %[XA], 4 op_sel_hi:[1,0]\n\t"                                                             \
+	"v_pk_min_i16 %[t8], %[YA], 8 op_sel_hi:[1,0]\n\t"                                                             \
+	"v_add3_u32 %[t1], %[t4], %[t1], %[t8]\n\t"                                                                    \
+	"v_pk_lshlrev_b16 %[acA], 4, %[acA] op_sel_hi:[0,1]\n\t"                                                       \
+	"v_pk_add_u16 %[acA], %[acA], %[t1]\n\t"                                                                       \
+	"v_cndmask_b32_e64 %[t2], %[GA], %[t2], %[sp]\n\t"   /* H[en0] = H[en0-1] + u (:318), the others += v */       \
+	"v_cndmask_b32_e64 %[t4], %[VA], %[UA], %[sp]\n\t"                                                             \
+	"v_pk_lshrrev_b16 %[t4], 8, %[t4] op_sel_hi:[0,1]\n\t"                                                         \
+	"v_pk_add_u16 %[GA], %[t4], %[t2]\n\t"                                                                         \
+	"s_and_b64 %[inT], %[ge], %[hi]\n\t"
+// one alignment behind the joint test (labels 3..7 are local to the instance: every branch is forward)
+#define IHP_PS_PER(M, THR, POS, ZS, INC, WORD, SEXT, BIT1, BIT2)                                                \
+	"s_and_b64 " M ", " M ", %[inT]\n\t"                                                                           \
+	"s_cbranch_scc0 3f\n\t"                                                                                        \
+	"s_bcnt1_i32_b64 %[i], " M "\n\t"                                                                              \
+	"s_cmp_eq_u32 %[i], 1\n\t"                                                                                     \
+	"s_cbranch_scc0 5f\n\t"                                                                                        \
+	"s_ff1_i32_b64 %[i], " M "\n\t"                                                                                \
+	"v_readlane_b32 %[g], %[GA], %[i]\n\t"                                                                         \
+	"s_lshl1_add_u32 %[b], %[i], %[c1]\n\t"                                                                        \
+	"s_add_i32 " ZS ", %[r], %[zq]\n\t"                                                                            \
+	"s_min_i32 " ZS ", " ZS ", %[b]\n\t"                                                                           \
+	"s_add_i32 %[i], %[i], %[st]\n\t"                                                                              \
+	"s_pack_ll_b32_b16 " POS ", %[i], %[r]\n\t"                                                                    \
+	SEXT "\n\t"                                                                                                    \
+	"s_and_b64 " M ", " M ", %[sp]\n\t"                                                                            \
+	"s_cselect_b32 " ZS ", %[r], " ZS "\n\t"                                                                       \
+	"s_add_i32 " THR ", %[g], " INC "\n\t"                                                                         \
+	"s_branch 7f\n"                                                                                                \
+	"3:\n\t"                                                                                                       \
+	"s_cmp_le_i32 %[r], " ZS "\n\t"                                                                                \
+	"s_cbranch_scc1 4f\n\t"                                                                                        \
+	"s_sub_i32 %[b], " THR ", %[zd]\n\t"                                                                           \
+	"s_max_i32 %[b], %[b], 0xffff8000\n\t"                                                                         \
+	"v_cmp_ge_i16_sdwa " M ", %[GA], %[b] src0_sel:" WORD " src1_sel:WORD_0\n\t"                                   \
+	"s_and_b64 " M ", " M ", %[inT]\n\t"                                                                           \
+	"s_cbranch_scc0 6f\n"                                                                                          \
+	"4:\n\t"                                                                                                       \
+	"s_add_i32 " THR ", " THR ", " INC "\n\t"                                                                      \
+	"s_branch 7f\n"                                                                                                \
+	"5:\n\t"                                                                                                       \
+	"s_or_b32 %[stat], %[stat], " BIT1 "\n\t"                                                                      \
+	"s_branch 7f\n"                                                                                                \
+	"6:\n\t"                                                                                                       \
+	"s_or_b32 %[stat], %[stat], " BIT2 "\n"                                                                        \
+	"7:\n\t"
+#define IHP_PS_EZ(EXIT)                                                                                         \
+	"v_cmp_gt_i16_sdwa %[m0], %[GA], %[thr0] src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                  \
+	"v_cmp_gt_i16_sdwa %[m1], %[GA], %[thr1] src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                  \
+	"s_or_b64 vcc, %[m0], %[m1]\n\t"                                                                               \
+	"s_and_b64 vcc, vcc, %[inT]\n\t"                                                                               \
+	"s_cbranch_scc1 1f\n\t"                                                                                        \
+	"s_cmp_le_i32 %[r], %[zsm]\n\t"                                                                                \
+	"s_cbranch_scc0 1f\n\t"                                                                                        \
+	"s_add_i32 %[thr0], %[thr0], %[inc0]\n\t"                                                                      \
+	"s_add_i32 %[thr1], %[thr1], %[inc1]\n\t"                                                                      \
+	"s_branch 9f\n"                                                                                                \
+	"1:\n\t"                                                                                                       \
+	IHP_PS_PER("%[m0]", "%[thr0]", "%[pos0]", "%[zs0]", "%[inc0]", "WORD_0", "s_sext_i32_i16 %[g], %[g]", "1", "2")  \
+	IHP_PS_PER("%[m1]", "%[thr1]", "%[pos1]", "%[zs1]", "%[inc1]", "WORD_1", "s_ashr_i32 %[g], %[g], 16", "4", "8")  \
+	"s_min_i32 %[zsm], %[zs0], %[zs1]\n\t"                                                                         \
+	"s_cmp_lg_u32 %[stat], 0\n\t"                                                                                  \
+	"s_cbranch_scc1 " EXIT "\n"                                                                                    \
+	"9:\n\t"
+
+// Runs pairs of steady diagonals from C.r ((C.r + w) even, w even, no block 4, C.geLoM / spM / hiM current) while
+// C.r + 1 < C.lim.  Returns 0 when that bound is reached; otherwise diagonal C.r is done except for pair_ez_lean of the
+// alignments named in bits 3..0 and the step to C.r + 1, and bit 4 says that it was the second diagonal of its pair.
+__device__ __forceinline__ int pair_steady_pairs_asm(PairState &S, const PairEnv &E, PairCtl &C, const int zq_)
+{
+	typedef const __attribute__((address_space(3))) unsigned *lds_cu32;
+	unsigned qp = (unsigned)(unsigned long long)(lds_cu32)S.qptr;
+	const unsigned qp0 = qp;
+	unsigned vof = (unsigned)lane_id() * 4u + (unsigned)((C.r >> 2) + (S.st >> 4)) * 320u;   // the traceback slot the next store goes to
+	unsigned long long ge = (unsigned long long)uni((long long)C.geLoM), sp = (unsigned long long)uni((long long)C.spM), hi = (unsigned long long)uni((long long)C.hiM);
+	int r = uni(C.r), stat;
+	const int lim = uni(C.lim), st = uni(S.st), zq = uni(zq_), c1 = uni(2 * S.st + E.w), zd = uni(E.zd), inc0 = uni(S.inc0), inc1 = uni(S.inc1);
+	const unsigned Mp = (unsigned)uni((int)E.Mp), Qp = (unsigned)uni((int)E.Qp), k22 = 0x00020002u;
+	const unsigned long long pbase = (unsigned long long)uni((long long)(unsigned long long)E.p);
+	unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8;
+	unsigned long long m0, m1, inT;
+	int i, g, b, zsm;
+	asm volatile(
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_min_i32 %[zsm], %[zs0], %[zs1]\n\t"
+		"s_mov_b32 %[stat], 0\n"
+		"10:\n\t"
+		"s_add_i32 %[b], %[r], 1\n\t"
+		"s_cmp_lt_i32 %[b], %[lim]\n\t"
+		"s_cbranch_scc0 90f\n\t"
+		"v_add_u32_e32 %[qp], -8, %[qp]\n\t"
+		"ds_read_b32 %[t6], %[qp] offset:8\n\t"
+		"ds_read_b32 %[t7], %[qp] offset:4\n\t"
+		// ---- the first diagonal of the pair: st0 grows on the step behind it
+		IHP_PS_VEC("%[t6]", "1")
+		IHP_PS_EZ("80f")
+		"s_lshl_b64 %[ge], %[ge], 1\n\t"
+		"s_add_i32 %[r], %[r], 1\n\t"
+		// ---- the second: it closes a traceback group when r & 2; en0 grows behind it
+		IHP_PS_VEC("%[t7]", "0")
+		"s_bitcmp1_b32 %[r], 1\n\t"
+		"s_cbranch_scc0 2f\n\t"
+		"global_store_dword %[vof], %[acA], %[pb]\n\t"
+		"global_store_dword %[vof], %[acB], %[pb] offset:256\n\t"
+		"v_add_u32_e32 %[vof], 0x140, %[vof]\n"
+		"2:\n\t"
+		IHP_PS_EZ("81f")
+		"s_lshl_b64 %[sp], %[sp], 1\n\t"
+		"s_lshl_b64 %[hi], %[hi], 1\n\t"
+		"s_or_b64 %[hi], %[hi], 1\n\t"
+		"s_add_i32 %[r], %[r], 1\n\t"
+		"s_branch 10b\n"
+		"80:\n\t"                                            // left on the first diagonal: its partner's score word is not used
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"v_add_u32_e32 %[qp], 4, %[qp]\n\t"
+		"s_branch 90f\n"
+		"81:\n\t"
+		"s_or_b32 %[stat], %[stat], 16\n"
+		"90:\n\t"
+		"s_nop 1"
+		: [XA] "+v"(S.XA), [VA] "+v"(S.VA), [UA] "+v"(S.UA), [YA] "+v"(S.YA), [ZA] "+v"(S.ZA), [GA] "+v"(S.GA), [acA] "+v"(S.accA),
+		  [qp] "+v"(qp), [vof] "+v"(vof), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+		  [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8),
+		  [ge] "+s"(ge), [sp] "+s"(sp), [hi] "+s"(hi), [thr0] "+s"(S.thr0), [thr1] "+s"(S.thr1), [pos0] "+s"(S.pos0), [pos1] "+s"(S.pos1),
+		  [zs0] "+s"(C.zsafe0), [zs1] "+s"(C.zsafe1), [r] "+s"(r), [stat] "=&s"(stat), [m0] "=&s"(m0), [m1] "=&s"(m1), [inT] "=&s"(inT),
+		  [i] "=&s"(i), [g] "=&s"(g), [b] "=&s"(b), [zsm] "=&s"(zsm)
+		: [acB] "v"(S.accB), [TA0] "v"(S.TA0), [TA1] "v"(S.TA1), [Mp] "s"(Mp), [Qp] "s"(Qp), [k22] "s"(k22), [inc0] "s"(inc0), [inc1] "s"(inc1),
+		  [lim] "s"(lim), [st] "s"(st), [zq] "s"(zq), [c1] "s"(c1), [zd] "s"(zd), [pb] "s"(pbase)
+		: "vcc", "scc", "memory");
+	S.qptr += (int)(qp - qp0) / 4;
+	C.geLoM = ge; C.spM = sp; C.hiM = hi; C.r = r;
+	C.st0 = (r - E.w + 1) >> 1; C.en0 = (r + E.w) >> 1;
+	return stat;
+}
+#undef IHP_PS_VEC
+#undef IHP_PS_PER
+#undef IHP_PS_EZ
+
 // The diagonals C.r .. bound-1, all with or all without block 4: single steps until r + w is even, then pairs.  With an even
 // w the first diagonal of a pair is an even one: only the second can close a group of four (FLUSH).
 template <bool HASB>
@@ -584,7 +766,22 @@ __device__ __forceinline__ void pair_steady_run(PairState &S, const PairEnv &E, 
 	if (C.r < C.lim && ((C.r + E.w) & 1)) pair_steady_step<HASB, 0, -1, -1>(S, E, C, zq);
 	C.geLoM = ~0ull << (C.st0 - S.st);
 	C.spM = HASB ? 0ull : 1ull << ((C.en0 - S.st) & 63); C.hiM = HASB ? ~0ull : C.spM | (C.spM - 1);
-	if (!(E.w & 1)) {
+	if (!(E.w & 1) && !HASB) {
+		// the everyday case by hand (pair_steady_pairs_asm); what it hands back is finished here with the general code
+		while (C.r + 1 < C.lim) {
+			const int stat = pair_steady_pairs_asm(S, E, C, zq);
+			if (!stat) break;
+			const int r = C.r;
+			const unsigned long long inTA = C.geLoM & C.hiM;
+			if (stat & 3) pair_ez_lean<0, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+			if (stat & 12) pair_ez_lean<1, false>(S, E, C, r, inTA, 0ull, C.spM, zq);
+			if (stat & 16) { C.en0 += 1; C.spM <<= 1; C.hiM = (C.hiM << 1) | 1ull; C.r = r + 1; }
+			else {
+				C.st0 += 1; C.geLoM <<= 1; C.r = r + 1;
+				if (C.r < C.lim) pair_steady_step<false, 0, 1, 1>(S, E, C, zq);
+			}
+		}
+	} else if (!(E.w & 1)) {
 		while (C.r + 1 < C.lim) {
 			pair_steady_step<HASB, 0, 0, 0>(S, E, C, zq);
 			pair_steady_step<HASB, 0, 1, 1>(S, E, C, zq);

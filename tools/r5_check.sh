@@ -7,9 +7,8 @@ sel=${1:-all}; shift
 if [ "$sel" = all ]; then timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5_pytest.txt 2>&1
 elif [ "$sel" != none ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$sel" > gpurun_out/r5_pytest.txt 2>&1; fi
 tail -5 gpurun_out/r5_pytest.txt 2>/dev/null
-/usr/bin/time -v -o gpurun_out/r5_bench.time timeout 1500 python bench.py "$@" > gpurun_out/r5_bench.json 2> gpurun_out/r5_bench.err
+t0=$(date +%s); timeout 1500 python bench.py "$@" > gpurun_out/r5_bench.json 2> gpurun_out/r5_bench.err; echo "bench wall $(( $(date +%s) - t0 )) s"
 grep -v amdgpu.ids gpurun_out/r5_bench.err | tail -5
-grep -E "Elapsed|Maximum resident" gpurun_out/r5_bench.time
 python - <<PY
 import json
 try:
