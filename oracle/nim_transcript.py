@@ -468,6 +468,7 @@ def callsemble(reads, fai, ksw_lib, min_ctg_len=74, min_reads=4, min_event_len=4
                 continue
             alt_kmer = ctg_seq[qstart:qstart + K]
             if alt_kmer == ref_kmer:
+                ev["retried"] = True                             # (for the diff script's coverage count; not a result)
                 qstart = max(qloc[0] - 3, 0)
                 if qstart + K > len(ctg_seq):
                     qend = min(qloc[1] + 4, len(ctg))

@@ -5,7 +5,7 @@ restatements produced).
 
     python tests/golden/make_transcript_golden.py [n_regions_total] [workers]
 
-Workloads: the BASELINE shapes (C2 / C3 / C5-like), high error rates (many single-read contigs: > 20 pre-combine contigs,
+Workloads: tandem-repeat expansions (the `alt_kmer == ref_kmer` retry), the BASELINE shapes (C2 / C3 / C5-like), high error rates (many single-read contigs: > 20 pre-combine contigs,
 votes firing in combine), tandem duplications (the alignment fallback), low base qualities at the read ends and reads that
 empty under trim, low mapping qualities on either side of the three thresholds (5 / 10 / 20), skippable reads, the CLI's
 parameters (min_reads 3, min_ctg_len 73) beside the proc defaults, K = 21 / 27 / 31.
@@ -41,7 +41,7 @@ def workloads(n_total, seed=2025):
               ("clean", dict(read_len=150, n_reads=(8, 48), err_rate=0.0), 0.10), ("noisy", dict(read_len=150, n_reads=(20, 64), err_rate=1e-2), 0.14),
               ("verynoisy", dict(read_len=100, n_reads=(24, 48), err_rate=3e-2), 0.10), ("dup", dict(read_len=150, n_reads=(12, 48), err_rate=1e-3, dup_frac=0.7), 0.12),
               ("short", dict(read_len=80, n_reads=(10, 40), err_rate=2e-3), 0.08), ("lowq", dict(read_len=150, n_reads=(16, 64), err_rate=2e-3), 0.12),
-              ("refmut", dict(read_len=150, n_reads=(16, 48), err_rate=1e-3), 0.12)]
+              ("refmut", dict(read_len=150, n_reads=(16, 48), err_rate=1e-3), 0.10), ("repeat", dict(), 0.06)]
     cid = 7000
     for name, g, share in shapes:
         n = max(8, int(n_total * share))
@@ -105,6 +105,48 @@ def mutate_ref(b, rng):
             w[p:p + 60] = ord("T")
         ref[f0:f1] = w
     return RegionBatch(b.region_read_off, b.read_off, b.bases, b.quals, b.read_start, b.read_stop, b.mapq, b.read_skip, b.ref_off, ref, b.ref_origin)
+
+
+def repeat_batch(n_regions, seed, read_len=150):
+    """Regions whose event is an expansion / contraction of a tandem repeat or homopolymer longer than K: the alternate k-mer
+    equals the reference k-mer at first (indelope.nim:255-262 retries further left or at the end), some stay equal (:264)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    rro, ro, bases, quals, rstart, rstop, mapq, skip, fo, ref, origin = [0], [0], [], [], [], [], [], [], [0], [], []
+    for r in range(n_regions):
+        unit = rng.choice(acgt, int(rng.choice([1, 1, 2, 3, 4])))
+        m = int(rng.integers(40, 70)) // len(unit) + 8
+        left, right = rng.choice(acgt, 220), rng.choice(acgt, 260)
+        d = int(rng.integers(5, 30)) // len(unit) + 1
+        if rng.random() < 0.5:
+            d = -min(d, m - 6)
+        W = np.concatenate([left, np.tile(unit, m), right])
+        alt = np.concatenate([left, np.tile(unit, m + d), right])
+        shift = d * len(unit)
+        org = 1_000_000 + 10_000 * r
+        reads = []
+        for _ in range(int(rng.integers(16, 48))):
+            hap, sh = (alt, shift) if rng.random() < 0.6 else (W, 0)
+            st = int(rng.integers(60, 230))
+            sq = hap[st:st + read_len].copy()
+            err = rng.random(len(sq)) < 1e-3
+            sq[err] = rng.choice(acgt, int(err.sum()))
+            reads.append((st, sq))
+        reads.sort(key=lambda x: x[0])                           # BAM order (stable: ties keep generation order)
+        for st, sq in reads:
+            bases.append(sq); quals.append(np.full(len(sq), 30, np.uint8))
+            ro.append(ro[-1] + len(sq)); rstart.append(org + st); rstop.append(org + st + len(sq)); mapq.append(60); skip.append(0)
+        rro.append(rro[-1] + len(reads))
+        ref.append(W); fo.append(fo[-1] + len(W)); origin.append(org)
+    return RegionBatch(np.array(rro, np.int64), np.array(ro, np.int64), np.concatenate(bases), np.concatenate(quals), np.array(rstart, np.int64),
+                       np.array(rstop, np.int64), np.array(mapq, np.uint8), np.array(skip, np.uint8), np.array(fo, np.int64), np.concatenate(ref),
+                       np.array(origin, np.int64))
+
+
+def make_batch(name, g):
+    if name == "repeat":
+        return repeat_batch(g["n_regions"], g["config_id"])
+    return synth.generate(**g)[0]
 
 
 def oracle_region_record(res, r, b):
@@ -185,13 +227,14 @@ def job(args):
     o = orc.get()
     o.use_reference_ksw(True)
     lib = T.load_reference_ksw2(REF_SO)
-    b, _ = synth.generate(**g)
+    b = make_batch(name, g)
     if mut:
         b = mutate(b, np.random.default_rng(g["config_id"]))
     if name == "refmut":
         b = mutate_ref(b, np.random.default_rng(g["config_id"] + 1))
     res = o.run_regions(b, o.params(**pk))
     diffs = []
+    retried = 0
     for r in range(b.n_regions):
         r0, r1 = int(b.region_read_off[r]), int(b.region_read_off[r + 1])
         reads = []
@@ -201,10 +244,11 @@ def job(args):
         fai = T.Fai(b.ref_bases[int(b.ref_off[r]):int(b.ref_off[r + 1])].tobytes(), int(b.ref_origin[r]))
         kw = dict(K=pk["K"], min_reads=pk.get("min_reads", 4), min_ctg_len=pk.get("min_ctg_len", 74))
         mine = T.callsemble(reads, fai, lib, **kw)
+        retried += sum(1 for c in mine["contigs"] for e in c.get("events", []) if e.get("retried"))
         d = compare(mine, oracle_region_record(res, r, b))
         if d:
             diffs.append((name, g["config_id"], r, d))
-    stats = dict(regions=b.n_regions, pre_gt20=int((res.n_contigs_pre > 20).sum()), contigs=int(res.n_contigs), events=int(res.n_events),
+    stats = dict(regions=b.n_regions, kmer_retry=retried, pre_gt20=int((res.n_contigs_pre > 20).sum()), contigs=int(res.n_contigs), events=int(res.n_events),
                  tallied=int((res.events["status"] == 0).sum()), fallback=int((res.events["aligned"] == 1).sum()),
                  same_kmer=int((res.events["status"] == A.IHP_EV_SAME_KMER).sum()), short=int((res.events["status"] == A.IHP_EV_SHORT).sum()),
                  low_cplx=int((res.events["status"] == A.IHP_EV_LOW_CPLX).sum()), clamped=int(((res.aln_flags & A.IHP_ALN_REF_CLAMPED) != 0).sum()),
@@ -243,7 +287,7 @@ def main():
             continue
         per_kind[name] = per_kind.get(name, 0) + 1
         g2 = dict(g, n_regions=min(g["n_regions"], 12))
-        b, _ = synth.generate(**g2)
+        b = make_batch(name, g2)
         if mut:
             b = mutate(b, np.random.default_rng(g["config_id"]))   # (the same stream as the compared batch: its first reads)
         if name == "refmut":

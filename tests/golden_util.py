@@ -122,3 +122,30 @@ def check_duo(api):
             assert cigs[i][k].tolist() == exp_cig, (i, k)
         taken += 1
     return len(cs), taken
+
+
+def transcript_sets():
+    """tests/golden/transcript_golden.npz: regions on which the two independent restatements of the path (the C oracle and
+    the Python transcription of the Nim sources, oracle/nim_transcript.py) agreed field by field in the build container;
+    -> [(key, RegionBatch, (K, min_reads, min_ctg_len), Expected)]."""
+    z = np.load(os.path.join(HERE, "golden", "transcript_golden.npz"))
+    keys = sorted({k.split(".")[0] for k in z.files})
+    out = []
+    for key in keys:
+        b = RegionBatch(*[z["%s.in.%s" % (key, f)] for f in IN_FIELDS])
+        e = Expected()
+        for f in BatchResult.FIELDS:
+            setattr(e, f, z["%s.out.%s" % (key, f)])
+        out.append((key, b, tuple(int(x) for x in z["%s.params" % key]), e))
+    return out
+
+
+def check_transcript(api):
+    n = 0
+    for key, b, (K, min_reads, min_ctg_len), exp in transcript_sets():
+        got = api.run_regions(b, api.params(K=K, min_reads=min_reads, min_ctg_len=min_ctg_len))
+        d = BatchResult.first_difference(got, exp)
+        assert d is None, (key, d)
+        np.testing.assert_allclose(got.events["gl"], exp.events["gl"], rtol=1e-12, atol=0)
+        n += b.n_regions
+    return n

@@ -27,3 +27,11 @@ def test_two_target_sweep_against_the_reference(hip):
     (gapo 5, unbanded, no z-drop: indelope.nim:318-319, ksw2.nim:159) on (read, window suffix, contig suffix) triples."""
     n, taken = golden_util.check_duo(hip)
     assert n == 120 and taken >= 100, (n, taken)
+
+
+def test_regions_both_restatements_agree_on(hip):
+    """tests/golden/transcript_golden.npz: ~360 regions across the parity parameter space (votes firing in combine, more than 20
+    pre-combine contigs, a trailing D, the `alt_kmer == ref_kmer` retry, reads that empty under trim, mapping qualities around the
+    three thresholds, the CLI's min_reads / min_ctg_len, K 21 / 27 / 31) whose expected results were produced identically by the C
+    oracle and by the Python transcription of contig.nim / indelope.nim:157-372 / ksw2.nim:22-91 written from the Nim alone."""
+    assert golden_util.check_transcript(hip) >= 300

@@ -169,3 +169,10 @@ def test_edge_regions(oracle):
     one.region_read_off, one.read_off = np.array([0, 0], np.int64), np.array([0], np.int64)
     one.bases, one.quals, one.mapq, one.read_skip, one.read_start, one.read_stop = z8, z8, z8, z8, z64, z64
     assert oracle.run_regions(one).n_contigs == 0
+
+
+def test_oracle_reproduces_the_transcript_fixtures(oracle):
+    """The committed fixtures of tests/golden/make_transcript_golden.py (both restatements agreed on them in the build
+    container) replayed through the C oracle as built here."""
+    import golden_util
+    assert golden_util.check_transcript(oracle) >= 300
