@@ -595,13 +595,14 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 // statement), no VALU reads an SGPR that a VALU wrote (the compare masks go to the scalar unit, v_readlane's lane select
 // comes from s_ff1), lgkmcnt counts only this loop's two LDS reads (the statement opens with lgkmcnt(0)) and is 0 again at
 // every exit, the statement ends with two wait states before the compiler's code may read its outputs through DPP.
-#define IHP_PS_VEC(ZW, CNT)                                                                                     \
+#define IHP_PS_VEC(ZW, WAIT, RM, LM, PRE)                                                                         \
 	"v_mov_b32_dpp %[t0], %[XA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
 	"v_mov_b32_dpp %[t1], %[VA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
 	"v_mov_b32_dpp %[t2], %[GA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
-	"s_waitcnt lgkmcnt(" CNT ")\n\t"                                                                               \
+	PRE                                                                                                            \
+	WAIT "\n\t"                                                                                                    \
 	"v_perm_b32 %[t3], %[TA1], %[TA0], " ZW "\n\t"                                                                 \
-	"v_cndmask_b32_e64 %[ZA], %[ZA], %[t3], %[ge]\n\t"                                                             \
+	"v_cndmask_b32_e64 %[ZA], %[ZA], %[t3], " RM "\n\t"  /* the refreshed scores (:214-228) */                     \
 	"v_pk_add_u16 %[t0], %[t0], %[t1]\n\t"               /* a = x' + v' */                                         \
 	"v_pk_add_u16 %[t3], %[YA], %[UA]\n\t"               /* b = y + u */                                           \
 	"v_pk_sub_i16 %[t4], %[ZA], %[t0] clamp\n\t"         /* s1: negative <=> a > z */                              \
@@ -628,9 +629,10 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 	"v_cndmask_b32_e64 %[t4], %[VA], %[UA], %[sp]\n\t"                                                             \
 	"v_pk_lshrrev_b16 %[t4], 8, %[t4] op_sel_hi:[0,1]\n\t"                                                         \
 	"v_pk_add_u16 %[GA], %[t4], %[t2]\n\t"                                                                         \
-	"s_and_b64 %[inT], %[ge], %[hi]\n\t"
-// one alignment behind the joint test (labels 3..7 are local to the instance: every branch is forward)
-#define IHP_PS_PER(M, THR, POS, ZS, INC, WORD, SEXT, BIT1, BIT2)                                                \
+	"s_and_b64 %[inT], " LM ", %[hi]\n\t"
+// one alignment behind the joint test (labels 3..7 are local to the instance: every branch is forward).  ZS2: more terms of
+// the vouching limit (the tail's t* + qlen - 1), with the lane of the new maximum in %[i].
+#define IHP_PS_PER(M, THR, POS, ZS, INC, WORD, SEXT, BIT1, BIT2, ZS2)                                           \
 	"s_and_b64 " M ", " M ", %[inT]\n\t"                                                                           \
 	"s_cbranch_scc0 3f\n\t"                                                                                        \
 	"s_bcnt1_i32_b64 %[i], " M "\n\t"                                                                              \
@@ -641,6 +643,7 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 	"s_lshl1_add_u32 %[b], %[i], %[c1]\n\t"                                                                        \
 	"s_add_i32 " ZS ", %[r], %[zq]\n\t"                                                                            \
 	"s_min_i32 " ZS ", " ZS ", %[b]\n\t"                                                                           \
+	ZS2                                                                                                            \
 	"s_add_i32 %[i], %[i], %[st]\n\t"                                                                              \
 	"s_pack_ll_b32_b16 " POS ", %[i], %[r]\n\t"                                                                    \
 	SEXT "\n\t"                                                                                                    \
@@ -665,7 +668,7 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 	"6:\n\t"                                                                                                       \
 	"s_or_b32 %[stat], %[stat], " BIT2 "\n"                                                                        \
 	"7:\n\t"
-#define IHP_PS_EZ(EXIT)                                                                                         \
+#define IHP_PS_EZ(EXIT, ZS2)                                                                                    \
 	"v_cmp_gt_i16_sdwa %[m0], %[GA], %[thr0] src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                  \
 	"v_cmp_gt_i16_sdwa %[m1], %[GA], %[thr1] src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                  \
 	"s_or_b64 vcc, %[m0], %[m1]\n\t"                                                                               \
@@ -677,12 +680,14 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 	"s_add_i32 %[thr1], %[thr1], %[inc1]\n\t"                                                                      \
 	"s_branch 9f\n"                                                                                                \
 	"1:\n\t"                                                                                                       \
-	IHP_PS_PER("%[m0]", "%[thr0]", "%[pos0]", "%[zs0]", "%[inc0]", "WORD_0", "s_sext_i32_i16 %[g], %[g]", "1", "2")  \
-	IHP_PS_PER("%[m1]", "%[thr1]", "%[pos1]", "%[zs1]", "%[inc1]", "WORD_1", "s_ashr_i32 %[g], %[g], 16", "4", "8")  \
+	IHP_PS_PER("%[m0]", "%[thr0]", "%[pos0]", "%[zs0]", "%[inc0]", "WORD_0", "s_sext_i32_i16 %[g], %[g]", "1", "2", ZS2("%[zs0]"))  \
+	IHP_PS_PER("%[m1]", "%[thr1]", "%[pos1]", "%[zs1]", "%[inc1]", "WORD_1", "s_ashr_i32 %[g], %[g], 16", "4", "8", ZS2("%[zs1]"))  \
 	"s_min_i32 %[zsm], %[zs0], %[zs1]\n\t"                                                                         \
 	"s_cmp_lg_u32 %[stat], 0\n\t"                                                                                  \
 	"s_cbranch_scc1 " EXIT "\n"                                                                                    \
 	"9:\n\t"
+#define IHP_PS_ZS2_NONE(ZS) ""
+#define IHP_PS_ZS2_TAIL(ZS) "s_add_i32 %[b], %[i], %[c2]\n\t" "s_min_i32 " ZS ", " ZS ", %[b]\n\t"
 
 // Runs pairs of steady diagonals from C.r ((C.r + w) even, w even, no block 4, C.geLoM / spM / hiM current) while
 // C.r + 1 < C.lim.  Returns 0 when that bound is reached; otherwise diagonal C.r is done except for pair_ez_lean of the
@@ -713,19 +718,19 @@ __device__ __forceinline__ int pair_steady_pairs_asm(PairState &S, const PairEnv
 		"ds_read_b32 %[t6], %[qp] offset:8\n\t"
 		"ds_read_b32 %[t7], %[qp] offset:4\n\t"
 		// ---- the first diagonal of the pair: st0 grows on the step behind it
-		IHP_PS_VEC("%[t6]", "1")
-		IHP_PS_EZ("80f")
+		IHP_PS_VEC("%[t6]", "s_waitcnt lgkmcnt(1)", "%[ge]", "%[ge]", "")
+		IHP_PS_EZ("80f", IHP_PS_ZS2_NONE)
 		"s_lshl_b64 %[ge], %[ge], 1\n\t"
 		"s_add_i32 %[r], %[r], 1\n\t"
 		// ---- the second: it closes a traceback group when r & 2; en0 grows behind it
-		IHP_PS_VEC("%[t7]", "0")
+		IHP_PS_VEC("%[t7]", "s_waitcnt lgkmcnt(0)", "%[ge]", "%[ge]", "")
 		"s_bitcmp1_b32 %[r], 1\n\t"
 		"s_cbranch_scc0 2f\n\t"
 		"global_store_dword %[vof], %[acA], %[pb]\n\t"
 		"global_store_dword %[vof], %[acB], %[pb] offset:256\n\t"
 		"v_add_u32_e32 %[vof], 0x140, %[vof]\n"
 		"2:\n\t"
-		IHP_PS_EZ("81f")
+		IHP_PS_EZ("81f", IHP_PS_ZS2_NONE)
 		"s_lshl_b64 %[sp], %[sp], 1\n\t"
 		"s_lshl_b64 %[hi], %[hi], 1\n\t"
 		"s_or_b64 %[hi], %[hi], 1\n\t"
@@ -753,9 +758,217 @@ __device__ __forceinline__ int pair_steady_pairs_asm(PairState &S, const PairEnv
 	C.st0 = (r - E.w + 1) >> 1; C.en0 = (r + E.w) >> 1;
 	return stat;
 }
+// The same for a run of TAIL diagonals (pair_tail_qrun: the band cut by the end of the query; no move, no change of the
+// computed blocks or of the refreshed score groups inside the run).  What differs from the steady run: st0 grows on EVERY
+// diagonal (lo: the lanes >= st0 - st; rf: the refreshed lanes st0 - st .. sc, both shift by one per diagonal), en0 behind an
+// odd one; H[st0] is the end-of-query score of every diagonal (:353-354), kept here as mq = mqe + r (q+e) beside the
+// thresholds; the vouching limit has its third term back (t* + qlen - 1); a diagonal loads the NEXT one's score word, so a
+// run may start and end on either parity (the runs of the tail are 5-15 diagonals long).  All 64 lanes are computed and
+// committed: the lanes above the last computed block hold zeros when they enter the band (nothing has touched them since
+// the sweep began or since a move cleared block 4), and the caller puts the zeros back.
+// Both alignments must be live.  Returns 0 at C.lim; otherwise diagonal C.r lacks pair_ez_lean of the alignments in bits 3..0
+// and the step to C.r + 1 (mq is then already that of C.r + 1).
+__device__ __forceinline__ int pair_tail_run_asm(PairState &S, const PairEnv &E, PairCtl &C, const int zq_, unsigned long long lo_, unsigned long long rf_,
+                                                 unsigned long long sp_, unsigned long long hi_, int la_)
+{
+	typedef const __attribute__((address_space(3))) unsigned *lds_cu32;
+	const unsigned qp0 = (unsigned)(unsigned long long)(lds_cu32)S.qptr;
+	unsigned qp = qp0 - 4u;                                  // the next diagonal's score word
+	unsigned vof = (unsigned)lane_id() * 4u + (unsigned)((C.r >> 2) + (S.st >> 4)) * 320u;
+	unsigned long long lo = (unsigned long long)uni((long long)lo_), rf = (unsigned long long)uni((long long)rf_), sp = (unsigned long long)uni((long long)sp_), hi = (unsigned long long)uni((long long)hi_);
+	int r = uni(C.r), la = uni(la_), stat;
+	const int r_in = r;
+	const int lim = uni(C.lim), st = uni(S.st), zq = uni(zq_), c1 = uni(2 * S.st + E.w), c2 = uni(S.st + E.qlm1), zd = uni(E.zd), inc0 = uni(S.inc0), inc1 = uni(S.inc1);
+	const unsigned Mp = (unsigned)uni((int)E.Mp), Qp = (unsigned)uni((int)E.Qp), k22 = 0x00020002u;
+	const unsigned long long pbase = (unsigned long long)uni((long long)(unsigned long long)E.p);
+	int mq0 = uni(S.mqe0 + r * E.qe), mq1 = uni(S.mqe1 + r * E.qe);
+	const int mt0_in = pair_cold_get(S, PC_MQE_T0), mt1_in = pair_cold_get(S, PC_MQE_T1);
+	int mt0 = mt0_in, mt1 = mt1_in;
+	unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8;
+	unsigned long long m0, m1, inT;
+	int i, g, b, zsm;
+#define IHP_PT_MQE                                                                                              \
+	"v_readlane_b32 %[g], %[GA], %[la]\n\t"              /* H[st0] + r (q+e) of both */                            \
+	"s_add_i32 %[b], %[la], %[st]\n\t"                                                                             \
+	"s_sext_i32_i16 %[i], %[g]\n\t"                                                                                \
+	"s_cmp_gt_i32 %[i], %[mq0]\n\t"                                                                                \
+	"s_cselect_b32 %[mq0], %[i], %[mq0]\n\t"                                                                       \
+	"s_cselect_b32 %[mt0], %[b], %[mt0]\n\t"                                                                       \
+	"s_ashr_i32 %[i], %[g], 16\n\t"                                                                                \
+	"s_cmp_gt_i32 %[i], %[mq1]\n\t"                                                                                \
+	"s_cselect_b32 %[mq1], %[i], %[mq1]\n\t"                                                                       \
+	"s_cselect_b32 %[mt1], %[b], %[mt1]\n\t"                                                                       \
+	"s_add_i32 %[mq0], %[mq0], %[inc0]\n\t"                                                                        \
+	"s_add_i32 %[mq1], %[mq1], %[inc1]\n\t"
+#define IHP_PT_NEXT(EXIT)                                                                                       \
+	"s_lshl_b64 %[lo], %[lo], 1\n\t"                                                                               \
+	"s_lshl_b64 %[rf], %[rf], 1\n\t"                                                                               \
+	"s_add_i32 %[la], %[la], 1\n\t"                                                                                \
+	"v_add_u32_e32 %[qp], -4, %[qp]\n\t"                                                                           \
+	"s_add_i32 %[r], %[r], 1\n\t"                                                                                  \
+	"s_cmp_lt_i32 %[r], %[lim]\n\t"                                                                                \
+	"s_cbranch_scc0 " EXIT "\n\t"
+	asm volatile(
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_min_i32 %[zsm], %[zs0], %[zs1]\n\t"
+		"s_mov_b32 %[stat], 0\n\t"
+		"s_bitcmp1_b32 %[r], 0\n\t"
+		"s_cbranch_scc1 11f\n\t"
+		"ds_read_b32 %[t6], %[qp] offset:4\n"
+		"10:\n\t"
+		// ---- an even diagonal: en0 stays
+		"ds_read_b32 %[t7], %[qp]\n\t"
+		IHP_PS_VEC("%[t6]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[lo]", "")
+		IHP_PT_MQE
+		IHP_PS_EZ("90f", IHP_PS_ZS2_TAIL)
+		IHP_PT_NEXT("90f")
+		"s_branch 12f\n"
+		"11:\n\t"
+		"ds_read_b32 %[t7], %[qp] offset:4\n"
+		"12:\n\t"
+		// ---- an odd one: it closes a traceback group when r & 2; en0 grows behind it
+		"ds_read_b32 %[t6], %[qp]\n\t"
+		IHP_PS_VEC("%[t7]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[lo]", "")
+		"s_bitcmp1_b32 %[r], 1\n\t"
+		"s_cbranch_scc0 2f\n\t"
+		"global_store_dword %[vof], %[acA], %[pb]\n\t"
+		"global_store_dword %[vof], %[acB], %[pb] offset:256\n\t"
+		"v_add_u32_e32 %[vof], 0x140, %[vof]\n"
+		"2:\n\t"
+		IHP_PT_MQE
+		IHP_PS_EZ("90f", IHP_PS_ZS2_TAIL)
+		"s_lshl_b64 %[sp], %[sp], 1\n\t"
+		"s_lshl_b64 %[hi], %[hi], 1\n\t"
+		"s_or_b64 %[hi], %[hi], 1\n\t"
+		IHP_PT_NEXT("90f")
+		"s_branch 10b\n"
+		"90:\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_nop 1"
+		: [XA] "+v"(S.XA), [VA] "+v"(S.VA), [UA] "+v"(S.UA), [YA] "+v"(S.YA), [ZA] "+v"(S.ZA), [GA] "+v"(S.GA), [acA] "+v"(S.accA),
+		  [qp] "+v"(qp), [vof] "+v"(vof), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+		  [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8),
+		  [lo] "+s"(lo), [rf] "+s"(rf), [sp] "+s"(sp), [hi] "+s"(hi), [la] "+s"(la), [thr0] "+s"(S.thr0), [thr1] "+s"(S.thr1), [pos0] "+s"(S.pos0), [pos1] "+s"(S.pos1),
+		  [zs0] "+s"(C.zsafe0), [zs1] "+s"(C.zsafe1), [mq0] "+s"(mq0), [mq1] "+s"(mq1), [mt0] "+s"(mt0), [mt1] "+s"(mt1),
+		  [r] "+s"(r), [stat] "=&s"(stat), [m0] "=&s"(m0), [m1] "=&s"(m1), [inT] "=&s"(inT),
+		  [i] "=&s"(i), [g] "=&s"(g), [b] "=&s"(b), [zsm] "=&s"(zsm)
+		: [acB] "v"(S.accB), [TA0] "v"(S.TA0), [TA1] "v"(S.TA1), [Mp] "s"(Mp), [Qp] "s"(Qp), [k22] "s"(k22), [inc0] "s"(inc0), [inc1] "s"(inc1),
+		  [lim] "s"(lim), [st] "s"(st), [zq] "s"(zq), [c1] "s"(c1), [c2] "s"(c2), [zd] "s"(zd), [pb] "s"(pbase)
+		: "vcc", "scc", "memory");
+#undef IHP_PT_MQE
+#undef IHP_PT_NEXT
+	// qp points at the score word of the diagonal after the last one computed: r when the run ended, r + 1 behind a pending one
+	const int done = stat ? r + 1 - r_in : r - r_in;
+	(void)qp;
+	S.qptr -= done;
+	const int r_mq = stat ? r + 1 : r;
+	S.mqe0 = mq0 - r_mq * E.qe; S.mqe1 = mq1 - r_mq * E.qe;
+	if (mt0 != mt0_in) pair_cold_set(S, PC_MQE_T0, mt0);
+	if (mt1 != mt1_in) pair_cold_set(S, PC_MQE_T1, mt1);
+	C.r = r;
+	return stat;
+}
+// The same for the EARLY diagonals 1 .. w + 30 while block 4 is not computed (st = 0; pair_steady_step<false, 2, ...>): lane 0
+// takes v1 = q (:211), the cell t = r is the boundary y = 0, u = q while the computed blocks reach it (:212), the band grows
+// from one cell.  GROW = 1: r <= w -- st0 = 0, en0 = r: the top cell IS the boundary cell and moves up every diagonal, the
+// scores of all computed blocks are refreshed (rf = the computed lanes, constant: the caller cuts the runs where a block
+// enters).  GROW = 0: w < r -- the steady pattern (st0 behind an even r, en0 behind an odd one; rf = the lanes >= st0).
+// All 64 lanes are computed and committed; the caller puts the zeros back above the computed blocks.  Runs start and end on
+// either parity.  Returns as pair_tail_run_asm (without the end-of-query part: the query's end is far away).
+template <int GROW>
+__device__ __forceinline__ int pair_early_run_asm(PairState &S, const PairEnv &E, PairCtl &C, const int zq_, unsigned long long rf_, unsigned long long sp_,
+                                                  unsigned long long hi_, unsigned long long tr_)
+{
+	typedef const __attribute__((address_space(3))) unsigned *lds_cu32;
+	const unsigned qp0 = (unsigned)(unsigned long long)(lds_cu32)S.qptr;
+	unsigned qp = qp0 - 4u;                                  // the next diagonal's score word
+	unsigned vof = (unsigned)lane_id() * 4u + (unsigned)(C.r >> 2) * 320u;
+	unsigned long long rf = (unsigned long long)uni((long long)rf_), sp = (unsigned long long)uni((long long)sp_), hi = (unsigned long long)uni((long long)hi_), tr = (unsigned long long)uni((long long)tr_);
+	int r = uni(C.r), stat;
+	const int r_in = r;
+	const int lim = uni(C.lim), st = 0, zq = uni(zq_), c1 = uni(E.w), zd = uni(E.zd), inc0 = uni(S.inc0), inc1 = uni(S.inc1);
+	const unsigned Mp = (unsigned)uni((int)E.Mp), Qp = (unsigned)uni((int)E.Qp), k22 = 0x00020002u;
+	const unsigned Qv = Qp;                                  // (a vector copy: a select cannot take its mask and a value from the scalar file)
+	// (the early diagonals sit in front of a loop whose control the compiler takes for divergent: say again what is uniform)
+	int thr0 = uni(S.thr0), thr1 = uni(S.thr1), pos0 = uni(S.pos0), pos1 = uni(S.pos1), zs0 = uni(C.zsafe0), zs1 = uni(C.zsafe1);
+	const unsigned long long pbase = (unsigned long long)uni((long long)(unsigned long long)E.p);
+	unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8;
+	unsigned long long m0, m1, inT;
+	int i, g, b, zsm;
+#define IHP_PE_PRE                                                                                              \
+	"v_writelane_b32 %[t1], %[Qp], 0\n\t"                /* v1 = q (:211) */                                       \
+	"v_cndmask_b32_e64 %[UA], %[UA], %[Qv], %[tr]\n\t"   /* u[r] = q, y[r] = 0 (:212) */                           \
+	"v_cndmask_b32_e64 %[YA], %[YA], 0, %[tr]\n\t"
+#define IHP_PE_NEXT(EXIT)                                                                                       \
+	"v_add_u32_e32 %[qp], -4, %[qp]\n\t"                                                                           \
+	"s_add_i32 %[r], %[r], 1\n\t"                                                                                  \
+	"s_cmp_lt_i32 %[r], %[lim]\n\t"                                                                                \
+	"s_cbranch_scc0 " EXIT "\n\t"
+#define IHP_PE_UP                                                                                               \
+	"s_lshl_b64 %[sp], %[sp], 1\n\t"                                                                               \
+	"s_lshl_b64 %[hi], %[hi], 1\n\t"                                                                               \
+	"s_or_b64 %[hi], %[hi], 1\n\t"
+#define IHP_PE_ASM(EVEN_EXTRA) \
+	asm volatile( \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		"s_min_i32 %[zsm], %[zs0], %[zs1]\n\t" \
+		"s_mov_b32 %[stat], 0\n\t" \
+		"s_bitcmp1_b32 %[r], 0\n\t" \
+		"s_cbranch_scc1 11f\n\t" \
+		"ds_read_b32 %[t6], %[qp] offset:4\n" \
+		"10:\n\t" \
+		"ds_read_b32 %[t7], %[qp]\n\t" \
+		IHP_PS_VEC("%[t6]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[rf]", IHP_PE_PRE) \
+		IHP_PS_EZ("90f", IHP_PS_ZS2_NONE) \
+		"s_lshl_b64 %[tr], %[tr], 1\n\t" \
+		EVEN_EXTRA \
+		IHP_PE_NEXT("90f") \
+		"s_branch 12f\n" \
+		"11:\n\t" \
+		"ds_read_b32 %[t7], %[qp] offset:4\n" \
+		"12:\n\t" \
+		"ds_read_b32 %[t6], %[qp]\n\t" \
+		IHP_PS_VEC("%[t7]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[rf]", IHP_PE_PRE) \
+		"s_bitcmp1_b32 %[r], 1\n\t" \
+		"s_cbranch_scc0 2f\n\t" \
+		"global_store_dword %[vof], %[acA], %[pb]\n\t" \
+		"global_store_dword %[vof], %[acB], %[pb] offset:256\n\t" \
+		"v_add_u32_e32 %[vof], 0x140, %[vof]\n" \
+		"2:\n\t" \
+		IHP_PS_EZ("90f", IHP_PS_ZS2_NONE) \
+		"s_lshl_b64 %[tr], %[tr], 1\n\t" \
+		IHP_PE_UP \
+		IHP_PE_NEXT("90f") \
+		"s_branch 10b\n" \
+		"90:\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		"s_nop 1" \
+		: [XA] "+v"(S.XA), [VA] "+v"(S.VA), [UA] "+v"(S.UA), [YA] "+v"(S.YA), [ZA] "+v"(S.ZA), [GA] "+v"(S.GA), [acA] "+v"(S.accA), \
+		  [qp] "+v"(qp), [vof] "+v"(vof), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), \
+		  [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), \
+		  [rf] "+s"(rf), [sp] "+s"(sp), [hi] "+s"(hi), [tr] "+s"(tr), [thr0] "+s"(thr0), [thr1] "+s"(thr1), [pos0] "+s"(pos0), [pos1] "+s"(pos1), \
+		  [zs0] "+s"(zs0), [zs1] "+s"(zs1), \
+		  [r] "+s"(r), [stat] "=&s"(stat), [m0] "=&s"(m0), [m1] "=&s"(m1), [inT] "=&s"(inT), \
+		  [i] "=&s"(i), [g] "=&s"(g), [b] "=&s"(b), [zsm] "=&s"(zsm) \
+		: [acB] "v"(S.accB), [TA0] "v"(S.TA0), [TA1] "v"(S.TA1), [Qv] "v"(Qv), [Mp] "s"(Mp), [Qp] "s"(Qp), [k22] "s"(k22), [inc0] "s"(inc0), [inc1] "s"(inc1), \
+		  [lim] "s"(lim), [st] "s"(st), [zq] "s"(zq), [c1] "s"(c1), [zd] "s"(zd), [pb] "s"(pbase) \
+		: "vcc", "scc", "memory");
+	if (GROW) { IHP_PE_ASM(IHP_PE_UP) } else { IHP_PE_ASM("s_lshl_b64 %[rf], %[rf], 1\n\t") }
+#undef IHP_PE_ASM
+	S.qptr -= stat ? r + 1 - r_in : r - r_in;
+	(void)qp;
+	S.thr0 = thr0; S.thr1 = thr1; S.pos0 = pos0; S.pos1 = pos1; C.zsafe0 = zs0; C.zsafe1 = zs1;
+	C.r = r;
+	return stat;
+}
+#undef IHP_PE_PRE
+#undef IHP_PE_NEXT
+#undef IHP_PE_UP
 #undef IHP_PS_VEC
 #undef IHP_PS_PER
 #undef IHP_PS_EZ
+#undef IHP_PS_ZS2_NONE
+#undef IHP_PS_ZS2_TAIL
 
 // The diagonals C.r .. bound-1, all with or all without block 4: single steps until r + w is even, then pairs.  With an even
 // w the first diagonal of a pair is an even one: only the second can close a group of four (FLUSH).
@@ -797,7 +1010,7 @@ __device__ __forceinline__ void pair_steady_run(PairState &S, const PairEnv &E, 
 
 // The early and steady diagonals r .. r_hi-1 (see narrow_steady_loop): on return r is the next diagonal (or, when both
 // alignments have z-dropped, one behind the last computed).
-__device__ __forceinline__ void pair_steady_loop(PairState &S, const PairEnv &E, int &r, const int r_hi)
+__device__ __forceinline__ void pair_steady_loop(PairState &S, const PairEnv &E, int &r, const int r_hi, long long *pacc = nullptr)
 {
 	const int lane = lane_id();
 	const int w = E.w;
@@ -807,14 +1020,50 @@ __device__ __forceinline__ void pair_steady_loop(PairState &S, const PairEnv &E,
 	C.geLoM = C.spM = C.hiM = 0; C.lim = r_hi;
 	C.zsafe0 = S.inc0 ? -1 : 0x7fffffff; C.zsafe1 = S.inc1 ? -1 : 0x7fffffff;
 	if (r < w + 31) {                                    // the band grows from one cell (EDGE = 2)
+		const long long te0 = pacc ? (long long)clock64() : 0;   // (diagnostics: the cycles of the early diagonals, as ksw_narrow.h's)
 		C.st0 = C.st0 > 0 ? C.st0 : 0; C.en0 = C.en0 < r ? C.en0 : r;
 		C.lim = r_hi < w + 31 ? r_hi : w + 31;
+		if (!(w & 1)) {
+			// by hand while block 4 is not computed and both alignments are live (pair_early_run_asm): r <= w in runs that end where a
+			// block of sixteen cells enters (r = 16, 32, 48: the lanes above the computed blocks are cleared again behind a run), then
+			// w < r up to the diagonal on which en0 reaches lane 64; what a run hands back is finished with the general code
+			const int lim_all = C.lim;
+			while (C.r < C.lim && S.inc0 && S.inc1) {
+				const int r0 = uni(C.r), grow = r0 <= w;
+				int e = grow ? (r0 | 15) + 1 : 128 - w;                     // (r + w) >> 1 >= 64 from r = 128 - w
+				if (grow && e > w + 1) e = w + 1;
+				e = e < lim_all ? e : lim_all;
+				if (e - r0 < 2) break;
+				const int st0 = grow ? 0 : (r0 - w + 1) >> 1, en0 = grow ? r0 : (r0 + w) >> 1, en = en0 | 15;
+				C.lim = e;
+				const unsigned long long rf = grow ? ~0ull >> (63 - en) : ~0ull << st0, tr = r0 < 64 ? 1ull << r0 : 0ull;
+				const int stat = grow ? pair_early_run_asm<1>(S, E, C, zq, rf, 1ull << en0, (2ull << en0) - 1ull, tr)
+				                      : pair_early_run_asm<0>(S, E, C, zq, rf, 1ull << en0, (2ull << en0) - 1ull, tr);
+				if (en < 63) {
+					const bool act = lane <= en;
+					S.XA = act ? S.XA : 0u; S.VA = act ? S.VA : 0u; S.UA = act ? S.UA : 0u; S.YA = act ? S.YA : 0u;
+				}
+				const int rr = C.r;
+				{ const int a = (rr - w + 1) >> 1, b = (rr + w) >> 1; C.st0 = a > 0 ? a : 0; C.en0 = b < rr ? b : rr; }
+				C.lim = lim_all;
+				if (stat) {
+					const unsigned long long inTA = lane_range(C.st0, C.en0), spM = 1ull << C.en0;
+					if (stat & 3) pair_ez_lean<0, false>(S, E, C, rr, inTA, 0ull, spM, zq);
+					if (stat & 12) pair_ez_lean<1, false>(S, E, C, rr, inTA, 0ull, spM, zq);
+					const int a = (rr - w + 2) >> 1, b = (rr + 1 + w) >> 1;
+					C.r = rr + 1; C.st0 = a > 0 ? a : 0; C.en0 = b < rr + 1 ? b : rr + 1;
+				}
+				C.r = uni(C.r); C.st0 = uni(C.st0); C.en0 = uni(C.en0); C.lim = uni(C.lim); C.zsafe0 = uni(C.zsafe0); C.zsafe1 = uni(C.zsafe1);
+				pair_uniform(S);
+			}
+		}
 		while (uni(C.r) < uni(C.lim)) {
 			if (uni(C.en0) < 64) pair_steady_step<false, 2, -1, -1>(S, E, C, zq);
 			else pair_steady_step<true, 2, -1, -1>(S, E, C, zq);
 		}
 		C.r = uni(C.r); C.st0 = uni(C.st0); C.en0 = uni(C.en0); C.zsafe0 = uni(C.zsafe0); C.zsafe1 = uni(C.zsafe1);
 		pair_uniform(S);
+		if (pacc && lane == 0) pacc[4] += (long long)clock64() - te0;
 	}
 	while (C.r < r_hi && (S.inc0 | S.inc1)) {
 		C.lim = r_hi;
@@ -916,11 +1165,31 @@ template <bool FULL>
 __device__ __forceinline__ void pair_tail_qrun(PairState &S, const PairEnv &E, PairCtl &C, const int zq)
 {
 	const int st = S.st;
+	const int nTop = (C.en0 | 15) - st;                  // last computed lane
+	const unsigned long long actM = ~0ull >> (63 - nTop);
+	// the run by hand while both alignments are live (pair_tail_run_asm); what it hands back is finished with the general code
+	while (!(E.w & 1) && S.inc0 && S.inc1 && C.r + 1 < C.lim) {
+		const int loA = C.st0 - st, hiT = C.en0 - st;
+		const int sc = loA + (((hiT - loA) >> 4) + 1) * 16 - 1;
+		const int stat = pair_tail_run_asm(S, E, C, zq, ~0ull << loA, lane_span(loA, sc), 1ull << hiT, lane_span(0, hiT), loA);
+		if (!FULL) {                                                     // the lanes above the computed blocks: zeros, as before the run
+			const bool act = lane_in(actM);
+			S.XA = act ? S.XA : 0u; S.VA = act ? S.VA : 0u; S.UA = act ? S.UA : 0u; S.YA = act ? S.YA : 0u;
+		}
+		const int r = C.r;
+		C.st0 = r - E.qlen + 1; C.en0 = (r + E.w) >> 1;
+		if (!stat) break;
+		{
+			const unsigned long long inTM = lane_span(C.st0 - st, C.en0 - st), spM = 1ull << (C.en0 - st);
+			if (stat & 3) pair_ez_lean<0, false>(S, E, C, r, inTM, 0ull, spM, zq);
+			if (stat & 12) pair_ez_lean<1, false>(S, E, C, r, inTM, 0ull, spM, zq);
+			C.r = r + 1; C.st0 = r + 2 - E.qlen; C.en0 = (r + 1 + E.w) >> 1;
+		}
+	}
+	if (C.r >= C.lim) return;
 	int loA = C.st0 - st, hiT = C.en0 - st;
 	int sc = loA + (((hiT - loA) >> 4) + 1) * 16 - 1;    // last refreshed score lane (:215): <= 62
-	const int nTop = (C.en0 | 15) - st;                  // last computed lane
 	unsigned long long inTM = lane_span(loA, hiT), refM = lane_span(loA, sc), spM = 1ull << hiT;
-	const unsigned long long actM = ~0ull >> (63 - nTop);
 	do {
 		const int r = C.r;
 		const unsigned xpA = (unsigned)dppz_shr1((int)S.XA), vpA = (unsigned)dppz_shr1((int)S.VA), GpA = (unsigned)dppz_shr1((int)S.GA);   // (no move: edge 0, :210)
@@ -1093,8 +1362,12 @@ __device__ inline bool ksw_pair_sweep(const uint8_t *q0, const uint8_t *t0, int 
 	pair_uniform(S);
 	int r = 1;
 	// steady diagonals: st0 = (r-w+1)>>1 > r-qlen+1 (the window never cuts the band): up to 2 qlen - w - 3
-	pair_steady_loop(S, E, r, 2 * qlen - w - 2);
-	if (S.inc0 | S.inc1) pair_tail_loop(S, E, r, r_end);
+	pair_steady_loop(S, E, r, 2 * qlen - w - 2, pacc);
+	{
+		const long long tt0 = pacc ? (long long)clock64() : 0;
+		if (S.inc0 | S.inc1) pair_tail_loop(S, E, r, r_end);
+		if (pacc && lane == 0) pacc[5] += (long long)clock64() - tt0;
+	}
 	// r - 1 is the last diagonal whose cells were computed; thr* stand at diagonal r
 	if (((r - 1) & 3) != 3) pair_flush(S, E, r - 1, S.st);
 	WSYNC();
