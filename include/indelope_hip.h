@@ -250,6 +250,36 @@ typedef struct {
 #define IHP_SLAB_HAS_SKIP 1
 int  ihp_slab_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, ihp_slab_layout *out);
 
+/*
+ * Round 5: the COMPACT slab -- the same batch in about three quarters of the bytes (C2: 59 MB instead of 75.6), because the
+ * slab's copy over PCIe is what bounds a sweep that keeps the GPU fed (the copy of the form above takes longer than the
+ * kernels need for the batch).  What a `roi` of src/indelope.nim:21 holds per read, in the narrowest types that hold it:
+ *   start_rel  int32   Record.start - ref_origin[region]           (a region's reads lie within +-2^31 of its window)
+ *   len        uint16  length of Record.sequence                   (read_off becomes a prefix sum, made on the device)
+ *   span       uint16  Record.stop - Record.start                  (read_stop = start + span)
+ *   trim_lo/hi uint16  the kept range of trim(sequence, base_qualities), src/indelope.nim:23-38, as in ihp_batch_in
+ *   mapq       uint8   Record.qual
+ *   rflags     uint8   bit 0: skippable(r), src/indelope.nim:40-47
+ * = 14 bytes per read instead of 34.  Per region: region_read_off, region_base_off (read_off of the region's first read: the
+ * stager has it, it places the bases by it), ref_off, ref_origin as int64.  The reference windows 4 bits per base in BAM's code
+ * ("=ACMGRSVTWYHKDBN"; region r from byte (ref_off[r] >> 1) + r, first base in the high nibble), or -- IHP_SLAB2_REF_2BIT,
+ * when every window base is one of A C G T -- 2 bits per base (A C G T = 0 1 2 3; region r from byte (ref_off[r] >> 2) + r,
+ * first base in the low bits).  The read bases as in the slab above.  A k_slab_expand launch in front of the batch's first
+ * run writes the arrays of ihp_batch_in from it (and checks that a region's lengths add up to its region_base_off step:
+ * ihp_batch_sync reports IHP_E_ARG otherwise).
+ */
+typedef struct {
+	int64_t region_read_off, region_base_off, ref_off, ref_origin;                   /* int64 [n_regions + 1] x 3, [n_regions] */
+	int64_t start_rel;                                                               /* int32 [n_reads]                    */
+	int64_t len, span, trim_lo, trim_hi;                                             /* uint16 [n_reads]                   */
+	int64_t mapq, rflags;                                                            /* uint8 [n_reads]                    */
+	int64_t ref_packed;                                                              /* (n_ref >> 1) + n_regions bytes, or (n_ref >> 2) + n_regions */
+	int64_t bases4;                                                                  /* (n_bases >> 1) + n_reads bytes      */
+	int64_t bytes;
+} ihp_slab2_layout;
+#define IHP_SLAB2_REF_2BIT 2
+int  ihp_slab2_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, int32_t flags, ihp_slab2_layout *out);
+
 /* event status: why the tally did or did not run for an alignment event.      */
 #define IHP_EV_TALLIED     0
 #define IHP_EV_SHORT       1   /* tloc.len < min_event_len     indelope.nim:234 */
@@ -425,6 +455,8 @@ int  ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out);
 void ihp_batch_free(ihp_batch *b);
 /* ihp_batch_upload for a slab (see ihp_slab_layout).  The copy is asynchronous on the batch's stream: the slab must stay
  * untouched until the first ihp_batch_sync / fetch of the batch has returned.                                         */
+int  ihp_batch_upload_slab2(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab,
+                            const ihp_slab2_layout *layout, int32_t flags, ihp_batch **b);   /* the compact slab (above); otherwise as ihp_batch_upload_slab */
 int  ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab,
                            const ihp_slab_layout *layout, int32_t flags, ihp_batch **out);
 /* What ihp_batch_fetch / ihp_batch_pack_dev bring back.  IHP_FETCH_NO_BASES: everything but the contigs' bases and

@@ -68,6 +68,17 @@ class HipApi(Api):
                                                C.byref(h)), "batch_upload_slab")
         return h
 
+    def make_slab2(self, batch):
+        """The batch as one page-locked COMPACT slab (ihp_slab2_layout: 14 bytes per read, windows 2 or 4 bits per base)."""
+        return Slab2(self, batch)
+
+    def batch_upload_slab2(self, slab, params=None):
+        p = params if params is not None else self.params()
+        h = C.c_void_p()
+        self._chk_hip(self.b.batch_upload_slab2(C.byref(p), slab.n_regions, slab.n_reads, slab.ptr, C.byref(slab.layout), slab.flags,
+                                                C.byref(h)), "batch_upload_slab2")
+        return h
+
     def batch_set_fetch(self, h, no_bases=False, eager=False):
         fl = (_abi.IHP_FETCH_NO_BASES if no_bases else 0) | (_abi.IHP_FETCH_EAGER if eager else 0)
         self._chk_hip(self.b.batch_set_fetch(h, fl), "batch_set_fetch")
@@ -201,6 +212,87 @@ class Slab:
         lib = synth._lib()
         lib.ihp_synth_pack4.argtypes = [_abi.u8p, _abi.i64p, C.c_int64, C.c_void_p]
         ro = np.ascontiguousarray(b.read_off, np.int64)
+        bases = np.ascontiguousarray(b.bases if len(b.bases) else np.zeros(1, np.uint8), np.uint8)
+        rc = lib.ihp_synth_pack4(_abi.ptr(bases, _abi.u8p), _abi.ptr(ro, _abi.i64p), b.n_reads, self.ptr + L.bases4)
+        if rc != 0:
+            self.free()
+            raise ValueError("a base that BAM's 4-bit alphabet (=ACMGRSVTWYHKDBN) cannot hold")
+
+    def free(self):
+        if self.ptr:
+            self.api.b.host_free(self.ptr)
+            self.ptr = None
+
+
+class Slab2:
+    """A RegionBatch laid out in one ihp_host_alloc'ed compact slab (include/indelope_hip.h, ihp_slab2_layout): what a stager written
+    for this library fills per `roi` (src/indelope.nim:21) instead of the arrays of ihp_batch_in."""
+
+    def __init__(self, api_, batch):
+        import numpy as np
+        from . import synth
+        b = batch if batch.trim_lo is not None else batch.with_trim_bounds()
+        self.api, self.n_regions, self.n_reads = api_, b.n_regions, b.n_reads
+        ref = np.ascontiguousarray(b.ref_bases, np.uint8)
+        code2 = np.full(256, 255, np.uint8)
+        code2[[65, 67, 71, 84]] = [0, 1, 2, 3]
+        r2 = code2[ref]
+        two_bit = not bool((r2 == 255).any())
+        self.flags = _abi.IHP_SLAB2_REF_2BIT if two_bit else 0
+        self.layout = _abi.Slab2Layout()
+        api_._chk_hip(api_.b.slab2_layout_for(b.n_regions, b.n_reads, len(b.bases), len(ref), self.flags, C.byref(self.layout)), "slab2_layout_for")
+        self.ptr = api_.b.host_alloc(self.layout.bytes)
+        if not self.ptr:
+            raise MemoryError("ihp_host_alloc(%d)" % self.layout.bytes)
+        mem = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), (self.layout.bytes,))
+        L = self.layout
+
+        def put(off, a, dt):
+            a = np.ascontiguousarray(a, dt).view(np.uint8).reshape(-1)
+            mem[off:off + len(a)] = a
+        ro = np.ascontiguousarray(b.read_off, np.int64)
+        rro = np.ascontiguousarray(b.region_read_off, np.int64)
+        ln = np.diff(ro)
+        region_of = np.repeat(np.arange(b.n_regions), np.diff(rro))
+        start_rel = np.asarray(b.read_start, np.int64) - np.asarray(b.ref_origin, np.int64)[region_of]
+        span = np.asarray(b.read_stop, np.int64) - np.asarray(b.read_start, np.int64)
+        if len(ln) and (ln.max() > 65535 or span.max() > 65535 or span.min() < 0 or abs(start_rel).max() >= 2 ** 31 or
+                        np.asarray(b.trim_hi).max() > 65535 or np.asarray(b.trim_lo).min() < 0):
+            api_.b.host_free(self.ptr)
+            raise ValueError("a read that the compact slab's 16 / 32-bit fields cannot hold")
+        put(L.region_read_off, rro, np.int64); put(L.region_base_off, ro[rro], np.int64)
+        put(L.ref_off, b.ref_off, np.int64); put(L.ref_origin, b.ref_origin, np.int64)
+        put(L.start_rel, start_rel, np.int32); put(L.len, ln, np.uint16); put(L.span, span, np.uint16)
+        put(L.trim_lo, b.trim_lo, np.uint16); put(L.trim_hi, b.trim_hi, np.uint16)
+        put(L.mapq, b.mapq, np.uint8)
+        put(L.rflags, (np.asarray(b.read_skip, np.uint8) & 1) if b.read_skip is not None else np.zeros(b.n_reads, np.uint8), np.uint8)
+        # the windows: region r from byte (ref_off[r] >> shift) + r
+        fo = np.asarray(b.ref_off, np.int64)
+        if two_bit:
+            for r in range(b.n_regions):
+                w = r2[fo[r]:fo[r + 1]]
+                pad = (-len(w)) % 4
+                q = np.concatenate([w, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+                pk = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
+                at = L.ref_packed + (int(fo[r]) >> 2) + r
+                mem[at:at + len(pk)] = pk
+        else:
+            code4 = np.full(256, 255, np.uint8)
+            for i, ch in enumerate(b"=ACMGRSVTWYHKDBN"):
+                code4[ch] = i
+            r4 = code4[ref]
+            if (r4 == 255).any():
+                api_.b.host_free(self.ptr)
+                raise ValueError("a window base that BAM's 4-bit alphabet cannot hold")
+            for r in range(b.n_regions):
+                w = r4[fo[r]:fo[r + 1]]
+                pad = len(w) & 1
+                q = np.concatenate([w, np.zeros(pad, np.uint8)]).reshape(-1, 2)
+                pk = ((q[:, 0] << 4) | q[:, 1]).astype(np.uint8)
+                at = L.ref_packed + (int(fo[r]) >> 1) + r
+                mem[at:at + len(pk)] = pk
+        lib = synth._lib()
+        lib.ihp_synth_pack4.argtypes = [_abi.u8p, _abi.i64p, C.c_int64, C.c_void_p]
         bases = np.ascontiguousarray(b.bases if len(b.bases) else np.zeros(1, np.uint8), np.uint8)
         rc = lib.ihp_synth_pack4(_abi.ptr(bases, _abi.u8p), _abi.ptr(ro, _abi.i64p), b.n_reads, self.ptr + L.bases4)
         if rc != 0:

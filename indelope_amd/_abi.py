@@ -98,7 +98,13 @@ class SlabLayout(C.Structure):        # ihp_slab_layout
                                           "trim_lo", "trim_hi", "mapq", "read_skip", "ref_bases", "bases4", "bytes")]
 
 
+class Slab2Layout(C.Structure):       # ihp_slab2_layout
+    _fields_ = [(n, C.c_int64) for n in ("region_read_off", "region_base_off", "ref_off", "ref_origin", "start_rel", "len", "span",
+                                          "trim_lo", "trim_hi", "mapq", "rflags", "ref_packed", "bases4", "bytes")]
+
+
 IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES, IHP_FETCH_EAGER = 1, 1, 2
+IHP_SLAB2_REF_2BIT = 2
 
 
 class Event(C.Structure):
@@ -215,6 +221,9 @@ _PRODUCT_ONLY = {
     "slab_layout_for": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(SlabLayout)]),
     "batch_upload_slab": (C.c_int, [C.POINTER(Params), C.c_int32, C.c_int64, C.c_void_p, C.POINTER(SlabLayout), C.c_int32,
                                     C.POINTER(C.c_void_p)]),
+    "slab2_layout_for": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(Slab2Layout)]),
+    "batch_upload_slab2": (C.c_int, [C.POINTER(Params), C.c_int32, C.c_int64, C.c_void_p, C.POINTER(Slab2Layout), C.c_int32,
+                                     C.POINTER(C.c_void_p)]),
     "batch_set_fetch": (C.c_int, [C.c_void_p, C.c_int32]),
     "batch_run": (C.c_int, [C.c_void_p]),
     "batch_sync": (C.c_int, [C.c_void_p]),

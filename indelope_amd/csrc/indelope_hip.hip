@@ -978,7 +978,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 
 // ------------------------------------------------------- the batched region path
 enum { WQ_SETS = 24 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles)
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32 };
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32,
+       M_SLAB_BAD = 48 };   // (behind the stamps, inside the report block: raised by k_slab_expand when a compact slab's lengths do not add up)
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -989,6 +990,7 @@ struct ihp_batch {
 	DBuf trim_lo, trim_hi;
 	DBuf in_slab, bases4;                                  // ihp_batch_upload_slab: every input in one device buffer; BAM 4-bit bases (k_prepack writes the ASCII ones)
 	bool has_quals = false, has_skip = false, has_trim = false, has_b4 = false;
+	bool slab_bad = false;                                 // a compact slab whose lengths did not add up (k_slab_expand): every wait reports IHP_E_ARG
 	int fetch_flags = 0;                                   // IHP_FETCH_*
 	// scratch
 	DBuf arena_seq, arena_sup, lds_sup, lds_sup2, corr, p_scratch, cig_tmp, misc, prof, retry_list, retry_list2;
@@ -1196,7 +1198,12 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 	b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
 }
 
-static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout);
+// The compact slab's host view (ihp_batch_upload_slab2): what batch_upload_common reads on the host comes from here when set.
+struct Slab2In {
+	const void *slab; const ihp_slab2_layout *L; int flags;
+	const int64_t *region_base_off; const uint16_t *len;
+};
+static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout, const Slab2In *s2 = nullptr);
 
 extern "C" int ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **bout)
 {
@@ -1219,6 +1226,48 @@ extern "C" int ihp_slab_layout_for(int32_t n_regions, int64_t n_reads, int64_t n
 	L->bases4 = sec((n_bases >> 1) + n_reads + 64);
 	L->bytes = o;
 	return 0;
+}
+
+// Section offsets of the compact slab (include/indelope_hip.h, ihp_slab2_layout).
+extern "C" int ihp_slab2_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, int32_t flags, ihp_slab2_layout *L)
+{
+	if (!L || n_regions < 0 || n_reads < 0 || n_bases < 0 || n_ref < 0 || (flags & ~IHP_SLAB2_REF_2BIT)) return IHP_E_ARG;
+	int64_t o = 0;
+	auto sec = [&](int64_t bytes) { const int64_t at = o; o += (bytes + 63) / 64 * 64; return at; };
+	L->region_read_off = sec(8 * ((int64_t)n_regions + 1)); L->region_base_off = sec(8 * ((int64_t)n_regions + 1));
+	L->ref_off = sec(8 * ((int64_t)n_regions + 1)); L->ref_origin = sec(8 * (int64_t)n_regions);
+	L->start_rel = sec(4 * n_reads);
+	L->len = sec(2 * n_reads); L->span = sec(2 * n_reads); L->trim_lo = sec(2 * n_reads); L->trim_hi = sec(2 * n_reads);
+	L->mapq = sec(n_reads); L->rflags = sec(n_reads);
+	L->ref_packed = sec(((flags & IHP_SLAB2_REF_2BIT) ? (n_ref >> 2) : (n_ref >> 1)) + n_regions + 64);
+	L->bases4 = sec((n_bases >> 1) + n_reads + 64);
+	L->bytes = o;
+	return 0;
+}
+
+extern "C" int ihp_batch_upload_slab2(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab, const ihp_slab2_layout *L,
+                                      int32_t flags, ihp_batch **bout)
+{
+	if (!slab || !L || n_regions < 0 || n_reads < 0 || (flags & ~IHP_SLAB2_REF_2BIT)) return IHP_E_ARG;
+	const char *h = (const char *)slab;
+	{
+		// as for the first slab form: the layout is checked against ihp_slab2_layout_for before any offset is followed
+		ihp_slab2_layout X;
+		if (ihp_slab2_layout_for(n_regions, n_reads, 0, 0, flags, &X)) return IHP_E_ARG;
+		if (L->region_read_off != X.region_read_off || L->region_base_off != X.region_base_off || L->ref_off != X.ref_off || L->ref_origin != X.ref_origin ||
+		    L->start_rel != X.start_rel || L->len != X.len || L->span != X.span || L->trim_lo != X.trim_lo || L->trim_hi != X.trim_hi || L->mapq != X.mapq ||
+		    L->rflags != X.rflags || L->ref_packed != X.ref_packed || L->bytes < X.bytes) return IHP_E_ARG;
+		const int64_t n_bases = n_regions ? ((const int64_t *)(h + L->region_base_off))[n_regions] : 0, n_ref = n_regions ? ((const int64_t *)(h + L->ref_off))[n_regions] : 0;
+		if (n_bases < 0 || n_ref < 0 || (n_reads && !n_regions) || ihp_slab2_layout_for(n_regions, n_reads, n_bases, n_ref, flags, &X)) return IHP_E_ARG;
+		if (L->bases4 != X.bases4 || L->bytes != X.bytes) return IHP_E_ARG;
+	}
+	ihp_batch_in in;
+	memset(&in, 0, sizeof(in));
+	in.n_regions = n_regions; in.n_reads = n_reads;
+	in.region_read_off = (const int64_t *)(h + L->region_read_off);
+	in.ref_off = (const int64_t *)(h + L->ref_off); in.ref_origin = (const int64_t *)(h + L->ref_origin);
+	Slab2In s2 = {slab, L, flags, (const int64_t *)(h + L->region_base_off), (const uint16_t *)(h + L->len)};
+	return batch_upload_common(p, &in, slab, nullptr, bout, &s2);
 }
 
 extern "C" int ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab, const ihp_slab_layout *L,
@@ -1251,14 +1300,14 @@ extern "C" int ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int
 	return batch_upload_common(p, &in, slab, L, bout);
 }
 
-static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout)
+static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, const void *slab, const ihp_slab_layout *SL, ihp_batch **bout, const Slab2In *s2)
 {
 	if (!p || !in || !bout || p->struct_size != (int32_t)sizeof(ihp_params)) return IHP_E_ARG;
 	if (p->K < 1 || p->K > 31 || in->n_regions < 0 || in->n_reads < 0) return IHP_E_ARG;
 	if (!ksw_flags_supported(p->ksw_flag)) return IHP_E_UNSUPPORTED;
 	if (p->fallback && !ksw_flags_supported(p->fb_flag)) return IHP_E_UNSUPPORTED;
 	if (in->n_regions && (!in->region_read_off || !in->ref_off || !in->ref_origin)) return IHP_E_ARG;
-	if (in->n_reads && (!in->read_off || (!in->bases && !slab) || !in->read_start || !in->read_stop || !in->mapq)) return IHP_E_ARG;
+	if (!s2 && in->n_reads && (!in->read_off || (!in->bases && !slab) || !in->read_start || !in->read_stop || !in->mapq)) return IHP_E_ARG;
 	int rc = ensure_init();
 	if (rc) return rc;
 	ihp_batch *b = new (std::nothrow) ihp_batch();
@@ -1267,20 +1316,37 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	b->P = *p; b->R = in->n_regions; b->n_reads = in->n_reads;
 	const int R = b->R; const long long NR = b->n_reads;
 	static const int64_t zero2[2] = {0, 0};
-	const int64_t *rro = R ? in->region_read_off : zero2, *ro = NR ? in->read_off : zero2, *fo = R ? in->ref_off : zero2;
+	const int64_t *rro = R ? in->region_read_off : zero2, *fo = R ? in->ref_off : zero2;
 	if (rro[0] != 0 || rro[R] != NR) { delete b; return IHP_E_ARG; }
-	b->n_bases = ro[NR]; b->n_ref = fo[R];
+	// read_off at the regions' first reads: all the host needs of it (a compact slab brings exactly that; its per-read lengths
+	// become read_off on the device, k_slab_expand)
+	std::vector<int64_t> rb_((size_t)R + 1, 0);
+	if (s2) { for (int r = 0; r <= R; ++r) rb_[(size_t)r] = R ? s2->region_base_off[r] : 0; }
+	else {
+		const int64_t *ro_ = NR ? in->read_off : zero2;
+		for (int r = 0; r <= R; ++r) { if (rro[r] < 0 || rro[r] > NR) { delete b; return IHP_E_ARG; } rb_[(size_t)r] = ro_[rro[r]]; }
+	}
+	const int64_t *rb = rb_.data();
+	if (rb[0] != 0) { delete b; return IHP_E_ARG; }
+	b->n_bases = rb[R]; b->n_ref = fo[R];
 	for (int r = 0; r < R; ++r) {
-		if (rro[r + 1] < rro[r] || fo[r + 1] < fo[r]) { delete b; return IHP_E_ARG; }
-		const int64_t nb = ro[rro[r + 1]] - ro[rro[r]];
+		if (rro[r + 1] < rro[r] || fo[r + 1] < fo[r] || rb[r + 1] < rb[r]) { delete b; return IHP_E_ARG; }
+		const int64_t nb = rb[r + 1] - rb[r];
 		if (nb > (1 << 30) || fo[r + 1] - fo[r] > (1 << 30)) { delete b; return IHP_E_CAPACITY; }
 		b->max_region_bases = std::max(b->max_region_bases, (int)nb);
 		b->max_region_reads = (int)std::max<int64_t>(b->max_region_reads, std::min<int64_t>(rro[r + 1] - rro[r], 1 << 30));
 		b->max_ref_len = std::max(b->max_ref_len, (int)(fo[r + 1] - fo[r]));
 	}
-	for (long long i = 0; i < NR; ++i) {
-		if (ro[i + 1] < ro[i]) { delete b; return IHP_E_ARG; }
-		b->max_read_len = std::max<int>(b->max_read_len, (int)std::min<int64_t>(ro[i + 1] - ro[i], 1 << 30));
+	if (s2) {
+		unsigned mx = 0;
+		for (long long i = 0; i < NR; ++i) mx = std::max<unsigned>(mx, s2->len[i]);
+		b->max_read_len = (int)mx;
+	} else {
+		const int64_t *ro = NR ? in->read_off : zero2;
+		for (long long i = 0; i < NR; ++i) {
+			if (ro[i + 1] < ro[i]) { delete b; return IHP_E_ARG; }
+			b->max_read_len = std::max<int>(b->max_read_len, (int)std::min<int64_t>(ro[i + 1] - ro[i], 1 << 30));
+		}
 	}
 	b->h_region_read_off.assign(rro, rro + R + 1);
 	b->h_ref_origin.assign(in->ref_origin, in->ref_origin + R);
@@ -1292,9 +1358,22 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	std::vector<long long> hoff;                             // (v2_hoff): staged in one page-locked block, one copy (see `aux` below)
 	int cn_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define UP(buf, ptr, bytes) do { if ((rc = b->buf.upload(ptr, (size_t)(bytes), s))) { delete b; return rc; } } while (0)
-	b->has_trim = in->trim_lo != nullptr && in->trim_hi != nullptr;     // trim() done by the stager: qualities not needed
-	b->has_quals = in->quals != nullptr && !b->has_trim; b->has_skip = in->read_skip != nullptr;
-	if (slab) {
+	b->has_trim = (in->trim_lo != nullptr && in->trim_hi != nullptr) || s2;     // trim() done by the stager: qualities not needed
+	b->has_quals = in->quals != nullptr && !b->has_trim; b->has_skip = in->read_skip != nullptr || s2;
+	if (s2) {
+		// the compact slab: one copy; the per-read arrays of ihp_batch_in are made on the device (k_slab_expand, enqueued below)
+		const ihp_slab2_layout *L2 = s2->L;
+		if ((rc = b->in_slab.alloc((size_t)L2->bytes + 64))) { delete b; return rc; }
+		HIPB(hipMemcpyAsync(b->in_slab.p, s2->slab, (size_t)L2->bytes, hipMemcpyHostToDevice, s));
+		void *d = b->in_slab.p;
+		b->region_read_off.view(d, L2->region_read_off, sizeof(int64_t) * (R + 1));
+		b->ref_off.view(d, L2->ref_off, sizeof(int64_t) * (R + 1)); b->ref_origin.view(d, L2->ref_origin, sizeof(int64_t) * R);
+		b->bases4.view(d, L2->bases4, (size_t)(b->n_bases >> 1) + NR);
+		b->has_b4 = true;
+		if ((rc = b->bases.alloc(b->n_bases)) || (rc = b->read_off.alloc(sizeof(int64_t) * (NR + 1))) || (rc = b->read_start.alloc(sizeof(int64_t) * NR)) ||
+		    (rc = b->read_stop.alloc(sizeof(int64_t) * NR)) || (rc = b->trim_lo.alloc(sizeof(int32_t) * NR)) || (rc = b->trim_hi.alloc(sizeof(int32_t) * NR)) ||
+		    (rc = b->mapq.alloc(NR)) || (rc = b->read_skip.alloc(NR)) || (rc = b->ref_bases.alloc(b->n_ref))) { delete b; return rc; }
+	} else if (slab) {
 		// one copy for everything (the caller filled a page-locked slab: ihp_host_alloc); the read bases come 4 bits each as
 		// BAM stores them, k_prepack writes the ASCII ones the byte-based kernels read
 		if ((rc = b->in_slab.alloc((size_t)SL->bytes + 64))) { delete b; return rc; }
@@ -1311,7 +1390,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		if ((rc = b->bases.alloc(b->n_bases))) { delete b; return rc; }
 	} else {
 	UP(region_read_off, rro, sizeof(int64_t) * (R + 1));
-	UP(read_off, ro, sizeof(int64_t) * (NR + 1));
+	UP(read_off, NR ? in->read_off : zero2, sizeof(int64_t) * (NR + 1));
 	UP(bases, in->bases, b->n_bases);
 	if (b->has_quals) UP(quals, in->quals, b->n_bases);
 	if (b->has_trim) { UP(trim_lo, in->trim_lo, sizeof(int32_t) * NR); UP(trim_hi, in->trim_hi, sizeof(int32_t) * NR); }
@@ -1335,7 +1414,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		// arena that minimises  sum(cost / occupancy)  over the two passes.
 		std::vector<std::pair<long long, long long>> need((size_t)R);          // (bytes needed, cost)
 		for (long long r = 0; r < R; ++r) {
-			const long long nb = ro[rro[r + 1]] - ro[rro[r]];
+			const long long nb = rb[r + 1] - rb[r];
 			need[(size_t)r] = {nb / 2 + 2 * b->stage_cap, nb + 1};
 		}
 		std::sort(need.begin(), need.end());
@@ -1372,7 +1451,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		const long long lim[3] = {b->lds_arena1, b->lds_arena2, b->lds_arena3};
 		const bool packed_ok = !g_knob.asm_v1 && !g_knob.no_rich && p->max_mismatch == 0 && p->min_overlap_pct > 0 && p->min_overlap_pct <= 1.0;
 		for (int r = 0; r < R; ++r) {
-			const long long nb = ro[rro[r + 1]] - ro[rro[r]];
+			const long long nb = rb[r + 1] - rb[r];
 			const long long want = nb * 3 / 10 + 2 * b->stage_cap;
 			int k = 0;
 			while (k < 3 && want > lim[k]) ++k;
@@ -1401,7 +1480,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		if (b->v2) {
 			long long nb1 = 0, nr1 = 0, nbL = 0, nrL = 0;
 			for (int r = 0; r < R; ++r) {
-				const long long nb = ro[rro[r + 1]] - ro[rro[r]];
+				const long long nb = rb[r + 1] - rb[r];
 				if (nb * 3 / 10 + 2 * b->stage_cap <= b->lds_arena1) { nb1 = std::max(nb1, nb); nr1 = std::max<long long>(nr1, rro[r + 1] - rro[r]); }
 				else if (b->n_rich && rro[r + 1] - rro[r] <= 256 && nb <= 120000) { nbL = std::max(nbL, nb); nrL = std::max<long long>(nrL, rro[r + 1] - rro[r]); }
 			}
@@ -1438,7 +1517,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 				// hand-over records between the two kernels: 8 + 9 min(64, reads) + reads + bases / 16 + 8 dwords per region
 				hoff.assign((size_t)R + 1, 0);
 				for (int r = 0; r < R; ++r) {
-					const long long nr = rro[r + 1] - rro[r], nb = ro[rro[r + 1]] - ro[rro[r]];
+					const long long nr = rro[r + 1] - rro[r], nb = rb[r + 1] - rb[r];
 					hoff[(size_t)r + 1] = hoff[(size_t)r] + ((16 + 9 * std::min<long long>(64, nr) + nr + nb / 16 + 3) / 4 * 4);
 				}
 				b->v2_hand_dwords = hoff[(size_t)R];
@@ -1563,6 +1642,23 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	b->report = g_reports.get();
 	if (!b->report) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of the report page failed"); return IHP_E_NOMEM; }
 	HIPB(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // the only memset of the batch's life (see ihp_batch::misc)
+	if (s2) {
+		const ihp_slab2_layout *L2 = s2->L;
+		const char *d = (const char *)b->in_slab.p;
+		SlabExpandArgs x;
+		x.n_regions = R; x.n_reads = NR;
+		x.region_read_off = (const long long *)(d + L2->region_read_off); x.region_base_off = (const long long *)(d + L2->region_base_off);
+		x.ref_off = (const long long *)(d + L2->ref_off); x.ref_origin = (const long long *)(d + L2->ref_origin);
+		x.start_rel = (const int *)(d + L2->start_rel); x.len = (const unsigned short *)(d + L2->len); x.span = (const unsigned short *)(d + L2->span);
+		x.trim_lo_in = (const unsigned short *)(d + L2->trim_lo); x.trim_hi_in = (const unsigned short *)(d + L2->trim_hi);
+		x.mapq_in = (const uint8_t *)(d + L2->mapq); x.rflags = (const uint8_t *)(d + L2->rflags);
+		x.ref_packed = (const uint8_t *)(d + L2->ref_packed); x.ref_2bit = (s2->flags & IHP_SLAB2_REF_2BIT) ? 1 : 0;
+		x.read_off = b->read_off.as<long long>(); x.read_start = b->read_start.as<long long>(); x.read_stop = b->read_stop.as<long long>();
+		x.trim_lo = b->trim_lo.as<int>(); x.trim_hi = b->trim_hi.as<int>(); x.mapq = b->mapq.as<uint8_t>(); x.read_skip = b->read_skip.as<uint8_t>();
+		x.ref_bases = b->ref_bases.as<uint8_t>(); x.bad = b->misc.as<int>() + M_SLAB_BAD;
+		hipLaunchKernelGGL(k_slab_expand, dim3(std::max(1, grid_for(std::max(R, 1), 32))), dim3(64), 0, s, x);
+		HIPB(hipGetLastError());
+	}
 	// separate arrays may change once this returns; a slab stays as it is until a wait for the batch has returned
 	// (ihp_batch_sync, fetch, ...: see ihp_batch_upload_slab in the header), so its copy is left in flight
 	if (!slab) HIPB(hipStreamSynchronize(s));
@@ -1970,6 +2066,11 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 static int report_overflow(const ihp_batch *b)
 {
 	const int *m = b->report;
+	if (m[M_SLAB_BAD] || b->slab_bad) {
+		const_cast<ihp_batch *>(b)->slab_bad = true;           // (the flag is cleared with the counters; the batch stays refused)
+		snprintf(g.err, sizeof(g.err), "compact slab: the read lengths of a region do not add up to its region_base_off step");
+		return IHP_E_ARG;
+	}
 	if (m[M_OVF] || m[M_OVF + 1] || m[M_OVF + 2] || m[M_OVF_HIT]) {
 		snprintf(g.err, sizeof(g.err), "device pool overflow: cigar=%d ksw-scratch=%d events=%d hits=%d", m[M_OVF], m[M_OVF + 1],
 		         m[M_OVF + 2], m[M_OVF_HIT]);
@@ -2011,6 +2112,7 @@ static void hint_refresh(const ihp_batch *b)
 static int finish_run(ihp_batch *b)
 {
 	HIPC(hipStreamSynchronize(b->stream));
+	if (b->ran && b->report[M_SLAB_BAD]) b->slab_bad = true;   // (raised once, by k_slab_expand; the counters are cleared with every run)
 	if (spec_failed(b)) {
 		const int rc = run_again_in_full(b);
 		if (rc) return rc;

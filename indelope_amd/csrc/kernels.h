@@ -1266,6 +1266,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	}
 }
 
+// ------------------------------------------------------------ the compact slab (ihp_slab2_layout) -> ihp_batch_in's arrays
+// One wavefront per region: read_off as the prefix sum of the lengths behind region_base_off[r], read_start / read_stop from
+// the 32-bit start relative to the window's origin and the 16-bit span, the trim bounds and the two bytes widened, the window's
+// bases from 4 (BAM's code) or 2 bits each to ASCII.  A region whose lengths do not add up to its region_base_off step raises
+// *bad (reported as IHP_E_ARG by the first wait for the batch).
+struct SlabExpandArgs {
+	int n_regions; long long n_reads;
+	const long long *region_read_off, *region_base_off, *ref_off, *ref_origin;
+	const int *start_rel; const unsigned short *len, *span, *trim_lo_in, *trim_hi_in; const uint8_t *mapq_in, *rflags;
+	const uint8_t *ref_packed; int ref_2bit;
+	long long *read_off, *read_start, *read_stop; int *trim_lo, *trim_hi; uint8_t *mapq, *read_skip, *ref_bases;
+	int *bad;
+};
+
+__global__ __launch_bounds__(64) void k_slab_expand(const SlabExpandArgs a)
+{
+	const int lane = lane_id();
+	for (int r = (int)blockIdx.x; r < a.n_regions; r += (int)gridDim.x) {
+		const long long r0 = uni(a.region_read_off[r]), r1 = uni(a.region_read_off[r + 1]);
+		long long off = uni(a.region_base_off[r]);
+		const long long off_end = uni(a.region_base_off[r + 1]);   // (no read_off leaves the region's bases, whatever the lengths say)
+		const long long origin = uni(a.ref_origin[r]);
+		for (long long g0 = r0; g0 < r1; g0 += 64) {
+			const long long i = g0 + lane;
+			const bool live = i < r1;
+			const unsigned ln = live ? a.len[i] : 0u;
+			const unsigned incl = wave_scan_add(ln);
+			if (live) {
+				{ const long long ro = off + (long long)(incl - ln); a.read_off[i] = ro < off_end ? ro : off_end; }
+				const long long st = origin + (long long)a.start_rel[i];
+				a.read_start[i] = st; a.read_stop[i] = st + (long long)a.span[i];
+				a.trim_lo[i] = (int)a.trim_lo_in[i]; a.trim_hi[i] = (int)a.trim_hi_in[i];
+				a.mapq[i] = a.mapq_in[i]; a.read_skip[i] = a.rflags[i] & 1;
+			}
+			off += (long long)(unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+		}
+		if (off != off_end && lane == 0) atomicExch(a.bad, 1);
+		if (r == a.n_regions - 1 && lane == 0) a.read_off[a.n_reads] = off_end;
+		// the window
+		const long long f0 = uni(a.ref_off[r]), f1 = uni(a.ref_off[r + 1]);
+		if (a.ref_2bit) {
+			const uint8_t *src = a.ref_packed + (f0 >> 2) + r;
+			for (long long j = lane; j < f1 - f0; j += 64) a.ref_bases[f0 + j] = (uint8_t)"ACGT"[(src[j >> 2] >> (2 * (j & 3))) & 3];
+		} else {
+			const uint8_t *src = a.ref_packed + (f0 >> 1) + r;
+			for (long long j = lane; j < f1 - f0; j += 64) a.ref_bases[f0 + j] = (uint8_t)"=ACMGRSVTWYHKDBN"[(src[j >> 1] >> ((j & 1) ? 0 : 4)) & 15];
+		}
+	}
+	if (a.n_regions == 0 && blockIdx.x == 0 && lane == 0) a.read_off[0] = 0;
+}
+
 // ------------------------------------------------------------------- summary
 struct SummaryArgs {
 	int n_regions;

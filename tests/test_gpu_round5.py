@@ -1,8 +1,13 @@
 """Round 5: the sweeps that carry the load against fixtures produced by the compiled reference C."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import golden_util
+from indelope_amd import _abi as A
+from indelope_amd import synth
+from indelope_amd.host import BatchResult, RegionBatch
 
 pytestmark = pytest.mark.gpu
 
@@ -35,3 +40,98 @@ def test_regions_both_restatements_agree_on(hip):
     three thresholds, the CLI's min_reads / min_ctg_len, K 21 / 27 / 31) whose expected results were produced identically by the C
     oracle and by the Python transcription of contig.nim / indelope.nim:157-372 / ksw2.nim:22-91 written from the Nim alone."""
     assert golden_util.check_transcript(hip) >= 300
+
+
+def _same(got, exp):
+    d = BatchResult.first_difference(got, exp)
+    assert d is None, d
+
+
+def _mixed_batch():
+    """Reads with N / IUPAC codes, low mapping qualities, skippable reads, trimmed ends, a window with an N."""
+    b, _ = synth.generate(200, n_reads=(8, 96), err_rate=2e-3, config_id=78, dup_frac=0.2)
+    rng = np.random.default_rng(4)
+    bases = b.bases.copy()
+    bases[rng.integers(0, len(bases), 30)] = ord("N")
+    q = b.quals.copy()
+    for i in rng.integers(0, b.n_reads, 400):
+        q[int(b.read_off[i]):int(b.read_off[i]) + int(rng.integers(1, 9))] = 3
+    mapq = b.mapq.copy(); mapq[rng.integers(0, b.n_reads, 200)] = rng.choice([0, 5, 9, 19], 200)
+    skip = b.read_skip.copy(); skip[rng.integers(0, b.n_reads, 50)] = 1
+    return RegionBatch(b.region_read_off, b.read_off, bases, q, b.read_start, b.read_stop, mapq, skip, b.ref_off, b.ref_bases, b.ref_origin)
+
+
+@pytest.mark.parametrize("which", ["C2", "C3", "C5", "mixed", "mixed_refN", "empty"])
+def test_compact_slab_gives_the_same_results(hip, oracle, which):
+    """ihp_batch_upload_slab2 (14 bytes per read instead of 34, windows 2 or 4 bits per base; the arrays of
+    ihp_batch_in are made on the device by k_slab_expand) against the oracle on the separate arrays, and -- byte for byte --
+    against the first slab form."""
+    K = 31 if which == "C5" else 27
+    if which in ("C2", "C3", "C5"):
+        b, _ = synth.config(which, n_regions={"C2": 600, "C3": 300, "C5": 150}[which])
+    elif which == "empty":
+        b, _ = synth.generate(0)
+    else:
+        b = _mixed_batch()
+        if which == "mixed_refN":
+            ref = b.ref_bases.copy(); ref[np.random.default_rng(9).integers(0, len(ref), 5)] = ord("N")
+            b = RegionBatch(b.region_read_off, b.read_off, b.bases, b.quals, b.read_start, b.read_stop, b.mapq, b.read_skip, b.ref_off, ref, b.ref_origin)
+    exp = oracle.run_regions_mt(b, oracle.params(K=K), 16)
+    bt = b.with_trim_bounds()
+    s2 = hip.make_slab2(bt)
+    try:
+        assert bool(s2.flags & A.IHP_SLAB2_REF_2BIT) == (which != "mixed_refN")
+        h = hip.batch_upload_slab2(s2, hip.params(K=K))
+        try:
+            hip.batch_run(h); hip.batch_sync(h)
+            got = hip.batch_fetch(h)
+            hip.batch_run(h); hip.batch_sync(h)                       # a second run of the resident batch
+            again = hip.batch_fetch(h)
+        finally:
+            hip.batch_free(h)
+        n2 = s2.layout.bytes
+    finally:
+        s2.free()
+    _same(got, exp)
+    _same(again, exp)
+    if b.n_reads:
+        s1 = hip.make_slab(bt)
+        try:
+            assert n2 < (0.8 if which == "C2" else 0.9) * s1.layout.bytes, (n2, s1.layout.bytes)
+        finally:
+            s1.free()
+
+
+def test_a_compact_slab_that_is_not_the_librarys_is_refused(hip):
+    """The layout is checked against ihp_slab2_layout_for before an offset is followed; unknown flags are refused; lengths that
+    do not add up to a region's region_base_off step are caught on the device and every wait reports IHP_E_ARG."""
+    from indelope_amd.host import IhpError
+    b, _ = synth.config("C2", n_regions=40)
+    s2 = hip.make_slab2(b.with_trim_bounds())
+    try:
+        h = C.c_void_p()
+        bad = A.Slab2Layout.from_buffer_copy(s2.layout)
+        bad.len += 64
+        assert hip.b.batch_upload_slab2(C.byref(hip.params()), s2.n_regions, s2.n_reads, s2.ptr, C.byref(bad), s2.flags, C.byref(h)) == A.IHP_E_ARG
+        bad = A.Slab2Layout.from_buffer_copy(s2.layout)
+        bad.bytes -= 64
+        assert hip.b.batch_upload_slab2(C.byref(hip.params()), s2.n_regions, s2.n_reads, s2.ptr, C.byref(bad), s2.flags, C.byref(h)) == A.IHP_E_ARG
+        assert hip.b.batch_upload_slab2(C.byref(hip.params()), s2.n_regions, s2.n_reads, s2.ptr, C.byref(s2.layout), s2.flags | 8, C.byref(h)) == A.IHP_E_ARG
+        assert hip.b.batch_upload_slab2(C.byref(hip.params()), s2.n_regions, s2.n_reads + 1, s2.ptr, C.byref(s2.layout), s2.flags, C.byref(h)) == A.IHP_E_ARG
+        # one read's length off by one: the prefix sums no longer meet region_base_off
+        mem = np.ctypeslib.as_array(C.cast(s2.ptr, C.POINTER(C.c_uint8)), (s2.layout.bytes,))
+        ln = mem[s2.layout.len:s2.layout.len + 2 * s2.n_reads].view(np.uint16)
+        ln[7] -= 1
+        hb = hip.batch_upload_slab2(s2)
+        try:
+            hip.batch_run(hb)
+            with pytest.raises(IhpError) as e:
+                hip.batch_sync(hb)
+            assert e.value.code == A.IHP_E_ARG
+            hip.batch_run(hb)
+            with pytest.raises(IhpError):
+                hip.batch_sync(hb)                                    # it stays refused
+        finally:
+            hip.batch_free(hb)
+    finally:
+        s2.free()
