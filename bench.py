@@ -178,7 +178,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
     from indelope_amd import _abi as A
 
     def start(slab, no_bases):
-        h = api.batch_upload_slab(slab, params)
+        h = api.batch_upload_slab2(slab, params)
         api.batch_set_fetch(h, no_bases=no_bases, eager=True)
         api.batch_run(h)
         return h
@@ -196,7 +196,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
 
     def one(slab, no_bases):
         t0 = time.perf_counter()
-        h = api.batch_upload_slab(slab, params)
+        h = api.batch_upload_slab2(slab, params)
         api.batch_sync(h)                                    # the copy alone (the call itself only enqueues it)
         t1 = time.perf_counter()
         api.batch_set_fetch(h, no_bases=no_bases, eager=True)
@@ -204,7 +204,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
         t2, t3 = finish(h, no_bases)
         return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
 
-    slabs = [[api.make_slab(batch) for _ in range(depth)] for _ in range(threads)]
+    slabs = [[api.make_slab2(batch) for _ in range(max(depth, 2))] for _ in range(threads)]
     try:
         res = {}
         for name, nb in (("events_only", True), ("full", False)):
@@ -234,11 +234,33 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
             for x in th:
                 x.join()
             dt = time.perf_counter() - t0
+            # ONE host thread with three batches in flight on three streams (upload and run only enqueue; the thread waits for and
+            # fetches the oldest batch while the copies and kernels of the two behind it run)
+            pool = [sl for row in slabs for sl in row][:4]
+            d1 = 3
+            q = [start(pool[j], nb) for j in range(d1)]
+            for h in q:
+                finish(h, nb)
+            q, n1 = [], n_each * 2
+            host_up = 0.0
+            t0 = time.perf_counter()
+            for i in range(n1):
+                tu = time.perf_counter()
+                q.append(start(pool[i % len(pool)], nb))         # (four slabs for three in flight: a slab is reused after its batch's fetch)
+                host_up += time.perf_counter() - tu
+                if len(q) == d1:
+                    finish(q.pop(0), nb)
+            while q:
+                finish(q.pop(0), nb)
+            dt1 = time.perf_counter() - t0
             res[name] = {"one_batch_ms": {k: round(float(v), 3) for k, v in zip(("upload", "run", "fetch", "total"), med)},
                          "one_batch_regions_per_s": round(batch.n_regions / (med[3] * 1e-3), 1),
                          "sustained": {"threads": threads, "in_flight_per_thread": depth, "batches": n_each * threads,
                                        "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
-                                       "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)}}
+                                       "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)},
+                         "sustained_one_thread": {"threads": 1, "in_flight": d1, "batches": n1, "ms_per_batch": round(dt1 / n1 * 1e3, 3),
+                                                  "regions_per_s": round(batch.n_regions * n1 / dt1, 1),
+                                                  "host_ms_in_upload_and_run_calls": round(host_up / n1 * 1e3, 3)}}
         slab_bytes = int(slabs[0][0].layout.bytes)
     finally:
         for row in slabs:
@@ -272,9 +294,10 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
     dt = time.perf_counter() - t0
     ev = res["events_only"]
     return {"one_batch_ms": ev["one_batch_ms"], "one_batch_regions_per_s": ev["one_batch_regions_per_s"], "sustained": ev["sustained"],
+            "sustained_one_thread": ev["sustained_one_thread"],
             "slab_MB": round(slab_bytes / 1e6, 2),
-            "inputs": "one page-locked slab per batch (%d bytes: 4-bit bases, trim bounds), a single upload copy; results without contig "
-                      "bases/supports (IHP_FETCH_NO_BASES)" % slab_bytes,
+            "inputs": "one page-locked COMPACT slab per batch (ihp_slab2_layout, %d bytes: 4-bit read bases, 14 bytes per read, 2-bit windows), "
+                      "a single upload copy, the arrays made on the device; results without contig bases/supports (IHP_FETCH_NO_BASES)" % slab_bytes,
             "full_results": res["full"],
             "pageable_arrays": {"threads": threads, "batches": n_each * threads, "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
                                 "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1),
@@ -552,9 +575,9 @@ def digest(out):
         d["mixed"] = [m(ms["plans_per_shape"]["regions_per_s"]), ms["plans_per_shape"]["n_reruns"], ms["mixed_over_predicted"]]
     e = out.get("e2e")
     if e:
-        d["e2e"] = {"one_M": m(e["one_batch_regions_per_s"]), "sus_M": m(e["sustained"]["regions_per_s"]),
+        d["e2e"] = {"one_M": m(e["one_batch_regions_per_s"]), "sus_M": m(e["sustained"]["regions_per_s"]), "sus1t_M": m(e["sustained_one_thread"]["regions_per_s"]),
                     "full_one_M": m(e["full_results"]["one_batch_regions_per_s"]), "full_sus_M": m(e["full_results"]["sustained"]["regions_per_s"]),
-                    "slab_MB": e.get("slab_MB")}
+                    "full_sus1t_M": m(e["full_results"]["sustained_one_thread"]["regions_per_s"]), "slab_MB": e.get("slab_MB")}
     c = out.get("c1")
     if c:
         d["c1_us"] = [c["cpu_us_per_region"], c["gpu_us_per_region"], c["identical"]]

@@ -12,6 +12,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -1312,6 +1313,8 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	if (rc) return rc;
 	ihp_batch *b = new (std::nothrow) ihp_batch();
 	if (!b) return IHP_E_NOMEM;
+	const auto T0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { if (g_knob.verbose > 1) fprintf(stderr, "[ihp] upload %-12s %7.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
 #define HIPB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { delete b; return hip_fail(e_, #x, __LINE__); } } while (0)
 	b->P = *p; b->R = in->n_regions; b->n_reads = in->n_reads;
 	const int R = b->R; const long long NR = b->n_reads;
@@ -1348,6 +1351,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			b->max_read_len = std::max<int>(b->max_read_len, (int)std::min<int64_t>(ro[i + 1] - ro[i], 1 << 30));
 		}
 	}
+	lap("shape");
 	b->h_region_read_off.assign(rro, rro + R + 1);
 	b->h_ref_origin.assign(in->ref_origin, in->ref_origin + R);
 	b->stream = g_streams.get();
@@ -1403,6 +1407,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	UP(ref_origin, in->ref_origin, sizeof(int64_t) * R);
 	}
 #undef UP
+	lap("copies");
 	// scratch sizing
 	b->stage_cap = (b->max_read_len + 15) / 16 * 16 + 16;
 	b->grid_retry = grid_for(R, 2);
@@ -1433,6 +1438,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		b->grid_asm = grid_for(R, std::max(1, std::min(16, g.max_lds / (b->lds_arena1 + 3840))));
 		if (g_knob.asm_waves) b->grid_asm = grid_for(R, std::max(1, std::min(16, g_knob.asm_waves)));
 	}
+	lap("arena model");
 	b->lds_arena2 = std::max(12288, std::min(2 * b->lds_arena1, g.max_lds - 24576));   // + 7.5 KB (RegionStateT<128>)
 	{
 		long long want = ((long long)b->max_region_bases * 4 / 5 + 4 * ((b->max_read_len + 15) / 16 * 16 + 16) + 1024 + 15) / 16 * 16;
@@ -1469,6 +1475,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		const int cn6[6] = {b->n_cls[0], b->n_cls[1], b->n_cls[2], b->n_cls[3], b->n_small, b->n_rich};
 		memcpy(cn_host, cn6, sizeof(cn6));
 	}
+	lap("classes");
 	b->grid_asm = std::min(b->grid_asm, std::max(1, b->n_cls[0]));
 	b->grid_asm2 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena2 + 8192)));
 	b->grid_asm3 = grid_for(R, std::max(1, g.max_lds / (b->lds_arena3 + 14336)));
@@ -1604,6 +1611,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
 		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(16, g.max_lds / (b->lds_fb + 256))));
 	}
+	lap("sizing");
 	static_assert(sizeof(int) * M_WORDS <= ihp_batch::Z_TIMES, "misc counters overlap the stamps");
 	if ((rc = b->misc.alloc(b->z_bytes())) || (rc = b->summary.alloc(sizeof(ihp_region_summary) * (size_t)R))) { delete b; return rc; }
 	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
@@ -1629,7 +1637,9 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		b->cls_list.view(b->aux.p, 0, sizeof(int) * (size_t)R); b->cls_n.view(b->aux.p, o_cn, sizeof(cn_host));
 		if (!hoff.empty()) b->v2_hoff.view(b->aux.p, o_hoff, sizeof(long long) * hoff.size());
 	}
+	lap("aux");
 	if ((rc = alloc_work(b))) { delete b; return rc; }
+	lap("alloc_work");
 	for (auto &e : b->ev) HIPB(hipEventCreate(&e));
 	HIPB(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
@@ -1639,6 +1649,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	HIPB(hipEventCreateWithFlags(&b->ev_kjoin, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_rfork, hipEventDisableTiming));
 	HIPB(hipEventCreateWithFlags(&b->ev_rjoin, hipEventDisableTiming));
+	lap("events");
 	b->report = g_reports.get();
 	if (!b->report) { delete b; snprintf(g.err, sizeof(g.err), "hipHostMalloc of the report page failed"); return IHP_E_NOMEM; }
 	HIPB(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));      // the only memset of the batch's life (see ihp_batch::misc)
@@ -1663,6 +1674,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	// (ihp_batch_sync, fetch, ...: see ihp_batch_upload_slab in the header), so its copy is left in flight
 	if (!slab) HIPB(hipStreamSynchronize(s));
 #undef HIPB
+	lap("end");
 	*bout = b;
 	return 0;
 }

@@ -181,6 +181,16 @@ type IhpSlabLayout* {.importc: "ihp_slab_layout", header: "indelope_hip.h", byco
 proc ihp_slab_layout_for*(n_regions: int32, n_reads, n_bases, n_ref: int64, outp: ptr IhpSlabLayout): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_upload_slab*(p: ptr IhpParams, n_regions: int32, n_reads: int64, slab: pointer, layout: ptr IhpSlabLayout,
                             flags: int32, b: ptr ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+# round 5: the compact slab (14 bytes per read, windows 2 or 4 bits per base; the arrays of ihp_batch_in are made on the device)
+type IhpSlab2Layout* {.importc: "ihp_slab2_layout", header: "indelope_hip.h", bycopy.} = object
+  region_read_off*, region_base_off*, ref_off*, ref_origin*, start_rel*, len*, span*, trim_lo*, trim_hi*: int64
+  mapq*, rflags*, ref_packed*, bases4*, bytes*: int64
+const IHP_SLAB2_REF_2BIT* = 2'i32
+proc ihp_slab2_layout_for*(n_regions: int32, n_reads, n_bases, n_ref: int64, flags: int32, outp: ptr IhpSlab2Layout): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_batch_upload_slab2*(p: ptr IhpParams, n_regions: int32, n_reads: int64, slab: pointer, layout: ptr IhpSlab2Layout,
+                             flags: int32, b: ptr ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_host_alloc*(bytes: csize_t): pointer {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_set_fetch*(b: ptr IhpBatch, flags: int32): cint {.importc, cdecl, header: "indelope_hip.h".}
 # timing and diagnostics (what bench.py and the tests read; a caller needs none of them)
 proc ihp_batch_set_timing*(b: ptr IhpBatch, on: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
@@ -264,6 +274,57 @@ proc fill*(s: var Stager, b: var IhpBatchIn) =
   b.mapq = addr s.mapq[0]; b.read_skip = addr s.read_skip[0]
   b.ref_off = addr s.ref_off[0]; b.ref_bases = addr s.ref_bases[0]; b.ref_origin = addr s.ref_origin[0]
   if s.trim_lo.len > 0: (b.trim_lo = addr s.trim_lo[0]; b.trim_hi = addr s.trim_hi[0]; b.quals = nil)
+
+proc fill_slab2*(s: var Stager, L: var IhpSlab2Layout, flags: var int32): pointer =
+  ## The staged batch as ONE page-locked compact slab (ihp_slab2_layout): what goes over PCIe in a single copy.  Needs the trim
+  ## bounds (trim_on_host).  nil when a read does not fit the 16 / 32-bit fields (the caller then uses `fill` + the arrays).
+  ## A stager that holds hts Records writes `bases4` with a copy of bam_get_seq() per read instead of re-encoding the ASCII.
+  let nreg = int32(s.ref_origin.len)
+  let nr = int64(s.read_start.len)
+  var two_bit = true
+  for c in s.ref_bases:
+    if c != uint8('A') and c != uint8('C') and c != uint8('G') and c != uint8('T'): two_bit = false
+  flags = if two_bit: IHP_SLAB2_REF_2BIT else: 0'i32
+  if ihp_slab2_layout_for(nreg, nr, int64(s.bases.len), int64(s.ref_bases.len), flags, addr L) != 0: return nil
+  result = ihp_host_alloc(csize_t(L.bytes))
+  if result == nil: return nil
+  let m = cast[ptr UncheckedArray[uint8]](result)
+  template at(T: typedesc, off: int64): untyped = cast[ptr UncheckedArray[T]](addr m[off])
+  for r in 0..nreg:
+    at(int64, L.region_read_off)[r] = s.region_read_off[r]
+    at(int64, L.region_base_off)[r] = s.read_off[int(s.region_read_off[r])]
+    at(int64, L.ref_off)[r] = s.ref_off[r]
+  var r = 0
+  for i in 0..<int(nr):
+    while int64(i) >= s.region_read_off[r + 1]: r += 1
+    let rel = s.read_start[i] - s.ref_origin[r]
+    let ln = s.read_off[i + 1] - s.read_off[i]
+    let sp = s.read_stop[i] - s.read_start[i]
+    if rel < int64(low(int32)) or rel > int64(high(int32)) or ln > 65535 or sp < 0 or sp > 65535: (ihp_host_free(result); return nil)
+    at(int32, L.start_rel)[i] = int32(rel)
+    at(uint16, L.len)[i] = uint16(ln); at(uint16, L.span)[i] = uint16(sp)
+    at(uint16, L.trim_lo)[i] = uint16(s.trim_lo[i]); at(uint16, L.trim_hi)[i] = uint16(s.trim_hi[i])
+    at(uint8, L.mapq)[i] = s.mapq[i]; at(uint8, L.rflags)[i] = s.read_skip[i] and 1
+    # 4-bit bases: read i from byte (read_off[i] >> 1) + i, first base in the high nibble (BAM's own packing)
+    let dst = L.bases4 + (s.read_off[i] shr 1) + int64(i)
+    for j in 0..<int(ln):
+      let code = uint8("=ACMGRSVTWYHKDBN".find(char(s.bases[int(s.read_off[i]) + j])))
+      if (j and 1) == 0: m[dst + int64(j shr 1)] = code shl 4
+      else: m[dst + int64(j shr 1)] = m[dst + int64(j shr 1)] or code
+  for r in 0..<int(nreg):
+    at(int64, L.ref_origin)[r] = s.ref_origin[r]
+    let f0 = s.ref_off[r]
+    for j in 0..<int(s.ref_off[r + 1] - f0):
+      let c = char(s.ref_bases[int(f0) + j])
+      if two_bit:
+        let dst = L.ref_packed + (f0 shr 2) + int64(r) + int64(j shr 2)
+        if (j and 3) == 0: m[dst] = 0
+        m[dst] = m[dst] or (uint8("ACGT".find(c)) shl (2 * (j and 3)))
+      else:
+        let dst = L.ref_packed + (f0 shr 1) + int64(r) + int64(j shr 1)
+        let code = uint8("=ACMGRSVTWYHKDBN".find(c))
+        if (j and 1) == 0: m[dst] = code shl 4
+        else: m[dst] = m[dst] or code
 
 proc run*(s: var Stager, p: var IhpParams, outp: var IhpBatchOut): cint =
   var b: IhpBatchIn
