@@ -46,9 +46,9 @@ KERNELS = ["k_assemble", "k_ksw", "k_tally"]
 ISSUE_PEAK_ARCH = 2.0          # MI355X_MICROARCH.md: a SIMD-32 issues a wave64 VALU instruction over 2 cycles -- reached only by pure streams of
                                # mov / and / xor / add (1.5-1.8 measured); in a mixed stream every VALU instruction costs the half-rate slot
                                # (tools/ubench_ksw.hip: v_sub / v_max alternating 0.93 per cycle and CU)
-PMC_FILE = os.path.join("profiles", "r04_c2_pmc.json")
-MIX_FILE = os.path.join("profiles", "r04_c2_pmc_mix.json")
-STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_prepack_fast", "k_asm_reads", "k_asm_combine3", "k_assemble"),
+PMC_FILE = os.path.join("profiles", "r05_c2_pmc.json")
+MIX_FILE = os.path.join("profiles", "r05_c2_pmc_mix.json")
+STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_prepack_fast", "k_slab_expand", "k_asm_reads", "k_asm_combine3", "k_assemble"),
                  "k_ksw": ("k_ksw", "k_ksw_pair", "k_ksw_plan_count", "k_ksw_plan_place"), "k_tally": ("k_tally",)}
 
 

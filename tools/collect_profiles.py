@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
-pre = sys.argv[1] if len(sys.argv) > 1 else "r04"
+pre = sys.argv[1] if len(sys.argv) > 1 else "r05"
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
@@ -38,7 +38,8 @@ names = {"c2_kernel_stats.csv": "c2_kernel_stats.csv", "c2_pmc.json": "c2_pmc.js
          "ubench_issue.txt": "ubench_issue.txt", "c2_phase_cycles.json": "c2_phase_cycles.json",
          "c5_phase_cycles.json": "c5_phase_cycles.json", "resource_usage.txt": "resource_usage.txt", "ubench_ksw.txt": "ubench_ksw.txt",
          "ksw_pair_pmc.json": "ksw_pair_pmc.json", "ksw_pair_pmc.txt": "ksw_pair_pmc.txt", "dup10_kernel_stats.csv": "dup10_kernel_stats.csv",
-         "dup10_pmc_mix.json": "dup10_pmc_mix.json", "dup10_summary.txt": "dup10_summary.txt", "prepack_compare.txt": "prepack_compare.txt"}
+         "dup10_pmc_mix.json": "dup10_pmc_mix.json", "dup10_summary.txt": "dup10_summary.txt", "prepack_compare.txt": "prepack_compare.txt",
+         "e2e_bench.json": "e2e_bench.json", "e2e_host_time.txt": "e2e_host_time.txt"}
 refused = 0
 for a, b in names.items():
     p = os.path.join(src, a)

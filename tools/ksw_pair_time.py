@@ -12,18 +12,19 @@ def main():
     hip = indelope_amd.api(); hip.init(0)
     rng = np.random.default_rng(1)
     only = sys.argv[3] if len(sys.argv) > 3 else None
+    bw = int(sys.argv[4]) if len(sys.argv) > 4 else 50
     for name, sub in (("identical", 0.0), ("subst1", 0.01), ("unrelated", 1.0)):
         if only and name != only:
             continue
         qs, ts = [], []
         for i in range(n):
-            t = rng.integers(0, 4, ql + 80).astype(np.uint8)
+            t = rng.integers(0, 4, ql + 80 + max(0, bw - 50)).astype(np.uint8)
             q = t[:ql].copy() if sub < 1 else rng.integers(0, 4, ql).astype(np.uint8)
             if 0 < sub < 1:
                 m = rng.random(ql) < sub
                 q[m] = (q[m] + 1) % 4
             qs.append(q); ts.append(t)
-        kw = dict(match=1, mismatch=-2, gap_open=4, gap_ext=1, bw=50, z=400, flag=0, encoded=True)
+        kw = dict(match=1, mismatch=-2, gap_open=4, gap_ext=1, bw=bw, z=400, flag=0, encoded=True)
         for pair in (1, 0):
             hip.debug_set(ksw_pair=pair)
             hip.align_batch(qs[:2000], ts[:2000], **kw)

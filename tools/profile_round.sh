@@ -73,7 +73,7 @@ for f in ("gpurun_out/prof/c2_pmc_mix.json", "gpurun_out/prof/steady100k_pmc_mix
     except Exception as e:
         print("mix", f, e)
 raw = json.load(open("gpurun_out/prof/pmc_raw.json"))
-out = {"workload": "C2 (10000 regions x 64 x 150bp), bench.py --steps 5 --warmup 2 (two sub-batches of 5000 regions per step)",
+out = {"workload": "C2 (two resident batches of 10000 regions x 64 x 150bp taking turns), bench.py --steps 5 --warmup 2: one launch of a kernel = one batch = 10000 regions",
        "unit": "bytes per launch", "src_sha16": sha,
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = counter(KB) * 1024; traffic = "
                "2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read "
@@ -88,6 +88,9 @@ for k, v in raw.items():
                          "launches_averaged": v.get("_launches")}
 json.dump(out, open("gpurun_out/prof/c2_pmc.json", "w"), indent=1)
 PY
+# round 5: the PCIe-inclusive leg on the compact slab (host buffers in -> host buffers out), the host's share of an upload
+python3 bench.py --no-cpu --no-other --no-check > $OUT/e2e_bench.json 2>> $OUT/err
+python3 tools/e2e_host_time.py > $OUT/e2e_host_time.txt 2>&1
 # round 4: the alignment fallback under load (C2 with 10 % duplications), k_prepack vs k_prepack_fast, the pair sweep's instruction mix
 bash tools/r4_fb.sh > $OUT/dup10_summary.txt 2>&1
 cp gpurun_out/fb/kernel_stats.csv $OUT/dup10_kernel_stats.csv; cp gpurun_out/fb/mix.json $OUT/dup10_pmc_mix.json
