@@ -135,3 +135,12 @@ def test_a_compact_slab_that_is_not_the_librarys_is_refused(hip):
             hip.batch_free(hb)
     finally:
         s2.free()
+
+
+@pytest.mark.parametrize("K", [7, 15, 16, 17, 21, 31])
+def test_tally_on_packed_reads_for_every_kmer_width(hip, oracle, K):
+    """k_tally rolls the k-mer code in two 32-bit halves and screens every window on the lower one (round 5): K below, at and above
+    the 16 bases a half holds, reads of unequal lengths, duplications (both k-mers in a read), against the oracle."""
+    b, _ = synth.generate(120, n_reads=(8, 70), err_rate=2e-3, config_id=500 + K, dup_frac=0.3)
+    p = dict(K=K, min_ctg_len=40, min_reads=3)
+    _same(hip.run_regions(b, hip.params(**p)), oracle.run_regions_mt(b, oracle.params(**p), 16))

@@ -1,4 +1,4 @@
-"""Diagnostics: the slab path (ihp_batch_upload_slab / run / fetch) driven by T host threads with D batches in flight each:
+"""Diagnostics: the compact-slab path (ihp_batch_upload_slab2 / run / fetch) driven by T host threads with D batches in flight each:
 a thread enqueues upload + run of batch k+D-1 (both return at once) before it waits for and fetches batch k."""
 import ctypes as C
 import sys
@@ -20,10 +20,10 @@ N = 12
 MODE = sys.argv[2] if len(sys.argv) > 2 else "fetch"
 EAGER = MODE != "lazy"
 for nth, depth in combos:
-    slabs = [[api.make_slab(b) for _ in range(depth)] for _ in range(nth)]
+    slabs = [[api.make_slab2(b) for _ in range(depth)] for _ in range(nth)]
 
     def start(sl):
-        h = api.batch_upload_slab(sl, p)
+        h = api.batch_upload_slab2(sl, p)
         api.batch_set_fetch(h, no_bases=True, eager=EAGER)
         api.batch_run(h)
         return h
