@@ -205,11 +205,28 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
         return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
 
     slabs = [[api.make_slab2(batch) for _ in range(max(depth, 2))] for _ in range(threads)]
+    # one batch at a time, handed over as two halves: the second half's copy runs beside the first half's kernels, and two launch
+    # chains fill each other's tails (the batch is still alone on the device from its first byte to its last result)
+    half = batch.n_regions // 2
+    halves = [api.make_slab2(batch.slice(0, half)), api.make_slab2(batch.slice(half, batch.n_regions))] if half > 0 else None
+
+    def one_split(no_bases):
+        t0 = time.perf_counter()
+        hs_ = []
+        for sl in halves:
+            h = api.batch_upload_slab2(sl, params)
+            api.batch_set_fetch(h, no_bases=no_bases, eager=True)
+            api.batch_run(h)
+            hs_.append(h)
+        for h in hs_:
+            finish(h, no_bases)
+        return time.perf_counter() - t0
     try:
         res = {}
         for name, nb in (("events_only", True), ("full", False)):
             t = np.array([one(slabs[0][0], nb) for _ in range(reps + 1)][1:]) * 1e3
             med = np.median(t, axis=0)
+            split_ms = float(np.median([one_split(nb) for _ in range(reps + 1)][1:])) * 1e3 if halves else None
             n_each = max(16, reps * 6)
 
             gate = threading.Barrier(threads + 1)
@@ -255,6 +272,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
             dt1 = time.perf_counter() - t0
             res[name] = {"one_batch_ms": {k: round(float(v), 3) for k, v in zip(("upload", "run", "fetch", "total"), med)},
                          "one_batch_regions_per_s": round(batch.n_regions / (med[3] * 1e-3), 1),
+                         "one_batch_as_two_halves": ({"ms": round(split_ms, 3), "regions_per_s": round(batch.n_regions / (split_ms * 1e-3), 1)} if split_ms else None),
                          "sustained": {"threads": threads, "in_flight_per_thread": depth, "batches": n_each * threads,
                                        "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
                                        "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1)},
@@ -266,6 +284,8 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
         for row in slabs:
             for sl in row:
                 sl.free()
+        for sl in halves or []:
+            sl.free()
     # round 2's leg for comparison: separate pageable arrays, ASCII bases, full results
     n_each = max(3, reps)
 
@@ -294,7 +314,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
     dt = time.perf_counter() - t0
     ev = res["events_only"]
     return {"one_batch_ms": ev["one_batch_ms"], "one_batch_regions_per_s": ev["one_batch_regions_per_s"], "sustained": ev["sustained"],
-            "sustained_one_thread": ev["sustained_one_thread"],
+            "sustained_one_thread": ev["sustained_one_thread"], "one_batch_as_two_halves": ev["one_batch_as_two_halves"],
             "slab_MB": round(slab_bytes / 1e6, 2),
             "inputs": "one page-locked COMPACT slab per batch (ihp_slab2_layout, %d bytes: 4-bit read bases, 14 bytes per read, 2-bit windows), "
                       "a single upload copy, the arrays made on the device; results without contig bases/supports (IHP_FETCH_NO_BASES)" % slab_bytes,
@@ -575,7 +595,7 @@ def digest(out):
         d["mixed"] = [m(ms["plans_per_shape"]["regions_per_s"]), ms["plans_per_shape"]["n_reruns"], ms["mixed_over_predicted"]]
     e = out.get("e2e")
     if e:
-        d["e2e"] = {"one_M": m(e["one_batch_regions_per_s"]), "sus_M": m(e["sustained"]["regions_per_s"]), "sus1t_M": m(e["sustained_one_thread"]["regions_per_s"]),
+        d["e2e"] = {"one_M": m(e["one_batch_regions_per_s"]), "one2h_M": m((e.get("one_batch_as_two_halves") or {}).get("regions_per_s")), "sus_M": m(e["sustained"]["regions_per_s"]), "sus1t_M": m(e["sustained_one_thread"]["regions_per_s"]),
                     "full_one_M": m(e["full_results"]["one_batch_regions_per_s"]), "full_sus_M": m(e["full_results"]["sustained"]["regions_per_s"]),
                     "full_sus1t_M": m(e["full_results"]["sustained_one_thread"]["regions_per_s"]), "slab_MB": e.get("slab_MB")}
     c = out.get("c1")
