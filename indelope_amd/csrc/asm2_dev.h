@@ -48,6 +48,24 @@ struct PrepackArgs {
 	unsigned long long *t_start;              // optional: device wall clock when the launch starts to execute (see mark_start())
 };
 
+// Sixteen bases, 4 bits each as BAM stores them (n0 = the first eight, first base in the high nibble of the first byte), as ASCII
+// ("=ACMGRSVTWYHKDBN") into w and -- the `rem` of them that belong to the read -- to o.
+__device__ __forceinline__ void b4_to_ascii(unsigned n0, unsigned n1, int rem, uint8_t *o, unsigned (&w)[4])
+{
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const unsigned x = ((k < 2 ? n0 : n1) >> (16 * (k & 1))) & 0xffffu;          // two bytes = four bases
+		const unsigned sel = ((x >> 4) & 0xfu) | ((x & 0xfu) << 8) | (((x >> 12) & 0xfu) << 16) | (((x >> 8) & 0xfu) << 24);
+		const unsigned lo8 = __builtin_amdgcn_perm(0x56535247u, 0x4d43413du, sel & 0x07070707u);   // "=ACM" "GRSV"
+		const unsigned hi8 = __builtin_amdgcn_perm(0x4e42444bu, 0x48595754u, sel & 0x07070707u);   // "TWYH" "KDBN"
+		const unsigned m = ((sel >> 3) & 0x01010101u) * 0xffu;
+		w[k] = (lo8 & ~m) | (hi8 & m);
+		const int v = rem - 4 * k;
+		if (v >= 4) *(u32_unaligned_t *)(o + 4 * k) = w[k];
+		else for (int j = 0; j < v; ++j) o[4 * k + j] = (uint8_t)(w[k] >> (8 * j));
+	}
+}
+
 // One 16-lane group per read (four reads per wave at a time), grid-stride over all reads of the batch.
 __global__ __launch_bounds__(64) void k_prepack(const PrepackArgs a)
 {
@@ -110,19 +128,7 @@ __global__ __launch_bounds__(64) void k_prepack(const PrepackArgs a)
 			if (a.bases4) {
 				const uint8_t *q = a.bases4 + (off >> 1) + ri + 8 * d;
 				const unsigned n0 = *(const u32_unaligned_t *)q, n1 = *(const u32_unaligned_t *)(q + 4);
-				uint8_t *o = a.bases_w + off + 16 * d;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const unsigned x = ((k < 2 ? n0 : n1) >> (16 * (k & 1))) & 0xffffu;          // two bytes = four bases
-					const unsigned sel = ((x >> 4) & 0xfu) | ((x & 0xfu) << 8) | (((x >> 12) & 0xfu) << 16) | (((x >> 8) & 0xfu) << 24);
-					const unsigned lo8 = __builtin_amdgcn_perm(0x56535247u, 0x4d43413du, sel & 0x07070707u);   // "=ACM" "GRSV"
-					const unsigned hi8 = __builtin_amdgcn_perm(0x4e42444bu, 0x48595754u, sel & 0x07070707u);   // "TWYH" "KDBN"
-					const unsigned m = ((sel >> 3) & 0x01010101u) * 0xffu;
-					w[k] = (lo8 & ~m) | (hi8 & m);
-					const int v = rem - 4 * k;
-					if (v >= 4) *(u32_unaligned_t *)(o + 4 * k) = w[k];
-					else for (int j = 0; j < v; ++j) o[4 * k + j] = (uint8_t)(w[k] >> (8 * j));
-				}
+				b4_to_ascii(n0, n1, rem, a.bases_w + off + 16 * d, w);
 			} else {
 				const uint8_t *p = a.bases + off + 16 * d;
 #pragma unroll
@@ -164,11 +170,18 @@ __device__ __forceinline__ PrepackRaw prepack_raw(const PrepackArgs &a, long lon
 struct PrepackRead { long long off; int len; };
 __device__ __forceinline__ PrepackRead prepack_read(const PrepackRaw &m) { PrepackRead r; r.off = m.off0; r.len = (int)(m.off1 - m.off0); return r; }
 struct PrepackData { unsigned w[4]; };
-__device__ __forceinline__ PrepackData prepack_data(const PrepackArgs &a, const PrepackRead &m, int sub)
+template <bool B4>
+__device__ __forceinline__ PrepackData prepack_data(const PrepackArgs &a, const PrepackRead &m, long long ri, int sub)
 {   // dwords [4 sub, 4 sub + 4) of the read's bytes (lanes past the read load its first ones; like k_prepack, the last group may
-	// reach up to 15 bytes past the read: masked when it is packed)
-	const uint8_t *p = a.bases + m.off + (16 * sub < m.len ? 16 * sub : 0);
+	// reach up to 15 bytes past the read: masked when it is packed); B4: the eight bytes that hold those sixteen bases in w[0..1]
 	PrepackData d;
+	if (B4) {
+		const long long rc = ri < a.n_reads ? ri : a.n_reads - 1;
+		const uint8_t *q = a.bases4 + (m.off >> 1) + rc + (16 * sub < m.len ? 8 * sub : 0);
+		d.w[0] = *(const u32_unaligned_t *)q; d.w[1] = *(const u32_unaligned_t *)(q + 4); d.w[2] = d.w[3] = 0;
+		return d;
+	}
+	const uint8_t *p = a.bases + m.off + (16 * sub < m.len ? 16 * sub : 0);
 #pragma unroll
 	for (int k = 0; k < 4; ++k) d.w[k] = *(const u32_unaligned_t *)(p + 4 * k);
 	return d;
@@ -192,7 +205,8 @@ __device__ __forceinline__ unsigned prepack_words(const unsigned (&w)[4], int re
 
 // U reads per 16-lane group and iteration (4 U per wave).  The kept ranges are a map over the reads of their own (lane <-> read,
 // coalesced) in front of the pipeline, which then carries a read's offset and length and nothing else.
-template <int U>
+// B4: the bases come 4 bits each (a batch uploaded as a slab) and their ASCII form is written on the way, as k_prepack does.
+template <int U, bool B4 = false>
 __global__ __launch_bounds__(64) void k_prepack_fast(const PrepackArgs a)
 {
 	const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
@@ -213,11 +227,11 @@ __global__ __launch_bounds__(64) void k_prepack_fast(const PrepackArgs a)
 #pragma unroll
 	for (int u = 0; u < U; ++u) cur[u] = prepack_read(prepack_raw(a, i0 + 4 * u + grp));
 #pragma unroll
-	for (int u = 0; u < U; ++u) { nn[u] = prepack_raw(a, i0 + stride + 4 * u + grp); dcur[u] = prepack_data(a, cur[u], sub); }
+	for (int u = 0; u < U; ++u) { nn[u] = prepack_raw(a, i0 + stride + 4 * u + grp); dcur[u] = prepack_data<B4>(a, cur[u], i0 + 4 * u + grp, sub); }
 	for (; i0 < a.n_reads; i0 += stride) {
 		PrepackData dnxt[U];
 #pragma unroll
-		for (int u = 0; u < U; ++u) { nxt[u] = prepack_read(nn[u]); dnxt[u] = prepack_data(a, nxt[u], sub); }
+		for (int u = 0; u < U; ++u) { nxt[u] = prepack_read(nn[u]); dnxt[u] = prepack_data<B4>(a, nxt[u], i0 + stride + 4 * u + grp, sub); }
 #pragma unroll
 		for (int u = 0; u < U; ++u) nn[u] = prepack_raw(a, i0 + 2 * stride + 4 * u + grp);
 #pragma unroll
@@ -228,13 +242,24 @@ __global__ __launch_bounds__(64) void k_prepack_fast(const PrepackArgs a)
 			unsigned diff = 0;
 			const long long pkb = (cur[u].off >> 4) + ri;
 			const int nd = (len + 15) >> 4;
-			if (sub < nd) a.pk[pkb + sub] = prepack_words(dcur[u].w, len - 16 * sub, diff);
+			if (sub < nd) {
+				if (B4) {
+					unsigned w[4];
+					b4_to_ascii(dcur[u].w[0], dcur[u].w[1], len - 16 * sub, a.bases_w + cur[u].off + 16 * sub, w);
+					a.pk[pkb + sub] = prepack_words(w, len - 16 * sub, diff);
+				} else a.pk[pkb + sub] = prepack_words(dcur[u].w, len - 16 * sub, diff);
+			}
 			if (nd > 16) {                                       // reads longer than 256 bases: the rest as it comes
 				for (int d = sub + 16; d < nd; d += 16) {
 					unsigned w[4];
-					const uint8_t *p = a.bases + cur[u].off + 16 * d;
+					if (B4) {
+						const uint8_t *q = a.bases4 + (cur[u].off >> 1) + ri + 8 * d;
+						b4_to_ascii(*(const u32_unaligned_t *)q, *(const u32_unaligned_t *)(q + 4), len - 16 * d, a.bases_w + cur[u].off + 16 * d, w);
+					} else {
+						const uint8_t *p = a.bases + cur[u].off + 16 * d;
 #pragma unroll
-					for (int k = 0; k < 4; ++k) w[k] = *(const u32_unaligned_t *)(p + 4 * k);
+						for (int k = 0; k < 4; ++k) w[k] = *(const u32_unaligned_t *)(p + 4 * k);
+					}
 					a.pk[pkb + d] = prepack_words(w, len - 16 * d, diff);
 				}
 			}

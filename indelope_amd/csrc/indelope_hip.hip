@@ -1806,8 +1806,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			pa.trim_hi = b->v2_trim_hi.as<int>(); pa.read_bad = b->v2_read_bad.as<uint8_t>();
 			pa.t_start = tm;                                       // the first launch of the stage
 			// (the pipelined kernel loads without asking whether a read has bases: not for a batch without any)
-			const int pf = (!pa.bases4 && pa.trim_lo_in && pa.n_reads > 0 && b->n_bases >= 16) ? g_knob.prepack_fast : 0;
-			if (pf == 1) hipLaunchKernelGGL(k_prepack_fast<1>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			const int pf = (pa.trim_lo_in && pa.n_reads > 0 && b->n_bases >= 16) ? g_knob.prepack_fast : 0;
+			if (pf > 0 && pa.bases4) {                             // (a slab: 4-bit bases in, their ASCII form written on the way)
+				if (pf == 1) hipLaunchKernelGGL((k_prepack_fast<1, true>), dim3(b->grid_pack), dim3(64), 0, s, pa);
+				else hipLaunchKernelGGL((k_prepack_fast<2, true>), dim3(b->grid_pack), dim3(64), 0, s, pa);
+			}
+			else if (pf == 1) hipLaunchKernelGGL(k_prepack_fast<1>, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			else if (pf == 2) hipLaunchKernelGGL(k_prepack_fast<2>, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			else if (pf == 3) hipLaunchKernelGGL(k_prepack_fast<3>, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			else if (pf == 4) hipLaunchKernelGGL(k_prepack_fast<4>, dim3(b->grid_pack), dim3(64), 0, s, pa);

@@ -144,3 +144,41 @@ def test_tally_on_packed_reads_for_every_kmer_width(hip, oracle, K):
     b, _ = synth.generate(120, n_reads=(8, 70), err_rate=2e-3, config_id=500 + K, dup_frac=0.3)
     p = dict(K=K, min_ctg_len=40, min_reads=3)
     _same(hip.run_regions(b, hip.params(**p)), oracle.run_regions_mt(b, oracle.params(**p), 16))
+
+
+@pytest.mark.parametrize("pf", [0, 1, 2])
+def test_a_slab_through_either_packing_kernel(hip, oracle, pf):
+    """A batch that came as a slab has its bases 4 bits each; k_prepack_fast<U, true> (the software pipeline of round 4, now also
+    for that input: the ASCII bases the byte-based kernels read are written on the way) and the plain k_prepack give the oracle's
+    results -- reads with N / IUPAC codes, trimmed ends, 300-base reads (more than one dword round per 16-lane group), and a
+    batch whose reads hold three bases or none (the pipeline loads without asking)."""
+    import copy
+    hip.debug_set(prepack_fast=pf)
+    try:
+        long_reads, _ = synth.config("C5", n_regions=40)
+        tiny, _ = synth.generate(6, n_reads=(3, 5), err_rate=0.0, config_id=161)
+        tiny = tiny.with_trim_bounds()
+        batches = [(_mixed_batch().with_trim_bounds(), 27), (long_reads.with_trim_bounds(), 31)]
+        for keep in (0, 3):
+            c = copy.copy(tiny)
+            nr = c.n_reads
+            c.read_off = (np.arange(nr + 1) * keep).astype(np.int64)
+            c.bases = np.frombuffer(b"ACG" * nr, np.uint8).copy()[:keep * nr] if keep else np.zeros(0, np.uint8)
+            c.quals = np.full(len(c.bases), 40, np.uint8)
+            c.read_stop = c.read_start + keep
+            c.trim_lo = np.zeros(nr, np.int32); c.trim_hi = np.full(nr, keep, np.int32)
+            batches.append((c, 27))
+        for b, K in batches:
+            exp = oracle.run_regions_mt(b, oracle.params(K=K), 16)
+            s2 = hip.make_slab2(b)
+            try:
+                h = hip.batch_upload_slab2(s2, hip.params(K=K))
+                try:
+                    hip.batch_run(h); hip.batch_sync(h)
+                    _same(hip.batch_fetch(h), exp)
+                finally:
+                    hip.batch_free(h)
+            finally:
+                s2.free()
+    finally:
+        hip.debug_set()

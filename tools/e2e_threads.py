@@ -16,9 +16,12 @@ b, _ = synth.config("C2")
 b = b.with_trim_bounds()
 p = api.params(K=27)
 combos = [tuple(int(x) for x in c.split("x")) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1x1", "3x1", "2x2", "3x2", "4x2"])]
-N = 12
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 MODE = sys.argv[2] if len(sys.argv) > 2 else "fetch"
 EAGER = MODE != "lazy"
+for kv in sys.argv[4:]:                                  # library switches, e.g. chains=0
+    k, v = kv.split("=")
+    api.debug_set(**{k: int(v)})
 for nth, depth in combos:
     slabs = [[api.make_slab2(b) for _ in range(depth)] for _ in range(nth)]
 
@@ -41,7 +44,8 @@ for nth, depth in combos:
     gate = threading.Barrier(nth + 1)
 
     def worker(k):
-        finish(start(slabs[k][0]))                       # warm: pools filled
+        for h in [start(slabs[k][j]) for j in range(depth)]:   # warm: pools filled with as many batches in flight as the timed loop keeps
+            finish(h)
         gate.wait()
         q = []
         for i in range(N):
