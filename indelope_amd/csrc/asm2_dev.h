@@ -391,7 +391,9 @@ struct ReadArgs {
 	int *lpt_cnt, *lpt_seg; int lpt_stride;                   // regions for k_asm_combine3 by arena tier and cost class, longest first (see lpt_class)
 	int *n_tier_b;                                            // counts the regions filed under the second and third tier (diagnostics)
 	int tier_a_cap, tier_b_cap;                               // arena capacities of the first two combine launches: a region is filed under the first that holds it
-	int hist_cap[7]; int *hist;                               // hist[k] counts the regions whose need fits hist_cap[k] (ascending) and no smaller one: what the
+	int tier_a_maxc;                                          // ... and has no more contigs than the first launch keeps a table for
+	int manyc_thr; int *n_manyc;                              // counts the regions with more than manyc_thr contigs (the short table's size): what decides the first tier's build
+	int hist_cap[11]; int *hist;                               // hist[k] counts the regions whose need fits hist_cap[k] (ascending) and no smaller one: what the
 	                                                          // next batch of this shape sizes its first tier from (TierHint, indelope_hip.hip)
 	double min_overlap_pct;
 	int min_mapq_assemble, v2_pdw, n_regions;

@@ -24,18 +24,23 @@ constexpr int V3_MAXLEN = 2047;           // longest contig: 11 bits in the rank
 constexpr int V3_CORR = 1024;             // most corrections one merge may have (they sit at the top of the packed area, counting down)
 constexpr int V3_NOZONE = 0x3fff;
 
-struct V3State {                          // static LDS, one per wave
-	int dw[V3_MAXC];                      // packed slot: first dword in PM
-	int so[V3_MAXC];                      // support slot: first byte in SUP; -1: a contig of one read, support 1 on every base, no bytes kept
-	int len[V3_MAXC], cap[V3_MAXC];       // bases; cap = bases both slots have room for from the current start
-	int nreads[V3_MAXC];
-	long long start[V3_MAXC];
-	short lo3[V3_MAXC], hi3[V3_MAXC];     // every base in [lo3, hi3) has support >= 3 and no other has (V3_NOZONE / 0: not one run)
-	short loT[V3_MAXC], hiT[V3_MAXC];     // the longest run of bases with support >= v3_thr(nreads): bases no vote can overrule (see v3_slide_votes)
-	unsigned char sh[V3_MAXC];            // bases into dword dw where the contig starts (trim moves it)
-	unsigned char smin[V3_MAXC], smax[V3_MAXC];
-	short listA[V3_MAXC], listB[V3_MAXC];
-	short qt[V3_MAXC], mt[V3_MAXC];       // step at which the contig was the query of pass 1 (0: never), step of its last change (0: none)
+// (MAXC: the first tier's launch keeps room for 32 contigs -- what nearly every region has when the read phase is done --,
+// 1.7 KB instead of 3.2: LDS is what decides how many regions a CU holds, and a region's chain is latency bound, so the launch
+// runs as fast as it has regions resident: 16 per CU 2.83 ms per 100 000 C2 regions, 14: 3.14, 12: 3.95, 10: 4.74.)
+template <int MAXC_>
+struct V3StateT {                         // static LDS, one per wave
+	static constexpr int MAXC = MAXC_;
+	int dw[MAXC_];                      // packed slot: first dword in PM
+	int so[MAXC_];                      // support slot: first byte in SUP; -1: a contig of one read, support 1 on every base, no bytes kept
+	int len[MAXC_], cap[MAXC_];       // bases; cap = bases both slots have room for from the current start
+	int nreads[MAXC_];
+	long long start[MAXC_];
+	short lo3[MAXC_], hi3[MAXC_];     // every base in [lo3, hi3) has support >= 3 and no other has (V3_NOZONE / 0: not one run)
+	short loT[MAXC_], hiT[MAXC_];     // the longest run of bases with support >= v3_thr(nreads): bases no vote can overrule (see v3_slide_votes)
+	unsigned char sh[MAXC_];            // bases into dword dw where the contig starts (trim moves it)
+	unsigned char smin[MAXC_], smax[MAXC_];
+	short listA[MAXC_], listB[MAXC_];
+	short qt[MAXC_], mt[MAXC_];       // step at which the contig was the query of pass 1 (0: never), step of its last change (0: none)
 	long long prof[16];
 	int cnt[16];                          // diagnostics (profile): see ihp_batch_profile [32..47]
 };
@@ -87,7 +92,7 @@ struct SupStats {
 		if (run > blen) { blen = run; bend = i; }
 		carry = (unsigned)__builtin_amdgcn_readlane((int)pb, 63);
 	}
-	__device__ __forceinline__ void store(V3State &S, int c)
+	template <class ST> __device__ __forceinline__ void store(ST &S, int c)
 	{   // wave-uniform control flow; lane 0 writes
 		mn = wave_min_u32(mn); mx = wave_max_u32(mx);
 		f3 = wave_min_i32(f3); l3 = wave_max_i32s(l3); c3 = wave_sum_i(c3);
@@ -110,7 +115,8 @@ __device__ __forceinline__ bool allowed3(unsigned qs, unsigned ts, int qreads, i
 
 // ------------------------------------------------------------------------------------------------ take-over
 // Support extrema and zones of SUP[so .. so + len), one base per lane.
-__device__ inline void v3_stats(V3State &S, const V3Ctx &C, int c)
+template <class ST>
+__device__ inline void v3_stats(ST &S, const V3Ctx &C, int c)
 {
 	const int lane = lane_id();
 	const int so = uni(S.so[c]), n = uni(S.len[c]);
@@ -126,7 +132,8 @@ __device__ inline void v3_stats(V3State &S, const V3Ctx &C, int c)
 
 // Hand-over record of k_asm_reads -> directory in S, packed bases in PM, supports counted from the read records in SUP.
 // Returns 1 if the read phase did not take the region, 0 when ready, IHP_E_CAPACITY when it does not fit / is not for this path.
-__device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r, int &n_pre)
+template <class ST>
+__device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int &n_pre)
 {
 	const int lane = lane_id();
 	const uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
@@ -134,7 +141,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 	n_pre = 0;
 	if (n < 0) return 1;
 	n_pre = n;
-	if (nrr > 256 || n > V3_MAXC) return IHP_E_CAPACITY;           // (the records of a region are kept in four registers)
+	if (nrr > 256 || n > ST::MAXC) return IHP_E_CAPACITY;           // (the records of a region are kept in four registers)
 	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
 	if (lane < n) {
 		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
@@ -207,7 +214,8 @@ __device__ inline int v3_take_over(const AsmArgs &a, V3State &S, V3Ctx &C, int r
 
 // ------------------------------------------------------------------------------------------------ trim
 // trim(c, min_support) of contig.nim:49-68 on the u8 supports; only the slot's start / length move.
-__device__ inline void v3_trim(V3State &S, const V3Ctx &C, int c, int ms)
+template <class ST>
+__device__ inline void v3_trim(ST &S, const V3Ctx &C, int c, int ms)
 {
 	const int lane = lane_id();
 	const int so = uni(S.so[c]), len = uni(S.len[c]);
@@ -248,7 +256,8 @@ struct Dir3 {
 	bool valid;
 };
 
-__device__ inline void dir3_build(const V3State &S, const V3Ctx &C, const short *in, int n, int min_overlap, Dir3 &D)
+template <class ST>
+__device__ inline void dir3_build(const ST &S, const V3Ctx &C, const short *in, int n, int min_overlap, Dir3 &D)
 {
 	const int lane = lane_id();
 	n = uni(n);
@@ -340,7 +349,8 @@ struct Best3 { int found, ma, pos, slot, off, ord; };   // ord: place of the off
 // `best` is shared by the targets of one best_match call in list order: strictly more matches win (contig.nim:107, :239).
 // (part, nparts, ctr): the 64-offset chunks of all vote pairs of a best_match call are dealt round robin to the waves that
 // share the call (v3_best_match); ctr counts them.
-__device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, int ts, int pos, int min_overlap, Best3 &best,
+template <class ST>
+__device__ inline void v3_slide_votes(const ST &S, const V3Ctx &C, int qs, int ts, int pos, int min_overlap, Best3 &best,
                                       int part, int nparts, int &ctr)
 {
 	const int lane = lane_id();
@@ -438,7 +448,8 @@ __device__ inline void v3_slide_votes(const V3State &S, const V3Ctx &C, int qs, 
 // One wave's share (part of nparts) of a best_match call: the vote pairs' chunks, the target-offset turns and the query-offset
 // chunks are dealt round robin; `bestkey` = its best exact candidate (0xffffffff: none), G = its best vote-pair offset.
 // Reads LDS only.
-__device__ inline void v3_bm_part(const V3State &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since,
+template <class ST>
+__device__ inline void v3_bm_part(const ST &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since,
                                   int part, int nparts, unsigned &bestkey_out, Best3 &G)
 {
 	const int lane = lane_id();
@@ -607,8 +618,8 @@ struct V3Par {
 };
 struct V3Team { V3Par *par; int nparts; int list_b, n; int dver; };   // wave 0's side: dver counts the dir3_build calls
 
-template <bool TEAM>
-__device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since, const V3Team &T)
+template <bool TEAM, class ST>
+__device__ inline Best3 v3_best_match(const ST &S, const V3Ctx &C, const Dir3 &D, int qi, int min_overlap, int since, const V3Team &T)
 {
 	const int lane = lane_id();
 	unsigned key; Best3 G;
@@ -644,7 +655,8 @@ __device__ inline Best3 v3_best_match(const V3State &S, const V3Ctx &C, const Di
 }
 
 // waves 1 .. of the workgroup: see V3Par
-__device__ inline void v3_helper_loop(const V3State &S, const V3Ctx &C, V3Par *P, int part, int nparts)
+template <class ST>
+__device__ inline void v3_helper_loop(const ST &S, const V3Ctx &C, V3Par *P, int part, int nparts)
 {
 	const int lane = lane_id();
 	Dir3 D;
@@ -667,10 +679,12 @@ __device__ inline void v3_helper_loop(const V3State &S, const V3Ctx &C, V3Par *P
 }
 
 // ------------------------------------------------------------------------------------------------ corrections + insert
-__device__ inline void v3_compact(V3State &S, V3Ctx &C);
+template <class ST>
+__device__ inline void v3_compact(ST &S, V3Ctx &C);
 
 // The allowed mismatches of (q, t, offset) in scan order to the top of the packed area, counting down (contig.nim:99, :128).  Returns the count or -1.
-__device__ inline int v3_corrections(V3State &S, V3Ctx &C, int qs, int ts, int off)
+template <class ST>
+__device__ inline int v3_corrections(ST &S, V3Ctx &C, int qs, int ts, int off)
 {
 	const int lane = lane_id();
 	if (C.pm_cap - C.bump_pm < 160) v3_compact(S, C);                // the corrections go to the top of the packed area: make room there first
@@ -711,7 +725,8 @@ __device__ inline int v3_corrections(V3State &S, V3Ctx &C, int qs, int ts, int o
 
 // Close the holes of both areas: the live contigs, in slot order, move down to the start (ascending copies, 64 elements
 // at a time through registers, so a slot may overlap its own old place).
-__device__ inline void v3_compact(V3State &S, V3Ctx &C)
+template <class ST>
+__device__ inline void v3_compact(ST &S, V3Ctx &C)
 {
 	const int lane = lane_id();
 	V3_CNT(C, 13, 1);
@@ -767,7 +782,8 @@ __device__ __forceinline__ unsigned pk_base(const uint32_t *PM, int b) { return 
 
 // insert(t, q, m) of contig.nim:156-222 with the ncorr corrections v3_corrections left at the top of the packed area.  q is not kept up to date (combine
 // drops it right after: its corrected bases and supports are never looked at again).  Leaves t's support extrema / zone.
-__device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, int ncorr)
+template <class ST>
+__device__ inline int v3_insert(ST &S, V3Ctx &C, int ts, int qs, int off, int ncorr)
 {
 	const int lane = lane_id();
 	const int qlen = uni(S.len[qs]), tlen = uni(S.len[ts]);
@@ -873,8 +889,8 @@ __device__ inline int v3_insert(V3State &S, V3Ctx &C, int ts, int qs, int off, i
 
 // ------------------------------------------------------------------------------------------------ one pass of combine
 // contig.nim:263-281: `in` -> `out`, returns the new count or < 0.
-template <bool TEAM>
-__device__ inline int v3_combine_pass(V3State &S, V3Ctx &C, short *in, int n, short *out, int min_support, int min_overlap, V3Team &T)
+template <bool TEAM, class ST>
+__device__ inline int v3_combine_pass(ST &S, V3Ctx &C, short *in, int n, short *out, int min_support, int min_overlap, V3Team &T)
 {
 	const int lane = lane_id();
 	int nout = 0, usedi = 0;

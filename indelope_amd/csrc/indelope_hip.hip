@@ -32,6 +32,7 @@ struct Ctx {
 	int64_t hbm = 0;
 	int max_lds = 65536;
 	int comb_static = 4608;                                // static LDS of k_asm_combine3 (hipFuncGetAttributes)
+	int comb_static_a = 1536;                              // ... of the first tier's build (room for COMB_MAXC_A contigs)
 	hipStream_t stream = nullptr;
 	char err[512] = "";
 };
@@ -72,6 +73,7 @@ struct Knobs {
 	int ksw_p_cap = 0;     // bytes: caps the traceback scratch per wave of the MAIN ksw2 launch (its jobs that need more go to the roomy launch)
 	int comb_waves = 0;    // waves per workgroup of k_asm_combine3 (1, 2, 4; 0 = by the tier's occupancy): wave 0 runs the region, the others share its best_match calls
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
+	int comb_minw = 6;     // waves per SIMD the first combine tier's build is compiled for (5: 95 VGPRs; 6: 80; 7: 72 -- with spills)
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
@@ -92,9 +94,10 @@ Knobs g_knob;
 // hist[k]: regions of the last batch whose contigs fit the first-tier arena of HIST_OCC[k] waves per CU and no smaller one
 // (the read kernel files them); sig: the shape of that batch (read length, read bases per region): a batch of another
 // shape does not use the histogram.
-constexpr int HIST_N = 7;
-constexpr int HIST_OCC[HIST_N] = {16, 14, 12, 10, 9, 8, 6};
-struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0}; };
+constexpr int HIST_N = 11;
+constexpr int HIST_OCC[HIST_N] = {24, 22, 20, 18, 16, 14, 12, 10, 9, 8, 6};
+constexpr int COMB_MAXC_A = 32;                              // contigs the first combine tier's build keeps a table for (V3StateT, asm3_dev.h)
+struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
 // One hint per batch SHAPE (hint_key: read length, read bases per region, the packed / byte-based path, the parameters that
 // decide which launches a run needs), sixteen shapes remembered: a sweep that interleaves batches of different shapes, or
 // several host threads with different workloads, keep their plans apart (round 3 had one process-wide hint; only the tier
@@ -479,9 +482,14 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5, false, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<6, false, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<7, false, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<4, true, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		{
 			hipFuncAttributes fa;
 			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5, false>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static = (int)fa.sharedSizeBytes;
+			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5, false, COMB_MAXC_A>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static_a = (int)fa.sharedSizeBytes;
 		}
 		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -526,7 +534,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -979,8 +987,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 
 // ------------------------------------------------------- the batched region path
 enum { WQ_SETS = 24 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles)
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_HIST = 25, M_WORDS = 32,
-       M_SLAB_BAD = 48 };   // (behind the stamps, inside the report block: raised by k_slab_expand when a compact slab's lengths do not add up)
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_WORDS = 32,
+       M_SLAB_BAD = 48, M_HIST = 49, M_MANYC = 60 };   // M_MANYC: regions with more contigs than the first tier's short table holds   // (behind the stamps, inside the report block: raised by k_slab_expand when a compact slab's lengths do not add up)
 struct ihp_batch {
 	ihp_params P;
 	int R = 0; long long n_reads = 0, n_bases = 0, n_ref = 0;
@@ -1045,6 +1053,7 @@ struct ihp_batch {
 	bool ksw_skipped = false;                              // the run left out the roomy ksw2 launch (no job needed it in the last batch): checked at the wait
 	DBuf ksw_ovf, p_scratch_big, cig_tmp_big;              // jobs the main ksw2 launch could not hold, and the roomy launch's scratch
 	size_t p_cap_big = 0; int cig_cap_big = 0, grid_kovf = 0;
+	bool tier_wide = false;                                // the first combine tier runs the build with the full contig table (many regions with more than COMB_MAXC_A contigs)
 	long long v2_nb1 = 0; int tier_occ = 0, tier_occ_default = 0, tier_sig = 0;   // first-tier sizing of the combine launches (size_combine_tiers)
 	bool counted = false;                                  // k_pack_count / k_pack_scan of the last run are enqueued (or done)
 	long long n_reruns = 0;
@@ -1152,8 +1161,10 @@ static void release_work(ihp_batch *b)
 // contigs only) + C / 8 + 128 dwords of packed bases (every contig) beside the kernel's static LDS (asked of the runtime: a
 // stale constant here once cost every tier a wave per CU).
 static long long comb_stat() { return (g.comb_static + 255) / 256 * 256 + 256; }          // + allocation granularity
+static long long comb_stat_a() { return (std::max(g.comb_static_a, 512) + 255) / 256 * 256 + 256; }   // the first tier's build (COMB_MAXC_A contigs)
 static long long comb_pm_of(long long C) { return C / 8 + 128; }
-static long long comb_cap_for(int occ) { return (long long)(((long long)g.max_lds / occ - comb_stat() - 512) * 2 / 3) / 16 * 16; }
+static long long comb_cap_for(int occ, long long stat = -1) { return (long long)(((long long)g.max_lds / occ - (stat < 0 ? comb_stat() : stat) - 512) * 2 / 3) / 16 * 16; }
+static_assert(M_HIST + HIST_N <= M_MANYC && M_MANYC < REPORT_INTS, "the tier histogram leaves the report block");
 
 // The three tiers and the roomy launch for a first tier of at most `occ_first` waves per CU (0: what the read bases of the
 // usual region suggest).  Called at upload, and again by ihp_batch_run when the last batch of this shape showed that most
@@ -1162,17 +1173,23 @@ static long long comb_cap_for(int occ) { return (long long)(((long long)g.max_ld
 static void size_combine_tiers(ihp_batch *b, int occ_first)
 {
 	const int R = b->R;
-	const long long nb1 = b->v2_nb1, stat = comb_stat();
+	const long long nb1 = b->v2_nb1, stat = comb_stat(), stat_a = b->tier_wide ? comb_stat() : comb_stat_a();
 	auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + stat; };
+	auto wave_bytes_a = [&](long long C) { return C + 4 * comb_pm_of(C) + stat_a; };
 	// 16 waves per CU.  (Round 3 took 14 for launches of about one round of regions per wave slot: such a launch lasts as long
 	// as its heaviest regions, and a caller that waited for every batch before starting the next saw those run faster with
 	// fewer waves beside them.  A caller that keeps batches in flight -- a sweep, bench.py since round 4 -- has another
 	// chain's kernels in those tails: C2, 5 000 regions per launch, 14: 1.74 ms per step, 16: 1.70, 18: 1.72.)
-	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 16;
+	// (Round 5: the first tier's build keeps a contig table of 32 entries, 1.7 KB instead of 3.2 -- regions with more contigs are
+	// filed under the second tier --, and the cap is 28 waves per CU, what the kernel's 112 SGPRs allow: the launch is bound by the
+	// latency of every region's chain and runs in proportion to the regions a CU holds -- C2, per 100 000 regions: 10 waves per
+	// CU 4.74 ms, 12: 3.95, 14: 3.14, 16: 2.83.)
+	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 4 * std::max(5, std::min(7, g_knob.comb_minw));
 	long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
-	int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes(need_C)));
-	if (occ_first > 0) occ_c = std::max(1, std::min(occ_c, occ_first));
-	need_C = std::max(need_C, comb_cap_for(occ_c));
+	int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes_a(need_C)));
+	// occ_first: what the last batch of this shape needed (the tier histogram) -- below OR above what the read bases suggest
+	if (occ_first > 0) { occ_c = std::max(1, std::min(occ_max, occ_first)); need_C = 1024; }
+	need_C = std::max(need_C, comb_cap_for(occ_c, stat_a));
 	b->tier_occ = occ_c;
 	// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
 	b->v2_arena_big = (int)std::min<long long>(comb_cap_for(2), std::max<long long>(4 * need_C, (nb1 + 1024 + 15) / 16 * 16));
@@ -1195,8 +1212,8 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 	b->v2_pm_c = (int)comb_pm_of(b->v2_arena_c);
 	while (b->v2_arena_big > 1024 && b->v2_arena_big + 4 * comb_pm_of(b->v2_arena_big) > dyn_max) b->v2_arena_big -= 256;
 	b->v2_pm = (int)comb_pm_of(b->v2_arena); b->v2_pm_b = (int)comb_pm_of(b->v2_arena_b); b->v2_pm_big = (int)comb_pm_of(b->v2_arena_big);
-	const int per_wave = (int)wave_bytes(b->v2_arena);
-	b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 20, g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
+	const int per_wave = (int)wave_bytes_a(b->v2_arena);
+	b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 4 * std::max(5, std::min(7, g_knob.comb_minw)), g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
 }
 
 // The compact slab's host view (ihp_batch_upload_slab2): what batch_upload_common reads on the host comes from here when set.
@@ -1505,7 +1522,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			b->tier_occ_default = b->tier_occ;
 			b->tier_sig = (b->max_read_len / 32) | ((int)std::min<long long>(nb1 / 2048, 0xffff) << 8) | (b->tier_occ_default << 24);
 			const int dyn_max = g.max_lds - 8192 - 1024;
-			auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + comb_stat(); };
+			auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + (b->tier_wide ? comb_stat() : comb_stat_a()); };
 			const int per_wave = (int)wave_bytes(b->v2_arena), per_wave_r = 4 * b->v2_pdw + 256;
 			if (b->v2_arena + 4 * b->v2_pm > dyn_max || per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
 			else {
@@ -1757,22 +1774,32 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		// this shape filed most of its regions above that, the tiers are cut again so that the first one holds 85 % of them.
 		if (b->v2 && have_hint && !g_knob.comb_occ && !g_knob.v2_arena && H.sig == b->tier_sig && H.regions > 0) {
 			const long long tot = H.regions;
+			// more than a hundredth of the regions with more contigs than the short table holds: the first tier runs the build with
+			// the full table (C3, C5: 6-7 % -- a second tier for them alone, at two thirds of the occupancy, every step)
+			const bool wide = (long long)H.n_manyc * 100 > tot;
 			// a tier of its own for a few percent of the regions costs a round of the heaviest ones at the end: when a first tier
 			// of not much lower occupancy holds (nearly) all regions -- a narrow distribution just above the predicted arena --
-			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest
+			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest.
+			// The histogram's capacities are those of the build the last batch ran (H.wide); when the build changes the tiers
+			// are first cut for it from the read bases and settle with the batch after.
+			const int occ_lim = 4 * std::max(5, std::min(7, g_knob.comb_minw));   // (above ~20 regions per CU the launch gains nothing more)
 			int want = 0, want_all = 0;
 			long long cum = 0;
 			for (int k = 0; k < HIST_N; ++k) {
 				cum += H.hist[k];
-				if (HIST_OCC[k] > b->tier_occ_default) continue;
+				if (HIST_OCC[k] > occ_lim) continue;
 				if (!want && cum * 100 >= 85 * tot) want = HIST_OCC[k];
 				if (!want_all && cum * 200 >= 199 * tot) want_all = HIST_OCC[k];
 			}
 			if (!want) want = HIST_OCC[HIST_N - 1];
-			if (want_all && want_all * 10 >= b->tier_occ_default * 6) want = want_all;
-			want = std::min(want, b->tier_occ_default);
-			if (want != b->tier_occ) size_combine_tiers(b, want == b->tier_occ_default ? 0 : want);
+			if (want_all && want_all * 10 >= want * 7) want = want_all;
+			if (wide != b->tier_wide) { b->tier_wide = wide; size_combine_tiers(b, wide == (H.wide != 0) ? want : 0); }
+			else if (wide == (H.wide != 0) && want != b->tier_occ) size_combine_tiers(b, want);
 		}
+		if (g_knob.verbose && b->v2 && have_hint)
+			fprintf(stderr, "[ihp] hist (regions whose contigs fit a first tier of 24 22 20 18 16 14 12 10 9 8 6 waves/CU and no higher one): %d %d %d %d %d %d %d %d %d %d %d of %d\n",
+			        H.hist[0], H.hist[1], H.hist[2], H.hist[3], H.hist[4], H.hist[5], H.hist[6], H.hist[7], H.hist[8], H.hist[9], H.hist[10], H.regions);
+		if (g_knob.verbose && b->v2 && have_hint) fprintf(stderr, "[ihp] %d regions with more than %d contigs; first tier's contig table: %s\n", H.n_manyc, COMB_MAXC_A, b->tier_wide ? "full" : "short");
 		if (g_knob.verbose && b->v2)
 			fprintf(stderr, "[ihp] run: %d regions, first tier %d waves/CU (default %d): arenas %d / %d / %d / %d, grids %d / %d / %d / %d; hint valid %d b %d c %d big %d back %d\n",
 			        b->R, b->tier_occ, b->tier_occ_default, b->v2_arena, b->v2_arena_b, b->v2_arena_c, b->v2_arena_big, b->grid_v2, b->grid_v2b, b->grid_v2c, b->grid_v2big,
@@ -1842,7 +1869,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			const bool lpt_on = g_knob.lpt != 0;                   // region order of the combine launch
 			ra.lpt_cnt = lpt_on ? wq + 14 * WQ_WORDS : nullptr; ra.lpt_seg = b->lpt_seg.as<int>(); ra.lpt_stride = b->R;
 			ra.tier_a_cap = b->v2_arena; ra.tier_b_cap = b->v2_arena_b; ra.n_tier_b = misc + M_NTIERB;
-			for (int k = 0; k < HIST_N; ++k) ra.hist_cap[k] = (int)comb_cap_for(HIST_OCC[k]);
+			ra.tier_a_maxc = b->tier_wide ? V3_MAXC : COMB_MAXC_A; ra.manyc_thr = COMB_MAXC_A; ra.n_manyc = misc + M_MANYC;
+			for (int k = 0; k < HIST_N; ++k) ra.hist_cap[k] = (int)comb_cap_for(HIST_OCC[k], b->tier_wide ? comb_stat() : comb_stat_a());
 			ra.hist = misc + M_HIST;
 			ra.min_mapq_assemble = x.min_mapq_assemble; ra.v2_pdw = x.v2_pdw; ra.n_regions = x.n_regions; ra.in_list = x.in_list; ra.n_in = x.n_in;
 			ra.out_list = x.out_list; ra.n_out = x.n_out; ra.work_counter = x.work_counter; ra.prof = x.prof; ra.t_start = x.t_start;
@@ -1877,8 +1905,14 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// waves per workgroup: as many as the tier's occupancy leaves wave slots for (32 per CU)
 			// (the team build is for 4 waves per SIMD, 128 VGPRs: 16 waves per CU; measured on C5 at 8 workgroups per CU: 2 waves +3 %,
 			// 4 waves -30 % -- half the workgroups resident)
-			auto launch_comb = [&](int grid, int threads, size_t lds, hipStream_t st, const AsmArgs &args) {
-				if (threads > 64) hipLaunchKernelGGL((k_asm_combine3<4, true>), dim3(grid), dim3(threads), lds, st, args);
+			auto launch_comb = [&](int grid, int threads, size_t lds, hipStream_t st, const AsmArgs &args, bool first = false) {
+				if (first) {                                           // the build with the short contig table (a region with more contigs takes the retry route)
+					if (threads > 64) hipLaunchKernelGGL((k_asm_combine3<4, true, COMB_MAXC_A>), dim3(grid), dim3(threads), lds, st, args);
+					else if (g_knob.comb_minw == 7) hipLaunchKernelGGL((k_asm_combine3<7, false, COMB_MAXC_A>), dim3(grid), dim3(64), lds, st, args);
+					else if (g_knob.comb_minw == 6) hipLaunchKernelGGL((k_asm_combine3<6, false, COMB_MAXC_A>), dim3(grid), dim3(64), lds, st, args);
+					else hipLaunchKernelGGL((k_asm_combine3<5, false, COMB_MAXC_A>), dim3(grid), dim3(64), lds, st, args);
+				}
+				else if (threads > 64) hipLaunchKernelGGL((k_asm_combine3<4, true>), dim3(grid), dim3(threads), lds, st, args);
 				else hipLaunchKernelGGL((k_asm_combine3<5, false>), dim3(grid), dim3(64), lds, st, args);
 			};
 			auto team = [&](int occ) { const int w = g_knob.comb_waves ? g_knob.comb_waves : occ <= 8 ? 2 : 1; return 64 * std::max(1, std::min(w, (int)V3_MAXW)); };
@@ -1890,7 +1924,10 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				else {
 					const long long nb = nb_hint * std::max(1, b->n_cls[0]) / reg + 1;
 					gb = (int)std::min<long long>(gb, std::max<long long>(g.cus, nb + nb / 4));
-					const long long wb_a = b->v2_arena + 4 * comb_pm_of(b->v2_arena) + comb_stat(), wb_b = b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) + comb_stat();
+					// (never more than a quarter of a CU's LDS: a second tier with thousands of regions is not over in one round, and
+					// the first tier must not be left with a workgroup per CU)
+					gb = (int)std::min<long long>(gb, g.cus * std::max<long long>(1, g.max_lds / 4 / (b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) + comb_stat())));
+					const long long wb_a = b->v2_arena + 4 * comb_pm_of(b->v2_arena) + (b->tier_wide ? comb_stat() : comb_stat_a()), wb_b = b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) + comb_stat();
 					const long long per_cu_b = (gb + g.cus - 1) / g.cus;
 					const long long occ_a = std::max<long long>(1, ((long long)g.max_lds - per_cu_b * wb_b) / wb_a);
 					ga = (int)std::min<long long>(ga, occ_a * g.cus);
@@ -1915,7 +1952,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				}
 				x.lpt_nclass = LPT_CLASSES * (fold_b ? 3 : fold_c ? 2 : 1);
 			} else HIPC(hipEventRecord(b->ev_bjoin, s));
-			launch_comb(ga, tm_a, b->v2_arena + 4 * b->v2_pm, s, x);
+			launch_comb(ga, tm_a, b->v2_arena + 4 * b->v2_pm, s, x, !b->tier_wide);
 			HIPC(hipStreamWaitEvent(s, b->ev_bjoin, 0));           // (recorded right away when there is no second-tier launch)
 			// regions that ran out of room in their launch: the same kernel with a roomy arena, few workgroups per CU -- or, when
 			// the previous batch had none, a token launch with the first tier's arena (it gets scheduled at once; a region that
@@ -1930,7 +1967,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && H.n_big == 0 && H.n_back == 0;
 			if (!spec_skip) {
 			if (hint && H.n_big == 0) {
-				launch_comb(std::min(b->grid_v2big, 64), tm_a, b->v2_arena + 4 * b->v2_pm, s, x);
+				launch_comb(std::min(b->grid_v2big, 64), tm_a, b->v2_arena + 4 * b->v2_pm, s, x, !b->tier_wide);
 			} else {
 				x.arena_cap = b->v2_arena_big; x.lds_arena = b->v2_arena_big; x.v2_pm_dw = b->v2_pm_big;
 				launch_comb(b->grid_v2big, tm_big, b->v2_arena_big + 4 * b->v2_pm_big, s, x);
@@ -2120,6 +2157,7 @@ static void hint_refresh(const ihp_batch *b)
 	h.n_back = b->report[M_NRETRY0]; h.n_kovf = b->report[M_KSW_OVF];
 	if (b->v2 && g_knob.lpt) {
 		for (int k = 0; k < HIST_N; ++k) h.hist[k] = b->report[M_HIST + k];
+		h.n_manyc = b->report[M_MANYC]; h.wide = b->tier_wide ? 1 : 0;
 		h.regions = b->n_cls[0] - b->report[M_NRETRY0]; h.sig = b->tier_sig;
 	}
 	if (g_knob.verbose) fprintf(stderr, "[ihp] confirmed: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);

@@ -466,11 +466,14 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 			// (n_final = 0: the launches that take the list may have been left out of this run -- ihp_batch_run -- and k_summary walks n_final contigs)
 			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 		} else if (lane == 0 && a.hist) {
-			for (int k = 0; k < 7; ++k) if (need <= a.hist_cap[k]) { atomicAdd(&a.hist[k], 1); break; }
+			// (a region with more contigs than the first tier's table holds counts as one that only the roomiest first tier would take)
+			if (nc > a.manyc_thr) atomicAdd(a.n_manyc, 1);
+			if (nc > a.tier_a_maxc) atomicAdd(&a.hist[10], 1);
+			else for (int k = 0; k < 11; ++k) if (need <= a.hist_cap[k]) { atomicAdd(&a.hist[k], 1); break; }
 		}
 		if (!err && a.lpt_cnt && lane == 0) {
 			// the tiers in memory: first, third, second (the first tier's launch can then walk the third's lists, or all, behind its own)
-			const int tier = need <= a.tier_a_cap ? 0 : need <= a.tier_b_cap ? 2 : 1;
+			const int tier = need <= a.tier_a_cap && nc <= a.tier_a_maxc ? 0 : need <= a.tier_b_cap ? 2 : 1;
 			const int c = lpt_class(nc) + tier * LPT_CLASSES;
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
 			if (tier) atomicAdd(a.n_tier_b + (tier == 2 ? 0 : 1), 1);
@@ -486,7 +489,8 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 }
 
 // Final contigs of one region from the packed representation (asm3_dev.h) -> output slots, alignment jobs; see region_epilogue.
-__device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ctx &C, int r, int err, int n_pre, int &n_final)
+template <class ST>
+__device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C, int r, int err, int n_pre, int &n_final)
 {
 	const int lane = lane_id();
 	if (err) n_final = 0;
@@ -572,10 +576,10 @@ __device__ inline void region_epilogue3(const AsmArgs &a, V3State &S, const V3Ct
 // others join it inside best_match calls (V3Par, asm3_dev.h) and wait at a barrier otherwise; so wave 0 itself never uses a
 // workgroup barrier outside those calls (WAVE_SYNC: its own memory traffic done, nothing more).  128 VGPRs, 16 waves per CU.
 #define WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-template <int MINW, bool TEAM>
+template <int MINW, bool TEAM, int MAXC = V3_MAXC>
 __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_asm_combine3(const AsmArgs a)
 {
-	__shared__ V3State S;
+	__shared__ V3StateT<MAXC> S;
 	__shared__ int s_item;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
 	__shared__ V3Par s_par;                                    // (dropped from the one-wave build: nobody refers to it there)
