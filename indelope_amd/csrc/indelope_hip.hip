@@ -95,7 +95,7 @@ Knobs g_knob;
 // (the read kernel files them); sig: the shape of that batch (read length, read bases per region): a batch of another
 // shape does not use the histogram.
 constexpr int HIST_N = 11;
-constexpr int HIST_OCC[HIST_N] = {24, 22, 20, 18, 16, 14, 12, 10, 9, 8, 6};
+constexpr int HIST_OCC[HIST_N] = {25, 21, 18, 16, 14, 12, 11, 10, 9, 8, 7};     // what 128 LDS granules per CU divide into (see LDS_GRAN)
 constexpr int COMB_MAXC_A = 32;                              // contigs the first combine tier's build keeps a table for (V3StateT, asm3_dev.h)
 struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
 // One hint per batch SHAPE (hint_key: read length, read bases per region, the packed / byte-based path, the parameters that
@@ -1160,10 +1160,24 @@ static void release_work(ihp_batch *b)
 // LDS sizing of the combine launches (k_asm_combine3, asm3_dev.h).  Capacity C = C bytes of supports (kept for multi-read
 // contigs only) + C / 8 + 128 dwords of packed bases (every contig) beside the kernel's static LDS (asked of the runtime: a
 // stale constant here once cost every tier a wave per CU).
-static long long comb_stat() { return (g.comb_static + 255) / 256 * 256 + 256; }          // + allocation granularity
-static long long comb_stat_a() { return (std::max(g.comb_static_a, 512) + 255) / 256 * 256 + 256; }   // the first tier's build (COMB_MAXC_A contigs)
+// The hardware hands LDS to a workgroup in granules of 1280 bytes on gfx950 (160 KB = 128 granules): a wave whose static +
+// dynamic LDS is one byte over k granules costs k + 1, so only the occupancies 128 / k exist -- 25, 21, 18, 16, 14, 12, 11, 10,
+// 9, 8 ... per CU.  (Measured on the first tier, C2: 7652 bytes per wave -> 21 resident, 2.70 ms per 100 000 regions; 7748
+// bytes -> 18 resident, 2.89 ms.  Round 4 sized the arenas as if any number of waves could share the 160 KB: its "17 per CU"
+// were 16, and a tier cut "for 24" ran 21 with an arena a granule short of what 21 could have had.)
+constexpr long long LDS_GRAN = 1280;
+static long long comb_stat() { return g.comb_static + 16; }                                 // static LDS of the full-table builds (+ alignment of the dynamic part)
+static long long comb_stat_a() { return std::max(g.comb_static_a, 512) + 16; }               // ... of the first tier's short-table build (COMB_MAXC_A contigs)
 static long long comb_pm_of(long long C) { return C / 8 + 128; }
-static long long comb_cap_for(int occ, long long stat = -1) { return (long long)(((long long)g.max_lds / occ - (stat < 0 ? comb_stat() : stat) - 512) * 2 / 3) / 16 * 16; }
+static long long comb_wave_bytes(long long C, long long stat) { return (stat + C + 4 * comb_pm_of(C) + LDS_GRAN - 1) / LDS_GRAN * LDS_GRAN; }   // what the hardware sets aside
+static int comb_occ_of(long long C, long long stat) { return (int)std::max<long long>(1, (g.max_lds / LDS_GRAN) / (comb_wave_bytes(C, stat) / LDS_GRAN)); }
+// the largest capacity with which `occ` waves share a CU
+static long long comb_cap_for(int occ, long long stat = -1)
+{
+	if (stat < 0) stat = comb_stat();
+	const long long budget = std::max<long long>(1, (g.max_lds / LDS_GRAN) / std::max(1, occ)) * LDS_GRAN;
+	return std::max<long long>(256, (budget - stat - 4 * 128) * 2 / 3 / 16 * 16 - 16);
+}
 static_assert(M_HIST + HIST_N <= M_MANYC && M_MANYC < REPORT_INTS, "the tier histogram leaves the report block");
 
 // The three tiers and the roomy launch for a first tier of at most `occ_first` waves per CU (0: what the read bases of the
@@ -1174,26 +1188,26 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 {
 	const int R = b->R;
 	const long long nb1 = b->v2_nb1, stat = comb_stat(), stat_a = b->tier_wide ? comb_stat() : comb_stat_a();
-	auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + stat; };
-	auto wave_bytes_a = [&](long long C) { return C + 4 * comb_pm_of(C) + stat_a; };
-	// 16 waves per CU.  (Round 3 took 14 for launches of about one round of regions per wave slot: such a launch lasts as long
+	// Regions per CU.  The launch is bound by the latency of every region's chain and runs in proportion to the regions a CU
+	// holds until about 21 of them (C2, per 100 000 regions: 10 per CU 4.74 ms, 12: 3.95, 14: 3.14, 16: 2.83, 18: 2.89 with
+	// the six-wave build's spills, 21: 2.64; 24: 2.73): round 5 gave the first tier a build with a contig table of 32 entries
+	// (1.7 KB instead of 3.2; regions with more contigs are filed under the second tier, or the first tier runs the full-table
+	// build when they are many) compiled for six waves per SIMD, and sizes every tier in whole LDS granules.
+	// (Round 3 took 14 for launches of about one round of regions per wave slot: such a launch lasts as long
 	// as its heaviest regions, and a caller that waited for every batch before starting the next saw those run faster with
 	// fewer waves beside them.  A caller that keeps batches in flight -- a sweep, bench.py since round 4 -- has another
-	// chain's kernels in those tails: C2, 5 000 regions per launch, 14: 1.74 ms per step, 16: 1.70, 18: 1.72.)
-	// (Round 5: the first tier's build keeps a contig table of 32 entries, 1.7 KB instead of 3.2 -- regions with more contigs are
-	// filed under the second tier --, and the cap is 28 waves per CU, what the kernel's 112 SGPRs allow: the launch is bound by the
-	// latency of every region's chain and runs in proportion to the regions a CU holds -- C2, per 100 000 regions: 10 waves per
-	// CU 4.74 ms, 12: 3.95, 14: 3.14, 16: 2.83.)
-	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 4 * std::max(5, std::min(7, g_knob.comb_minw));
+	// chain's kernels in those tails.)
+	const int occ_hw = 4 * std::max(5, std::min(7, g_knob.comb_minw));
+	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : std::min(occ_hw, 21);
 	long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
-	int occ_c = (int)std::max<long long>(1, std::min<long long>(occ_max, g.max_lds / wave_bytes_a(need_C)));
+	int occ_c = std::max(1, std::min(occ_max, comb_occ_of(need_C, stat_a)));
 	// occ_first: what the last batch of this shape needed (the tier histogram) -- below OR above what the read bases suggest
 	if (occ_first > 0) { occ_c = std::max(1, std::min(occ_max, occ_first)); need_C = 1024; }
 	need_C = std::max(need_C, comb_cap_for(occ_c, stat_a));
 	b->tier_occ = occ_c;
 	// the roomy launch for regions whose contigs do not fit the first one's arena (many single-read contigs)
 	b->v2_arena_big = (int)std::min<long long>(comb_cap_for(2), std::max<long long>(4 * need_C, (nb1 + 1024 + 15) / 16 * 16));
-	b->grid_v2big = grid_for(R, std::max(1, std::min<int>(2, (int)(g.max_lds / wave_bytes(b->v2_arena_big)))));
+	b->grid_v2big = grid_for(R, std::max(1, std::min<int>(2, comb_occ_of(b->v2_arena_big, stat))));
 	// the second and third tier: regions whose contigs (known when the read phase ends) need more than the first arena
 	// -- many single-read contigs, long reads -- at about two thirds and a third of its occupancy
 	{
@@ -1212,8 +1226,7 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 	b->v2_pm_c = (int)comb_pm_of(b->v2_arena_c);
 	while (b->v2_arena_big > 1024 && b->v2_arena_big + 4 * comb_pm_of(b->v2_arena_big) > dyn_max) b->v2_arena_big -= 256;
 	b->v2_pm = (int)comb_pm_of(b->v2_arena); b->v2_pm_b = (int)comb_pm_of(b->v2_arena_b); b->v2_pm_big = (int)comb_pm_of(b->v2_arena_big);
-	const int per_wave = (int)wave_bytes_a(b->v2_arena);
-	b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : 4 * std::max(5, std::min(7, g_knob.comb_minw)), g.max_lds / per_wave))), std::max(1, b->n_cls[0]));
+	b->grid_v2 = std::min(grid_for(R, std::max(1, std::min(g_knob.asm_waves ? g_knob.asm_waves : occ_hw, comb_occ_of(b->v2_arena, stat_a)))), std::max(1, b->n_cls[0]));
 }
 
 // The compact slab's host view (ihp_batch_upload_slab2): what batch_upload_common reads on the host comes from here when set.
@@ -1522,8 +1535,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			b->tier_occ_default = b->tier_occ;
 			b->tier_sig = (b->max_read_len / 32) | ((int)std::min<long long>(nb1 / 2048, 0xffff) << 8) | (b->tier_occ_default << 24);
 			const int dyn_max = g.max_lds - 8192 - 1024;
-			auto wave_bytes = [&](long long C) { return C + 4 * comb_pm_of(C) + (b->tier_wide ? comb_stat() : comb_stat_a()); };
-			const int per_wave = (int)wave_bytes(b->v2_arena), per_wave_r = 4 * b->v2_pdw + 256;
+			const int per_wave = (int)comb_wave_bytes(b->v2_arena, b->tier_wide ? comb_stat() : comb_stat_a()), per_wave_r = 4 * b->v2_pdw + 256;
 			if (b->v2_arena + 4 * b->v2_pm > dyn_max || per_wave > g.max_lds - 1024 || per_wave_r > g.max_lds - 1024) b->v2 = false;
 			else {
 				b->grid_v2r = std::min(grid_for(R, std::max(1, std::min(g_knob.asmr_waves ? g_knob.asmr_waves : 32, g.max_lds / per_wave_r))), std::max(1, b->n_cls[0]));
@@ -1782,7 +1794,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest.
 			// The histogram's capacities are those of the build the last batch ran (H.wide); when the build changes the tiers
 			// are first cut for it from the read bases and settle with the batch after.
-			const int occ_lim = 4 * std::max(5, std::min(7, g_knob.comb_minw));   // (above ~20 regions per CU the launch gains nothing more)
+			const int occ_lim = std::min(21, 4 * std::max(5, std::min(7, g_knob.comb_minw)));   // (above 21 regions per CU the launch gains nothing more)
 			int want = 0, want_all = 0;
 			long long cum = 0;
 			for (int k = 0; k < HIST_N; ++k) {
@@ -1797,7 +1809,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			else if (wide == (H.wide != 0) && want != b->tier_occ) size_combine_tiers(b, want);
 		}
 		if (g_knob.verbose && b->v2 && have_hint)
-			fprintf(stderr, "[ihp] hist (regions whose contigs fit a first tier of 24 22 20 18 16 14 12 10 9 8 6 waves/CU and no higher one): %d %d %d %d %d %d %d %d %d %d %d of %d\n",
+			fprintf(stderr, "[ihp] hist (regions whose contigs fit a first tier of 25 21 18 16 14 12 11 10 9 8 7 waves/CU and no higher one): %d %d %d %d %d %d %d %d %d %d %d of %d\n",
 			        H.hist[0], H.hist[1], H.hist[2], H.hist[3], H.hist[4], H.hist[5], H.hist[6], H.hist[7], H.hist[8], H.hist[9], H.hist[10], H.regions);
 		if (g_knob.verbose && b->v2 && have_hint) fprintf(stderr, "[ihp] %d regions with more than %d contigs; first tier's contig table: %s\n", H.n_manyc, COMB_MAXC_A, b->tier_wide ? "full" : "short");
 		if (g_knob.verbose && b->v2)
@@ -1926,8 +1938,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 					gb = (int)std::min<long long>(gb, std::max<long long>(g.cus, nb + nb / 4));
 					// (never more than a quarter of a CU's LDS: a second tier with thousands of regions is not over in one round, and
 					// the first tier must not be left with a workgroup per CU)
-					gb = (int)std::min<long long>(gb, g.cus * std::max<long long>(1, g.max_lds / 4 / (b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) + comb_stat())));
-					const long long wb_a = b->v2_arena + 4 * comb_pm_of(b->v2_arena) + (b->tier_wide ? comb_stat() : comb_stat_a()), wb_b = b->v2_arena_b + 4 * comb_pm_of(b->v2_arena_b) + comb_stat();
+					const long long wb_a = comb_wave_bytes(b->v2_arena, b->tier_wide ? comb_stat() : comb_stat_a()), wb_b = comb_wave_bytes(b->v2_arena_b, comb_stat());
+					gb = (int)std::min<long long>(gb, g.cus * std::max<long long>(1, g.max_lds / 4 / wb_b));
 					const long long per_cu_b = (gb + g.cus - 1) / g.cus;
 					const long long occ_a = std::max<long long>(1, ((long long)g.max_lds - per_cu_b * wb_b) / wb_a);
 					ga = (int)std::min<long long>(ga, occ_a * g.cus);

@@ -182,3 +182,18 @@ def test_a_slab_through_either_packing_kernel(hip, oracle, pf):
                 s2.free()
     finally:
         hip.debug_set()
+
+
+def test_regions_with_more_contigs_than_the_short_table(hip, oracle):
+    """The first combine tier runs a build whose contig table holds 32 entries; regions with more pre-combine contigs are filed
+    under the second tier, and when the last batch of the shape had more than a hundredth of such regions the first tier runs
+    the full-table build instead.  Batch after batch of such regions (the plan changes with the hints) and a batch without any
+    in between give the oracle's results."""
+    hip.debug_set()
+    many, _ = synth.generate(240, n_reads=(120, 200), err_rate=1.2e-2, config_id=41)
+    few, _ = synth.generate(240, n_reads=(120, 200), err_rate=0.0, config_id=42)
+    exp_many, exp_few = oracle.run_regions_mt(many, oracle.params(K=27), 16), oracle.run_regions_mt(few, oracle.params(K=27), 16)
+    assert (exp_many.n_contigs_pre > 32).mean() > 0.05, float((exp_many.n_contigs_pre > 32).mean())
+    assert (exp_few.n_contigs_pre > 32).sum() == 0
+    for b, exp in ((many, exp_many), (many, exp_many), (few, exp_few), (few, exp_few), (many, exp_many), (many, exp_many)):
+        _same(hip.run_regions(b, hip.params(K=27)), exp)

@@ -6,7 +6,14 @@ export TMPDIR=/tmp
 OUT=gpurun_out/ks; rm -rf $OUT; mkdir -p $OUT
 run() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py "$@" > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*kernel_stats.csv" | head -1); echo "== $name: $(tail -1 $OUT/$name.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])' 2>/dev/null)"
-  [ -n "$f" ] && grep -E "k_asm|k_ksw|k_tally|k_prepack|k_fallback|k_summary|k_assemble" $f | cut -d, -f1-4 | sed 's/void ihp:://' | sort -t, -k3 -n -r | head -12; rm -rf $OUT/$name; }
+  [ -n "$f" ] && python3 - "$f" <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "ihp::" in r["Name"]]
+rows.sort(key=lambda r: -int(r["TotalDurationNs"]))
+for r in rows[:14]:
+    print("  %-52s %4s launches  avg %9.3f us  total %8.2f ms" % (r["Name"].replace("void ", "").replace("ihp::", "")[:52], r["Calls"], float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6))
+PY
+  rm -rf $OUT/$name; }
 for w in ${@:-steady c5 c3}; do
   case $w in
     steady) run steady --no-cpu --no-e2e --no-check --no-other --regions 100000 --steps 3 --warmup 1 --in-flight 1 --sub-batches 1;;
