@@ -73,6 +73,7 @@ struct Knobs {
 	int ksw_p_cap = 0;     // bytes: caps the traceback scratch per wave of the MAIN ksw2 launch (its jobs that need more go to the roomy launch)
 	int comb_waves = 0;    // waves per workgroup of k_asm_combine3 (1, 2, 4; 0 = by the tier's occupancy): wave 0 runs the region, the others share its best_match calls
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
+	int tally_minw = 8;    // waves per SIMD k_tally is compiled for (6: 78 VGPRs; 7: 72; 8: 64 and 20 bytes of scratch -- the kernel waits for memory 41 % of its time: 0.86 -> 0.79 ms per 100 000 C2 regions)
 	int comb_minw = 6;     // waves per SIMD the first combine tier's build is compiled for (5: 95 VGPRs; 6: 80; 7: 72 -- with spills)
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
@@ -479,7 +480,9 @@ extern "C" int ihp_init(int device)
 	if (g.max_lds > 65536) {
 		// opt in to the full 160 KiB LDS for the ksw2 kernel's dynamic region
 		(void)hipFuncSetAttribute((const void *)k_assemble<256, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 16384);
-		(void)hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
+		(void)hipFuncSetAttribute((const void *)k_tally<6>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
+		(void)hipFuncSetAttribute((const void *)k_tally<7>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
+		(void)hipFuncSetAttribute((const void *)k_tally<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 4096);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<5, false, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
@@ -534,7 +537,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -2076,7 +2079,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		// with the 2-bit reads at hand a group of 64 reads is a quarter of that; the rare region with a base that is not
 		// upper-case ACGT then walks its reads in HBM (tally_reads) instead of staging them
 		if (a.pk) a.lds_bytes = std::min(a.lds_bytes, 64 * 4 * ((b->max_read_len + 15) / 16 + 1) + 64);
-		hipLaunchKernelGGL(k_tally, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
+		if (g_knob.tally_minw == 8) hipLaunchKernelGGL(k_tally<8>, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
+		else if (g_knob.tally_minw == 7) hipLaunchKernelGGL(k_tally<7>, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
+		else hipLaunchKernelGGL(k_tally<6>, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		HIPC(hipGetLastError());
 	}
 	HIPC(hipEventRecord(b->ev[3], s));

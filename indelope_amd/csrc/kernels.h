@@ -1008,7 +1008,8 @@ struct TallyArgs {
 	unsigned long long *t_start;               // optional: see mark_start()
 };
 
-__global__ __launch_bounds__(64) void k_tally(const TallyArgs a)
+template <int MINW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_tally(const TallyArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t tally_lds[];
 	const int lane = lane_id();

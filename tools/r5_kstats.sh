@@ -1,10 +1,10 @@
 #!/bin/bash
 # Per-kernel time (rocprofv3 kernel stats) of the steady 100 000-region launch, C5 and C3 -- the quick look between two edits.
-#   tools/r5_kstats.sh [steady|c5|c3 ...]
+#   [KNOBS="--knob k=v ..."] tools/r5_kstats.sh [steady|c5|c3 ...]
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/ks; rm -rf $OUT; mkdir -p $OUT
-run() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py "$@" > $OUT/$name.log 2>&1
+run() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py "$@" $KNOBS > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*kernel_stats.csv" | head -1); echo "== $name: $(tail -1 $OUT/$name.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])' 2>/dev/null)"
   [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys
