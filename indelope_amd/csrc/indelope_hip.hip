@@ -73,6 +73,7 @@ struct Knobs {
 	int ksw_p_cap = 0;     // bytes: caps the traceback scratch per wave of the MAIN ksw2 launch (its jobs that need more go to the roomy launch)
 	int comb_waves = 0;    // waves per workgroup of k_asm_combine3 (1, 2, 4; 0 = by the tier's occupancy): wave 0 runs the region, the others share its best_match calls
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
+	int tally_rec_cap = 0; // test hook: records k_tally_prep may write (the other jobs with events take k_tally's own header path)
 	int tally_minw = 8;    // waves per SIMD k_tally is compiled for (6: 78 VGPRs; 7: 72; 8: 64 and 20 bytes of scratch -- the kernel waits for memory 41 % of its time: 0.86 -> 0.79 ms per 100 000 C2 regions)
 	int comb_minw = 6;     // waves per SIMD the first combine tier's build is compiled for (5: 95 VGPRs; 6: 80; 7: 72 -- with spills)
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
@@ -537,7 +538,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"tally_rec_cap", &g_knob.tally_rec_cap}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -990,7 +991,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 
 // ------------------------------------------------------- the batched region path
 enum { WQ_SETS = 24 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles)
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_WORDS = 32,
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_NRECS = 25 /* 2 */, M_WORDS = 32,
        M_SLAB_BAD = 48, M_HIST = 49, M_MANYC = 60 };   // M_MANYC: regions with more contigs than the first tier's short table holds   // (behind the stamps, inside the report block: raised by k_slab_expand when a compact slab's lengths do not add up)
 struct ihp_batch {
 	ihp_params P;
@@ -1030,6 +1031,7 @@ struct ihp_batch {
 	// alignment fallback (indelope.nim:312-372)
 	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
+	DBuf tally_recs, tally_ovf; int tally_rec_cap = 0;     // k_tally_prep -> k_tally (TallyRec)
 	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
 	bool timing = false;                                   // device wall-clock stamps: start / end of the four stages
 	// everything a run expects to be zero lives in ONE buffer (`misc`): [counters | stamps | work queues | per-region hit
@@ -1120,6 +1122,10 @@ static int alloc_work(ihp_batch *b)
 	AL(p_scratch, b->p_cap * b->grid_ksw);
 	AL(cig_tmp, sizeof(uint32_t) * (size_t)b->cig_cap * b->grid_ksw);
 	AL(ksw_ovf, sizeof(int) * (size_t)std::max<long long>(1, b->njobs_cap));
+	// the tally's records: the jobs with events -- a few per region; what does not fit takes k_tally's own header path
+	b->tally_rec_cap = (int)std::min<long long>(std::max<long long>(1, b->njobs_cap), g_knob.tally_rec_cap > 0 ? g_knob.tally_rec_cap : 4ll * b->R + 4096);
+	AL(tally_recs, sizeof(TallyRec) * (size_t)b->tally_rec_cap);
+	AL(tally_ovf, sizeof(int) * (size_t)std::max<long long>(1, b->njobs_cap));
 	if (b->p_cap_pair) {
 		AL(ksw_plan, sizeof(int) * ksw_plan_ints(std::max<long long>(1, b->njobs_cap)));
 		AL(p_scratch_pair, b->p_cap_pair * b->grid_ksw);
@@ -1155,7 +1161,7 @@ static void release_work(ihp_batch *b)
 	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->ksw_ovf, &b->ksw_plan, &b->p_scratch_pair, &b->cig_tmp_pair, &b->p_scratch_big, &b->cig_tmp_big, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
-	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab};
+	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab, &b->tally_recs, &b->tally_ovf};
 	for (DBuf *d : bufs) d->release();
 	b->work_live = false;
 }
@@ -2079,6 +2085,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		// with the 2-bit reads at hand a group of 64 reads is a quarter of that; the rare region with a base that is not
 		// upper-case ACGT then walks its reads in HBM (tally_reads) instead of staging them
 		if (a.pk) a.lds_bytes = std::min(a.lds_bytes, 64 * 4 * ((b->max_read_len + 15) / 16 + 1) + 64);
+		a.njobs_cap = (int)std::max<long long>(1, std::min<long long>(b->njobs_cap, 0x7fffffff));
+		a.recs = b->tally_recs.as<TallyRec>(); a.rec_cap = b->tally_rec_cap; a.n_recs = misc + M_NRECS; a.ovf_jobs = b->tally_ovf.as<int>();
+		hipLaunchKernelGGL(k_tally_prep, dim3((unsigned)((a.njobs_cap + 255) / 256)), dim3(256), 0, s, a);
 		if (g_knob.tally_minw == 8) hipLaunchKernelGGL(k_tally<8>, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		else if (g_knob.tally_minw == 7) hipLaunchKernelGGL(k_tally<7>, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);
 		else hipLaunchKernelGGL(k_tally<6>, dim3(b->grid_tally), dim3(64), a.lds_bytes, s, a);

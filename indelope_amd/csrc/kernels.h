@@ -1006,7 +1006,101 @@ struct TallyArgs {
 	int *hit_region_cnt;                       // [R] events of the region that took one of its own hit slots
 	long long hit_bump0;                       // start of the shared bump region
 	unsigned long long *t_start;               // optional: see mark_start()
+	// k_tally_prep -> k_tally: one record per job that has events to tally (see TallyRec), in the order the threads got there
+	struct TallyRec *recs; int rec_cap; int *n_recs;   // n_recs[0]: records written (may pass rec_cap), n_recs[1]: jobs on ovf_jobs
+	int *ovf_jobs;                             // jobs that found the record array full: k_tally works their header out itself
+	int njobs_cap;
 };
+
+// What k_tally needs to know of a job before it touches the sequences, gathered by k_tally_prep (one THREAD per job) into one
+// 128-byte line.  The header of a job used to be four dependent round trips to HBM (job -> alignment record, CIGAR offset,
+// contig start, region bounds -> CIGAR words, read offsets -> "not ACGT" flags of the region's reads) by a wave with nothing else
+// to do -- 46 % of the kernel's wave cycles -- and half of the jobs (contigs that equal the reference: no event) were nothing but
+// header.  A thread per job hides those trips behind thousands of others; k_tally gets the jobs WITH events only, one load each.
+struct TallyRec {
+	long long q_off, t_off;                    // dwords 0..3
+	long long rr0, rr1;                        // 4..7: the region's reads
+	long long base0, end0;                     // 8..11: read_off of the region's first read and of the end of its first group of 64
+	long long coff;                            // 12..13: CIGAR words in cig_pool
+	int qlen, tlen;                            // 14, 15
+	int region, out;                           // 16, 17
+	int n_cigar, job;                          // 18, 19
+	int ctg_rel;                               // 20: ctg.start - region origin
+	int nev, ntrunc;                           // 21, 22: count_events()
+	int packed;                                // 23: the 2-bit reads serve (no read of the region has a base that is not upper-case ACGT)
+	unsigned cig[8];                           // 24..31: the CIGAR when it has at most eight words
+};
+static_assert(sizeof(TallyRec) == 128, "TallyRec is one 128-byte line");
+
+// The header of job j.  False: nothing to tally (no event, or more than max_events, indelope.nim:229) -- ev_off / n_ev written.
+// Uniform or per-thread: only plain loads.
+__device__ inline bool tally_make_rec(const TallyArgs &a, int j, TallyRec &R)
+{
+	const AlnJob jb = a.jobs[j];
+	const KswOut ez = a.ez[jb.out];
+	const long long coff = a.cig_off[jb.out];
+	int nev = 0, ntrunc = 0;
+	if (ez.n_cigar > 0 && coff >= 0) {
+		const uint32_t *cg = a.cig_pool + coff;
+		const uint32_t max_off = (uint32_t)ez.max_q;
+		uint32_t off = 0;
+		for (int i = 0; i < ez.n_cigar; ++i) {                 // count_events (ksw2.nim:22-33)
+			if (off >= max_off) break;
+			const uint32_t w = cg[i], op = w & 0xf, len = w >> 4;
+			if (i < 8) R.cig[i] = w;
+			if (op != 2) off += len;
+			ntrunc++;
+			if (op == 1 || op == 2) nev++;
+		}
+		for (int i = ntrunc; i < 8 && i < ez.n_cigar; ++i) R.cig[i] = cg[i];
+	}
+	if (!(nev > 0 && nev <= a.P.max_events)) {
+		a.ev_off[jb.out] = -1; a.n_ev[jb.out] = 0;
+		return false;
+	}
+	const int r = jb.region;
+	const long long rr0 = a.region_read_off[r], rr1 = a.region_read_off[r + 1];
+	const long long ge0 = rr0 + 64 < rr1 ? rr0 + 64 : rr1;
+	R.q_off = jb.q_off; R.t_off = jb.t_off; R.rr0 = rr0; R.rr1 = rr1;
+	R.base0 = a.read_off[rr0]; R.end0 = a.read_off[ge0];
+	R.coff = coff; R.qlen = jb.qlen; R.tlen = jb.tlen; R.region = r; R.out = jb.out; R.n_cigar = ez.n_cigar; R.job = j;
+	R.ctg_rel = (int)(a.ctg_start[jb.out] - a.ref_origin[r]);
+	R.nev = nev; R.ntrunc = ntrunc;
+	int packed = a.pk != nullptr;
+	if (packed) {
+		// (eight flags a load, four loads in flight: a byte at a time this loop was a hundred dependent-looking trips per thread)
+		typedef unsigned long long u64_unaligned_t __attribute__((aligned(1)));
+		unsigned long long bad = 0;
+		long long i = rr0;
+		for (; i + 32 <= rr1; i += 32) {
+			const unsigned long long b0 = *(const u64_unaligned_t *)(a.read_bad + i), b1 = *(const u64_unaligned_t *)(a.read_bad + i + 8);
+			const unsigned long long b2 = *(const u64_unaligned_t *)(a.read_bad + i + 16), b3 = *(const u64_unaligned_t *)(a.read_bad + i + 24);
+			bad |= (b0 | b1) | (b2 | b3);
+		}
+		for (; i + 8 <= rr1; i += 8) bad |= *(const u64_unaligned_t *)(a.read_bad + i);
+		for (; i < rr1; ++i) bad |= a.read_bad[i];
+		packed = bad == 0;
+	}
+	R.packed = packed;
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_tally_prep(const TallyArgs a)
+{
+	const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (j >= *a.n_jobs || j >= a.njobs_cap) return;
+	TallyRec R;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) R.cig[i] = 0;
+	if (!tally_make_rec(a, j, R)) return;
+	const int idx = atomicAdd(&a.n_recs[0], 1);
+	if (idx < a.rec_cap) {
+		uint4 *dst = (uint4 *)&a.recs[idx];
+		const uint4 *src = (const uint4 *)&R;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) dst[i] = src[i];
+	} else a.ovf_jobs[atomicAdd(&a.n_recs[1], 1)] = j;
+}
 
 template <int MINW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_tally(const TallyArgs a)
@@ -1014,54 +1108,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) v
 	extern __shared__ __attribute__((aligned(16))) uint32_t tally_lds[];
 	const int lane = lane_id();
 	mark_start(a.t_start);
-	const int njobs = uni(*a.n_jobs);
-	// Items are dealt round robin (wave w takes w, w + grid, ...): they are short and alike, and a shared queue costs
-	// every wave a sweep over its eight counters at the end -- 65 000 same-address requests per launch, which at the
-	// ~40 per microsecond one address sustains took longer than the items themselves.
-	for (int j = (int)blockIdx.x; j < njobs; j += (int)gridDim.x) {
+	const int nrec_all = uni(a.n_recs[0]), nrec = nrec_all < a.rec_cap ? nrec_all : a.rec_cap, njobs = nrec + uni(a.n_recs[1]);
+	// Items (the jobs with events, k_tally_prep's records) are dealt round robin (wave w takes w, w + grid, ...): they are short
+	// and alike, and a shared queue costs every wave a sweep over its eight counters at the end -- 65 000 same-address requests
+	// per launch, which at the ~40 per microsecond one address sustains took longer than the items themselves.
+	for (int it = (int)blockIdx.x; it < njobs; it += (int)gridDim.x) {
 		const long long tj0 = a.prof ? (long long)clock64() : 0;
-		// A work item is a few microseconds of arithmetic behind a chain of dependent loads (job -> records -> CIGAR ->
-		// k-mer bytes -> reads); everything that depends on the same level is requested together.
-		const AlnJob jb = a.jobs[j];
-		const int r = jb.region;
-		const KswOut ez = a.ez[jb.out];
-		const long long coff = a.cig_off[jb.out];
-		const long long cstart = a.ctg_start[jb.out], origin = a.ref_origin[r];
-		const long long rr0 = a.region_read_off[r], rr1 = a.region_read_off[r + 1];
+		// the record: one line, a dword per lane (a job that found the array full: the same header, worked out here)
+		long long q_off, t_off, rr0, rr1, base0, end0, coff;
+		int qlen, tlen, r, out, n_cigar, j, ctg_rel, nev, ntrunc; bool packed;
 		CigSrc cig;
-		cig.mem = a.cig_pool + (coff >= 0 ? coff : 0);
-		cig.in_lanes = ez.n_cigar <= 64;
-		cig.cw = (cig.in_lanes && coff >= 0 && lane < ez.n_cigar) ? cig.mem[lane] : 0u;
-		const long long ge0 = rr0 + 64 < rr1 ? rr0 + 64 : rr1;
-		const long long base0 = a.read_off[rr0], end0 = a.read_off[ge0];
-		int nev = 0, ntrunc = 0;
-		if (ez.n_cigar > 0 && coff >= 0) nev = count_events(cig, ez.n_cigar, ez.max_q, &ntrunc);
-		// the 2-bit reads serve the tally when every read of the region is clean (the usual case)
-		bool packed = a.pk != nullptr && nev > 0;
-		if (packed) {
-			bool badr = false;
-			for (long long i = rr0 + lane; i < rr1; i += 64) badr |= a.read_bad[i] != 0;
-			packed = !ballot(badr);
+		if (it < nrec) {
+			const unsigned *rw = (const unsigned *)&a.recs[it];
+			const unsigned w = lane < 24 ? rw[lane] : 0u, cw8 = lane < 8 ? rw[24 + lane] : 0u;
+			auto f32 = [&](int k) { return __builtin_amdgcn_readlane((int)w, k); };
+			auto f64 = [&](int k) { return (long long)(((unsigned long long)(unsigned)f32(k + 1) << 32) | (unsigned)f32(k)); };
+			q_off = f64(0); t_off = f64(2); rr0 = f64(4); rr1 = f64(6); base0 = f64(8); end0 = f64(10); coff = f64(12);
+			qlen = f32(14); tlen = f32(15); r = f32(16); out = f32(17); n_cigar = f32(18); j = f32(19); ctg_rel = f32(20);
+			nev = f32(21); ntrunc = f32(22); packed = f32(23) != 0;
+			cig.mem = a.cig_pool + coff;
+			cig.in_lanes = n_cigar <= 64;
+			cig.cw = n_cigar <= 8 ? cw8 : (cig.in_lanes && lane < n_cigar) ? cig.mem[lane] : 0u;
+		} else {
+			TallyRec R;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) R.cig[i] = 0;
+			(void)tally_make_rec(a, uni(a.ovf_jobs[it - nrec]), R);   // (it has events: k_tally_prep said so)
+			q_off = uni(R.q_off); t_off = uni(R.t_off); rr0 = uni(R.rr0); rr1 = uni(R.rr1); base0 = uni(R.base0); end0 = uni(R.end0); coff = uni(R.coff);
+			qlen = uni(R.qlen); tlen = uni(R.tlen); r = uni(R.region); out = uni(R.out); n_cigar = uni(R.n_cigar); j = uni(R.job); ctg_rel = uni(R.ctg_rel);
+			nev = uni(R.nev); ntrunc = uni(R.ntrunc); packed = uni(R.packed) != 0;
+			cig.mem = a.cig_pool + coff;
+			cig.in_lanes = n_cigar <= 64;
+			cig.cw = (cig.in_lanes && lane < n_cigar) ? cig.mem[lane] : 0u;
 		}
-		long long eoff = -1;
+		long long eoff = (long long)j * a.P.max_events;         // the job's own slots: no atomic
 		const long long tj1 = a.prof ? (long long)clock64() : 0;
 		if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[20], (unsigned long long)(tj1 - tj0));
-		if (nev > 0 && nev <= a.P.max_events) {                 // indelope.nim:229
-			eoff = (long long)j * a.P.max_events;               // the job's own slots: no atomic
-			if (a.prof && lane == 0) atomicAdd((unsigned long long *)&a.prof[21], (unsigned long long)((long long)clock64() - tj1));
-			if (eoff + nev <= a.ev_pool_cap) {
-				fill_events(cig, ntrunc, a.out_seq + jb.q_off, jb.qlen,
-				            (int)(cstart - origin), a.ref_bases + jb.t_off, jb.tlen,
-				            a.bases, a.read_off, a.mapq, rr0, rr1,
-				            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count,
-				            a.hit_pool, a.hit_cursor, a.hit_cap, a.hit_overflow, a.hit_region_cnt ? a.hit_region_cnt + r : nullptr,
-				            8 * rr0, a.hit_bump0, base0, end0, packed ? a.pk : nullptr);
-			} else {
-				if (lane == 0) atomicExch(&a.overflow[2], 1);
-				eoff = -1; nev = 0;
-			}
-		} else nev = 0;
-		if (lane == 0) { a.ev_off[jb.out] = eoff; a.n_ev[jb.out] = nev; }
+		if (eoff + nev <= a.ev_pool_cap) {
+			fill_events(cig, ntrunc, a.out_seq + q_off, qlen,
+			            ctg_rel, a.ref_bases + t_off, tlen,
+			            a.bases, a.read_off, a.mapq, rr0, rr1,
+			            a.P, a.ev_pool + eoff, tally_lds, a.lds_bytes, j, (int)eoff, a.fb_items, a.fb_count,
+			            a.hit_pool, a.hit_cursor, a.hit_cap, a.hit_overflow, a.hit_region_cnt ? a.hit_region_cnt + r : nullptr,
+			            8 * rr0, a.hit_bump0, base0, end0, packed ? a.pk : nullptr);
+		} else {
+			if (lane == 0) atomicExch(&a.overflow[2], 1);
+			eoff = -1; nev = 0;
+		}
+		if (lane == 0) { a.ev_off[out] = eoff; a.n_ev[out] = nev; }
 		WSYNC();
 		if (a.prof && lane == 0) {
 			atomicAdd((unsigned long long *)&a.prof[nev ? 16 : 17], (unsigned long long)((long long)clock64() - tj0));

@@ -197,3 +197,18 @@ def test_regions_with_more_contigs_than_the_short_table(hip, oracle):
     assert (exp_few.n_contigs_pre > 32).sum() == 0
     for b, exp in ((many, exp_many), (many, exp_many), (few, exp_few), (few, exp_few), (many, exp_many), (many, exp_many)):
         _same(hip.run_regions(b, hip.params(K=27)), exp)
+
+
+def test_tally_records_and_the_jobs_that_find_the_array_full(hip, oracle):
+    """k_tally_prep gathers the header of every job with events into one 128-byte record (a thread per job); k_tally takes the
+    records, and the jobs that found the record array full work their header out themselves: the same events, k-mer counts and
+    hit positions with room for every record, for three, and for none."""
+    b = _mixed_batch()
+    exp = oracle.run_regions_mt(b, oracle.params(K=27), 16)
+    assert exp.n_events > 50
+    try:
+        for cap in (0, 3, 1):
+            hip.debug_set(tally_rec_cap=cap)
+            _same(hip.run_regions(b, hip.params(K=27)), exp)
+    finally:
+        hip.debug_set()
