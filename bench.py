@@ -49,7 +49,7 @@ ISSUE_PEAK_ARCH = 2.0          # MI355X_MICROARCH.md: a SIMD-32 issues a wave64 
 PMC_FILE = os.path.join("profiles", "r05_c2_pmc.json")
 MIX_FILE = os.path.join("profiles", "r05_c2_pmc_mix.json")
 STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_prepack_fast", "k_slab_expand", "k_asm_reads", "k_asm_combine3", "k_assemble"),
-                 "k_ksw": ("k_ksw", "k_ksw_pair", "k_ksw_plan_count", "k_ksw_plan_place"), "k_tally": ("k_tally",)}
+                 "k_ksw": ("k_ksw", "k_ksw_pair", "k_ksw_plan_count", "k_ksw_plan_place"), "k_tally": ("k_tally_prep", "k_tally")}
 
 
 def src_sha16():
