@@ -39,7 +39,7 @@ names = {"c2_kernel_stats.csv": "c2_kernel_stats.csv", "c2_pmc.json": "c2_pmc.js
          "c5_phase_cycles.json": "c5_phase_cycles.json", "resource_usage.txt": "resource_usage.txt", "ubench_ksw.txt": "ubench_ksw.txt",
          "ksw_pair_pmc.json": "ksw_pair_pmc.json", "ksw_pair_pmc.txt": "ksw_pair_pmc.txt", "dup10_kernel_stats.csv": "dup10_kernel_stats.csv",
          "dup10_pmc_mix.json": "dup10_pmc_mix.json", "dup10_summary.txt": "dup10_summary.txt", "prepack_compare.txt": "prepack_compare.txt",
-         "e2e_bench.json": "e2e_bench.json", "e2e_host_time.txt": "e2e_host_time.txt"}
+         "e2e_bench.json": "e2e_bench.json", "e2e_host_time.txt": "e2e_host_time.txt", "combine_occupancy.txt": "combine_occupancy.txt"}
 refused = 0
 for a, b in names.items():
     p = os.path.join(src, a)

@@ -113,6 +113,15 @@ for f in ("gpurun_out/prof/dup10_summary.txt", "gpurun_out/prof/prepack_compare.
     except Exception as e:
         print("stamp", f, e)
 PY
+# round 5: k_asm_combine3 against the regions a CU holds (whole LDS granules: 12, 14, 16, 18, 21 per CU)
+bash tools/r5_occ.sh "comb_occ=10" "comb_occ=12" "comb_occ=14" "comb_occ=16" "comb_occ=18" "" "comb_minw=5" > $OUT/combine_occupancy.txt 2>&1
+python3 - <<'PY'
+import sys
+sys.path.insert(0, ".")
+import bench
+f = "gpurun_out/prof/combine_occupancy.txt"
+t = open(f).read(); open(f, "w").write("src_sha16 %s  (tools/r5_occ.sh: steady 100 000-region launches; [knobs]: regions/s, ms per step; the tier line; k_asm_combine3's average launch)\n" % bench.src_sha16() + t)
+PY
 # the raw rocprofv3 output directories are large (gpurun merges at most 64 MiB back): keep the summaries only
 rm -rf $OUT/c2 $OUT/steady100k $OUT/c3 $OUT/c5 $OUT/fetch $OUT/write gpurun_out/pmc_mix/g1 gpurun_out/pmc_mix/g2 gpurun_out/pmc_mix/g3
 du -sh gpurun_out
