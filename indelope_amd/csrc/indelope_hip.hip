@@ -75,7 +75,7 @@ struct Knobs {
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
 	int tally_rec_cap = 0; // test hook: records k_tally_prep may write (the other jobs with events take k_tally's own header path)
 	int tally_minw = 8;    // waves per SIMD k_tally is compiled for (6: 78 VGPRs; 7: 72; 8: 64 and 20 bytes of scratch -- the kernel waits for memory 41 % of its time: 0.86 -> 0.79 ms per 100 000 C2 regions)
-	int comb_minw = 6;     // waves per SIMD the first combine tier's build is compiled for (5: 95 VGPRs; 6: 80; 7: 72 -- with spills)
+	int comb_minw = 5;     // waves per SIMD the first combine tier's build is compiled for (5: 95 VGPRs, 20 regions per CU; 6: 80 and 7: 72 -- with spills: 21 regions per CU run no faster than the 20 of the build without)
 	int spec_fail = 0;     // test hook: 1 = a run that left the retry launches out is treated as if a region had needed them
 	int tally_pk = 1;      // 0: k_tally reads the ASCII bases even when k_prepack's 2-bit reads are at hand
 	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
@@ -1198,16 +1198,17 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 	const int R = b->R;
 	const long long nb1 = b->v2_nb1, stat = comb_stat(), stat_a = b->tier_wide ? comb_stat() : comb_stat_a();
 	// Regions per CU.  The launch is bound by the latency of every region's chain and runs in proportion to the regions a CU
-	// holds until about 21 of them (C2, per 100 000 regions: 10 per CU 4.74 ms, 12: 3.95, 14: 3.14, 16: 2.83, 18: 2.89 with
-	// the six-wave build's spills, 21: 2.64; 24: 2.73): round 5 gave the first tier a build with a contig table of 32 entries
-	// (1.7 KB instead of 3.2; regions with more contigs are filed under the second tier, or the first tier runs the full-table
-	// build when they are many) compiled for six waves per SIMD, and sizes every tier in whole LDS granules.
+	// holds until about 20 of them (C2, per 100 000 regions: 10 per CU 4.53 ms, 12: 3.87, 14: 3.43, 16: 3.11, 18: 2.89, 20: 2.61;
+	// a build for six waves per SIMD -- 80 VGPRs, 19 of them spilled -- with 21: 2.64, with 24: 2.73;
+	// profiles/r05_combine_occupancy.txt): round 5 gave the first tier a build with a contig table of 32 entries (1.7 KB instead
+	// of 3.2; regions with more contigs are filed under the second tier, or the first tier runs the full-table build when they
+	// are many) and sizes every tier in whole LDS granules: six a wave, 20 regions per CU at the build's 95 VGPRs.
 	// (Round 3 took 14 for launches of about one round of regions per wave slot: such a launch lasts as long
 	// as its heaviest regions, and a caller that waited for every batch before starting the next saw those run faster with
 	// fewer waves beside them.  A caller that keeps batches in flight -- a sweep, bench.py since round 4 -- has another
 	// chain's kernels in those tails.)
 	const int occ_hw = 4 * std::max(5, std::min(7, g_knob.comb_minw));
-	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : std::min(occ_hw, 21);
+	const int occ_max = g_knob.comb_occ ? g_knob.comb_occ : 21;   // (six LDS granules a wave; the five-wave build keeps 20 of them resident)
 	long long need_C = std::max<long long>(1024, (nb1 * 30 / 100 + 512 + 15) / 16 * 16);   // the usual region needs 0.2-0.3 of its read bases in these units; the rest goes to the roomier launches
 	int occ_c = std::max(1, std::min(occ_max, comb_occ_of(need_C, stat_a)));
 	// occ_first: what the last batch of this shape needed (the tier histogram) -- below OR above what the read bases suggest
@@ -1803,7 +1804,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest.
 			// The histogram's capacities are those of the build the last batch ran (H.wide); when the build changes the tiers
 			// are first cut for it from the read bases and settle with the batch after.
-			const int occ_lim = std::min(21, 4 * std::max(5, std::min(7, g_knob.comb_minw)));   // (above 21 regions per CU the launch gains nothing more)
+			const int occ_lim = 21;                                  // (above 20-21 regions per CU the launch gains nothing more)
 			int want = 0, want_all = 0;
 			long long cum = 0;
 			for (int k = 0; k < HIST_N; ++k) {

@@ -114,7 +114,7 @@ for f in ("gpurun_out/prof/dup10_summary.txt", "gpurun_out/prof/prepack_compare.
         print("stamp", f, e)
 PY
 # round 5: k_asm_combine3 against the regions a CU holds (whole LDS granules: 12, 14, 16, 18, 21 per CU)
-bash tools/r5_occ.sh "comb_occ=10" "comb_occ=12" "comb_occ=14" "comb_occ=16" "comb_occ=18" "" "comb_minw=5" > $OUT/combine_occupancy.txt 2>&1
+bash tools/r5_occ.sh "comb_occ=10" "comb_occ=12" "comb_occ=14" "comb_occ=16" "comb_occ=18" "" "comb_minw=6" "comb_minw=6 v2_arena=2768 asm_waves=24" > $OUT/combine_occupancy.txt 2>&1
 python3 - <<'PY'
 import sys
 sys.path.insert(0, ".")
