@@ -601,9 +601,13 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 	if (lane < 16) S.cnt[lane] = 0;
 	WAVE_SYNC();
 	int n_items = a.in_list ? *a.n_in : a.n_regions;
+	// The cost classes laid end to end: lane c keeps where class c ends (the counts are final: the read phase's kernel is over).  An
+	// item is then a ballot and a v_readlane away from its (class, position) -- the loop over the classes' counts that used to stand
+	// here was up to fifteen scalar loads, each behind a branch on the one before: ~9 us of a C2 region's ~120.
+	int cls_end = 0;
 	if (a.lpt_cnt) {
-		n_items = 0;
-		for (int c = 0; c < a.lpt_nclass; ++c) n_items += uni(a.lpt_cnt[c]);
+		cls_end = (int)wave_scan_add(lane < a.lpt_nclass ? (unsigned)a.lpt_cnt[lane] : 0u);
+		n_items = __builtin_amdgcn_readlane(cls_end, 63);
 	}
 	unsigned wq_dead = 0;
 	for (;;) {
@@ -612,10 +616,10 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 		int r = __builtin_amdgcn_readfirstlane(s_item);
 		WAVE_SYNC();
 		if (r < 0) break;
-		if (a.lpt_cnt) {                                        // item -> (class, position): the classes laid end to end
-			int c = 0;
-			for (; c < a.lpt_nclass - 1; ++c) { const int nc_ = uni(a.lpt_cnt[c]); if (r < nc_) break; r -= nc_; }
-			r = uni(a.lpt_seg[(size_t)c * a.lpt_stride + r]);
+		if (a.lpt_cnt) {                                        // item -> (class, position)
+			const int c = popc64(ballot(lane < a.lpt_nclass && r >= cls_end));
+			const int pos = r - (c ? __builtin_amdgcn_readlane(cls_end, c - 1) : 0);
+			r = uni(a.lpt_seg[(size_t)c * a.lpt_stride + pos]);
 		} else if (a.in_list) r = a.in_list[r];
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
