@@ -140,6 +140,7 @@ const
   IHP_UNALIGNED* = low(int64)             # contig.nim:27
   IHP_ALLOW_DEFAULT* = 0.cint             # contig.nim:44-47
   IHP_ALLOW_SUPPORT* = 1.cint             # contig.nim:287-290 (the reference's test rule)
+  IHP_E_ARG* = -3.cint
   IHP_E_CAPACITY* = -5.cint
   IHP_ALN_DONE* = 1'i32
   IHP_EV_TALLIED* = 0'u8
@@ -191,6 +192,9 @@ proc ihp_batch_upload_slab2*(p: ptr IhpParams, n_regions: int32, n_reads: int64,
                              flags: int32, b: ptr ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_host_alloc*(bytes: csize_t): pointer {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
+const
+  IHP_FETCH_NO_BASES* = 1'i32   ## ihp_batch_fetch brings everything but the contigs' bases and supports
+  IHP_FETCH_EAGER* = 2'i32      ## every run also counts what its results will take: the fetch is one enqueue and one wait
 proc ihp_batch_set_fetch*(b: ptr IhpBatch, flags: int32): cint {.importc, cdecl, header: "indelope_hip.h".}
 # timing and diagnostics (what bench.py and the tests read; a caller needs none of them)
 proc ihp_batch_set_timing*(b: ptr IhpBatch, on: cint): cint {.importc, cdecl, header: "indelope_hip.h".}
@@ -331,6 +335,48 @@ proc run*(s: var Stager, p: var IhpParams, outp: var IhpBatchOut): cint =
   s.fill(b)
   result = ihp_run_regions(addr p, addr b, addr outp)
 
+
+# ---- ONE host thread, several batches in flight (what bench.py measures as `sustained_one_thread`) -------------------------------
+# ihp_batch_upload_slab2 and ihp_batch_run only enqueue (the slab's copy, the kernels), so the thread that walks gen_roi can hand
+# over batch k+2 while batch k+1 runs and batch k's results travel back: three in flight keep the copy engine and the compute
+# units busy from one thread (5.0-5.7 M regions/s on C2 against 2.9 M one batch at a time).  The stager's arrays of a batch must
+# outlive it (ihp_call_variants reads them when the batch is collected), so a caller keeps one Stager per batch in flight.
+type
+  InFlight* = object
+    b*: ptr IhpBatch
+    slab*: pointer                       ## from ihp_host_alloc: untouched until the batch's first wait has returned
+  Pipeline* = object
+    q*: seq[InFlight]                    ## oldest first
+    depth*: int                          ## 3: one batch uploading, one running, one on its way back
+
+proc submit*(pl: var Pipeline, s: var Stager, p: var IhpParams): cint =
+  ## The staged batch enqueued: compact slab, upload, run.  Returns at once.  (A batch that does not fit the slab's 16 / 32-bit
+  ## fields: collect everything in flight, then `s.run`.)
+  var L: IhpSlab2Layout
+  var flags: int32
+  let slab = s.fill_slab2(L, flags)
+  if slab == nil: return IHP_E_ARG
+  var b: ptr IhpBatch
+  result = ihp_batch_upload_slab2(addr p, int32(s.ref_origin.len), int64(s.read_start.len), slab, addr L, flags, addr b)
+  if result == 0:
+    discard ihp_batch_set_fetch(b, IHP_FETCH_NO_BASES or IHP_FETCH_EAGER)
+    result = ihp_batch_run(b)
+    if result != 0: ihp_batch_free(b)
+  if result != 0:
+    ihp_host_free(slab)
+    return
+  pl.q.add InFlight(b: b, slab: slab)
+
+proc collect*(pl: var Pipeline, outp: var IhpBatchOut): cint =
+  ## Waits for the OLDEST batch and fetches its results (ihp_free_out when done with them); its slab is free again.
+  let f = pl.q[0]
+  pl.q.delete(0)
+  result = ihp_batch_fetch(f.b, addr outp)
+  ihp_batch_free(f.b)
+  ihp_host_free(f.slab)
+
+# the sweep:   for every full stager:  if pl.q.len == pl.depth: (collect the oldest, print its variants);  pl.submit(stager, p)
+#              at the end:             while pl.q.len > 0: collect, print
 
 # ---- the main loop of indelope.nim:601-608 over batches ---------------------------------------------------------
 # `flush` runs one staged batch and prints what the reference's loop would have printed for those regions, in region
