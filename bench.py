@@ -844,6 +844,9 @@ def main():
             if block_cur[0] + v.numel() > blockbuf.numel():
                 block_cur[0] = 0                                 # (untimed blocks of another length wrap around)
             blockbuf[block_cur[0]:block_cur[0] + v.numel()].copy_(v)
+            # the copy runs on torch's stream and the batch's next run -- on the batch's OWN stream -- rewrites `summary` with its
+            # k_summary: the copy has to be over before that run is enqueued (it used to be ordered by timing only)
+            torch.cuda.current_stream().synchronize()
             block_slots[i] = block_cur[0]
             block_cur[0] += v.numel()
 

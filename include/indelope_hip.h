@@ -579,6 +579,51 @@ int  ihp_batch_summary_ptr(ihp_batch *b, void **dev_ptr, int64_t *n);
 /* The same records copied to the host (cap >= n_regions entries).             */
 int  ihp_batch_summary_host(ihp_batch *b, ihp_region_summary *out, int64_t cap);
 
+
+/* ------------------------------------------------- multi-GPU: one process per GPU, ONE gather at the end
+ * Regions are independent past indelope.nim:601-603, so every rank runs a contiguous range of them through the entry points
+ * above with no collective on the data path.  What the reference's main loop needs afterwards is every region's records in
+ * REGION ORDER ON ONE RANK: its last-two-variants dedupe (indelope.nim:604-608) is sequential.  These entry points are that
+ * one exchange, over librccl directly (ncclCommInitRank; grouped ncclSend / ncclRecv to the root -- every peer over its own
+ * xGMI link, no ring: a ring gather is bound by one link, the root's seven links take seven peers at once).  librccl.so.1 is
+ * opened with dlopen by the first ihp_dist_* call: a single-GPU caller never loads it, and a box without it gets
+ * IHP_E_UNSUPPORTED (text in ihp_last_hip_error), not a failure to load this library.
+ *
+ *   rank 0:        ihp_dist_unique_id(id)         -> the caller carries the 128 bytes to the other ranks (file, pipe, MPI, env ...)
+ *   every rank:    ihp_init(local_gpu); ihp_dist_init(rank, world, id, &d)
+ *                  ... ihp_batch_upload / ihp_batch_run over the rank's regions ...
+ *                  ihp_dist_gather_summaries(d, b, 0, ...)        the 32-byte records, rank (= region) order, on the root's host
+ *                  ihp_dist_gather_payload(d, b, 0, outs)         the full results: one ihp_batch_out per rank on the root
+ *                  ihp_dist_finalize(d)
+ * Calls on one communicator are collective: every rank makes the same calls in the same order.  One host thread per
+ * communicator at a time.                                                                                                     */
+typedef struct ihp_dist ihp_dist;
+#define IHP_DIST_ID_BYTES 128
+/* ncclGetUniqueId (no GPU needed yet).  cap >= IHP_DIST_ID_BYTES.                                                             */
+int  ihp_dist_unique_id(void *id, int64_t cap);
+/* ncclCommInitRank on the library's device (ihp_init first: rank r of a node binds GPU r).  Blocks until all `world` ranks
+ * have arrived.                                                                                                               */
+int  ihp_dist_init(int32_t rank, int32_t world, const void *id, int64_t id_bytes, ihp_dist **out);
+int  ihp_dist_rank(const ihp_dist *d);
+int  ihp_dist_world(const ihp_dist *d);
+/* n records of 32 bytes in device memory (final: the caller has waited for the runs that wrote them -- ihp_batch_sync) from
+ * every rank to `root`.  counts_in: records per rank [world] when every rank knows them (contiguous shards: it does), or NULL:
+ * they are exchanged first (one ncclAllGather of an int64 each).  On the root: out (host, cap records) gets the records in
+ * rank order, *n_total their number, counts_out [world] (optional) the per-rank counts; the other ranks pass what they like
+ * there (ignored).  IHP_E_CAPACITY when cap is short (after the exchange: the communicator stays usable).                     */
+int  ihp_dist_gather_records(ihp_dist *d, const void *dev_records, int64_t n, int32_t root, const int64_t *counts_in,
+                             ihp_region_summary *out, int64_t cap, int64_t *n_total, int64_t *counts_out);
+/* The same for a batch: waits for and confirms b's run (as ihp_batch_summary_dev does), then gathers its n_regions records.   */
+int  ihp_dist_gather_summaries(ihp_dist *d, ihp_batch *b, int32_t root, const int64_t *counts_in,
+                               ihp_region_summary *out, int64_t cap, int64_t *n_total, int64_t *counts_out);
+/* The variable-length half: every rank compacts b's results on its device (ihp_batch_pack_dev), the sizes go round in one
+ * ncclAllGather of seven int64, the slabs travel to the root point to point -- all receives posted before any is waited for --
+ * and arrive as outs[0 .. world) on the root (rank order = region order; each is released with ihp_free_out; genotypes filled
+ * in as by ihp_batch_fetch).  Other ranks: outs is ignored.  bytes_out (optional, root): bytes received per rank.               */
+int  ihp_dist_gather_payload(ihp_dist *d, ihp_batch *b, int32_t root, ihp_batch_out *outs, int64_t *bytes_out);
+/* ncclCommDestroy and the communicator's buffers.  NULL is fine.                                                              */
+int  ihp_dist_finalize(ihp_dist *d);
+
 #ifdef __cplusplus
 }
 #endif

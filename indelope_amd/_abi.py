@@ -250,7 +250,17 @@ _PRODUCT_ONLY = {
     "debug_limits": (C.c_int, [i64p]),
     "debug_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "ksw_last_status": (C.c_int, []),
+    # multi-GPU (dist_host.h): the end-of-job gather over librccl behind the C ABI
+    "dist_unique_id": (C.c_int, [C.c_void_p, C.c_int64]),
+    "dist_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "dist_rank": (C.c_int, [C.c_void_p]),
+    "dist_world": (C.c_int, [C.c_void_p]),
+    "dist_gather_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, i64p, C.c_void_p, C.c_int64, i64p, i64p]),
+    "dist_gather_summaries": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, i64p, C.c_void_p, C.c_int64, i64p, i64p]),
+    "dist_gather_payload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(BatchOut), i64p]),
+    "dist_finalize": (C.c_int, [C.c_void_p]),
 }
+IHP_DIST_ID_BYTES = 128
 
 KSW_ARGTYPES = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
                 C.c_int, C.c_int, C.c_int, C.POINTER(KswExtz)]

@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
     if hips and (force or _stale(lib, hips + hdrs)):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, "-I", CSRC,
                "-Wall", "-Wno-unused-function", "-ffp-contract=off",
-               "-o", lib] + hips
+               "-o", lib] + hips + ["-ldl"]      # dlopen: librccl.so.1 is opened by the first ihp_dist_* call, not linked
         if os.environ.get("IHP_SAVE_TEMPS"):
             cmd[1:1] = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
         if verbose:

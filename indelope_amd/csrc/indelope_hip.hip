@@ -99,7 +99,10 @@ Knobs g_knob;
 constexpr int HIST_N = 11;
 constexpr int HIST_OCC[HIST_N] = {25, 21, 18, 16, 14, 12, 11, 10, 9, 8, 7};     // what 128 LDS granules per CU divide into (see LDS_GRAN)
 constexpr int COMB_MAXC_A = 32;                              // contigs the first combine tier's build keeps a table for (V3StateT, asm3_dev.h)
-struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+// clean: batches of this shape in a row, up to now, without a region of more than COMB_MAXC_A contigs (what the short table of a first
+// tier that walks the other tiers' lists rests on; see ihp_batch_run)
+constexpr int CLEAN_MIN = 3;
+struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0, clean = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
 // One hint per batch SHAPE (hint_key: read length, read bases per region, the packed / byte-based path, the parameters that
 // decide which launches a run needs), sixteen shapes remembered: a sweep that interleaves batches of different shapes, or
 // several host threads with different workloads, keep their plans apart (round 3 had one process-wide hint; only the tier
@@ -1748,7 +1751,12 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	// counters, stamps, work queues and per-region hit counts are zero: cleared at upload and by the previous run's k_summary
 	int *wq = b->queues_dev();
 	const bool profiling = g_knob.profile != 0;
-	if (b->dirty) HIPC(hipMemsetAsync(b->misc.p, 0, b->z_bytes(), s));     // the previous run ended before its k_summary was enqueued
+	if (b->dirty) {                                                         // the previous run ended before its k_summary was enqueued
+		// (everything but M_SLAB_BAD: k_slab_expand raises it ONCE, at upload, and it has to reach the first wait however many runs
+		// -- cut short or not -- lie in between)
+		HIPC(hipMemsetAsync(b->misc.p, 0, sizeof(int) * M_SLAB_BAD, s));
+		HIPC(hipMemsetAsync((char *)b->misc.p + sizeof(int) * (M_SLAB_BAD + 1), 0, b->z_bytes() - sizeof(int) * (M_SLAB_BAD + 1), s));
+	}
 	b->dirty = true;
 	if (profiling) HIPC(hipMemsetAsync(b->prof.p, 0, sizeof(long long) * 64, s));
 	int *misc = b->misc.as<int>();
@@ -1798,7 +1806,15 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			const long long tot = H.regions;
 			// more than a hundredth of the regions with more contigs than the short table holds: the first tier runs the build with
 			// the full table (C3, C5: 6-7 % -- a second tier for them alone, at two thirds of the occupancy, every step)
-			const bool wide = (long long)H.n_manyc * 100 > tot;
+			// A first tier that walks the other tiers' lists behind its own (no launch for them: fold_b / fold_c below) meets
+			// whatever region is filed there -- with the short table a region of more than COMB_MAXC_A contigs is refused by
+			// v3_take_over, lands on the retry list, and a run that left the retry launches out is then repeated in full: a
+			// sweep whose batches hold such a region now and then paid twice for every batch that followed one without
+			// (ADVICE r5).  So the short table serves a folding first tier only when the last CLEAN_MIN batches of the shape
+			// had no such region at all; until then (and again after every batch that had one) it runs the full-table build,
+			// which takes them where they are filed.
+			const bool folds = H.n_c == 0;
+			const bool wide = (long long)H.n_manyc * 100 > tot || (folds && H.clean < CLEAN_MIN);
 			// a tier of its own for a few percent of the regions costs a round of the heaviest ones at the end: when a first tier
 			// of not much lower occupancy holds (nearly) all regions -- a narrow distribution just above the predicted arena --
 			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest.
@@ -1918,7 +1934,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// scheduled, 0.05-0.3 ms on the critical path in front of k_ksw while another batch's kernels fill the CUs: the first
 			// tier's launch walks its lists behind its own instead (a straggler does not fit there and takes the retry route).
 			const bool hint = have_hint;
-			const bool fold_c = hint && H.n_c == 0, fold_b = fold_c && H.n_b == 0;
+			// (never with the short table before the shape has been clean for CLEAN_MIN batches: see `wide` above -- this is the case
+			// in which the tiers were not cut again, e.g. under the occupancy knobs)
+			const bool fold_c = hint && H.n_c == 0 && (b->tier_wide || H.clean >= CLEAN_MIN), fold_b = fold_c && H.n_b == 0;
 			HIPC(hipEventRecord(b->ev_bfork, s));
 			// The second tier runs beside the first on the other stream -- if its workgroups find LDS: the first tier's persistent
 			// grid fills every CU and keeps it until its queue is dry, so a second tier launched next to it in fact ran behind it
@@ -2126,7 +2144,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.status = b->status.as<int>(); a.n_pre = b->n_pre.as<int>(); a.n_final = b->n_final.as<int>();
 		a.aln_flags = b->aln_flags.as<int>(); a.n_ev = b->n_ev.as<int>(); a.ev_off = b->ev_off.as<long long>();
 		a.ev_pool = b->ev_pool.as<DevEvent>(); a.out = b->summary.as<ihp_region_summary>();
-		a.zero = misc; a.n_zero = (int)(b->z_bytes() / sizeof(int)); a.n_report = REPORT_INTS;
+		a.zero = misc; a.n_zero = (int)(b->z_bytes() / sizeof(int)); a.n_report = REPORT_INTS; a.sticky = M_SLAB_BAD;
 		HIPC(hipHostGetDevicePointer((void **)&a.report, b->report, 0));
 		a.t_end = tm ? (int)(ihp_batch::Z_TIMES / sizeof(int)) + 14 : -1;    // stamp [7]
 		hipLaunchKernelGGL(k_summary, dim3((b->R + 255) / 256), dim3(256), 0, s, a);
@@ -2185,6 +2203,8 @@ static void hint_refresh(const ihp_batch *b)
 	if (b->v2 && g_knob.lpt) {
 		for (int k = 0; k < HIST_N; ++k) h.hist[k] = b->report[M_HIST + k];
 		h.n_manyc = b->report[M_MANYC]; h.wide = b->tier_wide ? 1 : 0;
+		TierHint prev;
+		h.clean = h.n_manyc == 0 ? std::min(1 << 20, (g_hints.get(b->hint_key, prev) ? prev.clean : 0) + 1) : 0;
 		h.regions = b->n_cls[0] - b->report[M_NRETRY0]; h.sig = b->tier_sig;
 	}
 	if (g_knob.verbose) fprintf(stderr, "[ihp] confirmed: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);
@@ -2751,3 +2771,6 @@ extern "C" int ihp_run_regions(const ihp_params *p, const ihp_batch_in *in, ihp_
 	ihp_batch_free(b);
 	return rc;
 }
+
+// ---- multi-GPU: the end-of-job gather over RCCL behind the C ABI (dist_host.h) -----------------------------------
+#include "dist_host.h"

@@ -1433,6 +1433,8 @@ struct SummaryArgs {
 	// everything the next run expects to be zero is cleared here, so a run needs no memset
 	int *zero; int n_zero;           // counters | stamps | work queues | per-region hit counts, in ints
 	int *report; int n_report;       // the first n_report ints of `zero`
+	int sticky;                      // the one int of `zero` that is reported and NOT cleared: raised once per batch (k_slab_expand), it has to
+	                                 // be in every run's report until a wait has latched it (upload, run, run, sync; a run cut short)
 	int t_end;                       // >= 0: the two ints at this index of `report` get the device wall clock at the start of this
 	                                 // launch (= the end of the stage before it, in stream order)
 };
@@ -1445,7 +1447,7 @@ __global__ void k_summary(const SummaryArgs a)
 		const int nt = (int)(gridDim.x * blockDim.x);
 		for (int i = r; i < a.n_zero; i += nt) {
 			if (i < a.n_report) a.report[i] = a.zero[i];
-			a.zero[i] = 0;
+			if (i != a.sticky) a.zero[i] = 0;
 		}
 		if (a.t_end >= 0 && r == a.t_end) { a.report[r] = (int)(unsigned)t_now; a.report[r + 1] = (int)(unsigned)(t_now >> 32); }
 	}

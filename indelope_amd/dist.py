@@ -1,7 +1,15 @@
 """Multi-GPU sharding of the per-region path: one process per GPU, contiguous region ranges per rank
 (regions are independent), no collective on the data path, and ONE gather of the fixed-size
-per-region summary records to rank 0 at the end (RCCL over xGMI with backend "nccl"; "gloo" in CPU tests).
+per-region summary records to rank 0 at the end.
+
+On GPUs the gather is the library's own (`Communicator`: ctypes over ihp_dist_* of include/indelope_hip.h, which
+drives librccl directly -- the same entry points the Nim host binds, nim/indelope_hip.nim); torch is then only
+the launcher (torchrun's RANK / WORLD_SIZE and the store that carries the 128-byte id).  The torch functions
+below (`gather_summaries`, `gather_payload`) are the same exchange on a torch process group: what the CPU tests
+run on gloo, where there is no device and no RCCL.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _abi as A
@@ -105,3 +113,113 @@ def gather_summaries(local, rank, world, dst=0, force=False):
     if rank != dst:
         return None
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+class Communicator:
+    """ihp_dist over ctypes: ncclCommInitRank on the library's device, grouped send / recv to the root (dist_host.h).
+
+    `api` is the HipApi of this process (api.init(local_gpu) done); `exchange_id(id_bytes_or_None) -> bytes` carries
+    rank 0's 128-byte id to every rank (a torch.distributed broadcast, a file, MPI ...): it gets the id on rank 0 and
+    None elsewhere, and returns the id everywhere."""
+
+    def __init__(self, api, rank, world, exchange_id):
+        self.api, self.rank, self.world = api, int(rank), int(world)
+        buf = (C.c_uint8 * A.IHP_DIST_ID_BYTES)()
+        mine = None
+        if self.rank == 0:
+            api._chk_hip(api.b.dist_unique_id(buf, A.IHP_DIST_ID_BYTES), "dist_unique_id")
+            mine = bytes(buf)
+        ident = exchange_id(mine)
+        if len(ident) != A.IHP_DIST_ID_BYTES:
+            raise ValueError("the id is %d bytes, not %d" % (len(ident), A.IHP_DIST_ID_BYTES))
+        C.memmove(buf, ident, A.IHP_DIST_ID_BYTES)
+        self.h = C.c_void_p()
+        api._chk_hip(api.b.dist_init(self.rank, self.world, buf, A.IHP_DIST_ID_BYTES, C.byref(self.h)), "dist_init")
+
+    def _counts(self, counts):
+        if counts is None:
+            return None, None
+        c = np.ascontiguousarray(counts, np.int64)
+        assert len(c) == self.world
+        return c, A.ptr(c, A.i64p)
+
+    def gather_records(self, dev_ptr, n, root=0, counts=None, cap=None):
+        """n 32-byte records at device address dev_ptr (final) -> SUMMARY_DTYPE array in rank order on `root`, None elsewhere."""
+        c, cp = self._counts(counts)
+        total = int(c.sum()) if c is not None else (int(cap) if cap is not None else None)
+        if total is None:
+            raise ValueError("counts or cap: the root has to size its buffer")
+        out = np.zeros(max(1, total), A.SUMMARY_DTYPE) if self.rank == root else None
+        n_total, counts_out = C.c_int64(), np.zeros(self.world, np.int64)
+        self.api._chk_hip(self.api.b.dist_gather_records(self.h, C.c_void_p(dev_ptr), int(n), root, cp,
+                                                         out.ctypes.data_as(C.c_void_p) if out is not None else None, total,
+                                                         C.byref(n_total), A.ptr(counts_out, A.i64p)), "dist_gather_records")
+        return (out[:n_total.value], counts_out) if self.rank == root else None
+
+    def gather_summaries(self, batch_handle, n_regions, root=0, counts=None, cap=None):
+        """The records of a batch (its run is waited for and confirmed first)."""
+        c, cp = self._counts(counts)
+        total = int(c.sum()) if c is not None else (int(cap) if cap is not None else int(n_regions) * self.world)
+        out = np.zeros(max(1, total), A.SUMMARY_DTYPE) if self.rank == root else None
+        n_total, counts_out = C.c_int64(), np.zeros(self.world, np.int64)
+        self.api._chk_hip(self.api.b.dist_gather_summaries(self.h, batch_handle, root, cp,
+                                                           out.ctypes.data_as(C.c_void_p) if out is not None else None, total,
+                                                           C.byref(n_total), A.ptr(counts_out, A.i64p)), "dist_gather_summaries")
+        return (out[:n_total.value], counts_out) if self.rank == root else None
+
+    def gather_payload(self, batch_handle, root=0):
+        """Every rank's full results on `root`: [BatchResult] in rank (= region) order and the bytes received per rank."""
+        from .host import BatchResult
+        outs = (A.BatchOut * self.world)()
+        nbytes = np.zeros(self.world, np.int64)
+        self.api._chk_hip(self.api.b.dist_gather_payload(self.h, batch_handle, root, outs, A.ptr(nbytes, A.i64p)), "dist_gather_payload")
+        if self.rank != root:
+            return None
+        res = []
+        try:
+            for r in range(self.world):
+                res.append(BatchResult(outs[r]))
+        finally:
+            for r in range(self.world):
+                self.api.b.free_out(C.byref(outs[r]))
+        return res, nbytes
+
+    def close(self):
+        if self.h:
+            self.api.b.dist_finalize(self.h)
+            self.h = C.c_void_p()
+
+
+def torch_id_exchange(device=None):
+    """exchange_id for Communicator over an initialised torch.distributed group (any backend): one 128-byte broadcast."""
+    import torch
+    import torch.distributed as dist
+
+    def ex(mine):
+        t = torch.zeros(A.IHP_DIST_ID_BYTES, dtype=torch.uint8, device=device if device is not None else "cpu")
+        if mine is not None:
+            t.copy_(torch.frombuffer(bytearray(mine), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+    return ex
+
+
+def file_id_exchange(path, timeout=120.0):
+    """exchange_id through a file every rank can see (no torch at all: what a Nim / C launcher would do)."""
+    import os
+    import time
+
+    def ex(mine):
+        if mine is not None:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(mine)
+            os.replace(tmp, path)
+            return mine
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("no id at " + path)
+            time.sleep(0.01)
+        return open(path, "rb").read()
+    return ex

@@ -281,7 +281,9 @@ proc fill*(s: var Stager, b: var IhpBatchIn) =
 
 proc fill_slab2*(s: var Stager, L: var IhpSlab2Layout, flags: var int32): pointer =
   ## The staged batch as ONE page-locked compact slab (ihp_slab2_layout): what goes over PCIe in a single copy.  Needs the trim
-  ## bounds (trim_on_host).  nil when a read does not fit the 16 / 32-bit fields (the caller then uses `fill` + the arrays).
+  ## bounds (trim_on_host).  nil when a read does not fit the 16 / 32-bit fields or a base has no 4-bit code -- a lower-case
+  ## (soft-masked) window base, any byte outside "=ACMGRSVTWYHKDBN" -- (the caller then uses `fill` + the arrays, whose kernels
+  ## take lower case as ksw2.nim:127-132 does).  Every base is checked BEFORE anything is written: find() == -1 never reaches uint8().
   ## A stager that holds hts Records writes `bases4` with a copy of bam_get_seq() per read instead of re-encoding the ASCII.
   let nreg = int32(s.ref_origin.len)
   let nr = int64(s.read_start.len)
@@ -289,6 +291,12 @@ proc fill_slab2*(s: var Stager, L: var IhpSlab2Layout, flags: var int32): pointe
   for c in s.ref_bases:
     if c != uint8('A') and c != uint8('C') and c != uint8('G') and c != uint8('T'): two_bit = false
   flags = if two_bit: IHP_SLAB2_REF_2BIT else: 0'i32
+  const codes4 = "=ACMGRSVTWYHKDBN"
+  for c in s.bases:
+    if codes4.find(char(c)) < 0: return nil
+  if not two_bit:
+    for c in s.ref_bases:
+      if codes4.find(char(c)) < 0: return nil      # e.g. hg19 / hg38 soft-masked lower case: the arrays carry it as it is
   if ihp_slab2_layout_for(nreg, nr, int64(s.bases.len), int64(s.ref_bases.len), flags, addr L) != 0: return nil
   result = ihp_host_alloc(csize_t(L.bytes))
   if result == nil: return nil

@@ -1,0 +1,187 @@
+"""Round 6: the end-of-job gather behind the C ABI (RCCL, ihp_dist_*), the launch-plan and compact-slab regressions of ADVICE r5."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from indelope_amd import _abi as A
+from indelope_amd import dist as idist
+from indelope_amd import synth
+from indelope_amd.host import BatchResult, RegionBatch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(got, exp):
+    d = BatchResult.first_difference(got, exp)
+    assert d is None, d
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU behind the C ABI
+def test_gather_in_a_group_of_one_through_the_c_entry_points(hip, oracle):
+    """ihp_dist_unique_id / ihp_dist_init / ihp_dist_gather_summaries / ihp_dist_gather_payload / ihp_dist_finalize (dist_host.h:
+    ncclCommInitRank, grouped send / recv to the root) on the hardware at hand: the gathered records are the batch's own
+    (`summaries_from_result` of its fetched results, what the reference's main loop would walk: indelope.nim:601-608) and the
+    gathered payload is what ihp_batch_fetch returns, which is what the oracle produces."""
+    b, _ = synth.generate(300, n_reads=(24, 96), err_rate=1e-3, config_id=61, dup_frac=0.1)
+    b = b.with_trim_bounds()
+    comm = idist.Communicator(hip, 0, 1, lambda mine: mine)
+    h = hip.batch_upload(b)
+    try:
+        assert hip.b.dist_rank(comm.h) == 0 and hip.b.dist_world(comm.h) == 1
+        hip.batch_run(h)
+        recs, counts = comm.gather_summaries(h, b.n_regions, root=0)          # sizes exchanged (ncclAllGather)
+        res = hip.batch_fetch(h)
+        want = idist.summaries_from_result(res)
+        assert counts.tolist() == [b.n_regions] and len(recs) == b.n_regions
+        assert recs.tobytes() == want.tobytes()
+        recs2, _ = comm.gather_summaries(h, b.n_regions, root=0, counts=[b.n_regions])   # sizes known to every rank: no exchange
+        assert recs2.tobytes() == want.tobytes()
+        # the device-pointer form (a caller that keeps the records of several runs in a buffer of its own)
+        ptr, n = hip.batch_summary_dev(h)
+        recs3, _ = comm.gather_records(ptr, n, root=0, cap=n)
+        assert recs3.tobytes() == want.tobytes()
+        # a buffer that is too short: IHP_E_CAPACITY, and the communicator still works
+        out = np.zeros(4, A.SUMMARY_DTYPE)
+        nt = C.c_int64()
+        assert hip.b.dist_gather_summaries(comm.h, h, 0, None, out.ctypes.data_as(C.c_void_p), 4, C.byref(nt), None) == A.IHP_E_CAPACITY
+        assert nt.value == b.n_regions
+        (got,), nbytes = comm.gather_payload(h, root=0)
+        assert nbytes[0] > 0
+        _same(got, res)
+        _same(got, oracle.run_regions(b))
+    finally:
+        hip.batch_free(h)
+        comm.close()
+
+
+def test_two_ranks_from_c_with_no_python_in_them(hip):
+    """tests/abi_harness.c --dist: two fresh processes, each a plain C program over include/indelope_hip.h -- the id travels in a
+    file, ihp_init(0) + ihp_dist_init(rank, 2, id), a few regions each, ihp_dist_gather_summaries + ihp_dist_gather_payload to
+    rank 0, which checks counts, rank order and the contigs' starts.  This box has ONE GPU, so both ranks bind device 0: RCCL
+    either forms the group (then everything must check out) or refuses two ranks on one device at ncclCommInitRank -- in which
+    case both ranks must come back with that refusal as IHP_E_HIP and its text, not hang and not crash."""
+    from test_abi_exports import _build_harness
+    exe = _build_harness()
+    with tempfile.TemporaryDirectory() as td:
+        idf = os.path.join(td, "id")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+        procs = [subprocess.Popen([exe, "--dist", str(r), "2", idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in (0, 1)]
+        outs = []
+        for p in procs:
+            try:
+                o, e = p.communicate(timeout=180)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                pytest.fail("the two-rank harness hung")
+            outs.append((p.returncode, o, e))
+    rc0, o0, e0 = outs[0]
+    if rc0 == 0:
+        rep = json.loads(o0.strip().splitlines()[-1])
+        assert rep["ok"] is True and rep["world"] == 2 and rep["n_total"] == 5, (rep, e0)
+        assert outs[1][0] == 0, outs[1]
+        print("two ranks on one device: RCCL formed the group; gather verified")
+    else:
+        # refused: every rank reports it through the ABI's error convention
+        for rc, o, e in outs:
+            assert rc == 3, (rc, o, e)
+            rep = json.loads(o.strip().splitlines()[-1])
+            assert rep["dist_init"] == A.IHP_E_HIP and "rccl" in rep["error"], rep
+        print("two ranks on one device: RCCL refuses at ncclCommInitRank (%s)" % json.loads(o0.strip().splitlines()[-1])["error"])
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r5
+def _many_contig_variant(b, region, n_mut=44):
+    """The same batch with n_mut reads of one region carrying a substitution in their middle: each becomes a contig of its own in
+    the read phase (min_overlap 132 of 150 always covers base 75), more than the 32 the first combine tier's short table holds."""
+    bases = b.bases.copy()
+    r0, r1 = int(b.region_read_off[region]), int(b.region_read_off[region + 1])
+    assert r1 - r0 >= n_mut + 8
+    for k, i in enumerate(range(r0 + 4, r0 + 4 + n_mut)):
+        p = int(b.read_off[i]) + 60 + (k % 30)
+        bases[p] = ord("ACGT"[("ACGT".index(chr(bases[p])) + 1 + k % 3) % 4])
+    return RegionBatch(b.region_read_off, b.read_off, bases, b.quals, b.read_start, b.read_stop, b.mapq, b.read_skip, b.ref_off, b.ref_bases, b.ref_origin)
+
+
+def test_a_rare_many_contig_region_does_not_make_every_other_batch_run_twice(hip, oracle):
+    """ADVICE r5 (kernels.h:476): a batch WITHOUT a region of more than 32 contigs lets the next batch's first combine tier walk
+    the other tiers' lists with the short-table build; a region of 33..64 contigs in that next batch was then refused by
+    v3_take_over, landed on the retry list of a run that had left the retry launches out, and the whole run was repeated.  A stream
+    that alternates batches with none and with one such region must not repeat anything: the short table serves a folding first
+    tier only after CLEAN_MIN batches of the shape without any (indelope_hip.hip, TierHint::clean)."""
+    raw, _ = synth.generate(600, n_reads=(64, 64), err_rate=1e-3, config_id=62)
+    clean, dirty = raw.with_trim_bounds(), _many_contig_variant(raw, 7).with_trim_bounds()
+    exp = {id(clean): oracle.run_regions(clean), id(dirty): oracle.run_regions(dirty)}
+    assert exp[id(dirty)].n_contigs_pre[7] > 32 and exp[id(clean)].n_contigs_pre.max() <= 32
+    hip.debug_set()                                                  # (forgets every launch plan: none of this shape from an earlier test)
+    reruns = 0
+    for k in range(10):
+        bt = dirty if k % 2 else clean
+        h = hip.batch_upload(bt)
+        try:
+            hip.batch_run(h)
+            hip.batch_sync(h)
+            _same(hip.batch_fetch(h), exp[id(bt)])
+            reruns += int(hip.batch_profile(h)[31])
+        finally:
+            hip.batch_free(h)
+    assert reruns == 0, reruns
+    # and behind a long clean streak (the short table is back) ONE such batch costs at most its own repeat, after which the plan is safe again
+    for k in range(6):
+        h = hip.batch_upload(clean)
+        hip.batch_run(h); hip.batch_sync(h); hip.batch_free(h)
+    seq, rr = [dirty, clean, dirty, clean], []
+    for bt in seq:
+        h = hip.batch_upload(bt)
+        try:
+            hip.batch_run(h); hip.batch_sync(h)
+            _same(hip.batch_fetch(h), exp[id(bt)])
+            rr.append(int(hip.batch_profile(h)[31]))
+        finally:
+            hip.batch_free(h)
+    assert rr[0] <= 1 and rr[1:] == [0, 0, 0], rr
+
+
+def test_a_malformed_compact_slab_stays_refused_however_many_runs_precede_the_first_wait(hip):
+    """ADVICE r5 (indelope_hip.hip:2196): k_slab_expand raises its flag once, at upload; upload, run, RUN, sync used to lose it
+    (the second run's k_summary reported the cleared word) and hand back results computed from clamped offsets with rc 0."""
+    b, _ = synth.generate(40, n_reads=(16, 32), err_rate=1e-3, config_id=63)
+    s2 = hip.make_slab2(b.with_trim_bounds())
+    try:
+        mem = np.ctypeslib.as_array(C.cast(s2.ptr, C.POINTER(C.c_uint8)), (s2.layout.bytes,))
+        mem[s2.layout.len:s2.layout.len + 2 * s2.n_reads].view(np.uint16)[5] -= 1   # a region's lengths no longer add up to its region_base_off step
+        h = hip.batch_upload_slab2(s2)
+        try:
+            hip.batch_run(h)
+            hip.batch_run(h)
+            assert hip.b.batch_sync(h) == A.IHP_E_ARG
+            hip.batch_run(h)
+            assert hip.b.batch_sync(h) == A.IHP_E_ARG                  # and it stays refused
+            out = A.BatchOut()
+            assert hip.b.batch_fetch(h, C.byref(out)) == A.IHP_E_ARG
+        finally:
+            hip.batch_free(h)
+    finally:
+        s2.free()
+
+
+def test_a_soft_masked_window_takes_the_arrays(hip, oracle):
+    """ADVICE r5 (nim/indelope_hip.nim fill_slab2): BAM's 4-bit alphabet has no lower case, so a window with soft-masked bases
+    (hg19 / hg38) cannot travel in the compact slab -- the slab builders refuse it (Python: ValueError; Nim: nil, before a byte is
+    written) and the caller hands over the arrays, whose kernels fold case as ksw2.nim:127-132 does."""
+    b, _ = synth.generate(60, n_reads=(24, 48), err_rate=1e-3, config_id=64)
+    ref = b.ref_bases.copy()
+    for r in range(0, 60, 3):                                          # soft-mask a stretch of every third window
+        lo = int(b.ref_off[r]) + 40
+        ref[lo:lo + 120] = np.char.lower(ref[lo:lo + 120].view("S1")).view(np.uint8)
+    low = RegionBatch(b.region_read_off, b.read_off, b.bases, b.quals, b.read_start, b.read_stop, b.mapq, b.read_skip, b.ref_off, ref, b.ref_origin).with_trim_bounds()
+    with pytest.raises(ValueError):
+        hip.make_slab2(low)
+    _same(hip.run_regions(low), oracle.run_regions(low))
