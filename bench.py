@@ -523,7 +523,7 @@ def mixed_stream(api, n_batches=48, in_flight=2):
 
 
 # ------------------------------------------------------------------------- the attached strong-scaling leg
-def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps=2, warmup=1):
+def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps=2, warmup=1, comm=None):
     """north_star's strong-scaling number in the same invocation as the weak one (`--gpus N`, no --config): the C4 generator's
     first `regions_total` regions split over the ranks (dist.shard_bounds), every rank's share resident in chunks, a step = one pass
     over all of them + THE gather of the per-region records to rank 0.  Every rank calls this; rank 0 gets the record."""
@@ -545,9 +545,7 @@ def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps
             views.append(torch.as_tensor(_DevArray(sptr, sn * 8), device="cuda"))
         summary = views[0] if len(views) == 1 else torch.cat(views)
         sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
-        m_pad = max(sizes)
-        send = summary if hi - lo == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
-        gl = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        last = [None]
 
         def step():
             for i, h in enumerate(hs):
@@ -557,9 +555,9 @@ def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps
             api.batch_sync(hs[-1])
             if len(views) > 1:
                 torch.cat(views, out=summary)
-            if send is not summary:
-                send[:summary.numel()] = summary
-            dist.gather(send, gl, dst=0)
+                torch.cuda.current_stream().synchronize()
+            # THE collective: ihp_dist_gather_records (RCCL behind the C ABI), the records land on rank 0's host in region order
+            last[0] = comm.gather_records(summary.data_ptr(), hi - lo, root=0, counts=sizes)
         for _ in range(warmup):
             step()
         dist.barrier()
@@ -574,13 +572,13 @@ def strong_leg(api, torch, dist, idist, rank, world, regions_total, chunk, steps
         dt = float(t.item())
         ok = None
         if rank == 0:
-            got = torch.cat([g[:n * idist.SUMMARY_WORDS] for g, n in zip(gl, sizes)])
-            ok = bool((got.view(-1, idist.SUMMARY_WORDS)[:, 0] == 0).all().item())       # every region's status
+            got = last[0][0]
+            ok = bool(len(got) == regions_total and (got["status"] == 0).all())          # every region's status
         return {"config": "C4 (BASELINE configs[3] generator), first %d of its 5 000 000 regions" % regions_total, "scaling": "strong",
                 "value": round(regions_total * steps / dt, 1), "unit": "regions/s", "ms_per_step": round(dt / steps * 1e3, 3),
                 "regions_total": regions_total, "regions_per_gpu": sizes, "steps": steps, "warmup": warmup,
                 "chunks_per_rank": len(hs), "all_regions_ok": ok,
-                "sharding": "contiguous region ranges (dist.shard_bounds), one RCCL gather of the per-region records per step"}
+                "sharding": "contiguous region ranges (dist.shard_bounds), one gather of the per-region records per step: ihp_dist_gather_records (librccl behind the C ABI)"}
     finally:
         for h in hs:
             api.batch_free(h)
@@ -756,6 +754,9 @@ def main():
     from indelope_amd import dist as idist
     api = indelope_amd.api()
     api.init(local_rank)
+    # the data path's one collective goes through the library's own entry points (ihp_dist_*: librccl behind the C ABI, what the
+    # Nim host binds); torch.distributed stays for the launch, the barriers around the timed region and the max over ranks
+    comm = idist.Communicator(api, rank, world, idist.torch_id_exchange(device="cuda")) if use_dist else None
     if args.profile:
         api.debug_set(profile=1)
     for kv in args.knob:
@@ -826,13 +827,8 @@ def main():
     block_cur, block_slots = [0], {}
     # shard sizes are known to every rank (bounds / equal shares): shards are padded to the longest, ONE gather per step / block
     shard_sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)] if strong else [R * (args.steps if per_block else 1)] * world
-    m_pad = max(shard_sizes)
-    if per_block:
-        send = blockbuf
-    else:
-        send = summary if R == m_pad else torch.full((m_pad * idist.SUMMARY_WORDS,), idist.PAD_STATUS, dtype=torch.int32, device="cuda")
-    gather_list = [torch.empty_like(send) for _ in range(world)] if (use_dist and rank == 0) else None
-    last_payload = [None]
+    send = blockbuf if per_block else summary
+    last_gather, last_payload = [None], [None]
 
     def wait(i):
         """Wait for handle i's run; in weak mode its records join the block's buffer (they are final now, and the next run of the
@@ -885,17 +881,14 @@ def main():
 
     def gather():
         # THE collective of the path: the fixed-size per-region records of every rank to rank 0 (+ the result slabs with --payload)
-        if not per_block:
-            if S > 1:
-                torch.cat(views, out=summary)
-            if send is not summary:
-                send[:summary.numel()] = summary
-        dist.gather(send, gather_list, dst=0)
+        if not per_block and S > 1:
+            torch.cat(views, out=summary)
+            torch.cuda.current_stream().synchronize()
+        # (every run whose records are gathered has been waited for: ihp_batch_sync in wait() / step())
+        last_gather[0] = comm.gather_records(send.data_ptr(), shard_sizes[rank], root=0, counts=shard_sizes)
         if args.payload and not stream_outputs:
             for h in (hs if strong else hs[:S]):
-                ptr, nbytes, counts = api.batch_pack_dev(h)
-                slab = torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda")
-                last_payload[0] = idist.gather_payload(slab, counts, rank, world, dst=0, force=True)
+                last_payload[0] = comm.gather_payload(h, root=0)
 
     pending = {}
     step_no = [0]
@@ -965,7 +958,7 @@ def main():
     fb_ms = float(km[3])
     strong_rec = None
     if use_dist and world > 1 and not config_given and not strong:
-        strong_rec = strong_leg(api, torch, dist, idist, rank, world, args.strong_regions, args.chunk)
+        strong_rec = strong_leg(api, torch, dist, idist, rank, world, args.strong_regions, args.chunk, comm=comm)
 
     if rank == 0:
         from indelope_amd.host import concat_results
@@ -1063,7 +1056,7 @@ def main():
                                          "a batch is run again as soon as its own last run is done (run, sync, run per batch: %d step%s in flight), every run waited for before the clock stops"
                                          % (B, "s" if B > 1 else "")),
                        "regions_per_gpu": R, "regions_total": total,
-                       "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one RCCL gather of per-region result "
+                       "sharding": ("contiguous region ranges per rank (dist.shard_bounds), one gather (ihp_dist_gather_records: librccl behind the C ABI, records on rank 0's host) of per-region result "
                                     "records per %s" % ("step" if (strong or args.gather_per_step) else "timed block (the job's one gather at its end: the records of every "
                                                         "region the block processed)") + (" + result slabs to rank 0" if args.payload else "")) if use_dist else "single GPU",
                        "gather": ({"per": "step" if (strong or args.gather_per_step) else "block", "records_per_rank_per_gather": int(send.numel() // idist.SUMMARY_WORDS),
@@ -1090,7 +1083,7 @@ def main():
         if args.verify_gather and use_dist:
             # what rank 0 received in the last step against its own results: the records of the RCCL gather are the per-region
             # summaries of the fetched results, the payload slab unpacks to the same results
-            got = torch.cat([g[:n * idist.SUMMARY_WORDS] for g, n in zip(gather_list, shard_sizes)]).cpu().numpy()
+            got = last_gather[0][0].view(np.int32).reshape(-1)
             mine = idist.summaries_from_result(res_first).view(np.int32).reshape(-1)
             if per_block:
                 # the block's buffer holds one set of records per step; every resident batch's LAST run landed at block_slots[handle]:
@@ -1104,13 +1097,12 @@ def main():
                 # (strong scaling keeps only the first chunk's results on the host: its records are the head of the gathered ones)
                 ok = bool(np.array_equal(got[:len(mine)], mine)) and (len(got) == len(mine) if (world == 1 and not strong) else len(got) >= len(mine))
             chk = {"records": int(len(got) // idist.SUMMARY_WORDS), "regions_processed": int((R * args.steps if per_block else R if not strong else total) * (world if not strong else 1)),
-                   "records_identical_to_own_results": ok, "backend": dist.get_backend()}
+                   "records_identical_to_own_results": ok, "backend": "ihp_dist (librccl behind the C ABI); launcher: torch.distributed/" + dist.get_backend()}
             if args.payload and last_payload[0] is not None and not strong:
                 from indelope_amd.host import BatchResult
-                slab, counts = last_payload[0][0]
-                back = api.unpack_slab(slab.cpu().numpy(), counts)
+                back, nbytes_ = last_payload[0][0][0], last_payload[0][1]
                 d = BatchResult.first_difference(back, parts[S - 1] if not strong else parts[-1])
-                chk["payload_bytes"] = int(slab.numel())
+                chk["payload_bytes"] = int(nbytes_[0])
                 chk["payload_identical_to_own_results"] = d is None
                 ok = ok and d is None
             out["gather_check"] = chk
@@ -1199,6 +1191,7 @@ def main():
         api.batch_free(h)
     if use_dist:
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
 
 

@@ -99,10 +99,14 @@ Knobs g_knob;
 constexpr int HIST_N = 11;
 constexpr int HIST_OCC[HIST_N] = {25, 21, 18, 16, 14, 12, 11, 10, 9, 8, 7};     // what 128 LDS granules per CU divide into (see LDS_GRAN)
 constexpr int COMB_MAXC_A = 32;                              // contigs the first combine tier's build keeps a table for (V3StateT, asm3_dev.h)
-// clean: batches of this shape in a row, up to now, without a region of more than COMB_MAXC_A contigs (what the short table of a first
-// tier that walks the other tiers' lists rests on; see ihp_batch_run)
+// clean_c / clean_b: batches of this shape in a row, up to now, that filed NO region under the third combine tier / under the second
+// and none with more than COMB_MAXC_A contigs.  A first tier that walks the other tiers' lists instead of giving them a
+// launch of their own (fold_b / fold_c in ihp_batch_run) rests on that: whatever region IS filed there meets the first tier's
+// arena and (short) contig table, is refused, lands on the retry list, and a run that left the retry launches out is then
+// repeated in full.  One batch without such a region says little about the next (a sweep whose batches hold one now
+// and then paid twice for every batch that followed one without); CLEAN_MIN of them in a row is what the fold waits for.
 constexpr int CLEAN_MIN = 3;
-struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0, clean = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0, clean_c = 0, clean_b = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
 // One hint per batch SHAPE (hint_key: read length, read bases per region, the packed / byte-based path, the parameters that
 // decide which launches a run needs), sixteen shapes remembered: a sweep that interleaves batches of different shapes, or
 // several host threads with different workloads, keep their plans apart (round 3 had one process-wide hint; only the tier
@@ -1806,15 +1810,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			const long long tot = H.regions;
 			// more than a hundredth of the regions with more contigs than the short table holds: the first tier runs the build with
 			// the full table (C3, C5: 6-7 % -- a second tier for them alone, at two thirds of the occupancy, every step)
-			// A first tier that walks the other tiers' lists behind its own (no launch for them: fold_b / fold_c below) meets
-			// whatever region is filed there -- with the short table a region of more than COMB_MAXC_A contigs is refused by
-			// v3_take_over, lands on the retry list, and a run that left the retry launches out is then repeated in full: a
-			// sweep whose batches hold such a region now and then paid twice for every batch that followed one without
-			// (ADVICE r5).  So the short table serves a folding first tier only when the last CLEAN_MIN batches of the shape
-			// had no such region at all; until then (and again after every batch that had one) it runs the full-table build,
-			// which takes them where they are filed.
-			const bool folds = H.n_c == 0;
-			const bool wide = (long long)H.n_manyc * 100 > tot || (folds && H.clean < CLEAN_MIN);
+			const bool wide = (long long)H.n_manyc * 100 > tot;
 			// a tier of its own for a few percent of the regions costs a round of the heaviest ones at the end: when a first tier
 			// of not much lower occupancy holds (nearly) all regions -- a narrow distribution just above the predicted arena --
 			// it is taken; otherwise (regions of very different sizes) the first tier is cut for 85 % and the others take the rest.
@@ -1934,9 +1930,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// scheduled, 0.05-0.3 ms on the critical path in front of k_ksw while another batch's kernels fill the CUs: the first
 			// tier's launch walks its lists behind its own instead (a straggler does not fit there and takes the retry route).
 			const bool hint = have_hint;
-			// (never with the short table before the shape has been clean for CLEAN_MIN batches: see `wide` above -- this is the case
-			// in which the tiers were not cut again, e.g. under the occupancy knobs)
-			const bool fold_c = hint && H.n_c == 0 && (b->tier_wide || H.clean >= CLEAN_MIN), fold_b = fold_c && H.n_b == 0;
+			// (only behind CLEAN_MIN batches in a row that filed nothing there: see TierHint::clean_c / clean_b.  Until then the second tier keeps a
+			// launch of a few workgroups, which takes the odd region where it is filed)
+			const bool fold_c = hint && H.n_c == 0 && H.clean_c >= CLEAN_MIN, fold_b = fold_c && H.n_b == 0 && H.clean_b >= CLEAN_MIN;
 			HIPC(hipEventRecord(b->ev_bfork, s));
 			// The second tier runs beside the first on the other stream -- if its workgroups find LDS: the first tier's persistent
 			// grid fills every CU and keeps it until its queue is dry, so a second tier launched next to it in fact ran behind it
@@ -2204,7 +2200,9 @@ static void hint_refresh(const ihp_batch *b)
 		for (int k = 0; k < HIST_N; ++k) h.hist[k] = b->report[M_HIST + k];
 		h.n_manyc = b->report[M_MANYC]; h.wide = b->tier_wide ? 1 : 0;
 		TierHint prev;
-		h.clean = h.n_manyc == 0 ? std::min(1 << 20, (g_hints.get(b->hint_key, prev) ? prev.clean : 0) + 1) : 0;
+		const bool had = g_hints.get(b->hint_key, prev);
+		h.clean_c = h.n_c == 0 ? std::min(1 << 20, (had ? prev.clean_c : 0) + 1) : 0;
+		h.clean_b = (h.n_b == 0 && h.n_manyc == 0) ? std::min(1 << 20, (had ? prev.clean_b : 0) + 1) : 0;
 		h.regions = b->n_cls[0] - b->report[M_NRETRY0]; h.sig = b->tier_sig;
 	}
 	if (g_knob.verbose) fprintf(stderr, "[ihp] confirmed: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);

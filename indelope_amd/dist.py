@@ -136,6 +136,17 @@ class Communicator:
         self.h = C.c_void_p()
         api._chk_hip(api.b.dist_init(self.rank, self.world, buf, A.IHP_DIST_ID_BYTES, C.byref(self.h)), "dist_init")
 
+    def _out(self, total):
+        """A page-locked buffer for `total` records on the root, kept between calls (a pageable one costs the copy 5x)."""
+        if getattr(self, "_pin_n", 0) < total:
+            if getattr(self, "_pin", None):
+                self.api.b.host_free(self._pin)
+            self._pin_n = max(1, int(total) + int(total) // 4)
+            self._pin = self.api.b.host_alloc(self._pin_n * A.SUMMARY_DTYPE.itemsize)
+            if not self._pin:
+                raise MemoryError("ihp_host_alloc")
+        return np.ctypeslib.as_array(C.cast(self._pin, C.POINTER(C.c_uint8)), (self._pin_n * A.SUMMARY_DTYPE.itemsize,)).view(A.SUMMARY_DTYPE)
+
     def _counts(self, counts):
         if counts is None:
             return None, None
@@ -144,12 +155,13 @@ class Communicator:
         return c, A.ptr(c, A.i64p)
 
     def gather_records(self, dev_ptr, n, root=0, counts=None, cap=None):
-        """n 32-byte records at device address dev_ptr (final) -> SUMMARY_DTYPE array in rank order on `root`, None elsewhere."""
+        """n 32-byte records at device address dev_ptr (final) -> SUMMARY_DTYPE array in rank order on `root`, None elsewhere.
+        The array is a view of the communicator's page-locked buffer: valid until the next gather."""
         c, cp = self._counts(counts)
         total = int(c.sum()) if c is not None else (int(cap) if cap is not None else None)
         if total is None:
             raise ValueError("counts or cap: the root has to size its buffer")
-        out = np.zeros(max(1, total), A.SUMMARY_DTYPE) if self.rank == root else None
+        out = self._out(total) if self.rank == root else None
         n_total, counts_out = C.c_int64(), np.zeros(self.world, np.int64)
         self.api._chk_hip(self.api.b.dist_gather_records(self.h, C.c_void_p(dev_ptr), int(n), root, cp,
                                                          out.ctypes.data_as(C.c_void_p) if out is not None else None, total,
@@ -160,7 +172,7 @@ class Communicator:
         """The records of a batch (its run is waited for and confirmed first)."""
         c, cp = self._counts(counts)
         total = int(c.sum()) if c is not None else (int(cap) if cap is not None else int(n_regions) * self.world)
-        out = np.zeros(max(1, total), A.SUMMARY_DTYPE) if self.rank == root else None
+        out = self._out(total) if self.rank == root else None
         n_total, counts_out = C.c_int64(), np.zeros(self.world, np.int64)
         self.api._chk_hip(self.api.b.dist_gather_summaries(self.h, batch_handle, root, cp,
                                                            out.ctypes.data_as(C.c_void_p) if out is not None else None, total,
@@ -185,6 +197,9 @@ class Communicator:
         return res, nbytes
 
     def close(self):
+        if getattr(self, "_pin", None):
+            self.api.b.host_free(self._pin)
+            self._pin, self._pin_n = None, 0
         if self.h:
             self.api.b.dist_finalize(self.h)
             self.h = C.c_void_p()

@@ -175,6 +175,20 @@ proc ihp_batch_summary_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64)
 # the same address without the wait (fixed from upload to free): for callers that order by stream / call ihp_batch_sync themselves
 proc ihp_batch_summary_ptr*(b: ptr IhpBatch, dev_ptr: ptr pointer, n: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_summary_host*(b: ptr IhpBatch, outp: ptr IhpRegionSummary, cap: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+
+# ---- multi-GPU: one process per GPU, ONE gather at the end (dist_host.h: librccl behind the C ABI; include/indelope_hip.h) ----------
+type IhpDist* {.importc: "ihp_dist", header: "indelope_hip.h", incompleteStruct.} = object
+const IHP_DIST_ID_BYTES* = 128
+proc ihp_dist_unique_id*(id: pointer, cap: int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_init*(rank, world: int32, id: pointer, id_bytes: int64, outp: ptr ptr IhpDist): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_rank*(d: ptr IhpDist): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_world*(d: ptr IhpDist): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_gather_records*(d: ptr IhpDist, dev_records: pointer, n: int64, root: int32, counts_in: ptr int64,
+                              outp: ptr IhpRegionSummary, cap: int64, n_total: ptr int64, counts_out: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_gather_summaries*(d: ptr IhpDist, b: ptr IhpBatch, root: int32, counts_in: ptr int64,
+                                outp: ptr IhpRegionSummary, cap: int64, n_total: ptr int64, counts_out: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_gather_payload*(d: ptr IhpDist, b: ptr IhpBatch, root: int32, outs: ptr IhpBatchOut, bytes_out: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_dist_finalize*(d: ptr IhpDist): cint {.importc, cdecl, header: "indelope_hip.h".}
 # one page-locked slab per batch (4-bit bases as BAM stores them, trim bounds): the sections' offsets, the upload, what a fetch returns
 type IhpSlabLayout* {.importc: "ihp_slab_layout", header: "indelope_hip.h", bycopy.} = object
   region_read_off*, read_off*, read_start*, read_stop*, ref_off*, ref_origin*: int64
@@ -419,3 +433,51 @@ proc flush*(s: var Stager, pending: var seq[roi], p: var IhpParams, last_var, la
     ihp_free_variants(addr vars)
   ihp_free_out(addr outp)
   s.clear(); pending.set_len(0)
+
+
+# ---- eight processes, one chromosome each ... or one target list cut in eight: the sweep on a node of MI355X ----------------------
+# Regions are independent past gen_roi (indelope.nim:601-603), so every rank walks ITS contiguous range of the targets with the
+# Stager / Pipeline above and nothing crosses ranks until the end.  What the reference's main loop does with a region's result
+# is sequential -- the last-two-variants window (:604-608) -- so the results have to meet on one rank IN REGION ORDER: that is
+# the one collective of the path, and `MultiGpuSweep` is all of it.  A launcher starts the ranks (one per GPU: mpirun, srun, a
+# shell loop) and gives each its rank, the world size and a path every rank can read; rank 0 leaves the communicator's id there.
+import os                                  # file_exists, move_file, sleep (indelope.nim imports os already, :1-18)
+type MultiGpuSweep* = object
+  d*: ptr IhpDist
+  rank*, world*: int32
+
+proc open_sweep*(rank, world: int32, id_path: string): MultiGpuSweep =
+  ## ihp_init(rank) binds GPU `rank` of the node; the 128-byte id travels through `id_path`.
+  doAssert ihp_init(cint(rank)) == 0
+  var id: array[IHP_DIST_ID_BYTES, uint8]
+  if rank == 0:
+    doAssert ihp_dist_unique_id(addr id[0], int64(id.len)) == 0
+    var f = open(id_path & ".tmp", fmWrite)
+    discard f.write_buffer(addr id[0], id.len); f.close()
+    move_file(id_path & ".tmp", id_path)                 # (os) the others never see half a file
+  else:
+    while not file_exists(id_path): sleep(10)
+    var f = open(id_path, fmRead)
+    doAssert f.read_buffer(addr id[0], id.len) == id.len; f.close()
+  result.rank = rank; result.world = world
+  doAssert ihp_dist_init(rank, world, addr id[0], int64(id.len), addr result.d) == 0
+
+proc gather_results*(m: var MultiGpuSweep, b: ptr IhpBatch): seq[IhpBatchOut] =
+  ## Every rank calls this with its (last) batch; rank 0 gets one IhpBatchOut per rank in rank = region order (ihp_free_out each),
+  ## the others an empty seq.  Rank 0 then walks them exactly as `flush` walks one: ihp_call_variants per rank's batch needs that
+  ## rank's inputs, so in practice every rank calls ihp_call_variants on its OWN results first and only the printable records
+  ## travel -- or, as here, the packed results travel and rank 0 holds every rank's stager (the targets are known to all).
+  if m.rank == 0: result = new_seq[IhpBatchOut](int(m.world))
+  let rc = ihp_dist_gather_payload(m.d, b, 0, if m.rank == 0: addr result[0] else: nil, nil)
+  doAssert rc == 0, $ihp_strerror(rc) & " / " & $ihp_last_hip_error()
+
+proc gather_records*(m: var MultiGpuSweep, b: ptr IhpBatch, n_regions_total: int): seq[IhpRegionSummary] =
+  ## The fixed-size half: 32 bytes per region (status, contigs, events, the first tallied event's ref / alt support) to rank 0.
+  if m.rank == 0: result = new_seq[IhpRegionSummary](n_regions_total)
+  var n_total: int64
+  let rc = ihp_dist_gather_summaries(m.d, b, 0, nil, if m.rank == 0: addr result[0] else: nil, int64(n_regions_total), addr n_total, nil)
+  doAssert rc == 0, $ihp_strerror(rc) & " / " & $ihp_last_hip_error()
+  if m.rank == 0: result.set_len(int(n_total))
+
+proc close*(m: var MultiGpuSweep) =
+  discard ihp_dist_finalize(m.d); m.d = nil

@@ -115,7 +115,7 @@ def test_a_rare_many_contig_region_does_not_make_every_other_batch_run_twice(hip
     the other tiers' lists with the short-table build; a region of 33..64 contigs in that next batch was then refused by
     v3_take_over, landed on the retry list of a run that had left the retry launches out, and the whole run was repeated.  A stream
     that alternates batches with none and with one such region must not repeat anything: the short table serves a folding first
-    tier only after CLEAN_MIN batches of the shape without any (indelope_hip.hip, TierHint::clean)."""
+    tier only after CLEAN_MIN batches of the shape that filed nothing behind it (indelope_hip.hip, TierHint::clean_b / clean_c)."""
     raw, _ = synth.generate(600, n_reads=(64, 64), err_rate=1e-3, config_id=62)
     clean, dirty = raw.with_trim_bounds(), _many_contig_variant(raw, 7).with_trim_bounds()
     exp = {id(clean): oracle.run_regions(clean), id(dirty): oracle.run_regions(dirty)}
