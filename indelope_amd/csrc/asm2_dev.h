@@ -341,6 +341,7 @@ __device__ __forceinline__ unsigned long long lane_range64(int lo, int hi)
 // ------------------------------------------------------------------------------------------------ read phase
 constexpr int V2_MIN_READ = 20, V2_MAX_READ = 960;       // trimmed read lengths this path takes
 constexpr int V2_MAX_CONTIGS = 64;                       // one directory lane per contig
+constexpr int V2_MAX_REGION_READS = 640;                 // = V3_MAXREADS_WIDE (asm3_dev.h)
 constexpr int V2_WL = 128;                               // work-list entries in registers (two of them)
 constexpr int V2_WLX = 192;                              // ... and in LDS behind them, for regions of long reads (contigs of many dwords)
 constexpr int V2_HDR = 8, V2_DIRW = 8;                   // hand-over record: header dwords, dwords per contig
@@ -359,7 +360,7 @@ __device__ __forceinline__ long long bcast64(long long v, int src)
 // (contig.nim:254-281), so its time grows with the square of the contigs the read phase leaves.  k_asm_reads files every
 // region under its class and k_asm_combine3 takes the classes in order -- the longest chains start first and the short ones
 // fill the end of the launch instead of the other way round.
-constexpr int LPT_CLASSES = 16, LPT_TIERS = 3;     // three combine launches: arenas of growing size at falling occupancy
+constexpr int LPT_CLASSES = 16, LPT_TIERS = 4;     // three combine launches: arenas of growing size at falling occupancy; a fourth for the regions of more than 255 reads (16-bit supports)
 // (16 classes: two contigs apart over the range of 150 bp pile-ups, wider above.  The contig count is the best predictor the
 // read phase has -- correlation with the measured cycles 0.88 on C2, 0.65 on C5; counting the multi-read contigs in made it worse)
 __device__ __forceinline__ int lpt_class(int n)
@@ -422,6 +423,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	const int lane = lane_id();
 	const long long r0 = uni(a.region_read_off[r]), r1 = uni(a.region_read_off[r + 1]);
 	const int nrr = (int)(r1 - r0);
+	if (nrr > V2_MAX_REGION_READS) return IHP_E_CAPACITY;           // (what the wide combine build keeps records for; gen_roi caps a roi at 600 reads, indelope.nim:515)
 	long long tp_ = prof ? (long long)clock64() : 0;             // diagnostics: cycles per stage into prof[12..15] (prep, target filter, query phase, insert); [7] set-up
 #define V2_LAP(k) do { if (prof) { const long long t_ = (long long)clock64(); if (lane == 0) prof[k] += t_ - tp_; tp_ = t_; } } while (0)
 	// ---- pass 0: which reads take part (indelope.nim:164-165), preconditions, shortest / longest trimmed read

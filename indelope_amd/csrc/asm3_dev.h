@@ -14,7 +14,12 @@
 //   * corrections live in LDS; insert (contig.nim:156-222) is funnel-shift copies of packed dwords and byte adds.
 // Preconditions (anything else is handed to the byte-based passes, whose results are identical): the region has at most
 // 256 reads and no base is covered by all 256 of them, max_mismatch == 0, contigs shorter than 2048 bases, at most 64 contigs, combine_min_overlap >= 17.
+// Round 6, the WIDE build (V3StateT<MAXC, true>): the same code with 16-bit supports and room for the records of 640 reads, for
+// the regions the reference admits and the byte build cannot hold -- gen_roi hands over up to 600 reads per roi
+// (indelope.nim:483-485, :515), and a pile-up that deep has bases with more than 255 reads on them.  Offsets into the support
+// area (so, bump_sup, sup_cap) are in ELEMENTS in both builds; only the element type differs.
 #pragma once
+#include <type_traits>
 #include "asm2_dev.h"
 
 namespace ihp {
@@ -27,18 +32,24 @@ constexpr int V3_NOZONE = 0x3fff;
 // (MAXC: the first tier's launch keeps room for 32 contigs -- what nearly every region has when the read phase is done --,
 // 1.7 KB instead of 3.2: LDS is what decides how many regions a CU holds, and a region's chain is latency bound, so the launch
 // runs as fast as it has regions resident: 16 per CU 2.83 ms per 100 000 C2 regions, 14: 3.14, 12: 3.95, 10: 4.74.)
-template <int MAXC_>
+constexpr int V3_MAXREADS_WIDE = 640;     // reads of a region the wide build takes (ten record registers)
+template <int MAXC_, bool WIDE_ = false>
 struct V3StateT {                         // static LDS, one per wave
 	static constexpr int MAXC = MAXC_;
+	static constexpr bool WIDE = WIDE_;
+	typedef typename std::conditional<WIDE_, unsigned short, unsigned char>::type sup_t;   // one support
+	static constexpr unsigned SUP_MAX = WIDE_ ? 65535u : 255u;
+	static constexpr int NREC = WIDE_ ? V3_MAXREADS_WIDE / 64 : 4;     // record registers of the take-over (64 reads each)
+	static constexpr int CORR_DW = WIDE_ ? 2 : 1;                       // dwords per correction (the wide build keeps the site's final support in a dword of its own)
 	int dw[MAXC_];                      // packed slot: first dword in PM
-	int so[MAXC_];                      // support slot: first byte in SUP; -1: a contig of one read, support 1 on every base, no bytes kept
+	int so[MAXC_];                      // support slot: first element in SUP; -1: a contig of one read, support 1 on every base, nothing kept
 	int len[MAXC_], cap[MAXC_];       // bases; cap = bases both slots have room for from the current start
 	int nreads[MAXC_];
 	long long start[MAXC_];
 	short lo3[MAXC_], hi3[MAXC_];     // every base in [lo3, hi3) has support >= 3 and no other has (V3_NOZONE / 0: not one run)
 	short loT[MAXC_], hiT[MAXC_];     // the longest run of bases with support >= v3_thr(nreads): bases no vote can overrule (see v3_slide_votes)
 	unsigned char sh[MAXC_];            // bases into dword dw where the contig starts (trim moves it)
-	unsigned char smin[MAXC_], smax[MAXC_];
+	sup_t smin[MAXC_], smax[MAXC_];
 	short listA[MAXC_], listB[MAXC_];
 	short qt[MAXC_], mt[MAXC_];       // step at which the contig was the query of pass 1 (0: never), step of its last change (0: none)
 	long long prof[16];
@@ -47,13 +58,16 @@ struct V3StateT {                         // static LDS, one per wave
 
 struct V3Ctx {
 	uint32_t *PM; uint8_t *SUP;           // SUP first, PM right behind it (one dynamic LDS block)
-	int pm_cap, sup_cap;                  // dwords, bytes
+	int pm_cap, sup_cap;                  // dwords, supports (bytes, or 16-bit words in the wide build: sup_ld / sup_st)
 	int bump_pm, bump_sup;
 	unsigned long long alive;             // contigs (slots of V3State) whose bases and supports are still needed
 	int clock;                            // best_match calls of this region so far, over both passes (see V3State::qt)
 	long long *prof; int *cnt;
 };
 #define V3_CNT(C, k, n) do { if ((C).cnt && lane_id() == 0) (C).cnt[k] += (n); } while (0)
+
+template <class ST> __device__ __forceinline__ unsigned sup_ld(const V3Ctx &C, int i) { return ((const typename ST::sup_t *)C.SUP)[i]; }
+template <class ST> __device__ __forceinline__ void sup_st(const V3Ctx &C, int i, unsigned v) { ((typename ST::sup_t *)C.SUP)[i] = (typename ST::sup_t)v; }
 
 #define V3_T0(C) const long long t0_ = (C).prof ? (long long)clock64() : 0
 #define V3_T1(C, k) do { if ((C).prof && lane_id() == 0) (C).prof[k] += (long long)clock64() - t0_; } while (0)
@@ -78,7 +92,7 @@ struct SupStats {
 	unsigned mn, mx; int f3, l3, c3, thr;
 	unsigned carry;                                      // 1 + the last base seen so far that is below thr (0: none)
 	int blen, bend;                                      // per lane: the longest run ending at one of this lane's bases, and where
-	__device__ __forceinline__ void init(int thr_) { mn = 255u; mx = 0; f3 = 0x7fff; l3 = -1; c3 = 0; thr = thr_; carry = 0; blen = 0; bend = 0; }
+	__device__ __forceinline__ void init(int thr_) { mn = 65535u; mx = 0; f3 = 0x7fff; l3 = -1; c3 = 0; thr = thr_; carry = 0; blen = 0; bend = 0; }
 	__device__ __forceinline__ void add(unsigned v, int i, bool valid)
 	{
 		if (valid) {
@@ -99,7 +113,7 @@ struct SupStats {
 		const int best = wave_max_i32s(blen);
 		const int end = best > 0 ? __builtin_amdgcn_readlane(bend, ctz64(ballot(blen == best))) : 0;
 		if (lane_id() == 0) {
-			S.smin[c] = (unsigned char)mn; S.smax[c] = (unsigned char)mx;
+			S.smin[c] = (typename ST::sup_t)mn; S.smax[c] = (typename ST::sup_t)mx;
 			const bool clean = l3 >= f3 && c3 == l3 - f3 + 1;
 			S.lo3[c] = (short)(clean ? f3 : V3_NOZONE); S.hi3[c] = (short)(clean ? l3 + 1 : 0);
 			S.loT[c] = (short)(best > 0 ? end + 1 - best : V3_NOZONE); S.hiT[c] = (short)(best > 0 ? end + 1 : 0);
@@ -126,7 +140,7 @@ __device__ inline void v3_stats(ST &S, const V3Ctx &C, int c)
 		return;
 	}
 	SupStats st; st.init(v3_thr(uni(S.nreads[c])));
-	for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; st.add(i < n ? C.SUP[so + i] : 0u, i, i < n); }
+	for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; st.add(i < n ? sup_ld<ST>(C, so + i) : 0u, i, i < n); }
 	st.store(S, c);
 }
 
@@ -141,7 +155,8 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 	n_pre = 0;
 	if (n < 0) return 1;
 	n_pre = n;
-	if (nrr > 256 || n > ST::MAXC) return IHP_E_CAPACITY;           // (the records of a region are kept in four registers)
+	constexpr int NREC = ST::NREC, SB = (int)sizeof(typename ST::sup_t);
+	if (nrr > 64 * NREC || n > ST::MAXC) return IHP_E_CAPACITY;     // (the records of a region are kept in four registers; ten in the wide build)
 	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
 	if (lane < n) {
 		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
@@ -154,8 +169,8 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 	const int poff = (int)pincl - pnd, ptotal = __builtin_amdgcn_readlane((int)pincl, 63);
 	const int maxl = wave_max_i32s(lane < n ? d_len : 0);
 	// the difference array of one contig (4 B per base) sits at the tail of the block while the supports are counted
-	const int scratch_b = (C.sup_cap + 4 * C.pm_cap - 4 * (maxl + 2)) & ~15;
-	if (maxl > V3_MAXLEN || stotal > C.sup_cap || ptotal + 2 > C.pm_cap || stotal > scratch_b) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
+	const int scratch_b = (SB * C.sup_cap + 4 * C.pm_cap - 4 * (maxl + 2)) & ~15;     // (a byte offset from SUP)
+	if (maxl > V3_MAXLEN || stotal > C.sup_cap || ptotal + 2 > C.pm_cap || SB * stotal > scratch_b) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
 	if (lane < n) {
 		S.dw[lane] = poff; S.so[lane] = d_nreads != 1 ? soff : -1; S.len[lane] = d_len; S.cap[lane] = align4(d_len); S.nreads[lane] = d_nreads;
 		S.start[lane] = ((long long)d_shi << 32) | (unsigned)d_slo; S.sh[lane] = 0; S.listA[lane] = (short)lane;
@@ -164,12 +179,10 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 	C.clock = 0;
 	C.bump_sup = stotal; C.bump_pm = ptotal;
 	C.alive = n >= 64 ? ~0ull : (1ull << n) - 1ull;
-	unsigned rc0 = 0xffffffffu, rc1 = 0xffffffffu, rc2 = 0xffffffffu, rc3 = 0xffffffffu;     // nrr <= 256
-	bool over = false;                                               // a support that does not fit its byte
-	if (lane < nrr) rc0 = REC[lane];
-	if (64 + lane < nrr) rc1 = REC[64 + lane];
-	if (128 + lane < nrr) rc2 = REC[128 + lane];
-	if (192 + lane < nrr) rc3 = REC[192 + lane];
+	unsigned rc[NREC];                                               // nrr <= 64 NREC
+	bool over = false;                                               // a support that does not fit its element
+#pragma unroll
+	for (int k = 0; k < NREC; ++k) rc[k] = 64 * k + lane < nrr ? REC[64 * k + lane] : 0xffffffffu;
 	uint32_t *scratch = (uint32_t *)(C.SUP + scratch_b);
 	for (int c = 0; c < n; ++c) {
 		const int len = bcast(d_len, c), so = bcast(soff, c), nr = bcast(d_nreads, c), anchor = bcast(d_anchor, c);
@@ -179,14 +192,15 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 		}
 		for (int i = lane; i <= len; i += 64) scratch[i] = 0;
 		LDS_ORDER();
-		auto scatter = [&](unsigned rc) {
-			if (rc != 0xffffffffu && (int)(rc & 63u) == c) {
-				const int s = (int)((rc >> 6) & 0x7fffu) - 16384 + anchor, e = s + (int)(rc >> 21);
+		auto scatter = [&](unsigned rw) {
+			if (rw != 0xffffffffu && (int)(rw & 63u) == c) {
+				const int s = (int)((rw >> 6) & 0x7fffu) - 16384 + anchor, e = s + (int)(rw >> 21);
 				atomicAdd(&scratch[s], 1u);
 				atomicAdd(&scratch[e], 0xffffffffu);
 			}
 		};
-		scatter(rc0); scatter(rc1); scatter(rc2); scatter(rc3);
+#pragma unroll
+		for (int k = 0; k < NREC; ++k) scatter(rc[k]);
 		LDS_ORDER();
 		unsigned carry = 0;
 		SupStats st; st.init(v3_thr(nr));
@@ -194,7 +208,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 			const int i = i0 + lane;
 			unsigned v = i < len ? scratch[i] : 0u;
 			v = wave_scan_add(v) + carry;
-			if (i < len) { C.SUP[so + i] = (uint8_t)v; over |= v > 255u; }
+			if (i < len) { sup_st<ST>(C, so + i, v); over |= v > ST::SUP_MAX; }
 			st.add(v, i, i < len);
 			carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 		}
@@ -220,7 +234,7 @@ __device__ inline void v3_trim(ST &S, const V3Ctx &C, int c, int ms)
 	const int lane = lane_id();
 	const int so = uni(S.so[c]), len = uni(S.len[c]);
 	if (so < 0) return;                                              // support 1 everywhere: the caller never gets here with ms > 1 (ms <= nreads = 1)
-	const uint8_t *sup = C.SUP + so;
+	const typename ST::sup_t *sup = (const typename ST::sup_t *)C.SUP + so;
 	int a = len - 1 > 0 ? len - 1 : 0;
 	for (int b = 0; b < len - 1; b += 64) {
 		const int i = b + lane;
@@ -401,7 +415,7 @@ __device__ inline void v3_slide_votes(const ST &S, const V3Ctx &C, int qs, int t
 				for (int t = 0; t < 8 && mm && surv; ++t) {
 					const int j = __builtin_ctz(mm) >> 1;
 					mm &= mm - 1;
-					surv = allowed3(C.SUP[qso + qo0 + k + j], C.SUP[tso + to0 + k + j], qreads, treads);
+					surv = allowed3(sup_ld<ST>(C, qso + qo0 + k + j), sup_ld<ST>(C, tso + to0 + k + j), qreads, treads);
 				}
 			}
 			weak = ballot(surv && nozone);
@@ -429,7 +443,7 @@ __device__ inline void v3_slide_votes(const ST &S, const V3Ctx &C, int qs, int t
 					while (mm && !lbad) {
 						const int j = __builtin_ctz(mm) >> 1;
 						mm &= mm - 1;
-						lbad = !allowed3(C.SUP[qso + cq + k + j], C.SUP[tso + ct + k + j], qreads, treads);
+						lbad = !allowed3(sup_ld<ST>(C, qso + cq + k + j), sup_ld<ST>(C, tso + ct + k + j), qreads, treads);
 					}
 				}
 				bad = ballot(lbad) != 0;
@@ -694,7 +708,8 @@ __device__ inline int v3_corrections(ST &S, V3Ctx &C, int qs, int ts, int off)
 	const int qo0 = off < 0 ? -off : 0, to0 = off < 0 ? 0 : off;
 	const int n = qlen - qo0 < tlen - to0 ? qlen - qo0 : tlen - to0;
 	int cnt = 0;
-	int lim = C.pm_cap - C.bump_pm - 4;                              // free dwords above everything that is allocated
+	constexpr int CW = ST::CORR_DW;
+	int lim = (C.pm_cap - C.bump_pm - 4) / CW;                       // corrections that fit the free dwords above everything that is allocated
 	lim = lim < V3_CORR ? lim : V3_CORR;
 	for (int k0 = 0; k0 < n; k0 += 1024) {
 		const int k = k0 + 16 * lane;
@@ -712,9 +727,9 @@ __device__ inline int v3_corrections(ST &S, V3Ctx &C, int qs, int ts, int off)
 		while (m) {
 			const int j = __builtin_ctz(m) >> 1;
 			m &= m - 1;
-			const unsigned a = C.SUP[qso + qo0 + k + j], b = C.SUP[tso + to0 + k + j];
+			const unsigned a = sup_ld<ST>(C, qso + qo0 + k + j), b = sup_ld<ST>(C, tso + to0 + k + j);
 			// qoff | toff << 11 | qbest << 22 (| t's final support at the site << 23 once v3_insert has applied it)
-			if (w < lim) C.PM[C.pm_cap - 1 - w] = (unsigned)(qo0 + k + j) | ((unsigned)(to0 + k + j) << 11) | ((a > b ? 1u : 0u) << 22);
+			if (w < lim) C.PM[C.pm_cap - 1 - CW * w] = (unsigned)(qo0 + k + j) | ((unsigned)(to0 + k + j) << 11) | ((a > b ? 1u : 0u) << 22);
 			++w;
 		}
 		cnt += __builtin_amdgcn_readlane((int)incl, 63);
@@ -750,9 +765,9 @@ __device__ inline void v3_compact(ST &S, V3Ctx &C)
 		if (so >= 0 && so != nsup) {
 			for (int i0 = 0; i0 < len; i0 += 64) {
 				const int i = i0 + lane;
-				const unsigned v = i < len ? C.SUP[so + i] : 0u;
+				const unsigned v = i < len ? sup_ld<ST>(C, so + i) : 0u;
 				LDS_ORDER();
-				if (i < len) C.SUP[nsup + i] = (uint8_t)v;
+				if (i < len) sup_st<ST>(C, nsup + i, v);
 				LDS_ORDER();
 			}
 		}
@@ -773,9 +788,9 @@ __device__ inline void v3_compact(ST &S, V3Ctx &C)
 	LDS_ORDER();
 }
 
-__device__ __forceinline__ bool v3_room(const V3Ctx &C, int ncap, int ncorr)
-{   // (the corrections of the merge sit at the top of the packed area until the insert is done)
-	return C.bump_sup + ncap + SLOT_PAD <= C.sup_cap && C.bump_pm + ((ncap + 15) >> 4) + 2 + ncorr <= C.pm_cap;
+__device__ __forceinline__ bool v3_room(const V3Ctx &C, int ncap, int ncorr_dw)
+{   // (the corrections of the merge sit at the top of the packed area until the insert is done: ncorr_dw dwords)
+	return C.bump_sup + ncap + SLOT_PAD <= C.sup_cap && C.bump_pm + ((ncap + 15) >> 4) + 2 + ncorr_dw <= C.pm_cap;
 }
 
 __device__ __forceinline__ unsigned pk_base(const uint32_t *PM, int b) { return (PM[b >> 4] >> (2 * (b & 15))) & 3u; }
@@ -795,30 +810,33 @@ __device__ inline int v3_insert(ST &S, V3Ctx &C, int ts, int qs, int off, int nc
 	// (a target of one read has no support bytes: the merged contig gets a slot of its own whatever the offset)
 	const bool reloc = off < 0 || newlen > uni(S.cap[ts]) || uni(S.so[ts]) < 0;
 	int ncap = align4(newlen + headroom(newlen));
-	if (reloc && !v3_room(C, ncap, ncorr)) {
+	constexpr int CW = ST::CORR_DW;
+	if (reloc && !v3_room(C, ncap, CW * ncorr)) {
 		v3_compact(S, C);                                            // (before any address of q or t is taken)
-		if (!v3_room(C, ncap, ncorr)) {
+		if (!v3_room(C, ncap, CW * ncorr)) {
 			ncap = align4(newlen);
-			if (!v3_room(C, ncap, ncorr)) { V3_CNT(C, 9, 1); return IHP_E_CAPACITY; }
+			if (!v3_room(C, ncap, CW * ncorr)) { V3_CNT(C, 9, 1); return IHP_E_CAPACITY; }
 		}
 	}
 	const int qpb = uni(16 * S.dw[qs] + S.sh[qs]), qso = uni(S.so[qs]);
 	int tpb = uni(16 * S.dw[ts] + S.sh[ts]), tso = uni(S.so[ts]);
 	// ---- corrections (:161-173): the winner's base and support go to the loser; t's value at such a site is final
 	for (int c = lane; c < ncorr; c += 64) {                       // (corrections come from vote scans: both contigs have support bytes)
-		const unsigned cr = C.PM[C.pm_cap - 1 - c];
+		const unsigned cr = C.PM[C.pm_cap - 1 - CW * c];
 		const int qoff = (int)(cr & 2047u), toff = (int)((cr >> 11) & 2047u);
 		const bool qbest = (cr >> 22) & 1u;
-		unsigned val = C.SUP[tso + toff];
+		unsigned val = sup_ld<ST>(C, tso + toff);
 		if (qbest) {
 			const unsigned b = pk_base(C.PM, qpb + qoff);
 			const int tb = tpb + toff;
 			atomicAnd(&C.PM[tb >> 4], ~(3u << (2 * (tb & 15))));
 			atomicOr(&C.PM[tb >> 4], b << (2 * (tb & 15)));
-			val = C.SUP[qso + qoff];
-			C.SUP[tso + toff] = (uint8_t)val;
+			val = sup_ld<ST>(C, qso + qoff);
+			sup_st<ST>(C, tso + toff, val);
 		}
-		C.PM[C.pm_cap - 1 - c] = (cr & 0x7fffffu) | (val << 23);     // the site keeps this support whatever is added below (:198, :217)
+		// the site keeps this support whatever is added below (:198, :217)
+		if (CW == 1) C.PM[C.pm_cap - 1 - c] = (cr & 0x7fffffu) | (val << 23);
+		else C.PM[C.pm_cap - 2 - CW * c] = val;
 	}
 	LDS_ORDER();
 	int ndw = tpb >> 4, nsh = tpb & 15, nso = tso;
@@ -854,24 +872,26 @@ __device__ inline int v3_insert(ST &S, V3Ctx &C, int ts, int qs, int off, int nc
 	LDS_ORDER();
 	// ---- supports: new[i] = T(i) + Q(i) (:198-200, :216-219), then the corrected sites get their final value back
 	const int tshift = off < 0 ? aoff : 0, qshift = off < 0 ? 0 : off;
-	const uint8_t *ts_ = C.SUP + tso, *qs_ = C.SUP + qso;
-	uint8_t *ns_ = C.SUP + nso;
+	typedef typename ST::sup_t sup_t;
+	const sup_t *ts_ = (const sup_t *)C.SUP + tso, *qs_ = (const sup_t *)C.SUP + qso;
+	sup_t *ns_ = (sup_t *)C.SUP + nso;
 	const int lo = reloc ? 0 : off, hi = reloc ? newlen : (off + qlen < newlen ? off + qlen : newlen);
 	bool over = false;
 	for (int i = lo + lane; i < hi; i += 64) {
 		const int ti = i - tshift, qi = i - qshift;
 		unsigned v = (ti >= 0 && ti < tlen) ? (tso >= 0 ? ts_[ti] : 1u) : 0u;
 		if (qi >= 0 && qi < qlen) v += qso >= 0 ? qs_[qi] : 1u;
-		over |= v > 255u;
-		ns_[i] = (uint8_t)v;
+		over |= v > ST::SUP_MAX;
+		ns_[i] = (sup_t)v;
 	}
 	// (only a region of 256 reads can get here: the sum of two contigs' supports on a base is at most the reads of the region.
 	// A sum at a corrected site is replaced below and would not matter; the region is handed over all the same.)
 	if (ballot(over)) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }
 	LDS_ORDER();
 	for (int c = lane; c < ncorr; c += 64) {
-		const unsigned cr = C.PM[C.pm_cap - 1 - c];
-		ns_[off < 0 ? (int)(cr & 2047u) : (int)((cr >> 11) & 2047u)] = (uint8_t)(cr >> 23);   // index in the merged contig (:170-173)
+		const unsigned cr = C.PM[C.pm_cap - 1 - CW * c];
+		const unsigned fin = CW == 1 ? cr >> 23 : C.PM[C.pm_cap - 2 - CW * c];
+		ns_[off < 0 ? (int)(cr & 2047u) : (int)((cr >> 11) & 2047u)] = (sup_t)fin;   // index in the merged contig (:170-173)
 	}
 	LDS_ORDER();
 	const int nreads_new = uni(S.nreads[ts]) + uni(S.nreads[qs]);  // :203, :222

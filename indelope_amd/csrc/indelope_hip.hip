@@ -33,6 +33,7 @@ struct Ctx {
 	int max_lds = 65536;
 	int comb_static = 4608;                                // static LDS of k_asm_combine3 (hipFuncGetAttributes)
 	int comb_static_a = 1536;                              // ... of the first tier's build (room for COMB_MAXC_A contigs)
+	int comb_static_w = 4864;                              // ... of the wide build (16-bit supports: the regions of more than 255 reads)
 	hipStream_t stream = nullptr;
 	char err[512] = "";
 };
@@ -105,8 +106,10 @@ constexpr int COMB_MAXC_A = 32;                              // contigs the firs
 // arena and (short) contig table, is refused, lands on the retry list, and a run that left the retry launches out is then
 // repeated in full.  One batch without such a region says little about the next (a sweep whose batches hold one now
 // and then paid twice for every batch that followed one without); CLEAN_MIN of them in a row is what the fold waits for.
+// clean_r / clean_k: the same for the launches a run leaves out altogether -- batches in a row in which no region took the retry
+// route (n_big, n_back) / no job the roomy ksw2 launch (n_kovf).
 constexpr int CLEAN_MIN = 3;
-struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0, clean_c = 0, clean_b = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+struct TierHint { int valid = 0, n_b = 0, n_c = 0, n_big = 0, n_back = 0, n_kovf = 0, regions = 0, sig = 0, n_manyc = 0, wide = 0, clean_c = 0, clean_b = 0, clean_r = 0, clean_k = 0; int hist[HIST_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
 // One hint per batch SHAPE (hint_key: read length, read bases per region, the packed / byte-based path, the parameters that
 // decide which launches a run needs), sixteen shapes remembered: a sweep that interleaves batches of different shapes, or
 // several host threads with different workloads, keep their plans apart (round 3 had one process-wide hint; only the tier
@@ -497,10 +500,12 @@ extern "C" int ihp_init(int device)
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<6, false, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<7, false, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		(void)hipFuncSetAttribute((const void *)k_asm_combine3<4, true, COMB_MAXC_A>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
+		(void)hipFuncSetAttribute((const void *)k_asm_combine3<4, false, V3_MAXC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 8192);
 		{
 			hipFuncAttributes fa;
 			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5, false>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static = (int)fa.sharedSizeBytes;
 			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<5, false, COMB_MAXC_A>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static_a = (int)fa.sharedSizeBytes;
+			if (hipFuncGetAttributes(&fa, (const void *)k_asm_combine3<4, false, V3_MAXC, true>) == hipSuccess && fa.sharedSizeBytes > 0) g.comb_static_w = (int)fa.sharedSizeBytes;
 		}
 		(void)hipFuncSetAttribute((const void *)k_asm_reads<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 2048);
 		(void)hipFuncSetAttribute((const void *)k_ksw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, g.max_lds - 1024);
@@ -997,7 +1002,7 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 24 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles)
+enum { WQ_SETS = 25 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles); [24] the wide combine launch (regions of more than 255 reads)
 enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_NRECS = 25 /* 2 */, M_WORDS = 32,
        M_SLAB_BAD = 48, M_HIST = 49, M_MANYC = 60 };   // M_MANYC: regions with more contigs than the first tier's short table holds   // (behind the stamps, inside the report block: raised by k_slab_expand when a compact slab's lengths do not add up)
 struct ihp_batch {
@@ -1024,6 +1029,8 @@ struct ihp_batch {
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
 	int n_small = 0, n_rich = 0;                           // class 1 = the regions of the usual size + the read-rich ones the packed path takes (its own k_asm_reads launch)
+	int n_deep = 0;                                        // regions of the packed path with more than 255 reads: their combine runs the wide build (16-bit supports)
+	int v2_arena_deep = 0, v2_pm_deep = 0, grid_v2deep = 0;
 	int v2_pdw_rich = 0, grid_v2r_rich = 0;
 	hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr;
 	hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bfork = nullptr, ev_bjoin = nullptr, ev_kfork = nullptr, ev_kjoin = nullptr;
@@ -1235,6 +1242,21 @@ static void size_combine_tiers(ihp_batch *b, int occ_first)
 		b->grid_v2c = std::min(grid_for(R, occ_t), std::max(1, b->n_cls[0]));
 	}
 	b->v2_arena = g_knob.v2_arena ? g_knob.v2_arena / 16 * 16 : (int)need_C;
+	// the wide build's launch (regions of more than 255 reads): 2 bytes per support.  A deep pile-up holds about the contigs of a
+	// usual one -- the reads all cover the same few hundred bases -- plus a single-read contig per read with an error, so the
+	// arena of the usual region's second tier, at least, at eight regions per CU (their chains are the longest of the batch).
+	if (b->n_deep) {
+		const long long statw = g.comb_static_w + 16;
+		const int occ_d = 8;
+		const long long budget = std::max<long long>(1, (g.max_lds / LDS_GRAN) / occ_d) * LDS_GRAN;
+		long long Cd = std::max<long long>(1024, (budget - statw - 4 * 128) * 2 / 5 / 16 * 16 - 16);      // 2 C + 4 (C / 8 + 128) bytes
+		Cd = std::max<long long>(Cd, b->v2_arena_b);
+		const int dyn_max_d = g.max_lds - 8192 - 1024;
+		while (Cd > 1024 && 2 * Cd + 4 * comb_pm_of(Cd) > dyn_max_d) Cd -= 256;
+		b->v2_arena_deep = (int)Cd; b->v2_pm_deep = (int)comb_pm_of(Cd);
+		const int occ_real = (int)std::max<long long>(1, (g.max_lds / LDS_GRAN) / ((statw + 2 * Cd + 4 * comb_pm_of(Cd) + LDS_GRAN - 1) / LDS_GRAN));
+		b->grid_v2deep = std::min(grid_for(b->n_deep, std::min(occ_real, 16)), std::max(1, b->n_deep));
+	}
 	// every combine launch must fit what hipFuncSetAttribute allows (max_lds - 8192 of dynamic LDS beside the static part):
 	// the later tiers and the roomy launch give up arena first, the packed path is switched off only when the first tier does not fit
 	const int dyn_max = g.max_lds - 8192 - 1024;
@@ -1508,8 +1530,10 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			const long long want = nb * 3 / 10 + 2 * b->stage_cap;
 			int k = 0;
 			while (k < 3 && want > lim[k]) ++k;
-			if (k > 0 && packed_ok && rro[r + 1] - rro[r] <= 256 && nb <= 120000) rich.push_back({-nb, r});
+			const long long nr_ = rro[r + 1] - rro[r];
+			if (k > 0 && packed_ok && nr_ <= V3_MAXREADS_WIDE && nb <= 120000) rich.push_back({-nb, r});
 			else cls[k].push_back({-nb, r});
+			if (packed_ok && nr_ > 255 && nr_ <= V3_MAXREADS_WIDE && (k == 0 || nb <= 120000)) b->n_deep++;
 		}
 		order.reserve((size_t)R);
 		std::sort(rich.begin(), rich.end());
@@ -1536,7 +1560,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			for (int r = 0; r < R; ++r) {
 				const long long nb = rb[r + 1] - rb[r];
 				if (nb * 3 / 10 + 2 * b->stage_cap <= b->lds_arena1) { nb1 = std::max(nb1, nb); nr1 = std::max<long long>(nr1, rro[r + 1] - rro[r]); }
-				else if (b->n_rich && rro[r + 1] - rro[r] <= 256 && nb <= 120000) { nbL = std::max(nbL, nb); nrL = std::max<long long>(nrL, rro[r + 1] - rro[r]); }
+				else if (b->n_rich && rro[r + 1] - rro[r] <= V3_MAXREADS_WIDE && nb <= 120000) { nbL = std::max(nbL, nb); nrL = std::max<long long>(nrL, rro[r + 1] - rro[r]); }
 			}
 			if (nb1 == 0) { nb1 = std::min<long long>(nbL, 16384); nr1 = std::min<long long>(nrL, 64); }   // no region of the usual size: size the first tier for small ones
 			// what a region needs at least ...
@@ -1747,7 +1771,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	// the roomy ksw2 launch (below) is left out when the last batch of this shape had no job for it; its scratch -- up to 512 MB,
 	// a pool miss is a hipMalloc, which synchronises the device -- is taken HERE, before anything of this run is enqueued: a
 	// failure returns with nothing in the stream
-	const bool ksw_roomy = b->R > 0 && b->n_reads > 0 && !(have_hint && !g_knob.no_spec && !b->force_full && H.n_kovf == 0);
+	const bool ksw_roomy = b->R > 0 && b->n_reads > 0 && !(have_hint && !g_knob.no_spec && !b->force_full && H.n_kovf == 0 && H.clean_k >= CLEAN_MIN);
 	if (ksw_roomy) {
 		if (!b->p_scratch_big.p) { int rcb = b->p_scratch_big.alloc(b->p_cap_big * b->grid_kovf); if (rcb) return rcb; }
 		if (!b->cig_tmp_big.p) { int rcb = b->cig_tmp_big.alloc(sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf); if (rcb) { b->p_scratch_big.release(); return rcb; } }
@@ -1969,16 +1993,27 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 					ga = (int)std::min<long long>(ga, occ_a * g.cus);
 				}
 			}
+			const bool deep_on = ra.lpt_cnt && b->n_deep > 0 && b->grid_v2deep > 0;
+			if (deep_on) {
+				// the regions of more than 255 reads (the longest chains of the batch): the wide build, first on the second stream
+				HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
+				AsmArgs w = x;
+				w.lpt_cnt = ra.lpt_cnt + 3 * LPT_CLASSES; w.lpt_seg = ra.lpt_seg + (size_t)3 * LPT_CLASSES * ra.lpt_stride;
+				w.arena_cap = b->v2_arena_deep; w.lds_arena = b->v2_arena_deep; w.v2_pm_dw = b->v2_pm_deep;
+				w.work_counter = wq + 24 * WQ_WORDS;
+				hipLaunchKernelGGL((k_asm_combine3<4, false, V3_MAXC, true>), dim3(b->grid_v2deep), dim3(64), (size_t)2 * b->v2_arena_deep + 4 * (size_t)b->v2_pm_deep, s2, w);
+				HIPC(hipGetLastError());
+			}
 			if (ra.lpt_cnt) {
 				if (!fold_b) {
-					HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
+					if (!deep_on) HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));
 					AsmArgs y = x;
 					y.lpt_cnt = ra.lpt_cnt + 2 * LPT_CLASSES; y.lpt_seg = ra.lpt_seg + (size_t)2 * LPT_CLASSES * ra.lpt_stride;
 					y.arena_cap = b->v2_arena_b; y.lds_arena = b->v2_arena_b; y.v2_pm_dw = b->v2_pm_b;
 					y.work_counter = wq + 13 * WQ_WORDS;
 					launch_comb(gb, tm_b, b->v2_arena_b + 4 * b->v2_pm_b, s2, y);
 					HIPC(hipEventRecord(b->ev_bjoin, s2));
-				} else HIPC(hipEventRecord(b->ev_bjoin, s));
+				} else HIPC(hipEventRecord(b->ev_bjoin, deep_on ? s2 : s));
 				if (!fold_c) {
 					AsmArgs z = x;
 					z.lpt_cnt = ra.lpt_cnt + LPT_CLASSES; z.lpt_seg = ra.lpt_seg + (size_t)LPT_CLASSES * ra.lpt_stride;
@@ -2000,7 +2035,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			// launches that are empty for batch after batch, each waiting for wave slots while another batch's persistent grids
 			// fill the chip (0.2-0.4 ms in front of k_ksw).  When the last batch needed none of them they are left out, and
 			// whoever waits for this run checks the counters: a region that did need the route makes the run repeat in full.
-			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && H.n_big == 0 && H.n_back == 0;
+			spec_skip = hint && !g_knob.no_spec && !side && !b->force_full && H.n_big == 0 && H.n_back == 0 && H.clean_r >= CLEAN_MIN;
 			if (!spec_skip) {
 			if (hint && H.n_big == 0) {
 				launch_comb(std::min(b->grid_v2big, 64), tm_a, b->v2_arena + 4 * b->v2_pm, s, x, !b->tier_wide);
@@ -2196,6 +2231,12 @@ static void hint_refresh(const ihp_batch *b)
 	TierHint h;
 	h.n_b = b->report[M_NTIERB]; h.n_c = b->report[M_NTIERC]; h.n_big = b->report[M_NRETRYC];
 	h.n_back = b->report[M_NRETRY0]; h.n_kovf = b->report[M_KSW_OVF];
+	{
+		TierHint prev0;
+		const bool had0 = g_hints.get(b->hint_key, prev0);
+		h.clean_r = (h.n_big == 0 && h.n_back == 0) ? std::min(1 << 20, (had0 ? prev0.clean_r : 0) + 1) : 0;
+		h.clean_k = h.n_kovf == 0 ? std::min(1 << 20, (had0 ? prev0.clean_k : 0) + 1) : 0;
+	}
 	if (b->v2 && g_knob.lpt) {
 		for (int k = 0; k < HIST_N; ++k) h.hist[k] = b->report[M_HIST + k];
 		h.n_manyc = b->report[M_MANYC]; h.wide = b->tier_wide ? 1 : 0;
@@ -2203,7 +2244,7 @@ static void hint_refresh(const ihp_batch *b)
 		const bool had = g_hints.get(b->hint_key, prev);
 		h.clean_c = h.n_c == 0 ? std::min(1 << 20, (had ? prev.clean_c : 0) + 1) : 0;
 		h.clean_b = (h.n_b == 0 && h.n_manyc == 0) ? std::min(1 << 20, (had ? prev.clean_b : 0) + 1) : 0;
-		h.regions = b->n_cls[0] - b->report[M_NRETRY0]; h.sig = b->tier_sig;
+		h.regions = std::max(0, b->n_cls[0] - b->report[M_NRETRY0] - b->n_deep); h.sig = b->tier_sig;   // (the regions the histogram counts: the wide launch's are not filed by arena)
 	}
 	if (g_knob.verbose) fprintf(stderr, "[ihp] confirmed: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);
 	g_hints.put(b->hint_key, h);

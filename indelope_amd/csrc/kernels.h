@@ -461,11 +461,12 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		if (r < 0) break;
 		if (a.in_list) r = a.in_list[r];
 		int nc = 0, need = 0;
+		const bool deep = uni(a.region_read_off[r + 1]) - uni(a.region_read_off[r]) > 255;
 		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr, nc, need);
 		if (err) {                                             // not for this path: the byte-based passes take it
 			// (n_final = 0: the launches that take the list may have been left out of this run -- ihp_batch_run -- and k_summary walks n_final contigs)
 			if (lane == 0) { a.v2_hand[a.v2_hoff[r]] = 0xffffffffu; a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
-		} else if (lane == 0 && a.hist) {
+		} else if (lane == 0 && a.hist && !deep) {
 			// (a region with more contigs than the first tier's table holds counts as one that only the roomiest first tier would take)
 			if (nc > a.manyc_thr) atomicAdd(a.n_manyc, 1);
 			if (nc > a.tier_a_maxc) atomicAdd(&a.hist[10], 1);
@@ -473,10 +474,11 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		}
 		if (!err && a.lpt_cnt && lane == 0) {
 			// the tiers in memory: first, third, second (the first tier's launch can then walk the third's lists, or all, behind its own)
-			const int tier = need <= a.tier_a_cap && nc <= a.tier_a_maxc ? 0 : need <= a.tier_b_cap ? 2 : 1;
+			// (the fourth tier: the regions of more than 255 reads, whose supports do not fit a byte -- the wide build's launch)
+			const int tier = deep ? 3 : need <= a.tier_a_cap && nc <= a.tier_a_maxc ? 0 : need <= a.tier_b_cap ? 2 : 1;
 			const int c = lpt_class(nc) + tier * LPT_CLASSES;
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;
-			if (tier) atomicAdd(a.n_tier_b + (tier == 2 ? 0 : 1), 1);
+			if (tier == 1 || tier == 2) atomicAdd(a.n_tier_b + (tier == 2 ? 0 : 1), 1);
 			if (a.prof) {                                          // what the regions ask of the combine arena: sum and maximum of the capacity units
 				atomicAdd((unsigned long long *)&a.prof[62], (unsigned long long)need);
 				atomicMax((unsigned long long *)&a.prof[63], (unsigned long long)need);
@@ -513,13 +515,22 @@ __device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C,
 			const unsigned c8 = (fsh(C.PM[(b >> 4) + 1], C.PM[b >> 4], 2u * (unsigned)(b & 15))) & 0xffu;
 			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
 			const unsigned w = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
-			const unsigned sv = so >= 0 ? ld32u((const uint32_t *)C.SUP, so + i) : 0x01010101u;   // four supports (the slot is padded: reading past len is fine)
+			unsigned s4[4] = {1u, 1u, 1u, 1u};                           // four supports (the slot is padded: reading past len is fine)
+			if (so >= 0) {
+				if (ST::WIDE) {
+					const unsigned lo = ld32u((const uint32_t *)C.SUP, 2 * (so + i)), hi = ld32u((const uint32_t *)C.SUP, 2 * (so + i) + 4);
+					s4[0] = lo & 0xffffu; s4[1] = lo >> 16; s4[2] = hi & 0xffffu; s4[3] = hi >> 16;
+				} else {
+					const unsigned sv = ld32u((const uint32_t *)C.SUP, so + i);
+					s4[0] = sv & 0xffu; s4[1] = (sv >> 8) & 0xffu; s4[2] = (sv >> 16) & 0xffu; s4[3] = sv >> 24;
+				}
+			}
 			if (i + 4 <= len) {
 				*(u32_unaligned *)(oseq + i) = w;
-				osup[i] = sv & 0xffu; osup[i + 1] = (sv >> 8) & 0xffu; osup[i + 2] = (sv >> 16) & 0xffu; osup[i + 3] = sv >> 24;
+				osup[i] = s4[0]; osup[i + 1] = s4[1]; osup[i + 2] = s4[2]; osup[i + 3] = s4[3];
 			} else {
 #pragma unroll
-				for (int j = 0; j < 3; ++j) if (i + j < len) { oseq[i + j] = (uint8_t)(w >> (8 * j)); osup[i + j] = (sv >> (8 * j)) & 0xffu; }
+				for (int j = 0; j < 3; ++j) if (i + j < len) { oseq[i + j] = (uint8_t)(w >> (8 * j)); osup[i + j] = s4[j]; }
 			}
 		}
 		cursor += len;
@@ -576,10 +587,11 @@ __device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C,
 // others join it inside best_match calls (V3Par, asm3_dev.h) and wait at a barrier otherwise; so wave 0 itself never uses a
 // workgroup barrier outside those calls (WAVE_SYNC: its own memory traffic done, nothing more).  128 VGPRs, 16 waves per CU.
 #define WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-template <int MINW, bool TEAM, int MAXC = V3_MAXC>
+// WIDE: 16-bit supports and the records of up to 640 reads (asm3_dev.h): the launch of the regions with more than 255 reads.
+template <int MINW, bool TEAM, int MAXC = V3_MAXC, bool WIDE = false>
 __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_asm_combine3(const AsmArgs a)
 {
-	__shared__ V3StateT<MAXC> S;
+	__shared__ V3StateT<MAXC, WIDE> S;
 	__shared__ int s_item;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
 	__shared__ V3Par s_par;                                    // (dropped from the one-wave build: nobody refers to it there)
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 	const int lane = lane_id();
 	const int wave = TEAM ? (int)(threadIdx.x >> 6) : 0, n_waves = TEAM ? (int)(blockDim.x >> 6) : 1;
 	V3Ctx C;
-	C.SUP = lds_arena; C.sup_cap = a.lds_arena; C.PM = (uint32_t *)(lds_arena + a.lds_arena); C.pm_cap = a.v2_pm_dw;
+	C.SUP = lds_arena; C.sup_cap = a.lds_arena; C.PM = (uint32_t *)(lds_arena + (size_t)a.lds_arena * sizeof(typename V3StateT<MAXC, WIDE>::sup_t)); C.pm_cap = a.v2_pm_dw;   // (a.lds_arena: supports, not bytes)
 	C.bump_pm = C.bump_sup = 0; C.prof = a.prof ? S.prof : nullptr; C.cnt = a.prof ? S.cnt : nullptr;
 	if (TEAM && wave != 0) {
 		C.prof = nullptr; C.cnt = nullptr;

@@ -545,6 +545,32 @@ Api.pack_out = _pack_out
 Api.unpack_slab = _unpack_slab
 
 
+def concat_batches(parts):
+    """RegionBatches one behind the other as one batch (regions keep their order; trim bounds only if every part has them)."""
+    cat = np.concatenate
+
+    def offs(name, cnt):
+        out, base = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            a = np.asarray(getattr(p, name), np.int64)
+            out.append(a[1:] + base)
+            base += int(a[-1])
+        return cat(out)
+
+    def opt(name, fill, lens):
+        cols = [getattr(p, name) for p in parts]
+        if all(c is None for c in cols):
+            return None
+        return cat([np.full(n, fill, np.uint8) if c is None else c for c, n in zip(cols, lens)])
+    n_reads = [p.n_reads for p in parts]
+    n_bases = [len(p.bases) for p in parts]
+    trims = all(p.trim_lo is not None for p in parts)
+    return RegionBatch(offs("region_read_off", 0), offs("read_off", 0), cat([p.bases for p in parts]), opt("quals", 30, n_bases),
+                       cat([p.read_start for p in parts]), cat([p.read_stop for p in parts]), cat([p.mapq for p in parts]),
+                       opt("read_skip", 0, n_reads), offs("ref_off", 0), cat([p.ref_bases for p in parts]), cat([p.ref_origin for p in parts]),
+                       cat([p.trim_lo for p in parts]) if trims else None, cat([p.trim_hi for p in parts]) if trims else None)
+
+
 def concat_results(parts):
     """BatchResults of consecutive region ranges (the ranks' shards, in rank order) as one."""
     import copy

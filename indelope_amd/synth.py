@@ -26,6 +26,13 @@ CONFIGS = {
     "C4": dict(config_id=4, n_regions=5_000_000, read_len=150, n_reads=(64, 64), err_rate=1e-3, n_events=1, K=27),
     "C5": dict(config_id=5, n_regions=10_000, read_len=300, n_reads=(64, 64), err_rate=1e-3, n_events=2, K=31,
                window_len=1400, event_pos=500),
+    # Not a BASELINE config: the regions the reference admits above C3's 256 reads -- gen_roi hands over up to 600 reads per roi
+    # (src/indelope.nim:483-485, :515) and deep exome coverage is where indelope is run (README.md:5).  n ~ logU[257, 600], 150 bp.
+    # Substitution rate 2.5e-4 instead of the other configs' 1e-3: every read with an error inside its overlap opens a contig of
+    # its own in the read phase (contig.nim:243-248), and at 1e-3 a pile-up of more than ~450 reads leaves more than the 64
+    # contigs the packed path's directory holds (such regions take the byte-based passes; `deep_1e3` measures that mix).
+    "deep": dict(config_id=6, n_regions=20_000, read_len=150, n_reads=(257, 600), err_rate=2.5e-4, n_events=1, K=27),
+    "deep_1e3": dict(config_id=7, n_regions=20_000, read_len=150, n_reads=(257, 600), err_rate=1e-3, n_events=1, K=27),
 }
 
 _LIB = None

@@ -200,6 +200,10 @@ static int dist_rank_main(int rank, int world, const char *idfile, int device)
 int main(int argc, char **argv)
 {
 	if (argc >= 5 && strcmp(argv[1], "--dist") == 0) return dist_rank_main(atoi(argv[2]), atoi(argv[3]), argv[4], argc > 5 ? atoi(argv[5]) : 0);
+	/* the device checks first: librccl prints a banner on stdout when it starts, and the JSON object has to stay one (the last) line */
+	const int want_gpu = argc > 1 && strcmp(argv[1], "--gpu") == 0;
+	const int gpu_rc = want_gpu ? gpu_checks() : 0;
+	fflush(stdout);
 	printf("{");
 	SZ(ksw_extz_t); OFF(ksw_extz_t, max_q); OFF(ksw_extz_t, mqe); OFF(ksw_extz_t, mte); OFF(ksw_extz_t, score);
 	OFF(ksw_extz_t, m_cigar); OFF(ksw_extz_t, n_cigar); OFF(ksw_extz_t, cigar);
@@ -234,11 +238,7 @@ int main(int argc, char **argv)
 	ihp_genotype(0, 0, 1e-4, &g);                 /* :65-67: UNKNOWN */
 	printf("\"genotype_0_0\": %d, ", g.gt);
 	printf("\"strerror_capacity\": \"%s\", \"version\": \"%s\"", ihp_strerror(IHP_E_CAPACITY), ihp_version());
-	int rc = 0;
-	if (argc > 1 && strcmp(argv[1], "--gpu") == 0) {
-		rc = gpu_checks();
-		printf(", \"gpu_checks\": %s", rc ? "false" : "true");
-	}
+	if (want_gpu) printf(", \"gpu_checks\": %s", gpu_rc ? "false" : "true");
 	printf("}\n");
-	return rc;
+	return gpu_rc;
 }

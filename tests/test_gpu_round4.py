@@ -157,12 +157,13 @@ def test_release_outputs_and_summary_dev_confirm_the_run(hip, oracle):
     want = summaries_from_result(exp)
     for how in ("release", "summary_dev"):
         hip.debug_set()
-        h = hip.batch_upload(clean)
-        hip.batch_run(h); hip.batch_sync(h)
-        hip.batch_free(h)
+        for _ in range(3):                                      # (CLEAN_MIN batches in a row: only then is the retry route left out)
+            h = hip.batch_upload(clean)
+            hip.batch_run(h); hip.batch_sync(h)
+            hip.batch_free(h)
         h = hip.batch_upload(dirty)
         try:
-            hip.batch_run(h)                                    # speculates on the clean batch's plan
+            hip.batch_run(h)                                    # speculates on the clean batches' plan
             if how == "release":
                 hip.batch_release_outputs(h)
             ptr, n = hip.batch_summary_dev(h)
