@@ -1075,6 +1075,7 @@ struct ihp_batch {
 	bool tier_wide = false;                                // the first combine tier runs the build with the full contig table (many regions with more than COMB_MAXC_A contigs)
 	long long v2_nb1 = 0; int tier_occ = 0, tier_occ_default = 0, tier_sig = 0;   // first-tier sizing of the combine launches (size_combine_tiers)
 	bool counted = false;                                  // k_pack_count / k_pack_scan of the last run are enqueued (or done)
+	mutable bool hint_counted = false;                     // the last run has been added to the shape's streaks (TierHint::clean_*): once per run, however many waits confirm it
 	long long n_reruns = 0;
 	bool dirty = false;                                    // a run was cut short after some launches: `misc` is not known to be clear
 	int *report = nullptr;                                 // page-locked host block: the last run's counters, flags and stamps
@@ -2183,6 +2184,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	}
 	HIPC(hipEventRecord(b->ev[4], s));
 	b->ran = true;
+	b->hint_counted = false;
 	b->counted = false;
 	if (b->fetch_flags & IHP_FETCH_EAGER) { const int rcp = pack_counts_enqueue(b); if (rcp) return rcp; }
 	b->spec_skipped = spec_skipped_run;
@@ -2231,19 +2233,20 @@ static void hint_refresh(const ihp_batch *b)
 	TierHint h;
 	h.n_b = b->report[M_NTIERB]; h.n_c = b->report[M_NTIERC]; h.n_big = b->report[M_NRETRYC];
 	h.n_back = b->report[M_NRETRY0]; h.n_kovf = b->report[M_KSW_OVF];
-	{
-		TierHint prev0;
-		const bool had0 = g_hints.get(b->hint_key, prev0);
-		h.clean_r = (h.n_big == 0 && h.n_back == 0) ? std::min(1 << 20, (had0 ? prev0.clean_r : 0) + 1) : 0;
-		h.clean_k = h.n_kovf == 0 ? std::min(1 << 20, (had0 ? prev0.clean_k : 0) + 1) : 0;
-	}
+	// the streaks count RUNS, not waits: sync, fetch, pack and summary all confirm the same run
+	const int step = b->hint_counted ? 0 : 1;
+	b->hint_counted = true;
+	TierHint prev0;
+	const bool had0 = g_hints.get(b->hint_key, prev0);
+	auto streak = [&](bool ok, int before) { return ok ? std::min(1 << 20, (had0 ? before : 0) + step) : 0; };
+	h.clean_r = streak(h.n_big == 0 && h.n_back == 0, prev0.clean_r);
+	h.clean_k = streak(h.n_kovf == 0, prev0.clean_k);
+	h.clean_c = prev0.clean_c; h.clean_b = prev0.clean_b;
 	if (b->v2 && g_knob.lpt) {
 		for (int k = 0; k < HIST_N; ++k) h.hist[k] = b->report[M_HIST + k];
 		h.n_manyc = b->report[M_MANYC]; h.wide = b->tier_wide ? 1 : 0;
-		TierHint prev;
-		const bool had = g_hints.get(b->hint_key, prev);
-		h.clean_c = h.n_c == 0 ? std::min(1 << 20, (had ? prev.clean_c : 0) + 1) : 0;
-		h.clean_b = (h.n_b == 0 && h.n_manyc == 0) ? std::min(1 << 20, (had ? prev.clean_b : 0) + 1) : 0;
+		h.clean_c = streak(h.n_c == 0, prev0.clean_c);
+		h.clean_b = streak(h.n_b == 0 && h.n_manyc == 0, prev0.clean_b);
 		h.regions = std::max(0, b->n_cls[0] - b->report[M_NRETRY0] - b->n_deep); h.sig = b->tier_sig;   // (the regions the histogram counts: the wide launch's are not filed by arena)
 	}
 	if (g_knob.verbose) fprintf(stderr, "[ihp] confirmed: %d jobs, %d to the roomy ksw2 launch (skipped %d), overflow flags %d %d %d\n", b->report[M_NJOBS], b->report[M_KSW_OVF], (int)b->ksw_skipped, b->report[M_OVF], b->report[M_OVF + 1], b->report[M_OVF + 2]);
