@@ -383,6 +383,7 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=1, d
         dt = time.perf_counter() - t0
         km = np.array([api.batch_kernel_ms_mean(h)[0] for h in hs]).mean(axis=0)
         parts = [api.batch_fetch(h) for h in hs]
+        profs = [api.batch_profile(h) for h in hs]               # (the report's counters: no profiling switch needed for these)
     finally:
         for h in hs:
             api.batch_free(h)
@@ -402,7 +403,11 @@ def quick_config(api, name, regions, steps, warmup, check=True, sub_batches=1, d
            "kernel_ms": dict({k: round(float(v), 4) for k, v in zip(KERNELS, km[:3])}, k_fallback=round(float(km[3]), 4)),
            "roofline": {"kernel": KERNELS[dom], "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "whole_path_frac": round(whole / HBM_PEAK_GBS, 5)},
-           "failed_regions": int((res.status != 0).sum())}
+           "failed_regions": int((res.status != 0).sum()),
+           # regions the packed path handed back to the byte-based passes in the last run (0 = every region of the workload stayed
+           # on the packed path), runs repeated because a launch plan was wrong
+           "regions_to_byte_passes": int(sum(int(p[23]) for p in profs)), "n_reruns": int(sum(int(p[31]) for p in profs)),
+           "events": int(res.n_events), "fallback_events": int((res.events["aligned"] == 1).sum()) if res.n_events else 0}
     if check:
         import oracle
         o = oracle.get()
@@ -455,6 +460,39 @@ def c1_leg(api, K=27, reps=7):
             "gpu_us_per_region": round(float(np.median(gpu)) * 1e6, 1), "gpu_min_us": round(min(gpu) * 1e6, 1),
             "gpu_kind": "ihp_run_regions: upload + run + fetch of the one region (launch latency, not throughput)",
             "reps": reps, "identical": d is None, "first_difference": d}
+
+
+# ------------------------------------------------------------------------------------------ break-even batch size
+def break_even(api, K=27, sizes=(1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024), reps=5):
+    """Below which batch size a caller should stay on the CPU seam: n C2-shaped regions (64 x 150 bp) through
+    ihp_run_regions -- pageable host arrays in, host results out, everything a first-time caller pays -- against the CPU path on
+    ONE thread (what the reference is: `indelope.nim` is single-threaded) and on all the threads this process owns (regions are
+    independent, so a caller could also do that).  Median of `reps` per size."""
+    import oracle
+    from indelope_amd import synth
+    o = oracle.get()
+    usable, _ = _host_cpus()
+    used_ref = o.use_reference_ksw(True)
+    rows = []
+    try:
+        full, _ = synth.config("C2", n_regions=max(sizes))
+        for n in sizes:
+            b = full.slice(0, n)
+            api.run_regions(b, api.params(K=K))                  # (plan + pools of this shape)
+            g, c1, cm = [], [], []
+            for _ in range(reps):
+                t0 = time.perf_counter(); api.run_regions(b, api.params(K=K)); g.append(time.perf_counter() - t0)
+                t0 = time.perf_counter(); o.run_regions(b, o.params(K=K)); c1.append(time.perf_counter() - t0)
+                t0 = time.perf_counter(); o.run_regions_mt(b, o.params(K=K), min(usable, n)); cm.append(time.perf_counter() - t0)
+            rows.append({"regions": n, "gpu_us": round(float(np.median(g)) * 1e6, 1), "cpu_1thread_us": round(float(np.median(c1)) * 1e6, 1),
+                         "cpu_%dthreads_us" % usable: round(float(np.median(cm)) * 1e6, 1)})
+    finally:
+        o.use_reference_ksw(False)
+    key = "cpu_%dthreads_us" % usable
+    be1 = next((r["regions"] for r in rows if r["gpu_us"] < r["cpu_1thread_us"]), None)
+    bem = next((r["regions"] for r in rows if r["gpu_us"] < r[key]), None)
+    return {"workload": "n C2-shaped regions (64 x 150 bp) through ihp_run_regions (pageable arrays in, results out) vs the C oracle with the compiled reference ksw2",
+            "rows": rows, "gpu_faster_than_one_cpu_thread_from": be1, "gpu_faster_than_%d_cpu_threads_from" % usable: bem, "cpu_threads": usable}
 
 
 # ------------------------------------------------------------------------------------------ mixed stream
@@ -606,6 +644,15 @@ def digest(out):
     c = out.get("c1")
     if c:
         d["c1_us"] = [c["cpu_us_per_region"], c["gpu_us_per_region"], c["identical"]]
+    fcv = out.get("fallback_curve")
+    if fcv:
+        d["fb_curve_M"] = {k: m(v[0]) for k, v in fcv["by_dup_fraction"].items()}
+    be = out.get("break_even")
+    if be:
+        d["break_even"] = [be["gpu_faster_than_one_cpu_thread_from"], be.get("gpu_faster_than_%d_cpu_threads_from" % be["cpu_threads"])]
+    dp = oc.get("deep")
+    if dp:
+        d["deep_byte_pass_regions"] = dp.get("regions_to_byte_passes")
     cb = out.get("cpu_baseline")
     if cb:
         d["cpu"] = [cb["value"], cb["cores"], out.get("gpu_over_cpu")]
@@ -1170,8 +1217,22 @@ def main():
                                     "dup10": quick_config(api, "C2", 10_000, steps=6, warmup=4, check=not args.no_check, dup_frac=0.1),
                                     # the headline workload submitted as in rounds 1-3: ONE resident batch, two sub-batches, every step waited for
                                     "C2_one_batch_lockstep": quick_config(api, "C2", 10_000, steps=20, warmup=3, check=False, sub_batches=2, in_flight=1, lockstep=True)}
+            # the regions the reference admits above C3's 256 reads (gen_roi: up to 600 per roi, indelope.nim:515): 20 000 `deep` regions,
+            # n ~ logU[257, 600]; 6 000 of them through the oracle (a deep region costs the oracle seven C2 regions)
+            out["other_configs"]["deep"] = quick_config(api, "deep", 20_000, steps=3, warmup=2, check=not args.no_check, in_flight=1, sub_batches=2, check_regions=6_000)
+            # what the headline costs as a function of the share of events that take the alignment fallback (indelope.nim:312-372; the
+            # C2 generator plants clean indels: 0 of them do): C2 with 0 / 2 / 5 / 10 / 25 % of its events tandem duplications
+            fc = {"0": [out["value"], 0]}
+            for f in (0.02, 0.05, 0.25):
+                q = quick_config(api, "C2", 10_000, steps=6, warmup=4, check=False, dup_frac=f)
+                fc["%g" % f] = [q["value"], q["fallback_events"], q["kernel_ms"]["k_fallback"]]
+            d10 = out["other_configs"]["dup10"]
+            fc["0.1"] = [d10["value"], d10["fallback_events"], d10["kernel_ms"]["k_fallback"]]
+            out["fallback_curve"] = {"workload": "C2 (10 000 regions x 64 x 150 bp, two resident batches) with a share of the planted events made tandem duplications: [regions/s, events through the alignment fallback per batch pair, k_fallback ms per launch]",
+                                     "by_dup_fraction": {k: fc[k] for k in sorted(fc, key=float)}}
             out["mixed_stream"] = mixed_stream(api)
             out["c1"] = c1_leg(api)
+            out["break_even"] = break_even(api)
         if not args.no_cpu and world == 1:
             full = batch0
             out["cpu_baseline"] = cpu_baseline(full, K)
