@@ -138,22 +138,23 @@ __device__ inline void duo_resolve(const DuoState<NS> &S, int qlen, int tlen, Du
 template <int NS, int K>
 struct DuoSlots {
 	static __device__ __forceinline__ void run(DuoState<NS> &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned *sp, const int r,
-	                                           const unsigned (&ru)[NS], const unsigned (&ry)[NS], const unsigned ub, const bool l0, const int hi,
+	                                           const unsigned (&ru)[NS], const unsigned (&ry)[NS], const unsigned ub, const bool l0, const int hi, const int lo,
 	                                           const unsigned tag, const unsigned long long started, uint8_t *prow)
 	{
+		if (K <= hi && K < lo) { DuoSlots<NS, K + 1>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow); return; }
 		if (K <= hi) {
 			const unsigned uin = l0 ? (K ? ru[K ? K - 1 : 0] : ub) : ru[K], yin = l0 ? (K ? ry[K ? K - 1 : 0] : 0u) : ry[K];
 			const unsigned sel = sp[r + 64 * (NS - 1 - K)];
 			if (K < NS - 1 && K < hi) duo_slot<NS, K, false>(S, E, T1, QEp, sel, uin, yin, tag, started, prow);
 			else duo_slot<NS, K, true>(S, E, T1, QEp, sel, uin, yin, tag, started, prow);
-			DuoSlots<NS, K + 1>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow);
+			DuoSlots<NS, K + 1>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow);
 		}
 	}
 };
 template <int NS>
 struct DuoSlots<NS, NS> {
 	static __device__ __forceinline__ void run(DuoState<NS> &, const PairEnv &, const unsigned, const unsigned, const unsigned *, const int,
-	                                           const unsigned (&)[NS], const unsigned (&)[NS], const unsigned, const bool, const int,
+	                                           const unsigned (&)[NS], const unsigned (&)[NS], const unsigned, const bool, const int, const int,
 	                                           const unsigned, const unsigned long long, uint8_t *) {}
 };
 
@@ -210,12 +211,17 @@ __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8
 	unsigned tag = 0xffffu;
 	for (int r = 0; r < total; ++r) {
 		const int hi = (r >> 6) < nsl - 1 ? (r >> 6) : nsl - 1;
+		// Slot K is past the LONGER target's end from diagonal tmax + 64 K + 63 on (its lane 63 works on t = r - 64 K - 63): those
+		// cells are the wildcard continuation, which no maximum and no traceback path can come from (see above), and the last
+		// cell of the slot that feeds a real one -- (tmax - 1, 64 K + 63), the neighbour of slot K + 1's lane 0 -- was computed
+		// on diagonal tmax + 64 K + 62.  The slots below `lo` are left out (round 6: 7 % of a 150 x 460 item's slot-diagonals).
+		const int lo = r >= tmax + 63 ? ((r - tmax - 63) >> 6) + 1 : 0;
 		const int fill = r - 64 * hi;
 		const unsigned long long started = fill >= 63 ? ~0ull : ~0ull >> (63 - fill);
 		unsigned ru[NS], ry[NS];
 #pragma unroll
 		for (int k = 0; k < NS; ++k) { ru[k] = duo_ror1(S.U[k]); ry[k] = duo_ror1(S.Y[k]); }
-		DuoSlots<NS, 0>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow);
+		DuoSlots<NS, 0>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow);
 		ub = ub1;
 		tag -= 1;
 		prow += ncol;

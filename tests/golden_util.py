@@ -140,6 +140,40 @@ def transcript_sets():
     return out
 
 
+def deep_sets():
+    """tests/golden/deep_golden.npz (make_deep_golden.py): 300 regions of 257-600 reads on which both restatements agreed.  The
+    inputs come from the repository's own generator (indelope_amd/csrc/synth.cpp) and are checked against the SHA-256 the fixture
+    holds; -> [(key, RegionBatch, Expected)]."""
+    import hashlib
+    from indelope_amd import synth
+    z = np.load(os.path.join(HERE, "golden", "deep_golden.npz"))
+    out = []
+    for key in sorted({k.split(".")[0] for k in z.files}):
+        name, first, n = key.rsplit("_", 2)
+        b, _ = synth.config(name, n_regions=int(n), first_region=int(first))
+        h = hashlib.sha256()
+        for f in IN_FIELDS:
+            h.update(np.ascontiguousarray(getattr(b, f)).tobytes())
+        assert h.hexdigest() == z[key + ".sha256"].tobytes().decode(), "the generator no longer reproduces the inputs of " + key
+        e = Expected()
+        for f in BatchResult.FIELDS:
+            setattr(e, f, z["%s.out.%s" % (key, f)])
+        out.append((key, b, e))
+    return out
+
+
+def check_deep(api, trim_bounds=False, threads=None):
+    n = 0
+    for key, b, exp in deep_sets():
+        bt = b.with_trim_bounds() if trim_bounds else b
+        got = api.run_regions_mt(bt, api.params(K=27), threads) if threads else api.run_regions(bt, api.params(K=27))
+        d = BatchResult.first_difference(got, exp)
+        assert d is None, (key, d)
+        np.testing.assert_allclose(got.events["gl"], exp.events["gl"], rtol=1e-12, atol=0)
+        n += b.n_regions
+    return n
+
+
 def check_transcript(api):
     n = 0
     for key, b, (K, min_reads, min_ctg_len), exp in transcript_sets():

@@ -224,3 +224,12 @@ def test_deep_regions_region_by_region(hip, oracle):
     # the same regions at the other configs' error rate: the ones with more than 64 pre-combine contigs take the byte-based passes
     d3, _ = synth.config("deep_1e3", n_regions=150)
     _same(hip.run_regions(d3.with_trim_bounds()), oracle.run_regions_mt(d3.with_trim_bounds(), oracle.params(K=27), 16))
+
+
+def test_deep_regions_both_restatements_agree_on(hip):
+    """tests/golden/deep_golden.npz: 300 regions of 257-600 reads whose expected results the C oracle and the Python transcription
+    of the Nim sources produced identically in the build container (1 200 compared, 0 differences); here through the device,
+    with the reads' qualities (trim on the device) and with the stager's trim bounds."""
+    import golden_util
+    assert golden_util.check_deep(hip) == 300
+    assert golden_util.check_deep(hip, trim_bounds=True) == 300

@@ -176,3 +176,11 @@ def test_oracle_reproduces_the_transcript_fixtures(oracle):
     container) replayed through the C oracle as built here."""
     import golden_util
     assert golden_util.check_transcript(oracle) >= 300
+
+
+def test_oracle_reproduces_the_deep_fixtures(oracle):
+    """tests/golden/deep_golden.npz: 300 regions of 257-600 reads (what gen_roi may hand over, indelope.nim:483-485, :515) whose
+    expected results the C oracle and the Python transcription of the Nim sources produced identically (make_deep_golden.py:
+    1 200 regions compared, 0 differences, profiles/r06_transcript_deep_diff.txt); the inputs are regenerated and hash-checked."""
+    import golden_util
+    assert golden_util.check_deep(oracle, threads=8) == 300
