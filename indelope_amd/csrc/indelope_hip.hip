@@ -82,6 +82,7 @@ struct Knobs {
 	int lpt = 1;           // 0: k_asm_combine3 takes its regions in input order (no cost classes, no arena tiers)
 	int ksw_pair = 1;      // 0: every alignment through the single sweep (no k_ksw_plan / k_ksw_pair launches)
 	int prepack_fast = 2;  // 0: k_prepack for every batch; 1..4: k_prepack_fast<n> (n reads per 16-lane group in flight) when the bases are ASCII and the trim bounds came with the batch
+	int fb_skip = 1;       // 0: the two-target sweep computes every slot of query positions on every diagonal (round 5); 1: a slot is left out once it is past the longer target's end
 	int fb_duo = 1;        // 0: the alignment fallback runs its two alignments one after the other (ksw_wide.h) instead of in one sweep (ksw_duo.h)
 	int asm_waves = 0, asmr_waves = 0, comb_occ = 0, ksw_waves = 0, tally_waves = 0;   // waves per CU (0 = library sizing)
 	int v2_arena = 0, v2_pdw = 0;                                                       // LDS sizes of the packed assembly (0 = library sizing)
@@ -550,7 +551,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"tally_rec_cap", &g_knob.tally_rec_cap}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"prepack_fast", &g_knob.prepack_fast},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"tally_rec_cap", &g_knob.tally_rec_cap}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"fb_skip", &g_knob.fb_skip}, {"prepack_fast", &g_knob.prepack_fast},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -2165,7 +2166,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.p_scratch = b->fb_p_scratch.as<uint8_t>(); a.p_cap = b->fb_p_cap;
 		a.cig_tmp = b->fb_cig_tmp.as<uint32_t>(); a.cig_cap = b->fb_cig_cap;
 		a.overflow = misc + M_OVF; a.work_counter = wq + 9 * WQ_WORDS;
-		a.duo = g_knob.fb_duo;
+		a.duo = (g_knob.fb_duo ? 1 : 0) | (g_knob.fb_skip ? 2 : 0);
 		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
 		HIPC(hipGetLastError());
 	}

@@ -1288,11 +1288,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		bool over = false;
 		// both alignments in one sweep (ksw_duo.h) when the item is the usual kind: a read of at most 320 bases, both strings non-empty
 		bool duo = false;
-		if (a.duo && rl > 0 && rsub > 0 && csub > 0 && ksw_duo_ok(a.P, rl, rsub, csub) &&
+		if ((a.duo & 1) && rl > 0 && rsub > 0 && csub > 0 && ksw_duo_ok(a.P, rl, rsub, csub) &&
 		    ksw_duo_lds_bytes(tmax) <= (size_t)a.lds_budget && ksw_duo_p_bytes(rl, tmax) <= a.p_cap) {
 			DuoResult R;
 			const uint8_t *tr = a.ref_bases + uni(jb.t_off) + start, *tc = a.out_seq + uni(jb.q_off) + start;
-			duo = rl <= 192 ? ksw_duo_sweep<3>(qy, rl, tr, rsub, tc, csub, a.P, lds, p, R) : ksw_duo_sweep<5>(qy, rl, tr, rsub, tc, csub, a.P, lds, p, R);
+			const bool skip = (a.duo & 2) != 0;                            // ihp_debug_set("fb_skip", 0): every slot on every diagonal, as in round 5
+			duo = rl <= 192 ? ksw_duo_sweep<3>(qy, rl, tr, rsub, tc, csub, a.P, lds, p, R, skip) : ksw_duo_sweep<5>(qy, rl, tr, rsub, tc, csub, a.P, lds, p, R, skip);
 			if (duo) {
 				KswOut o;
 				ksw_duo_cigar<0>(R, p, rl, rsub, a.P.w, a.P.flag, ct, a.cig_cap, o);

@@ -162,7 +162,7 @@ struct DuoSlots<NS, NS> {
 // qlen <= 64 NS.  lds: ksw_duo_lds_bytes(max(tl0, tl1)); p: ksw_duo_p_bytes(qlen, max(tl0, tl1)).
 template <int NS>
 __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8_t *t0, int tl0, const uint8_t *t1, int tl1,
-                                     const KswParams &P, uint8_t *lds, uint8_t *p, DuoResult &R)
+                                     const KswParams &P, uint8_t *lds, uint8_t *p, DuoResult &R, const bool skip_done = true)
 {
 	const int lane = lane_id();
 	qlen = uni(qlen); tl0 = uni(tl0); tl1 = uni(tl1);
@@ -209,19 +209,30 @@ __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8
 	const unsigned ub1 = lane == 0 ? E.Qp : 0u;
 	const bool l0 = lane == 0;
 	unsigned tag = 0xffffu;
+	int lo_done = 0;
 	for (int r = 0; r < total; ++r) {
 		const int hi = (r >> 6) < nsl - 1 ? (r >> 6) : nsl - 1;
 		// Slot K is past the LONGER target's end from diagonal tmax + 64 K + 63 on (its lane 63 works on t = r - 64 K - 63): those
 		// cells are the wildcard continuation, which no maximum and no traceback path can come from (see above), and the last
 		// cell of the slot that feeds a real one -- (tmax - 1, 64 K + 63), the neighbour of slot K + 1's lane 0 -- was computed
 		// on diagonal tmax + 64 K + 62.  The slots below `lo` are left out (round 6: 7 % of a 150 x 460 item's slot-diagonals).
-		const int lo = r >= tmax + 63 ? ((r - tmax - 63) >> 6) + 1 : 0;
+		// What a slot that has been left behind still hands to the one above -- its lane 63's u / y -- is set to the LOWEST values
+		// once their last real use is over (below): the wildcard cells of the slot above are then an alignment matrix over a
+		// neighbour column that falls by q + e per cell with no gap open -- never above the true continuation (u, y >= 0 there) --,
+		// so their H stays at or below what the full sweep computes for them, which no maximum comes from.  (Frozen values would
+		// do as cell INPUTS -- nothing real reads them -- but the lanes' running maxima see every cell a lane computes.)
+		const int lo = skip_done && r >= tmax + 63 ? ((r - tmax - 63) >> 6) + 1 : 0;
 		const int fill = r - 64 * hi;
 		const unsigned long long started = fill >= 63 ? ~0ull : ~0ull >> (63 - fill);
 		unsigned ru[NS], ry[NS];
 #pragma unroll
 		for (int k = 0; k < NS; ++k) { ru[k] = duo_ror1(S.U[k]); ry[k] = duo_ror1(S.Y[k]); }
 		DuoSlots<NS, 0>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow);
+		if (lo != lo_done) {                                                    // (this diagonal was the last to read slot lo - 1's real lane 63)
+#pragma unroll
+			for (int k = 0; k < NS; ++k) if (k == lo - 1) { S.U[k] = 0; S.Y[k] = 0; }
+			lo_done = lo;
+		}
 		ub = ub1;
 		tag -= 1;
 		prow += ncol;
