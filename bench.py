@@ -177,9 +177,9 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
     import threading
     from indelope_amd import _abi as A
 
-    def start(slab, no_bases):
+    def start(slab, no_bases):                               # no_bases: (IHP_FETCH_NO_BASES, IHP_FETCH_COMPACT)
         h = api.batch_upload_slab2(slab, params)
-        api.batch_set_fetch(h, no_bases=no_bases, eager=True)
+        api.batch_set_fetch(h, no_bases=no_bases[0], compact=no_bases[1], eager=True)
         api.batch_run(h)
         return h
 
@@ -199,7 +199,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
         h = api.batch_upload_slab2(slab, params)
         api.batch_sync(h)                                    # the copy alone (the call itself only enqueues it)
         t1 = time.perf_counter()
-        api.batch_set_fetch(h, no_bases=no_bases, eager=True)
+        api.batch_set_fetch(h, no_bases=no_bases[0], compact=no_bases[1], eager=True)
         api.batch_run(h)
         t2, t3 = finish(h, no_bases)
         return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
@@ -215,7 +215,7 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
         hs_ = []
         for sl in halves:
             h = api.batch_upload_slab2(sl, params)
-            api.batch_set_fetch(h, no_bases=no_bases, eager=True)
+            api.batch_set_fetch(h, no_bases=no_bases[0], compact=no_bases[1], eager=True)
             api.batch_run(h)
             hs_.append(h)
         for h in hs_:
@@ -223,7 +223,9 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
         return time.perf_counter() - t0
     try:
         res = {}
-        for name, nb in (("events_only", True), ("full", False)):
+        # full: every contig's bases and supports come back too -- 4 bits + a byte per base (IHP_FETCH_COMPACT, round 6; the host
+        # expands what it reads: ihp_out_contig); full_plain: the same as ASCII bytes + 32-bit supports (rounds 3-5)
+        for name, nb in (("events_only", (True, False)), ("full", (False, True)), ("full_plain", (False, False))):
             t = np.array([one(slabs[0][0], nb) for _ in range(reps + 1)][1:]) * 1e3
             med = np.median(t, axis=0)
             split_ms = float(np.median([one_split(nb) for _ in range(reps + 1)][1:])) * 1e3 if halves else None
@@ -325,7 +327,8 @@ def e2e_rates(api, batch, params, threads=3, reps=5, depth=2):
             "slab_MB": round(slab_bytes / 1e6, 2),
             "inputs": "one page-locked COMPACT slab per batch (ihp_slab2_layout, %d bytes: 4-bit read bases, 14 bytes per read, 2-bit windows), "
                       "a single upload copy, the arrays made on the device; results without contig bases/supports (IHP_FETCH_NO_BASES)" % slab_bytes,
-            "full_results": res["full"],
+            "full_results": dict(res["full"], form="IHP_FETCH_COMPACT: contig bases 4 bits each, supports a byte each + escapes (1.5 bytes per base instead of 5)",
+                                 plain_form={k: res["full_plain"][k] for k in ("one_batch_ms", "one_batch_regions_per_s", "sustained", "sustained_one_thread")}),
             "pageable_arrays": {"threads": threads, "batches": n_each * threads, "ms_per_batch": round(dt / (n_each * threads) * 1e3, 3),
                                 "regions_per_s": round(batch.n_regions * n_each * threads / dt, 1),
                                 "inputs": "ihp_run_regions on separate pageable arrays, ASCII bases, full results"},

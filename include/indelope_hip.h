@@ -348,6 +348,15 @@ typedef struct {
 	 * that were not tallied have no entries.                                               */
 	int64_t *hit_off;             /* [E+1] into ref_hit / alt_hit                */
 	int32_t *ref_hit, *alt_hit;
+	/* IHP_FETCH_COMPACT (round 6): the contigs' bases and supports in 1.5 bytes per base instead of 5 -- ctg_seq and
+	 * ctg_support are then NULL.  ctg_seq4: BAM's 4-bit codes ("=ACMGRSVTWYHKDBN"), contig c from byte
+	 * (ctg_seq_off[c] >> 1) + c, first base in the high nibble; ctg_sup8[i]: support of base i of the flat base array,
+	 * 255 = look it up among the n_sup_escapes (sup_escape_idx ascending, sup_escape_val).  ihp_out_contig expands one
+	 * contig; ihp_call_variants takes either form (it needs the bases of the few contigs a variant is emitted from).    */
+	uint8_t *ctg_seq4, *ctg_sup8;
+	int64_t  n_sup_escapes;
+	int64_t *sup_escape_idx;
+	uint32_t *sup_escape_val;
 } ihp_batch_out;
 
 /* Page-locked host memory for the caller's flat batch arrays: uploads from it are DMA
@@ -452,6 +461,9 @@ int  ihp_batch_upload(const ihp_params *p, const ihp_batch_in *in, ihp_batch **b
 int  ihp_batch_run(ihp_batch *b);                     /* async on the batch stream */
 int  ihp_batch_sync(ihp_batch *b);                    /* waits; IHP_E_CAPACITY if a device pool overflowed in the run */
 int  ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out);
+/* Contig c of `out` (either form) as ASCII bases and 32-bit supports: seq / sup hold ctg_seq_off[c+1] - ctg_seq_off[c]
+ * entries each (either may be NULL).                                                                                  */
+int  ihp_out_contig(const ihp_batch_out *out, int64_t c, uint8_t *seq, uint32_t *sup);
 void ihp_batch_free(ihp_batch *b);
 /* ihp_batch_upload for a slab (see ihp_slab_layout).  The copy is asynchronous on the batch's stream: the slab must stay
  * untouched until the first ihp_batch_sync / fetch of the batch has returned.                                         */
@@ -467,6 +479,11 @@ int  ihp_batch_upload_slab(const ihp_params *p, int32_t n_regions, int64_t n_rea
  * last stage, totals into page-locked memory), so that the fetch after it is one enqueue (compaction + copy) and one wait
  * instead of three round trips -- for callers that fetch every run (a sweep); leave it off for runs nobody fetches.      */
 #define IHP_FETCH_EAGER 2
+/* IHP_FETCH_COMPACT: ihp_batch_fetch brings the contigs' bases 4 bits each and their supports one byte each (see
+ * ihp_batch_out: ctg_seq4 / ctg_sup8): the copy of a batch's full results is a third of what it was, and the host expands
+ * only what it reads (ihp_out_contig).  A batch with a contig base outside BAM's 16-letter alphabet (lower case: only
+ * possible when the reads came as ASCII arrays) is fetched in the plain form all the same.  ihp_batch_pack_dev ignores it.  */
+#define IHP_FETCH_COMPACT 4
 int  ihp_batch_set_fetch(ihp_batch *b, int32_t flags);
 /* Hand the batch's scratch and result buffers back to the device pool; its inputs and the per-region summary
  * records (ihp_batch_summary_dev) stay.  Waits for the run and confirms it first (a run that left launches out is

@@ -79,8 +79,8 @@ class HipApi(Api):
                                                 C.byref(h)), "batch_upload_slab2")
         return h
 
-    def batch_set_fetch(self, h, no_bases=False, eager=False):
-        fl = (_abi.IHP_FETCH_NO_BASES if no_bases else 0) | (_abi.IHP_FETCH_EAGER if eager else 0)
+    def batch_set_fetch(self, h, no_bases=False, eager=False, compact=False):
+        fl = (_abi.IHP_FETCH_NO_BASES if no_bases else 0) | (_abi.IHP_FETCH_EAGER if eager else 0) | (_abi.IHP_FETCH_COMPACT if compact else 0)
         self._chk_hip(self.b.batch_set_fetch(h, fl), "batch_set_fetch")
 
     def batch_run(self, h):
@@ -89,11 +89,13 @@ class HipApi(Api):
     def batch_sync(self, h):
         self._chk_hip(self.b.batch_sync(h), "batch_sync")
 
-    def batch_fetch(self, h):
+    def batch_fetch(self, h, expand=True):
+        """The batch's results.  Under batch_set_fetch(compact=True) they arrive with 4-bit bases and byte supports
+        (`compact` attribute of the result); expand=True turns them into the plain arrays through ihp_out_contig."""
         out = _abi.BatchOut()
         self._chk_hip(self.b.batch_fetch(h, C.byref(out)), "batch_fetch")
         try:
-            return BatchResult(out)
+            return BatchResult(out, expand_with=self.b.out_contig if expand else None)
         finally:
             self.b.free_out(C.byref(out))
 

@@ -103,7 +103,7 @@ class Slab2Layout(C.Structure):       # ihp_slab2_layout
                                           "trim_lo", "trim_hi", "mapq", "rflags", "ref_packed", "bases4", "bytes")]
 
 
-IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES, IHP_FETCH_EAGER = 1, 1, 2
+IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES, IHP_FETCH_EAGER, IHP_FETCH_COMPACT = 1, 1, 2, 4
 IHP_SLAB2_REF_2BIT = 2
 
 
@@ -141,7 +141,9 @@ class BatchOut(C.Structure):
                 ("aln_flags", i32p), ("aln_ref_start", i64p), ("aln_ref_len", i32p),
                 ("aln_ez", C.POINTER(Ez)), ("cigar_off", i64p), ("cigar", u32p),
                 ("event_off", i64p), ("events", C.POINTER(Event)),
-                ("hit_off", i64p), ("ref_hit", i32p), ("alt_hit", i32p)]
+                ("hit_off", i64p), ("ref_hit", i32p), ("alt_hit", i32p),
+                # IHP_FETCH_COMPACT: bases 4 bits each, supports a byte each + escapes (ctg_seq / ctg_support are then NULL)
+                ("ctg_seq4", u8p), ("ctg_sup8", u8p), ("n_sup_escapes", C.c_int64), ("sup_escape_idx", i64p), ("sup_escape_val", u32p)]
 
 
 class Variant(C.Structure):           # ihp_variant
@@ -228,6 +230,7 @@ _PRODUCT_ONLY = {
     "batch_run": (C.c_int, [C.c_void_p]),
     "batch_sync": (C.c_int, [C.c_void_p]),
     "batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(BatchOut)]),
+    "out_contig": (C.c_int, [C.POINTER(BatchOut), C.c_int64, u8p, u32p]),
     "batch_free": (None, [C.c_void_p]),
     "batch_release_outputs": (C.c_int, [C.c_void_p]),
     "batch_pack_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p, i64p]),

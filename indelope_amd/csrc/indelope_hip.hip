@@ -2413,7 +2413,7 @@ extern "C" void ihp_batch_free(ihp_batch *b) { delete b; }
 
 extern "C" int ihp_batch_set_fetch(ihp_batch *b, int32_t flags)
 {
-	if (!b || (flags & ~(IHP_FETCH_NO_BASES | IHP_FETCH_EAGER))) return IHP_E_ARG;
+	if (!b || (flags & ~(IHP_FETCH_NO_BASES | IHP_FETCH_EAGER | IHP_FETCH_COMPACT))) return IHP_E_ARG;
 	b->fetch_flags = flags;
 	return 0;
 }
@@ -2448,7 +2448,11 @@ namespace {
 struct OutLayout {
 	size_t status, n_pre, contig_off, ctg_start, ctg_nreads, ctg_seq_off, aln_ref_start, cigar_off, event_off, events,
 	       aln_ez, aln_flags, aln_ref_len, ctg_support, cigar, ctg_seq, hit_off, ref_hit, alt_hit, bytes;
-	OutLayout(long long R, long long C, long long B, long long W, long long E, long long Hn) {
+	size_t seq4 = 0, sup8 = 0, esc_idx = 0, esc_val = 0; long long esc_cap = 0;       // IHP_FETCH_COMPACT (compact = true): B bases as 4 + 8 bits
+	static long long esc_cap_for(long long B) { return B / 128 + 1024; }
+	OutLayout(long long R, long long C, long long B, long long W, long long E, long long Hn, bool compact = false) {
+		const long long Bc = compact ? B : 0;
+		if (compact) B = 0;
 		size_t o = 0;
 		auto sec = [&](size_t elem, long long n) { const size_t at = o; o += ((size_t)(n > 0 ? n : 1) * elem + 15) / 16 * 16; return at; };
 		contig_off = sec(8, R + 1); ctg_start = sec(8, C); ctg_nreads = sec(8, C); ctg_seq_off = sec(8, C + 1);
@@ -2456,6 +2460,10 @@ struct OutLayout {
 		events = sec(sizeof(ihp_event), E);
 		aln_ez = sec(sizeof(ihp_ez), C); status = sec(4, R); n_pre = sec(4, R); aln_flags = sec(4, C); aln_ref_len = sec(4, C);
 		ctg_support = sec(4, B); cigar = sec(4, W); ref_hit = sec(4, Hn); alt_hit = sec(4, Hn); ctg_seq = sec(1, B);
+		if (compact) {
+			esc_cap = esc_cap_for(Bc);
+			esc_idx = sec(8, esc_cap + 1); esc_val = sec(4, esc_cap + 1); seq4 = sec(1, (Bc + 1) / 2 + C + 1); sup8 = sec(1, Bc);
+		}
 		bytes = o;
 	}
 };
@@ -2477,12 +2485,24 @@ static void carve_out(char *host, const OutLayout &L, long long R, long long C, 
                       double error, ihp_batch_out *out)
 {
 	out->n_regions = (int32_t)R; out->n_contigs = C; out->n_events = E; out->n_cigar_words = W; out->n_bases = B; out->n_hits = Hn;
+	out->ctg_seq4 = out->ctg_sup8 = nullptr; out->n_sup_escapes = 0; out->sup_escape_idx = nullptr; out->sup_escape_val = nullptr;
 	out->hit_off = (int64_t *)(host + L.hit_off); out->ref_hit = (int32_t *)(host + L.ref_hit); out->alt_hit = (int32_t *)(host + L.alt_hit);
 	out->status = (int32_t *)(host + L.status); out->n_contigs_pre = (int32_t *)(host + L.n_pre);
 	out->contig_off = (int64_t *)(host + L.contig_off);
 	out->ctg_start = (int64_t *)(host + L.ctg_start); out->ctg_nreads = (int64_t *)(host + L.ctg_nreads);
 	out->ctg_seq_off = (int64_t *)(host + L.ctg_seq_off); out->ctg_seq = (uint8_t *)(host + L.ctg_seq);
 	out->ctg_support = (uint32_t *)(host + L.ctg_support);
+	if (L.esc_cap) {                                                // IHP_FETCH_COMPACT: 4-bit bases, byte supports + escapes (sorted by base index)
+		out->ctg_seq = nullptr; out->ctg_support = nullptr;
+		out->ctg_seq4 = (uint8_t *)(host + L.seq4); out->ctg_sup8 = (uint8_t *)(host + L.sup8);
+		int64_t *ei = (int64_t *)(host + L.esc_idx); uint32_t *ev = (uint32_t *)(host + L.esc_val);
+		const long long n = std::min<long long>(ei[0], L.esc_cap);
+		std::vector<std::pair<int64_t, uint32_t>> es((size_t)n);
+		for (long long k = 0; k < n; ++k) es[(size_t)k] = {ei[1 + k], ev[1 + k]};
+		std::sort(es.begin(), es.end());
+		for (long long k = 0; k < n; ++k) { ei[1 + k] = es[(size_t)k].first; ev[1 + k] = es[(size_t)k].second; }
+		out->n_sup_escapes = n; out->sup_escape_idx = ei + 1; out->sup_escape_val = ev + 1;
+	}
 	out->aln_flags = (int32_t *)(host + L.aln_flags); out->aln_ref_start = (int64_t *)(host + L.aln_ref_start);
 	out->aln_ref_len = (int32_t *)(host + L.aln_ref_len); out->aln_ez = (ihp_ez *)(host + L.aln_ez);
 	out->cigar_off = (int64_t *)(host + L.cigar_off); out->cigar = (uint32_t *)(host + L.cigar);
@@ -2522,7 +2542,7 @@ static int pack_counts_enqueue(ihp_batch *b)
 
 // Results compacted on the device into one slab (k_pack_count -> k_pack_scan -> k_pack); nothing is copied to the host
 // except the totals that define the layout.  k_pack is left in flight on the batch's stream (the callers wait).
-static int pack_enqueue(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6])
+static int pack_enqueue(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t counts[6], bool compact = false)
 {
 	if (!b->work_live) return IHP_E_ARG;                      // the results went back to the pool (ihp_batch_release_outputs)
 	const int R = b->R;
@@ -2544,7 +2564,8 @@ static int pack_enqueue(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t co
 	// IHP_FETCH_NO_BASES: the contigs' bases and supports stay on the device (ctg_seq_off still tells the lengths)
 	const bool no_bases = (b->fetch_flags & IHP_FETCH_NO_BASES) != 0;
 	const long long C = tot[0], B = no_bases ? 0 : tot[1], W = tot[2], E = tot[3], Hn = tot[4];
-	const OutLayout L(R, C, B, W, E, Hn);
+	compact = compact && !no_bases;
+	const OutLayout L(R, C, B, W, E, Hn, compact);
 	if (b->pack_slab.n < L.bytes) {
 		int rc = b->pack_slab.alloc(L.bytes + L.bytes / 8);
 		if (rc) return rc;
@@ -2565,7 +2586,14 @@ static int pack_enqueue(ihp_batch *b, void **dev_ptr, int64_t *bytes, int64_t co
 	a.o_status = (int32_t *)(dev + L.status); a.o_n_pre = (int32_t *)(dev + L.n_pre); a.o_contig_off = (int64_t *)(dev + L.contig_off);
 	a.o_ctg_start = (int64_t *)(dev + L.ctg_start); a.o_ctg_nreads = (int64_t *)(dev + L.ctg_nreads);
 	a.o_ctg_seq_off = (int64_t *)(dev + L.ctg_seq_off);
-	a.o_seq = no_bases ? nullptr : (uint8_t *)(dev + L.ctg_seq); a.o_sup = no_bases ? nullptr : (uint32_t *)(dev + L.ctg_support);
+	a.o_seq = no_bases || compact ? nullptr : (uint8_t *)(dev + L.ctg_seq); a.o_sup = no_bases || compact ? nullptr : (uint32_t *)(dev + L.ctg_support);
+	a.o_seq4 = nullptr; a.o_sup8 = nullptr; a.esc_idx = nullptr; a.esc_val = nullptr; a.esc_cap = 0;
+	if (compact) {
+		a.o_seq4 = (uint8_t *)(dev + L.seq4); a.o_sup8 = (uint8_t *)(dev + L.sup8);
+		a.esc_idx = (long long *)(dev + L.esc_idx); a.esc_val = (unsigned *)(dev + L.esc_val); a.esc_cap = L.esc_cap;
+		HIPC(hipMemsetAsync(a.esc_idx, 0, 8, s));                   // the escapes' count and the "no 4-bit code" flag
+		HIPC(hipMemsetAsync(a.esc_val, 0, 4, s));
+	}
 	a.o_aln_flags = (int32_t *)(dev + L.aln_flags); a.o_aln_ref_start = (int64_t *)(dev + L.aln_ref_start);
 	a.o_aln_ref_len = (int32_t *)(dev + L.aln_ref_len); a.o_ez = (ihp_ez *)(dev + L.aln_ez);
 	a.o_cigar_off = (int64_t *)(dev + L.cigar_off); a.o_cigar = (uint32_t *)(dev + L.cigar);
@@ -2632,17 +2660,47 @@ extern "C" int ihp_batch_fetch(ihp_batch *b, ihp_batch_out *out)
 	memset(out, 0, sizeof(*out));
 	void *dev = nullptr; int64_t bytes = 0, cnt6[6];
 	{ int rc0 = ensure_init(); if (rc0) return rc0; }
-	int rc = pack_enqueue(b, &dev, &bytes, cnt6);            // k_pack in flight; the copy follows it in stream order: one wait
-	if (rc) return rc;
-	hipStream_t s = b->stream;
-	void *slab = g_slabs.get((size_t)bytes);
-	if (!slab) { snprintf(g.err, sizeof(g.err), "hipHostMalloc of %lld bytes failed", (long long)bytes); return IHP_E_NOMEM; }
-	char *host = (char *)slab + sizeof(SlabHdr);
-	hipError_t e = hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, s);
-	if (e == hipSuccess) e = hipStreamSynchronize(s);
-	if (e != hipSuccess) { g_slabs.put(slab); return hip_fail(e, "copy of the packed results", __LINE__); }
-	const OutLayout L(cnt6[0], cnt6[1], cnt6[2], cnt6[3], cnt6[4], cnt6[5]);
-	carve_out(host, L, cnt6[0], cnt6[1], cnt6[2], cnt6[3], cnt6[4], cnt6[5], b->P.error, out);
+	bool compact = (b->fetch_flags & IHP_FETCH_COMPACT) && !(b->fetch_flags & IHP_FETCH_NO_BASES);
+	for (;;) {
+		int rc = pack_enqueue(b, &dev, &bytes, cnt6, compact);   // k_pack in flight; the copy follows it in stream order: one wait
+		if (rc) return rc;
+		hipStream_t s = b->stream;
+		void *slab = g_slabs.get((size_t)bytes);
+		if (!slab) { snprintf(g.err, sizeof(g.err), "hipHostMalloc of %lld bytes failed", (long long)bytes); return IHP_E_NOMEM; }
+		char *host = (char *)slab + sizeof(SlabHdr);
+		hipError_t e = hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess) e = hipStreamSynchronize(s);
+		if (e != hipSuccess) { g_slabs.put(slab); return hip_fail(e, "copy of the packed results", __LINE__); }
+		const OutLayout L(cnt6[0], cnt6[1], cnt6[2], cnt6[3], cnt6[4], cnt6[5], compact);
+		if (compact && (((const uint32_t *)(host + L.esc_val))[0] || ((const int64_t *)(host + L.esc_idx))[0] > L.esc_cap)) {
+			// a base outside the 16-letter alphabet, or more supports above 254 than the escape list holds: the plain form
+			g_slabs.put(slab);
+			compact = false;
+			continue;
+		}
+		carve_out(host, L, cnt6[0], cnt6[1], cnt6[2], cnt6[3], cnt6[4], cnt6[5], b->P.error, out);
+		return 0;
+	}
+}
+
+// Contig c of either form of ihp_batch_out as ASCII bases / 32-bit supports.
+extern "C" int ihp_out_contig(const ihp_batch_out *out, int64_t c, uint8_t *seq, uint32_t *sup)
+{
+	if (!out || c < 0 || c >= out->n_contigs || !out->ctg_seq_off) return IHP_E_ARG;
+	const int64_t o0 = out->ctg_seq_off[c], n = out->ctg_seq_off[c + 1] - o0;
+	if (out->ctg_seq4) {
+		const uint8_t *p4 = out->ctg_seq4 + (o0 >> 1) + c;
+		if (seq) for (int64_t i = 0; i < n; ++i) seq[i] = (uint8_t)"=ACMGRSVTWYHKDBN"[(p4[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+		if (sup) {
+			for (int64_t i = 0; i < n; ++i) sup[i] = out->ctg_sup8[o0 + i];
+			const int64_t *lo = std::lower_bound(out->sup_escape_idx, out->sup_escape_idx + out->n_sup_escapes, o0);
+			for (; lo < out->sup_escape_idx + out->n_sup_escapes && *lo < o0 + n; ++lo) sup[*lo - o0] = out->sup_escape_val[lo - out->sup_escape_idx];
+		}
+		return 0;
+	}
+	if (!out->ctg_seq || !out->ctg_support) return IHP_E_ARG;                   // IHP_FETCH_NO_BASES: nothing to expand
+	if (seq) memcpy(seq, out->ctg_seq + o0, (size_t)n);
+	if (sup) memcpy(sup, out->ctg_support + o0, sizeof(uint32_t) * (size_t)n);
 	return 0;
 }
 

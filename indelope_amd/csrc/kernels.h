@@ -1583,7 +1583,23 @@ struct PackArgs {
 	int32_t *o_aln_flags; int64_t *o_aln_ref_start; int32_t *o_aln_ref_len; ihp_ez *o_ez;
 	int64_t *o_cigar_off; uint32_t *o_cigar; int64_t *o_event_off; ihp_event *o_events;
 	int64_t *o_hit_off; int32_t *o_ref_hit, *o_alt_hit;
+	// IHP_FETCH_COMPACT: bases 4 bits each (contig c from byte (bb >> 1) + c), supports a byte each, 255 = see the escapes
+	// (esc_idx[0]: their number, counted here; esc_val[0]: raised when a base has no 4-bit code; entries from 1)
+	uint8_t *o_seq4, *o_sup8; long long *esc_idx; unsigned *esc_val; long long esc_cap;
 };
+// ASCII -> BAM's 4-bit code ("=ACMGRSVTWYHKDBN"), 255: none
+__device__ __forceinline__ unsigned code4_of(unsigned ch)
+{
+	unsigned c;
+	switch (ch) {
+	case '=': c = 0; break; case 'A': c = 1; break; case 'C': c = 2; break; case 'M': c = 3; break;
+	case 'G': c = 4; break; case 'R': c = 5; break; case 'S': c = 6; break; case 'V': c = 7; break;
+	case 'T': c = 8; break; case 'W': c = 9; break; case 'Y': c = 10; break; case 'H': c = 11; break;
+	case 'K': c = 12; break; case 'D': c = 13; break; case 'B': c = 14; break; case 'N': c = 15; break;
+	default: c = 255;
+	}
+	return c;
+}
 
 __global__ __launch_bounds__(64) void k_pack(const PackArgs a)
 {
@@ -1605,6 +1621,24 @@ __global__ __launch_bounds__(64) void k_pack(const PackArgs a)
 			const bool done = (flags & IHP_ALN_DONE) != 0;
 			const long long so = a.ctg_seq_off[sl];
 			if (a.o_seq) for (int i = lane; i < len; i += 64) { a.o_seq[bb + i] = a.out_seq[so + i]; a.o_sup[bb + i] = a.out_sup[so + i]; }
+			if (a.o_seq4) {
+				uint8_t *d4 = a.o_seq4 + (bb >> 1) + c;
+				bool bad = false;
+				for (int j = lane; 2 * j < len; j += 64) {
+					const unsigned c0 = code4_of(a.out_seq[so + 2 * j]), c1 = 2 * j + 1 < len ? code4_of(a.out_seq[so + 2 * j + 1]) : 0u;
+					bad |= c0 > 15u || c1 > 15u;
+					d4[j] = (uint8_t)((c0 & 15u) << 4 | (c1 & 15u));
+				}
+				if (ballot(bad) && lane == 0) atomicExch(a.esc_val, 1u);
+				for (int i = lane; i < len; i += 64) {
+					const uint32_t s = a.out_sup[so + i];
+					a.o_sup8[bb + i] = (uint8_t)(s < 255u ? s : 255u);
+					if (s >= 255u) {
+						const long long k = (long long)atomicAdd((unsigned long long *)a.esc_idx, 1ull);
+						if (k < a.esc_cap) { a.esc_idx[1 + k] = bb + i; a.esc_val[1 + k] = s; }
+					}
+				}
+			}
 			KswOut z;
 			z.max = z.zdropped = z.max_q = z.max_t = z.mqe = z.mqe_t = z.mte = z.mte_q = z.score = z.n_cigar = 0;
 			if (done) z = a.ez[sl];

@@ -76,8 +76,19 @@ inline int call_variants(const ihp_params &P, const ihp_batch_in &in, const ihp_
 		const long long ref_len = in.ref_off[r + 1] - in.ref_off[r], ref_at = in.ref_origin[r];
 		for (long long c = out.contig_off[r]; c < out.contig_off[r + 1]; ++c) {
 			const EzCigar cig(out.cigar + out.cigar_off[c], out.aln_ez[c].n_cigar, out.aln_ez[c].max_q);
-			const char *contig = (const char *)out.ctg_seq + out.ctg_seq_off[c];
 			const long long contig_len = out.ctg_seq_off[c + 1] - out.ctg_seq_off[c];
+			// (IHP_FETCH_COMPACT: 4-bit bases, expanded for the contigs an insertion's allele is cut from -- below -- and no others)
+			std::string contig_buf;
+			const char *contig = out.ctg_seq ? (const char *)out.ctg_seq + out.ctg_seq_off[c] : nullptr;
+			auto contig_bases = [&]() -> const char * {
+				if (contig) return contig;
+				if (contig_buf.empty() && contig_len > 0) {
+					contig_buf.resize((size_t)contig_len);
+					const uint8_t *p4 = out.ctg_seq4 + (out.ctg_seq_off[c] >> 1) + c;
+					for (long long i = 0; i < contig_len; ++i) contig_buf[(size_t)i] = "=ACMGRSVTWYHKDBN"[(p4[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+				}
+				return contig_buf.data();
+			};
 			for (long long e = out.event_off[c]; e < out.event_off[c + 1]; ++e) {
 				const ihp_event &E = out.events[e];
 				if (E.status != IHP_EV_TALLIED) continue;
@@ -135,7 +146,7 @@ inline int call_variants(const ihp_params &P, const ihp_batch_in &in, const ihp_
 						const long long at = E.tstart - 1 - ref_at;
 						if (at < 0 || at >= ref_len || E.qstart < 1 || E.qstop > contig_len) return IHP_VF_OOB;
 						ref_allele.assign(ref + at, 1);
-						alt_allele.assign(contig + E.qstart - 1, (size_t)(E.qstop - E.qstart + 1));
+						alt_allele.assign(contig_bases() + E.qstart - 1, (size_t)(E.qstop - E.qstart + 1));
 					}
 					v.ref_off = put(ref_allele.data(), (long long)ref_allele.size()); v.ref_len = (int32_t)ref_allele.size();
 					v.alt_off = put(alt_allele.data(), (long long)alt_allele.size()); v.alt_len = (int32_t)alt_allele.size();

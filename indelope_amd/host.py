@@ -178,8 +178,9 @@ class BatchResult:
               "ctg_seq", "ctg_support", "aln_flags", "aln_ref_start", "aln_ref_len", "aln_ez",
               "cigar_off", "cigar", "event_off", "events", "hit_off", "ref_hit", "alt_hit")
 
-    def __init__(self, o):
+    def __init__(self, o, expand_with=None):
         R, Cn, E, W, B = o.n_regions, o.n_contigs, o.n_events, o.n_cigar_words, o.n_bases
+        self.compact = bool(o.ctg_seq4)                     # IHP_FETCH_COMPACT: 4-bit bases + byte supports arrived
         self.n_regions, self.n_contigs, self.n_events = R, Cn, E
         self.status = _np(o.status, R, np.int32)
         self.n_contigs_pre = _np(o.n_contigs_pre, R, np.int32)
@@ -187,8 +188,23 @@ class BatchResult:
         self.ctg_start = _np(o.ctg_start, Cn, np.int64)
         self.ctg_nreads = _np(o.ctg_nreads, Cn, np.int64)
         self.ctg_seq_off = _np(o.ctg_seq_off, Cn + 1, np.int64)
-        self.ctg_seq = _np(o.ctg_seq, B, np.uint8)
-        self.ctg_support = _np(o.ctg_support, B, np.uint32)
+        if self.compact:
+            self.ctg_seq4 = _np(o.ctg_seq4, (B + 1) // 2 + Cn + 1, np.uint8)
+            self.ctg_sup8 = _np(o.ctg_sup8, B, np.uint8)
+            self.sup_escape_idx = _np(o.sup_escape_idx, o.n_sup_escapes, np.int64)
+            self.sup_escape_val = _np(o.sup_escape_val, o.n_sup_escapes, np.uint32)
+            self.ctg_seq, self.ctg_support = np.zeros(B, np.uint8), np.zeros(B, np.uint32)
+            self.expanded = expand_with is not None
+            if expand_with is not None:                     # contig by contig through ihp_out_contig (what a host does for the contigs it reads)
+                for c in range(Cn):
+                    o0, o1 = int(self.ctg_seq_off[c]), int(self.ctg_seq_off[c + 1])
+                    if o1 > o0:
+                        rc = expand_with(C.byref(o), c, self.ctg_seq[o0:o1].ctypes.data_as(A.u8p), self.ctg_support[o0:o1].ctypes.data_as(A.u32p))
+                        if rc != 0:
+                            raise IhpError(rc, "ihp_out_contig")
+        else:
+            self.ctg_seq = _np(o.ctg_seq, B, np.uint8)
+            self.ctg_support = _np(o.ctg_support, B, np.uint32)
         self.aln_flags = _np(o.aln_flags, Cn, np.int32)
         self.aln_ref_start = _np(o.aln_ref_start, Cn, np.int64)
         self.aln_ref_len = _np(o.aln_ref_len, Cn, np.int32)
@@ -216,6 +232,11 @@ class BatchResult:
         o.status, o.n_contigs_pre, o.contig_off = p(self.status, A.i32p), p(self.n_contigs_pre, A.i32p), p(self.contig_off, A.i64p)
         o.ctg_start, o.ctg_nreads, o.ctg_seq_off = p(self.ctg_start, A.i64p), p(self.ctg_nreads, A.i64p), p(self.ctg_seq_off, A.i64p)
         o.ctg_seq, o.ctg_support = p(self.ctg_seq, A.u8p), p(self.ctg_support, A.u32p)
+        if getattr(self, "compact", False) and not getattr(self, "expanded", True):   # the compact form as it arrived (ihp_call_variants expands what it reads)
+            o.ctg_seq, o.ctg_support = C.cast(None, A.u8p), C.cast(None, A.u32p)
+            o.ctg_seq4, o.ctg_sup8 = p(self.ctg_seq4, A.u8p), p(self.ctg_sup8, A.u8p)
+            o.n_sup_escapes = len(self.sup_escape_idx)
+            o.sup_escape_idx, o.sup_escape_val = p(self.sup_escape_idx, A.i64p), p(self.sup_escape_val, A.u32p)
         o.aln_flags, o.aln_ref_start, o.aln_ref_len = p(self.aln_flags, A.i32p), p(self.aln_ref_start, A.i64p), p(self.aln_ref_len, A.i32p)
         o.aln_ez, o.cigar_off, o.cigar = p(self.aln_ez, C.POINTER(A.Ez)), p(self.cigar_off, A.i64p), p(self.cigar, A.u32p)
         o.event_off, o.events = p(self.event_off, A.i64p), p(self.events, C.POINTER(A.Event))

@@ -71,6 +71,12 @@ type
     events*: ptr IhpEvent
     hit_off*: ptr int64                   # [E+1]; per tallied event one entry per read of its region:
     ref_hit*, alt_hit*: ptr int32         # start of the first ref / alt k-mer window in the read, -1 = none (indelope.nim:301-309)
+    # IHP_FETCH_COMPACT: ctg_seq / ctg_support nil; bases 4 bits each (contig c from byte (ctg_seq_off[c] shr 1) + c, first base in
+    # the high nibble), supports a byte each, 255 = among the escapes; ihp_out_contig expands one contig
+    ctg_seq4*, ctg_sup8*: ptr uint8
+    n_sup_escapes*: int64
+    sup_escape_idx*: ptr int64
+    sup_escape_val*: ptr uint32
 
   IhpVariant* {.importc: "ihp_variant", header: "indelope_hip.h", bycopy.} = object   # one per tallied event (indelope.nim:375-428)
     region*, contig*: int32
@@ -166,6 +172,7 @@ proc ihp_batch_upload*(p: ptr IhpParams, inp: ptr IhpBatchIn, b: ptr ptr IhpBatc
 proc ihp_batch_run*(b: ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_sync*(b: ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_fetch*(b: ptr IhpBatch, outp: ptr IhpBatchOut): cint {.importc, cdecl, header: "indelope_hip.h".}
+proc ihp_out_contig*(outp: ptr IhpBatchOut, c: int64, seq: ptr uint8, sup: ptr uint32): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_release_outputs*(b: ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_free*(b: ptr IhpBatch) {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_pack_dev*(b: ptr IhpBatch, dev_ptr: ptr pointer, bytes: ptr int64, counts: ptr int64): cint {.importc, cdecl, header: "indelope_hip.h".}
@@ -209,6 +216,7 @@ proc ihp_host_free*(p: pointer) {.importc, cdecl, header: "indelope_hip.h".}
 const
   IHP_FETCH_NO_BASES* = 1'i32   ## ihp_batch_fetch brings everything but the contigs' bases and supports
   IHP_FETCH_EAGER* = 2'i32      ## every run also counts what its results will take: the fetch is one enqueue and one wait
+  IHP_FETCH_COMPACT* = 4'i32    ## full results with the contigs' bases 4 bits each and their supports a byte each (a third of the copy)
 proc ihp_batch_set_fetch*(b: ptr IhpBatch, flags: int32): cint {.importc, cdecl, header: "indelope_hip.h".}
 # timing and diagnostics (what bench.py and the tests read; a caller needs none of them)
 proc ihp_batch_set_timing*(b: ptr IhpBatch, on: cint): cint {.importc, cdecl, header: "indelope_hip.h".}

@@ -233,3 +233,47 @@ def test_deep_regions_both_restatements_agree_on(hip):
     import golden_util
     assert golden_util.check_deep(hip) == 300
     assert golden_util.check_deep(hip, trim_bounds=True) == 300
+
+
+# ------------------------------------------------------------------------------------------------ full results in a third of the bytes
+def test_compact_fetch_is_the_plain_fetch(hip, oracle):
+    """IHP_FETCH_COMPACT: ihp_batch_fetch brings the contigs' bases 4 bits each and their supports a byte
+    each with an escape list for the values above 254; ihp_out_contig gives every contig back as the plain fetch holds it, and
+    ihp_call_variants (indelope.nim:375-428) on the compact form -- which expands only the contigs an insertion's allele is cut
+    from -- returns the records of the plain form.  Workloads: C2-like with duplications, deep pile-ups (supports above 255:
+    the escapes), reads with IUPAC codes (the 16-letter alphabet), lower-case reads (no 4-bit code: the plain form comes back)."""
+    import ctypes as C
+    from indelope_amd import _abi as A
+    sets = []
+    b, _ = synth.generate(300, n_reads=(24, 96), err_rate=2e-3, config_id=66, dup_frac=0.2)
+    sets.append(("dup", b.with_trim_bounds(), True))
+    d, _ = synth.config("deep", n_regions=60)
+    sets.append(("deep", d.with_trim_bounds(), True))
+    n = synth.generate(80, n_reads=(16, 48), err_rate=1e-3, config_id=67)[0]
+    bases = n.bases.copy()
+    idx = np.random.default_rng(8).integers(0, len(bases), 60)
+    bases[idx[:30]] = ord("N"); bases[idx[30:]] = np.frombuffer(b"RYKMSW", np.uint8)[np.arange(30) % 6]
+    sets.append(("iupac", RegionBatch(n.region_read_off, n.read_off, bases, n.quals, n.read_start, n.read_stop, n.mapq, n.read_skip, n.ref_off, n.ref_bases, n.ref_origin), True))
+    low = bases.copy(); low[idx[:10]] |= 0x20
+    sets.append(("lower", RegionBatch(n.region_read_off, n.read_off, low, n.quals, n.read_start, n.read_stop, n.mapq, n.read_skip, n.ref_off, n.ref_bases, n.ref_origin), False))
+    for name, bt, want_compact in sets:
+        h = hip.batch_upload(bt)
+        try:
+            hip.batch_run(h)
+            plain = hip.batch_fetch(h)
+            hip.batch_set_fetch(h, compact=True)
+            comp = hip.batch_fetch(h)                                  # expanded contig by contig through ihp_out_contig
+            assert comp.compact == want_compact, name
+            _same(comp, plain)
+            _same(plain, oracle.run_regions_mt(bt, oracle.params(), 8))
+            raw = hip.batch_fetch(h, expand=False)
+            if name == "deep":
+                assert len(raw.sup_escape_idx) > 0 and plain.ctg_support.max() > 255
+                assert np.array_equal(plain.ctg_support[raw.sup_escape_idx], raw.sup_escape_val)
+            if want_compact:
+                # the compact arrays are a third of the plain ones
+                assert raw.ctg_seq4.nbytes + raw.ctg_sup8.nbytes + 12 * len(raw.sup_escape_idx) < 0.35 * (plain.ctg_seq.nbytes + plain.ctg_support.nbytes)
+                v_plain, v_comp = hip.call_variants(bt, plain), hip.call_variants(bt, raw)
+                assert len(v_plain) == len(v_comp) and all(repr(a) == repr(b_) for a, b_ in zip(v_plain, v_comp)), name
+        finally:
+            hip.batch_free(h)
