@@ -18,6 +18,7 @@ from indelope_amd.host import BatchResult  # noqa: E402
 WIDE_PARAMS = False
 LONG_SHORT = None
 ONLY = None
+DEEP = False
 
 
 def main():
@@ -33,6 +34,10 @@ def main():
         if kv == "lengths":                                      # very short and very long reads (the packed path takes 20 .. 960 bases)
             global LONG_SHORT
             LONG_SHORT = [20, 25, 36, 50, 400, 700, 959, 960, 961, 1200, 1500]
+            continue
+        if kv == "deep":                                         # regions of 200 .. 700 reads (gen_roi hands over up to 600: the wide combine
+            global DEEP                                          # build; above 640 the byte-based passes), few regions per configuration
+            DEEP = True
             continue
         if kv.startswith("only="):
             global ONLY
@@ -53,7 +58,17 @@ def main():
                    config_id=1000 + it, dup_frac=float(rng.choice([0, 0.2, 0.6])), seed=int(rng.integers(1, 2**31)))
         if rl >= 250 and rng.random() < 0.5:
             cfg.update(n_events=2, window_len=1400, event_pos=500)
+        if DEEP:
+            lo = int(rng.choice([200, 250, 257, 300, 500, 600, 641]))
+            cfg.update(n_regions=int(rng.integers(3, 24)), read_len=int(rng.choice([75, 100, 150, 150, 250])), n_reads=(lo, int(lo + rng.choice([0, 40, 100]))),
+                       err_rate=float(rng.choice([0, 1e-4, 2.5e-4, 1e-3, 3e-3])))
+            cfg.pop("n_events", None); cfg.pop("window_len", None); cfg.pop("event_pos", None)
+            K = 21 if cfg["read_len"] < 100 else K
         b, _ = synth.generate(**cfg)
+        if DEEP and rng.random() < 0.5:                              # ordinary regions in front of and behind the deep ones
+            from indelope_amd.host import concat_batches
+            o1, _ = synth.generate(n_regions=int(rng.integers(1, 40)), read_len=cfg["read_len"], n_reads=(8, 120), err_rate=1e-3, config_id=5000 + it)
+            b = concat_batches([o1, b, o1.slice(0, max(1, o1.n_regions // 2))])
         kw = dict(K=K)
         if rng.random() < 0.5:
             kw.update(min_reads=3, min_ctg_len=73)
@@ -95,6 +110,16 @@ def main():
             print("    next", it, cfg, {k: v for k, v in kw.items()}, flush=True)
         try:
             got = hip.run_regions(b, hip.params(**kw))
+            if DEEP or it % 4 == 0:                                  # the same results through the compact fetch (4-bit bases, byte supports + escapes)
+                h = hip.batch_upload(b, hip.params(**kw))
+                hip.batch_set_fetch(h, compact=True)
+                hip.batch_run(h)
+                g2 = hip.batch_fetch(h)
+                hip.batch_free(h)
+                d2 = BatchResult.first_difference(g2, got)
+                if d2 is not None:
+                    print("%3d DIFF compact fetch: %s" % (it, d2), flush=True)
+                    bad += 1
         except Exception as e:                                   # an honest refusal (IHP_E_CAPACITY ...) is reported, not compared
             print("%3d ERR %s / %s  rl=%d reads=%s regions=%d %s" % (it, e, hip.b.last_hip_error().decode(), rl, cfg["n_reads"], b.n_regions, kw), flush=True)
             errs += 1
