@@ -355,6 +355,8 @@ constexpr int V2_MAX_REGION_READS = 640;                 // = V3_MAXREADS_WIDE (
 constexpr int V2_WL = 128;                               // work-list entries in registers (two of them)
 constexpr int V2_WLX = 192;                              // ... and in LDS behind them, for regions of long reads (contigs of many dwords)
 constexpr int V2_HDR = 8, V2_DIRW = 8;                   // hand-over record: header dwords, dwords per contig
+constexpr int V2_HB_DW = 32;                             // dwords of the contig-head bit map (1024 bits)
+__device__ __forceinline__ unsigned v2_head_hash(unsigned w) { return (w ^ (w >> 10) ^ (w >> 20)) & 1023u; }
 
 __device__ __forceinline__ int wl_make(int dword, int c, int k) { return (dword << 2) | (c << 16) | (k << 22); }
 __device__ __forceinline__ unsigned dpp_wave_shl1(unsigned v)
@@ -455,10 +457,18 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	const int QW = ((maxlen + 15) >> 4) + 2;
 	const int RECB = 1 + QW, WLXB = RECB + nrr;
 	const int wlx_n = maxlen > 200 ? V2_WLX : 0;              // work-list entries beyond the two registers
-	const int SLOT0 = WLXB + wlx_n;
+	// Round 6, a 1024-bit map of the contigs' HEADS (the hash of a contig's first 16 bases; bits are only ever set): a query offset
+	// (contig.nim:114-135) needs a window of the read that IS some contig's head, which in BAM order almost never exists -- one
+	// lookup per window lane says so instead of a walk over the offsets or the contigs (a set bit only costs the walk it used to).
+	const int HBB = WLXB + wlx_n, SLOT0 = HBB + V2_HB_DW;
 	if (SLOT0 + 8 > p_dwords) return IHP_E_CAPACITY;
 	int bump = SLOT0;
 	if (lane == 0) P[0] = 0;
+	if (lane < V2_HB_DW) P[HBB + lane] = 0;
+	auto head_seen = [&](unsigned head) {                        // wave-uniform head: one lane sets its bit
+		const unsigned h = v2_head_hash(head);
+		if (lane == 0) P[HBB + (int)(h >> 5)] |= 1u << (h & 31u);
+	};
 	const long long base_idx = nrr ? (uni(a.read_off[r0]) >> 4) + r0 : 0;   // the region's first packed dword
 	const uint32_t *pkp = a.v2_pk + base_idx;
 	// contig directory: lane c <-> contig c (creation order = list order of contig.nim:243-248)
@@ -568,7 +578,14 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 			// o <= tl - best.ma can still win (more matches, or as many on an earlier contig) -- for a read that extends its contig
 			// by a few bases that is a few offsets, and walking THEM (the window of offset o against every contig's head at once,
 			// lane <-> contig) costs a handful of compares where walking the contigs costs one per contig.
-			const int kq = best.found ? (omin < tl - best.ma ? omin : tl - best.ma) : omin;
+			int kq = best.found ? (omin < tl - best.ma ? omin : tl - best.ma) : omin;
+			if (kq >= 1) {
+				// is any window at an offset 1 .. kq the head of some contig?  (the bit map says "no" exactly; "maybe" takes the walk)
+				const unsigned h0 = v2_head_hash(wq0);
+				bool maybe = lane >= 1 && lane <= kq && ((P[HBB + (int)(h0 >> 5)] >> (h0 & 31u)) & 1u);
+				if (kq > 63) { const unsigned h1 = v2_head_hash(wq1); maybe |= 64 + lane <= kq && ((P[HBB + (int)(h1 >> 5)] >> (h1 & 31u)) & 1u); }
+				if (!ballot(maybe)) kq = 0;
+			}
 			if (kq >= 1 && kq <= 12) {
 				const unsigned long long live = n >= 64 ? ~0ull : (1ull << n) - 1ull;
 				for (int o = 1; o <= kq; ++o) {
@@ -650,6 +667,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 					const unsigned nh = (unsigned)uni((int)P[nw]);
 					d_woff = sel ? nw : d_woff; d_capw = sel ? ncapw : d_capw; d_len = sel ? newlen : d_len;
 					d_head = sel ? nh : d_head;
+					if (off < 0) head_seen(nh);                              // (a prepend: the contig has a new head)
 					if (off < 0) {
 						const long long qstart = bcast64(mstart, k);
 						d_slo = sel ? (int)qstart : d_slo; d_shi = sel ? (int)(qstart >> 32) : d_shi;   // t.start = q.start (:204)
@@ -684,6 +702,7 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 				const bool sel = lane == n;
 				const long long qstart = bcast64(mstart, k);
 				d_woff = sel ? nw : d_woff; d_capw = sel ? capw : d_capw; d_len = sel ? tl : d_len; d_head = sel ? qh : d_head;
+				head_seen(qh);
 				d_nreads = sel ? 1 : d_nreads; d_slo = sel ? (int)qstart : d_slo; d_shi = sel ? (int)(qstart >> 32) : d_shi;
 				d_anchor = sel ? 0 : d_anchor;
 				for (int kk = 0; kk < n_entries(tl); ++kk) if (!wl_append(nw + kk, n, kk)) return IHP_E_CAPACITY;

@@ -16,7 +16,7 @@
 // 256 reads and no base is covered by all 256 of them, max_mismatch == 0, contigs shorter than 2048 bases, at most 64 contigs, combine_min_overlap >= 17.
 // Round 6, the WIDE build (V3StateT<MAXC, true>): the same code with 16-bit supports and room for the records of 640 reads, for
 // the regions the reference admits and the byte build cannot hold -- gen_roi hands over up to 600 reads per roi
-// (indelope.nim:483-485, :515), and a pile-up that deep has bases with more than 255 reads on them.  Offsets into the support
+// (indelope.nim:483-485, :515), and a pile-up that deep has bases with more than 256 reads on them.  Offsets into the support
 // area (so, bump_sup, sup_cap) are in ELEMENTS in both builds; only the element type differs.
 #pragma once
 #include <type_traits>

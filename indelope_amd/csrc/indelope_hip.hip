@@ -1030,7 +1030,7 @@ struct ihp_batch {
 	long long v2_hand_dwords = 0;
 	int n_cls[4] = {0, 0, 0, 0};                           // regions per assembly class (host prediction from the read bases)
 	int n_small = 0, n_rich = 0;                           // class 1 = the regions of the usual size + the read-rich ones the packed path takes (its own k_asm_reads launch)
-	int n_deep = 0;                                        // regions of the packed path with more than 255 reads: their combine runs the wide build (16-bit supports)
+	int n_deep = 0;                                        // regions of the packed path with more than 256 reads: their combine runs the wide build (16-bit supports)
 	int v2_arena_deep = 0, v2_pm_deep = 0, grid_v2deep = 0;
 	int v2_pdw_rich = 0, grid_v2r_rich = 0;
 	hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr;
@@ -1535,7 +1535,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			const long long nr_ = rro[r + 1] - rro[r];
 			if (k > 0 && packed_ok && nr_ <= V3_MAXREADS_WIDE && nb <= 120000) rich.push_back({-nb, r});
 			else cls[k].push_back({-nb, r});
-			if (packed_ok && nr_ > 255 && nr_ <= V3_MAXREADS_WIDE && (k == 0 || nb <= 120000)) b->n_deep++;
+			if (packed_ok && nr_ > 256 && nr_ <= V3_MAXREADS_WIDE && (k == 0 || nb <= 120000)) b->n_deep++;
 		}
 		order.reserve((size_t)R);
 		std::sort(rich.begin(), rich.end());
@@ -1566,7 +1566,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			}
 			if (nb1 == 0) { nb1 = std::min<long long>(nbL, 16384); nr1 = std::min<long long>(nrL, 64); }   // no region of the usual size: size the first tier for small ones
 			// what a region needs at least ...
-			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
+			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + V2_HB_DW + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave.
 			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
@@ -1586,7 +1586,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 				if (b->n_rich) {
 					// the read-rich launch: the same kernel with the packed area its largest region needs (reads + slots of ~0.4
 					// of the read bases + relocations), at the occupancy that leaves
-					long long pdwL = 1 + (b->max_read_len + 15) / 16 + 2 + nrL + nbL / 16 * (b->max_read_len > 200 ? 12 : 7) / 10 + 192 + (b->max_read_len > 200 ? V2_WLX : 0);
+					long long pdwL = 1 + (b->max_read_len + 15) / 16 + 2 + nrL + nbL / 16 * (b->max_read_len > 200 ? 12 : 7) / 10 + 192 + V2_HB_DW + (b->max_read_len > 200 ? V2_WLX : 0);
 					pdwL = std::min<long long>(pdwL, (g.max_lds - 4096) / 4);
 					const int occL = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * pdwL + 256)));
 					pdwL = std::max<long long>(pdwL, (g.max_lds / occL - 256) / 4);
@@ -1996,6 +1996,16 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				}
 			}
 			const bool deep_on = ra.lpt_cnt && b->n_deep > 0 && b->grid_v2deep > 0;
+			if (deep_on && b->n_cls[0] > b->n_deep) {
+				// the wide launch's workgroups need LDS on the CUs the first tier's persistent grid would fill to the last granule (the
+				// first tier starts at once, the wide launch behind an event of this stream: it ran BEHIND the first tier -- C3 with
+				// 140 regions of 256 reads among 100 000: 5.2 ms for a launch of 2 ms): the first tier leaves them their share
+				const long long wb_a = comb_wave_bytes(b->v2_arena, b->tier_wide ? comb_stat() : comb_stat_a());
+				const long long wb_d = (g.comb_static_w + 16 + 2ll * b->v2_arena_deep + 4ll * b->v2_pm_deep + LDS_GRAN - 1) / LDS_GRAN * LDS_GRAN;
+				const long long per_cu_d = std::min<long long>((b->grid_v2deep + g.cus - 1) / g.cus, 4);
+				const long long occ_a = std::max<long long>(1, ((long long)g.max_lds - per_cu_d * wb_d) / wb_a);
+				ga = (int)std::min<long long>(ga, occ_a * g.cus);
+			}
 			if (deep_on) {
 				// the regions of more than 255 reads (the longest chains of the batch): the wide build, first on the second stream
 				HIPC(hipStreamWaitEvent(s2, b->ev_bfork, 0));

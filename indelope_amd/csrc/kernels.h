@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		if (r < 0) break;
 		if (a.in_list) r = a.in_list[r];
 		int nc = 0, need = 0;
-		const bool deep = uni(a.region_read_off[r + 1]) - uni(a.region_read_off[r]) > 255;
+		const bool deep = uni(a.region_read_off[r + 1]) - uni(a.region_read_off[r]) > 256;     // (what the byte build keeps records for; 256 reads on ONE base hand a region to the retry route as before)
 		const int err = v2_read_phase(a, P, a.v2_pdw, r, a.prof ? s_prof : nullptr, nc, need);
 		if (err) {                                             // not for this path: the byte-based passes take it
 			// (n_final = 0: the launches that take the list may have been left out of this run -- ihp_batch_run -- and k_summary walks n_final contigs)
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 		}
 		if (!err && a.lpt_cnt && lane == 0) {
 			// the tiers in memory: first, third, second (the first tier's launch can then walk the third's lists, or all, behind its own)
-			// (the fourth tier: the regions of more than 255 reads, whose supports do not fit a byte -- the wide build's launch)
+			// (the fourth tier: the regions of more than 256 reads, whose supports need not fit a byte -- the wide build's launch)
 			const int tier = deep ? 3 : need <= a.tier_a_cap && nc <= a.tier_a_maxc ? 0 : need <= a.tier_b_cap ? 2 : 1;
 			const int c = lpt_class(nc) + tier * LPT_CLASSES;
 			a.lpt_seg[(size_t)c * a.lpt_stride + atomicAdd(&a.lpt_cnt[c], 1)] = r;

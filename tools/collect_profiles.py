@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
-pre = sys.argv[1] if len(sys.argv) > 1 else "r05"
+pre = sys.argv[1] if len(sys.argv) > 1 else "r06"
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
@@ -39,6 +39,7 @@ names = {"c2_kernel_stats.csv": "c2_kernel_stats.csv", "c2_pmc.json": "c2_pmc.js
          "c5_phase_cycles.json": "c5_phase_cycles.json", "resource_usage.txt": "resource_usage.txt", "ubench_ksw.txt": "ubench_ksw.txt",
          "ksw_pair_pmc.json": "ksw_pair_pmc.json", "ksw_pair_pmc.txt": "ksw_pair_pmc.txt", "dup10_kernel_stats.csv": "dup10_kernel_stats.csv",
          "dup10_pmc_mix.json": "dup10_pmc_mix.json", "dup10_summary.txt": "dup10_summary.txt", "prepack_compare.txt": "prepack_compare.txt",
+         "deep_kernel_stats.csv": "deep_kernel_stats.csv", "deep_bench.json": "deep_bench.json", "ubench_wany.txt": "ubench_wany.txt",
          "e2e_bench.json": "e2e_bench.json", "e2e_host_time.txt": "e2e_host_time.txt", "combine_occupancy.txt": "combine_occupancy.txt"}
 refused = 0
 for a, b in names.items():

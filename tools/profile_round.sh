@@ -25,6 +25,10 @@ cp gpurun_out/pmc_mix/mix.json $OUT/steady100k_pmc_mix.json
 python3 bench.py $STEADY > $OUT/steady100k_bench.json 2>> $OUT/err
 stats c3 --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e --no-check
 stats c5 --config C5 --steps 5 --warmup 2 --no-cpu --no-e2e --no-check
+# round 6: the regions of 257-600 reads (wide combine build): the byte-based k_assemble passes must stay empty
+stats deep --config deep --regions 10000 --steps 3 --warmup 2 --in-flight 1 --sub-batches 2 --no-cpu --no-e2e --no-check
+python3 bench.py --config deep --regions 10000 --steps 3 --warmup 2 --in-flight 1 --sub-batches 2 --no-cpu --no-e2e > $OUT/deep_bench.json 2>> $OUT/err
+timeout 120 tools/ubench_wany.bin > $OUT/ubench_wany.txt 2>&1
 : > $OUT/other_workloads.jsonl
 python3 bench.py --config C3 --steps 3 --warmup 1 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
 python3 bench.py --config C5 --no-cpu --no-e2e >> $OUT/other_workloads.jsonl 2>> $OUT/err
