@@ -46,8 +46,8 @@ KERNELS = ["k_assemble", "k_ksw", "k_tally"]
 ISSUE_PEAK_ARCH = 2.0          # MI355X_MICROARCH.md: a SIMD-32 issues a wave64 VALU instruction over 2 cycles -- reached only by pure streams of
                                # mov / and / xor / add (1.5-1.8 measured); in a mixed stream every VALU instruction costs the half-rate slot
                                # (tools/ubench_ksw.hip: v_sub / v_max alternating 0.93 per cycle and CU)
-PMC_FILE = os.path.join("profiles", "r05_c2_pmc.json")
-MIX_FILE = os.path.join("profiles", "r05_c2_pmc_mix.json")
+PMC_FILE = os.path.join("profiles", "r06_c2_pmc.json")
+MIX_FILE = os.path.join("profiles", "r06_c2_pmc_mix.json")
 STAGE_MEMBERS = {"k_assemble": ("k_prepack", "k_prepack_fast", "k_slab_expand", "k_asm_reads", "k_asm_combine3", "k_assemble"),
                  "k_ksw": ("k_ksw", "k_ksw_pair", "k_ksw_plan_count", "k_ksw_plan_place"), "k_tally": ("k_tally_prep", "k_tally")}
 
@@ -483,7 +483,8 @@ def break_even(api, K=27, sizes=(1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024), r
         full, _ = synth.config("C2", n_regions=max(sizes))
         for n in sizes:
             b = full.slice(0, n)
-            api.run_regions(b, api.params(K=K))                  # (plan + pools of this shape)
+            for _ in range(4):                                   # (pools and the launch plan of this shape: a launch is left out only behind
+                api.run_regions(b, api.params(K=K))              # three runs in a row that did not need it)
             g, c1, cm = [], [], []
             for _ in range(reps):
                 t0 = time.perf_counter(); api.run_regions(b, api.params(K=K)); g.append(time.perf_counter() - t0)

@@ -135,27 +135,67 @@ __device__ inline void duo_resolve(const DuoState<NS> &S, int qlen, int tlen, Du
 // The slots of one diagonal, lowest first: slot K takes u / y of the lane below -- lane 0 from the slot below's lane 63
 // (`ru`, `ry`: the rotations of the PREVIOUS diagonal's values, all taken before any slot is overwritten), slot 0's lane 0 the
 // boundary.  Slots above `hi` have not started; slot `hi` is the one filling up.
-template <int NS, int K>
+// LO (compile time): the slots below it have been left behind (see ksw_duo_sweep) and are not computed.
+template <int NS, int K, int LO>
 struct DuoSlots {
 	static __device__ __forceinline__ void run(DuoState<NS> &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned *sp, const int r,
-	                                           const unsigned (&ru)[NS], const unsigned (&ry)[NS], const unsigned ub, const bool l0, const int hi, const int lo,
+	                                           const unsigned (&ru)[NS], const unsigned (&ry)[NS], const unsigned ub, const bool l0, const int hi,
 	                                           const unsigned tag, const unsigned long long started, uint8_t *prow)
 	{
-		if (K <= hi && K < lo) { DuoSlots<NS, K + 1>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow); return; }
+		if (K < LO) { DuoSlots<NS, K + 1, LO>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow); return; }
 		if (K <= hi) {
 			const unsigned uin = l0 ? (K ? ru[K ? K - 1 : 0] : ub) : ru[K], yin = l0 ? (K ? ry[K ? K - 1 : 0] : 0u) : ry[K];
 			const unsigned sel = sp[r + 64 * (NS - 1 - K)];
 			if (K < NS - 1 && K < hi) duo_slot<NS, K, false>(S, E, T1, QEp, sel, uin, yin, tag, started, prow);
 			else duo_slot<NS, K, true>(S, E, T1, QEp, sel, uin, yin, tag, started, prow);
-			DuoSlots<NS, K + 1>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow);
+			DuoSlots<NS, K + 1, LO>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow);
 		}
 	}
 };
-template <int NS>
-struct DuoSlots<NS, NS> {
+template <int NS, int LO>
+struct DuoSlots<NS, NS, LO> {
 	static __device__ __forceinline__ void run(DuoState<NS> &, const PairEnv &, const unsigned, const unsigned, const unsigned *, const int,
-	                                           const unsigned (&)[NS], const unsigned (&)[NS], const unsigned, const bool, const int, const int,
+	                                           const unsigned (&)[NS], const unsigned (&)[NS], const unsigned, const bool, const int,
 	                                           const unsigned, const unsigned long long, uint8_t *) {}
+};
+
+// Diagonals [r0, r1) with the slots below LO left out: one loop per LO, so that every loop is the straight-line chain of its
+// slots (a run-time `lo` inside ONE loop cost the kernel 80 spilled registers and a third more instructions).  Behind the first
+// diagonal of a run with LO > 0 -- the last to read slot LO - 1's real lane 63 -- that slot's u / y become the floor values.
+template <int NS, int LO>
+__device__ __forceinline__ void duo_run(DuoState<NS> &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned *sp, const int r0, const int r1,
+                                        const int nsl, const int ncol, const bool l0, const unsigned ub1, unsigned &ub, unsigned &tag, uint8_t *&prow)
+{
+	for (int r = r0; r < r1; ++r) {
+		const int hi = (r >> 6) < nsl - 1 ? (r >> 6) : nsl - 1;
+		const int fill = r - 64 * hi;
+		const unsigned long long started = fill >= 63 ? ~0ull : ~0ull >> (63 - fill);
+		unsigned ru[NS], ry[NS];
+#pragma unroll
+		for (int k = 0; k < NS; ++k) { ru[k] = duo_ror1(S.U[k]); ry[k] = duo_ror1(S.Y[k]); }
+		DuoSlots<NS, 0, LO>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, tag, started, prow);
+		if (LO > 0 && r == r0) { S.U[LO > 0 ? LO - 1 : 0] = 0; S.Y[LO > 0 ? LO - 1 : 0] = 0; }
+		ub = ub1;
+		tag -= 1;
+		prow += ncol;
+	}
+}
+template <int NS, int LO>
+struct DuoPhases {                                                             // the runs with LO, LO + 1, ... slots left behind, one after the other
+	static __device__ __forceinline__ void run(DuoState<NS> &S, const PairEnv &E, const unsigned T1, const unsigned QEp, const unsigned *sp, const int tmax, const int total,
+	                                           const int nsl, const int ncol, const bool l0, const unsigned ub1, unsigned &ub, unsigned &tag, uint8_t *&prow)
+	{
+		// slot K is past the longer target's end from diagonal tmax + 64 K + 63 on: LO slots are behind from tmax + 64 (LO - 1) + 63
+		const int r0 = tmax + 64 * LO - 1, r1 = tmax + 64 * LO + 63;
+		if (r0 >= total) return;
+		duo_run<NS, LO>(S, E, T1, QEp, sp, r0, r1 < total ? r1 : total, nsl, ncol, l0, ub1, ub, tag, prow);
+		DuoPhases<NS, LO + 1>::run(S, E, T1, QEp, sp, tmax, total, nsl, ncol, l0, ub1, ub, tag, prow);
+	}
+};
+template <int NS>
+struct DuoPhases<NS, NS> {
+	static __device__ __forceinline__ void run(DuoState<NS> &, const PairEnv &, const unsigned, const unsigned, const unsigned *, const int, const int,
+	                                           const int, const int, const bool, const unsigned, unsigned &, unsigned &, uint8_t *&) {}
 };
 
 // Returns false when the item is not for this sweep (a code outside the 5-letter alphabet).  Preconditions: ksw_duo_ok(),
@@ -209,34 +249,20 @@ __device__ inline bool ksw_duo_sweep(const uint8_t *query, int qlen, const uint8
 	const unsigned ub1 = lane == 0 ? E.Qp : 0u;
 	const bool l0 = lane == 0;
 	unsigned tag = 0xffffu;
-	int lo_done = 0;
-	for (int r = 0; r < total; ++r) {
-		const int hi = (r >> 6) < nsl - 1 ? (r >> 6) : nsl - 1;
+	if (skip_done) {
 		// Slot K is past the LONGER target's end from diagonal tmax + 64 K + 63 on (its lane 63 works on t = r - 64 K - 63): those
 		// cells are the wildcard continuation, which no maximum and no traceback path can come from (see above), and the last
 		// cell of the slot that feeds a real one -- (tmax - 1, 64 K + 63), the neighbour of slot K + 1's lane 0 -- was computed
-		// on diagonal tmax + 64 K + 62.  The slots below `lo` are left out (round 6: 7 % of a 150 x 460 item's slot-diagonals).
-		// What a slot that has been left behind still hands to the one above -- its lane 63's u / y -- is set to the LOWEST values
-		// once their last real use is over (below): the wildcard cells of the slot above are then an alignment matrix over a
-		// neighbour column that falls by q + e per cell with no gap open -- never above the true continuation (u, y >= 0 there) --,
-		// so their H stays at or below what the full sweep computes for them, which no maximum comes from.  (Frozen values would
-		// do as cell INPUTS -- nothing real reads them -- but the lanes' running maxima see every cell a lane computes.)
-		const int lo = skip_done && r >= tmax + 63 ? ((r - tmax - 63) >> 6) + 1 : 0;
-		const int fill = r - 64 * hi;
-		const unsigned long long started = fill >= 63 ? ~0ull : ~0ull >> (63 - fill);
-		unsigned ru[NS], ry[NS];
-#pragma unroll
-		for (int k = 0; k < NS; ++k) { ru[k] = duo_ror1(S.U[k]); ry[k] = duo_ror1(S.Y[k]); }
-		DuoSlots<NS, 0>::run(S, E, T1, QEp, sp, r, ru, ry, ub, l0, hi, lo, tag, started, prow);
-		if (lo != lo_done) {                                                    // (this diagonal was the last to read slot lo - 1's real lane 63)
-#pragma unroll
-			for (int k = 0; k < NS; ++k) if (k == lo - 1) { S.U[k] = 0; S.Y[k] = 0; }
-			lo_done = lo;
-		}
-		ub = ub1;
-		tag -= 1;
-		prow += ncol;
-	}
+		// on diagonal tmax + 64 K + 62.  The slots left behind are not computed (round 6: 7 % of a 150 x 460 item's slot-diagonals).
+		// What such a slot still hands to the one above -- its lane 63's u / y -- is set to the LOWEST values once their last real
+		// use is over (duo_run): the wildcard cells of the slot above are then an alignment matrix over a neighbour column that
+		// falls by q + e per cell with no gap open -- never above the true continuation (u, y >= 0 there) --, so their H stays at
+		// or below what the full sweep computes for them, which no maximum comes from.  (Frozen values would do as cell INPUTS --
+		// nothing real reads them -- but the lanes' running maxima see every cell a lane computes.)
+		const int e0 = tmax + 63 < total ? tmax + 63 : total;
+		duo_run<NS, 0>(S, E, T1, QEp, sp, 0, e0, nsl, ncol, l0, ub1, ub, tag, prow);
+		DuoPhases<NS, 1>::run(S, E, T1, QEp, sp, tmax, total, nsl, ncol, l0, ub1, ub, tag, prow);
+	} else duo_run<NS, 0>(S, E, T1, QEp, sp, 0, total, nsl, ncol, l0, ub1, ub, tag, prow);
 	WSYNC();
 	duo_resolve<NS, 0>(S, qlen, tl0, R);
 	duo_resolve<NS, 1>(S, qlen, tl1, R);

@@ -15,7 +15,7 @@ inside `;;#ASMSTART` .. `;;#ASMEND` and that none of those is a spill (the state
 import hashlib, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["k_ksw_pair", "k_kswILi3E", "k_asm_readsILi8E", "k_asm_combine3ILi5ELb0ELi32E", "k_asm_combine3ILi5ELb0ELi64E", "k_asm_combine3ILi6ELb0ELi32E", "k_tallyILi8E", "k_tally_prep", "k_fallback", "k_prepack_fastILi2ELb0E", "k_prepack_fastILi2ELb1E"]
+KERNELS = ["k_ksw_pair", "k_kswILi3E", "k_asm_readsILi8E", "k_asm_combine3ILi5ELb0ELi32E", "k_asm_combine3ILi5ELb0ELi64E", "k_asm_combine3ILi6ELb0ELi32E", "k_asm_combine3ILi4ELb0ELi64ELb1E", "k_tallyILi8E", "k_tally_prep", "k_fallback", "k_prepack_fastILi2ELb0E", "k_prepack_fastILi2ELb1E"]
 
 
 def main():
