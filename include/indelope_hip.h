@@ -274,10 +274,17 @@ typedef struct {
 	int64_t len, span, trim_lo, trim_hi;                                             /* uint16 [n_reads]                   */
 	int64_t mapq, rflags;                                                            /* uint8 [n_reads]                    */
 	int64_t ref_packed;                                                              /* (n_ref >> 1) + n_regions bytes, or (n_ref >> 2) + n_regions */
-	int64_t bases4;                                                                  /* (n_bases >> 1) + n_reads bytes      */
+	int64_t bases4;                                                                  /* (n_bases >> 1) + n_reads bytes; IHP_SLAB2_BASES_2BIT: 4 ((n_bases >> 4) + n_reads + 4) */
 	int64_t bytes;
 } ihp_slab2_layout;
 #define IHP_SLAB2_REF_2BIT 2
+/* Round 6: the READ bases 2 bits each too -- possible when every base of every read of the batch is upper-case A C G T (the
+ * usual batch; one N anywhere and the stager writes the 4-bit form).  The section `bases4` then holds the library's own packed
+ * form as it is: 32-bit little-endian words, read i from word (read_off[i] >> 4) + i (read_off = the running sum of `len`
+ * from region_base_off), sixteen bases per word, base j of the read in bits 2 (j & 15) .. of word j >> 4, code = (ASCII >> 1) & 3
+ * (A 0, C 1, T 2, G 3), unused bits zero.  Half the bytes of the 4-bit form (C2: 59 -> 35 MB per batch), and the device has
+ * nothing left to pack: it only writes the ASCII copy the byte-based kernels read.                                            */
+#define IHP_SLAB2_BASES_2BIT 4
 int  ihp_slab2_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, int32_t flags, ihp_slab2_layout *out);
 
 /* event status: why the tally did or did not run for an alignment event.      */

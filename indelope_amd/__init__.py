@@ -68,9 +68,10 @@ class HipApi(Api):
                                                C.byref(h)), "batch_upload_slab")
         return h
 
-    def make_slab2(self, batch):
-        """The batch as one page-locked COMPACT slab (ihp_slab2_layout: 14 bytes per read, windows 2 or 4 bits per base)."""
-        return Slab2(self, batch)
+    def make_slab2(self, batch, bases_2bit=None):
+        """The batch as one page-locked COMPACT slab (ihp_slab2_layout: 14 bytes per read, windows and -- when they are all
+        A C G T -- read bases 2 bits each, 4 bits otherwise; bases_2bit=False keeps BAM's 4-bit form)."""
+        return Slab2(self, batch, bases_2bit)
 
     def batch_upload_slab2(self, slab, params=None):
         p = params if params is not None else self.params()
@@ -230,7 +231,9 @@ class Slab2:
     """A RegionBatch laid out in one ihp_host_alloc'ed compact slab (include/indelope_hip.h, ihp_slab2_layout): what a stager written
     for this library fills per `roi` (src/indelope.nim:21) instead of the arrays of ihp_batch_in."""
 
-    def __init__(self, api_, batch):
+    def __init__(self, api_, batch, bases_2bit=None):
+        """bases_2bit: None = the reads 2 bits each when every base is upper-case A C G T (IHP_SLAB2_BASES_2BIT), else 4 bits;
+        False = always 4 bits (BAM's own packing)."""
         import numpy as np
         from . import synth
         b = batch if batch.trim_lo is not None else batch.with_trim_bounds()
@@ -241,6 +244,10 @@ class Slab2:
         r2 = code2[ref]
         two_bit = not bool((r2 == 255).any())
         self.flags = _abi.IHP_SLAB2_REF_2BIT if two_bit else 0
+        rd = np.ascontiguousarray(b.bases if len(b.bases) else np.zeros(1, np.uint8), np.uint8)
+        reads_2bit = bases_2bit is not False and len(b.bases) > 0 and not bool((code2[rd] == 255).any())
+        if reads_2bit:
+            self.flags |= _abi.IHP_SLAB2_BASES_2BIT
         self.layout = _abi.Slab2Layout()
         api_._chk_hip(api_.b.slab2_layout_for(b.n_regions, b.n_reads, len(b.bases), len(ref), self.flags, C.byref(self.layout)), "slab2_layout_for")
         self.ptr = api_.b.host_alloc(self.layout.bytes)
@@ -295,8 +302,12 @@ class Slab2:
                 mem[at:at + len(pk)] = pk
         lib = synth._lib()
         lib.ihp_synth_pack4.argtypes = [_abi.u8p, _abi.i64p, C.c_int64, C.c_void_p]
-        bases = np.ascontiguousarray(b.bases if len(b.bases) else np.zeros(1, np.uint8), np.uint8)
-        rc = lib.ihp_synth_pack4(_abi.ptr(bases, _abi.u8p), _abi.ptr(ro, _abi.i64p), b.n_reads, self.ptr + L.bases4)
+        lib.ihp_synth_pack2.argtypes = [_abi.u8p, _abi.i64p, C.c_int64, C.c_void_p]
+        bases = rd
+        if reads_2bit:
+            rc = lib.ihp_synth_pack2(_abi.ptr(bases, _abi.u8p), _abi.ptr(ro, _abi.i64p), b.n_reads, self.ptr + L.bases4)
+        else:
+            rc = lib.ihp_synth_pack4(_abi.ptr(bases, _abi.u8p), _abi.ptr(ro, _abi.i64p), b.n_reads, self.ptr + L.bases4)
         if rc != 0:
             self.free()
             raise ValueError("a base that BAM's 4-bit alphabet (=ACMGRSVTWYHKDBN) cannot hold")

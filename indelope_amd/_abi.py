@@ -104,7 +104,7 @@ class Slab2Layout(C.Structure):       # ihp_slab2_layout
 
 
 IHP_SLAB_HAS_SKIP, IHP_FETCH_NO_BASES, IHP_FETCH_EAGER, IHP_FETCH_COMPACT = 1, 1, 2, 4
-IHP_SLAB2_REF_2BIT = 2
+IHP_SLAB2_REF_2BIT, IHP_SLAB2_BASES_2BIT = 2, 4
 
 
 class Event(C.Structure):

@@ -271,6 +271,42 @@ __global__ __launch_bounds__(64) void k_prepack_fast(const PrepackArgs a)
 	}
 }
 
+// A batch whose compact slab brought the reads 2 bits each in this very form (IHP_SLAB2_BASES_2BIT): nothing to pack -- the kept
+// ranges, the (all clear) "not ACGT" flags and the ASCII copy of the bases that the byte-based kernels, the fallback and the
+// plain tally read.  One 16-lane group per read, a lane per packed word.
+__global__ __launch_bounds__(64) void k_unpack_pk(const PrepackArgs a)
+{
+	const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+	if (a.t_start && blockIdx.x == 0 && threadIdx.x == 0) *a.t_start = (unsigned long long)wall_clock64();
+	for (long long ri = (long long)blockIdx.x * 64 + lane; ri < a.n_reads; ri += (long long)gridDim.x * 64) {
+		const int len = (int)(a.read_off[ri + 1] - a.read_off[ri]);
+		int lo = a.trim_lo_in ? a.trim_lo_in[ri] : 0, hi = a.trim_hi_in ? a.trim_hi_in[ri] : (len == 1 ? 0 : len);
+		lo = lo < 0 ? 0 : lo > len ? len : lo;
+		hi = hi > len ? len : hi; hi = hi < lo ? lo : hi;
+		a.trim_lo[ri] = lo; a.trim_hi[ri] = hi; a.read_bad[ri] = 0;
+	}
+	const long long stride = (long long)gridDim.x * 4;
+	for (long long i0 = (long long)blockIdx.x * 4; i0 < a.n_reads; i0 += stride) {
+		const long long ri = i0 + grp;
+		if (ri >= a.n_reads) continue;
+		const long long off = a.read_off[ri];
+		const int len = (int)(a.read_off[ri + 1] - off);
+		const uint32_t *src = a.pk + (off >> 4) + ri;
+		uint8_t *dst = a.bases_w + off;
+		for (int d = sub; 16 * d < len; d += 16) {
+			const unsigned w = src[d];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {                            // four bases: 2-bit codes -> "ACTG" bytes
+				const unsigned c8 = (w >> (8 * q)) & 0xffu, t = c8 | (c8 << 6), u = t | (t << 12);
+				const unsigned x = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
+				const int at = 16 * d + 4 * q, v = len - at;
+				if (v >= 4) *(u32_unaligned_t *)(dst + at) = x;
+				else for (int j = 0; j < v; ++j) dst[at + j] = (uint8_t)(x >> (8 * j));
+			}
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ bit helpers
 // bits [sh, sh + 32) of the 64-bit value hi:lo (sh in 0..31)
 __device__ __forceinline__ unsigned fsh(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }

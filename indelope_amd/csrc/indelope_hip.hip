@@ -1016,6 +1016,7 @@ struct ihp_batch {
 	DBuf trim_lo, trim_hi;
 	DBuf in_slab, bases4;                                  // ihp_batch_upload_slab: every input in one device buffer; BAM 4-bit bases (k_prepack writes the ASCII ones)
 	bool has_quals = false, has_skip = false, has_trim = false, has_b4 = false;
+	bool has_pk2 = false;                                  // the compact slab brought the reads 2 bits each in the packed form itself (IHP_SLAB2_BASES_2BIT): v2_pk is a view of the slab
 	bool slab_bad = false;                                 // a compact slab whose lengths did not add up (k_slab_expand): every wait reports IHP_E_ARG
 	int fetch_flags = 0;                                   // IHP_FETCH_*
 	// scratch
@@ -1303,7 +1304,7 @@ extern "C" int ihp_slab_layout_for(int32_t n_regions, int64_t n_reads, int64_t n
 // Section offsets of the compact slab (include/indelope_hip.h, ihp_slab2_layout).
 extern "C" int ihp_slab2_layout_for(int32_t n_regions, int64_t n_reads, int64_t n_bases, int64_t n_ref, int32_t flags, ihp_slab2_layout *L)
 {
-	if (!L || n_regions < 0 || n_reads < 0 || n_bases < 0 || n_ref < 0 || (flags & ~IHP_SLAB2_REF_2BIT)) return IHP_E_ARG;
+	if (!L || n_regions < 0 || n_reads < 0 || n_bases < 0 || n_ref < 0 || (flags & ~(IHP_SLAB2_REF_2BIT | IHP_SLAB2_BASES_2BIT))) return IHP_E_ARG;
 	int64_t o = 0;
 	auto sec = [&](int64_t bytes) { const int64_t at = o; o += (bytes + 63) / 64 * 64; return at; };
 	L->region_read_off = sec(8 * ((int64_t)n_regions + 1)); L->region_base_off = sec(8 * ((int64_t)n_regions + 1));
@@ -1312,7 +1313,7 @@ extern "C" int ihp_slab2_layout_for(int32_t n_regions, int64_t n_reads, int64_t 
 	L->len = sec(2 * n_reads); L->span = sec(2 * n_reads); L->trim_lo = sec(2 * n_reads); L->trim_hi = sec(2 * n_reads);
 	L->mapq = sec(n_reads); L->rflags = sec(n_reads);
 	L->ref_packed = sec(((flags & IHP_SLAB2_REF_2BIT) ? (n_ref >> 2) : (n_ref >> 1)) + n_regions + 64);
-	L->bases4 = sec((n_bases >> 1) + n_reads + 64);
+	L->bases4 = sec((flags & IHP_SLAB2_BASES_2BIT) ? 4 * ((n_bases >> 4) + n_reads + 4) + 64 : (n_bases >> 1) + n_reads + 64);
 	L->bytes = o;
 	return 0;
 }
@@ -1320,7 +1321,7 @@ extern "C" int ihp_slab2_layout_for(int32_t n_regions, int64_t n_reads, int64_t 
 extern "C" int ihp_batch_upload_slab2(const ihp_params *p, int32_t n_regions, int64_t n_reads, const void *slab, const ihp_slab2_layout *L,
                                       int32_t flags, ihp_batch **bout)
 {
-	if (!slab || !L || n_regions < 0 || n_reads < 0 || (flags & ~IHP_SLAB2_REF_2BIT)) return IHP_E_ARG;
+	if (!slab || !L || n_regions < 0 || n_reads < 0 || (flags & ~(IHP_SLAB2_REF_2BIT | IHP_SLAB2_BASES_2BIT))) return IHP_E_ARG;
 	const char *h = (const char *)slab;
 	{
 		// as for the first slab form: the layout is checked against ihp_slab2_layout_for before any offset is followed
@@ -1443,8 +1444,8 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		void *d = b->in_slab.p;
 		b->region_read_off.view(d, L2->region_read_off, sizeof(int64_t) * (R + 1));
 		b->ref_off.view(d, L2->ref_off, sizeof(int64_t) * (R + 1)); b->ref_origin.view(d, L2->ref_origin, sizeof(int64_t) * R);
-		b->bases4.view(d, L2->bases4, (size_t)(b->n_bases >> 1) + NR);
-		b->has_b4 = true;
+		if (s2->flags & IHP_SLAB2_BASES_2BIT) { b->v2_pk.view(d, L2->bases4, sizeof(uint32_t) * (size_t)((b->n_bases >> 4) + NR + 4)); b->has_pk2 = true; }
+		else { b->bases4.view(d, L2->bases4, (size_t)(b->n_bases >> 1) + NR); b->has_b4 = true; }
 		if ((rc = b->bases.alloc(b->n_bases)) || (rc = b->read_off.alloc(sizeof(int64_t) * (NR + 1))) || (rc = b->read_start.alloc(sizeof(int64_t) * NR)) ||
 		    (rc = b->read_stop.alloc(sizeof(int64_t) * NR)) || (rc = b->trim_lo.alloc(sizeof(int32_t) * NR)) || (rc = b->trim_hi.alloc(sizeof(int32_t) * NR)) ||
 		    (rc = b->mapq.alloc(NR)) || (rc = b->read_skip.alloc(NR)) || (rc = b->ref_bases.alloc(b->n_ref))) { delete b; return rc; }
@@ -1688,9 +1689,9 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 	if ((rc = b->misc.alloc(b->z_bytes())) || (rc = b->summary.alloc(sizeof(ihp_region_summary) * (size_t)R))) { delete b; return rc; }
 	b->hit_cap = 2 * (2 * HIT_SLOTS * NR) + 128 * (long long)std::max(1, b->max_region_reads);
 	if (g_limits[2] > 0) b->hit_cap = std::min(b->hit_cap, std::max(g_limits[2], 2 * HIT_SLOTS * NR));   // the fixed slots stay; the bump region shrinks
-	if (b->v2 || b->has_b4) {
+	if (b->v2 || b->has_b4 || b->has_pk2) {
 		b->grid_pack = grid_for((int)std::min<long long>((NR + 3) / 4, 1 << 30), 32);
-		if ((rc = b->v2_pk.alloc(sizeof(uint32_t) * (size_t)((b->n_bases >> 4) + NR + 4))) || (rc = b->v2_trim_lo.alloc(sizeof(int) * (size_t)NR)) ||
+		if ((!b->has_pk2 && (rc = b->v2_pk.alloc(sizeof(uint32_t) * (size_t)((b->n_bases >> 4) + NR + 4)))) || (rc = b->v2_trim_lo.alloc(sizeof(int) * (size_t)NR)) ||
 		    (rc = b->v2_trim_hi.alloc(sizeof(int) * (size_t)NR)) || (rc = b->v2_read_bad.alloc((size_t)NR))) { delete b; return rc; }
 	}
 	{
@@ -1881,7 +1882,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		};
 		// k_prepack first: the 2-bit reads, the kept ranges and the "not ACGT" flags of every read (and, for a batch that came
 		// with 4-bit bases, the ASCII bases every other kernel reads)
-		const bool prepacked = (n1 && b->v2) || b->has_b4;
+		const bool prepacked = (n1 && b->v2) || b->has_b4 || b->has_pk2;
 		PrepackArgs pa;
 		memset(&pa, 0, sizeof(pa));
 		if (prepacked) {
@@ -1894,7 +1895,8 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 			pa.t_start = tm;                                       // the first launch of the stage
 			// (the pipelined kernel loads without asking whether a read has bases: not for a batch without any)
 			const int pf = (pa.trim_lo_in && pa.n_reads > 0 && b->n_bases >= 16) ? g_knob.prepack_fast : 0;
-			if (pf > 0 && pa.bases4) {                             // (a slab: 4-bit bases in, their ASCII form written on the way)
+			if (b->has_pk2) hipLaunchKernelGGL(k_unpack_pk, dim3(b->grid_pack), dim3(64), 0, s, pa);     // (the slab brought the packed form: only the ASCII copy, the kept ranges and the flags are left to write)
+			else if (pf > 0 && pa.bases4) {                             // (a slab: 4-bit bases in, their ASCII form written on the way)
 				if (pf == 1) hipLaunchKernelGGL((k_prepack_fast<1, true>), dim3(b->grid_pack), dim3(64), 0, s, pa);
 				else hipLaunchKernelGGL((k_prepack_fast<2, true>), dim3(b->grid_pack), dim3(64), 0, s, pa);
 			}
@@ -2128,7 +2130,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.out_seq = b->out_seq.as<uint8_t>(); a.ref_bases = b->ref_bases.as<uint8_t>();
 		a.bases = b->bases.as<uint8_t>(); a.mapq = b->mapq.as<uint8_t>();
 		{
-			const bool have = ((b->v2 && b->n_cls[0] > 0) || b->has_b4) && g_knob.tally_pk;    // k_prepack ran in this chain
+			const bool have = ((b->v2 && b->n_cls[0] > 0) || b->has_b4 || b->has_pk2) && g_knob.tally_pk;    // k_prepack ran in this chain
 			a.pk = have ? b->v2_pk.as<uint32_t>() : nullptr; a.read_bad = have ? b->v2_read_bad.as<uint8_t>() : nullptr;
 		}
 		a.read_off = b->read_off.as<long long>(); a.region_read_off = b->region_read_off.as<long long>();

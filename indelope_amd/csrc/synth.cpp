@@ -218,4 +218,28 @@ int ihp_synth_pack4(const uint8_t *bases, const int64_t *read_off, int64_t n_rea
 	return bad ? -1 : 0;
 }
 
+// The read bases 2 bits each in the library's packed form (ihp_slab2_layout under IHP_SLAB2_BASES_2BIT): read i from 32-bit word
+// (read_off[i] >> 4) + i of `out`, sixteen bases per word, base j in bits 2 (j & 15), code (ASCII >> 1) & 3.  Returns -1 (and
+// writes nothing useful) if a base is not upper-case A C G T.
+int ihp_synth_pack2(const uint8_t *bases, const int64_t *read_off, int64_t n_reads, uint32_t *out)
+{
+	int bad = 0;
+	for (int64_t i = 0; i < n_reads; ++i) {
+		const uint8_t *s = bases + read_off[i];
+		const int64_t len = read_off[i + 1] - read_off[i];
+		uint32_t *o = out + (read_off[i] >> 4) + i;
+		for (int64_t j = 0; j < len; j += 16) {
+			uint32_t w = 0;
+			const int64_t m = len - j < 16 ? len - j : 16;
+			for (int64_t k = 0; k < m; ++k) {
+				const uint8_t c = s[j + k];
+				if (c != 'A' && c != 'C' && c != 'G' && c != 'T') bad = 1;
+				w |= (uint32_t)((c >> 1) & 3) << (2 * k);
+			}
+			o[j >> 4] = w;
+		}
+	}
+	return bad ? -1 : 0;
+}
+
 }  // extern "C"

@@ -208,6 +208,7 @@ type IhpSlab2Layout* {.importc: "ihp_slab2_layout", header: "indelope_hip.h", by
   region_read_off*, region_base_off*, ref_off*, ref_origin*, start_rel*, len*, span*, trim_lo*, trim_hi*: int64
   mapq*, rflags*, ref_packed*, bases4*, bytes*: int64
 const IHP_SLAB2_REF_2BIT* = 2'i32
+const IHP_SLAB2_BASES_2BIT* = 4'i32   ## the read bases 2 bits each in the library's packed form (every base of the batch is A C G T)
 proc ihp_slab2_layout_for*(n_regions: int32, n_reads, n_bases, n_ref: int64, flags: int32, outp: ptr IhpSlab2Layout): cint {.importc, cdecl, header: "indelope_hip.h".}
 proc ihp_batch_upload_slab2*(p: ptr IhpParams, n_regions: int32, n_reads: int64, slab: pointer, layout: ptr IhpSlab2Layout,
                              flags: int32, b: ptr ptr IhpBatch): cint {.importc, cdecl, header: "indelope_hip.h".}
@@ -314,8 +315,11 @@ proc fill_slab2*(s: var Stager, L: var IhpSlab2Layout, flags: var int32): pointe
     if c != uint8('A') and c != uint8('C') and c != uint8('G') and c != uint8('T'): two_bit = false
   flags = if two_bit: IHP_SLAB2_REF_2BIT else: 0'i32
   const codes4 = "=ACMGRSVTWYHKDBN"
+  var reads_2bit = s.bases.len > 0
   for c in s.bases:
     if codes4.find(char(c)) < 0: return nil
+    if c != uint8('A') and c != uint8('C') and c != uint8('G') and c != uint8('T'): reads_2bit = false
+  if reads_2bit: flags = flags or IHP_SLAB2_BASES_2BIT     # half the bytes again: one N anywhere in the batch and the 4-bit form travels
   if not two_bit:
     for c in s.ref_bases:
       if codes4.find(char(c)) < 0: return nil      # e.g. hg19 / hg38 soft-masked lower case: the arrays carry it as it is
@@ -339,12 +343,21 @@ proc fill_slab2*(s: var Stager, L: var IhpSlab2Layout, flags: var int32): pointe
     at(uint16, L.len)[i] = uint16(ln); at(uint16, L.span)[i] = uint16(sp)
     at(uint16, L.trim_lo)[i] = uint16(s.trim_lo[i]); at(uint16, L.trim_hi)[i] = uint16(s.trim_hi[i])
     at(uint8, L.mapq)[i] = s.mapq[i]; at(uint8, L.rflags)[i] = s.read_skip[i] and 1
-    # 4-bit bases: read i from byte (read_off[i] >> 1) + i, first base in the high nibble (BAM's own packing)
-    let dst = L.bases4 + (s.read_off[i] shr 1) + int64(i)
-    for j in 0..<int(ln):
-      let code = uint8("=ACMGRSVTWYHKDBN".find(char(s.bases[int(s.read_off[i]) + j])))
-      if (j and 1) == 0: m[dst + int64(j shr 1)] = code shl 4
-      else: m[dst + int64(j shr 1)] = m[dst + int64(j shr 1)] or code
+    if reads_2bit:
+      # the library's packed form: read i from 32-bit word (read_off[i] >> 4) + i, base j in bits 2 (j and 15) of word j shr 4,
+      # code (ASCII shr 1) and 3 (A 0, C 1, T 2, G 3)
+      let w0 = (s.read_off[i] shr 4) + int64(i)
+      for j in 0..<int(ln):
+        let code = (uint32(s.bases[int(s.read_off[i]) + j]) shr 1) and 3'u32
+        if (j and 15) == 0: at(uint32, L.bases4)[w0 + int64(j shr 4)] = 0
+        at(uint32, L.bases4)[w0 + int64(j shr 4)] = at(uint32, L.bases4)[w0 + int64(j shr 4)] or (code shl (2 * (j and 15)))
+    else:
+      # 4-bit bases: read i from byte (read_off[i] >> 1) + i, first base in the high nibble (BAM's own packing)
+      let dst = L.bases4 + (s.read_off[i] shr 1) + int64(i)
+      for j in 0..<int(ln):
+        let code = uint8("=ACMGRSVTWYHKDBN".find(char(s.bases[int(s.read_off[i]) + j])))
+        if (j and 1) == 0: m[dst + int64(j shr 1)] = code shl 4
+        else: m[dst + int64(j shr 1)] = m[dst + int64(j shr 1)] or code
   for r in 0..<int(nreg):
     at(int64, L.ref_origin)[r] = s.ref_origin[r]
     let f0 = s.ref_off[r]

@@ -277,3 +277,56 @@ def test_compact_fetch_is_the_plain_fetch(hip, oracle):
                 assert len(v_plain) == len(v_comp) and all(repr(a) == repr(b_) for a, b_ in zip(v_plain, v_comp)), name
         finally:
             hip.batch_free(h)
+
+
+@pytest.mark.parametrize("which", ["C2", "C5", "deep", "lengths"])
+def test_compact_slab_with_the_reads_two_bits_each(hip, oracle, which):
+    """IHP_SLAB2_BASES_2BIT: when every read base of a batch is upper-case A C G T the compact slab carries the reads in the
+    library's own 2-bit packed form (half the bytes of BAM's 4-bit form; the device packs nothing, k_unpack_pk only writes the
+    ASCII copy) -- the same results as the 4-bit form and as the oracle on the separate arrays; one N anywhere and the slab
+    builder falls back to 4 bits."""
+    K = 31 if which == "C5" else 27
+    if which == "lengths":                                             # reads of 1 .. 40 bases around the 16-base word boundaries, some empty
+        b, _ = synth.generate(60, read_len=150, n_reads=(20, 40), err_rate=1e-3, config_id=68)
+        rng = np.random.default_rng(12)
+        ln = rng.choice(np.array([0, 1, 2, 15, 16, 17, 31, 32, 33, 40, 150]), b.n_reads)
+        ro = np.zeros(b.n_reads + 1, np.int64); ro[1:] = np.cumsum(ln)
+        bases = np.concatenate([b.bases[int(b.read_off[i]):int(b.read_off[i]) + int(ln[i])] for i in range(b.n_reads)] + [np.zeros(0, np.uint8)])
+        b = RegionBatch(b.region_read_off, ro, bases, np.full(len(bases), 30, np.uint8), b.read_start, b.read_start + ln, b.mapq, b.read_skip,
+                        b.ref_off, b.ref_bases, b.ref_origin)
+    else:
+        b, _ = synth.config(which, n_regions={"C2": 500, "C5": 120, "deep": 40}[which])
+    bt = b.with_trim_bounds()
+    exp = oracle.run_regions_mt(bt, oracle.params(K=K), 16)
+    sizes = {}
+    for form in (None, False):
+        s2 = hip.make_slab2(bt, bases_2bit=form)
+        try:
+            assert bool(s2.flags & A.IHP_SLAB2_BASES_2BIT) == (form is None)
+            sizes[form] = s2.layout.bytes
+            h = hip.batch_upload_slab2(s2, hip.params(K=K))
+            try:
+                for _ in range(2):
+                    hip.batch_run(h); hip.batch_sync(h)
+                    _same(hip.batch_fetch(h), exp)
+            finally:
+                hip.batch_free(h)
+        finally:
+            s2.free()
+    if which != "lengths":
+        assert sizes[None] < 0.66 * sizes[False], sizes
+    # a single N: the 4-bit form, whatever was asked for
+    bases = bt.bases.copy(); bases[len(bases) // 2] = ord("N")
+    bn = RegionBatch(bt.region_read_off, bt.read_off, bases, bt.quals, bt.read_start, bt.read_stop, bt.mapq, bt.read_skip, bt.ref_off, bt.ref_bases, bt.ref_origin,
+                     bt.trim_lo, bt.trim_hi)
+    s2 = hip.make_slab2(bn)
+    try:
+        assert not (s2.flags & A.IHP_SLAB2_BASES_2BIT)
+        h = hip.batch_upload_slab2(s2, hip.params(K=K))
+        try:
+            hip.batch_run(h); hip.batch_sync(h)
+            _same(hip.batch_fetch(h), oracle.run_regions_mt(bn, oracle.params(K=K), 16))
+        finally:
+            hip.batch_free(h)
+    finally:
+        s2.free()
