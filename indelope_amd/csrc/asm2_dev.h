@@ -392,7 +392,7 @@ constexpr int V2_WL = 128;                               // work-list entries in
 constexpr int V2_WLX = 192;                              // ... and in LDS behind them, for regions of long reads (contigs of many dwords)
 constexpr int V2_HDR = 8, V2_DIRW = 8;                   // hand-over record: header dwords, dwords per contig
 constexpr int V2_HB_DW = 32;                             // dwords of the contig-head bit map (1024 bits)
-__device__ __forceinline__ unsigned v2_head_hash(unsigned w) { return (w ^ (w >> 10) ^ (w >> 20)) & 1023u; }
+__device__ __forceinline__ unsigned v2_head_hash(unsigned w) { return w ^ (w >> 10) ^ (w >> 20); }      // (masked to the map's size by the caller)
 
 __device__ __forceinline__ int wl_make(int dword, int c, int k) { return (dword << 2) | (c << 16) | (k << 22); }
 __device__ __forceinline__ unsigned dpp_wave_shl1(unsigned v)
@@ -496,13 +496,16 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 	// Round 6, a 1024-bit map of the contigs' HEADS (the hash of a contig's first 16 bases; bits are only ever set): a query offset
 	// (contig.nim:114-135) needs a window of the read that IS some contig's head, which in BAM order almost never exists -- one
 	// lookup per window lane says so instead of a walk over the offsets or the contigs (a set bit only costs the walk it used to).
-	const int HBB = WLXB + wlx_n, SLOT0 = HBB + V2_HB_DW;
+	// (long reads: up to 127 query offsets a read and more contigs -- four times the bits)
+	const int hb_dw = maxlen > 200 ? 4 * V2_HB_DW : V2_HB_DW;
+	const unsigned hb_mask = 32u * (unsigned)hb_dw - 1u;
+	const int HBB = WLXB + wlx_n, SLOT0 = HBB + hb_dw;
 	if (SLOT0 + 8 > p_dwords) return IHP_E_CAPACITY;
 	int bump = SLOT0;
 	if (lane == 0) P[0] = 0;
-	if (lane < V2_HB_DW) P[HBB + lane] = 0;
+	for (int i = lane; i < hb_dw; i += 64) P[HBB + i] = 0;
 	auto head_seen = [&](unsigned head) {                        // wave-uniform head: one lane sets its bit
-		const unsigned h = v2_head_hash(head);
+		const unsigned h = v2_head_hash(head) & hb_mask;
 		if (lane == 0) P[HBB + (int)(h >> 5)] |= 1u << (h & 31u);
 	};
 	const long long base_idx = nrr ? (uni(a.read_off[r0]) >> 4) + r0 : 0;   // the region's first packed dword
@@ -617,9 +620,9 @@ __device__ inline int v2_read_phase(const ReadArgs &a, uint32_t *P, int p_dwords
 			int kq = best.found ? (omin < tl - best.ma ? omin : tl - best.ma) : omin;
 			if (kq >= 1) {
 				// is any window at an offset 1 .. kq the head of some contig?  (the bit map says "no" exactly; "maybe" takes the walk)
-				const unsigned h0 = v2_head_hash(wq0);
+				const unsigned h0 = v2_head_hash(wq0) & hb_mask;
 				bool maybe = lane >= 1 && lane <= kq && ((P[HBB + (int)(h0 >> 5)] >> (h0 & 31u)) & 1u);
-				if (kq > 63) { const unsigned h1 = v2_head_hash(wq1); maybe |= 64 + lane <= kq && ((P[HBB + (int)(h1 >> 5)] >> (h1 & 31u)) & 1u); }
+				if (kq > 63) { const unsigned h1 = v2_head_hash(wq1) & hb_mask; maybe |= 64 + lane <= kq && ((P[HBB + (int)(h1 >> 5)] >> (h1 & 31u)) & 1u); }
 				if (!ballot(maybe)) kq = 0;
 			}
 			if (kq >= 1 && kq <= 12) {

@@ -1567,7 +1567,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 			}
 			if (nb1 == 0) { nb1 = std::min<long long>(nbL, 16384); nr1 = std::min<long long>(nrL, 64); }   // no region of the usual size: size the first tier for small ones
 			// what a region needs at least ...
-			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + V2_HB_DW + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
+			long long need_pdw = 1 + (b->max_read_len + 15) / 16 + 2 + nr1 + nb1 / 16 * (b->max_read_len > 200 ? 12 : 6) / 10 + 64 + (b->max_read_len > 200 ? 4 : 1) * V2_HB_DW + (b->max_read_len > 200 ? V2_WLX : 0);   // long reads: more single-read contigs, longer relocations
 			// ... and what the occupancy that need allows leaves unused: a region that runs out of room is assembled again from
 			// scratch by the byte-based passes, one serial chain of ~0.6 ms, so room is worth more than the last wave.
 			const int occ_r = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * need_pdw + 256)));
@@ -1587,7 +1587,7 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 				if (b->n_rich) {
 					// the read-rich launch: the same kernel with the packed area its largest region needs (reads + slots of ~0.4
 					// of the read bases + relocations), at the occupancy that leaves
-					long long pdwL = 1 + (b->max_read_len + 15) / 16 + 2 + nrL + nbL / 16 * (b->max_read_len > 200 ? 12 : 7) / 10 + 192 + V2_HB_DW + (b->max_read_len > 200 ? V2_WLX : 0);
+					long long pdwL = 1 + (b->max_read_len + 15) / 16 + 2 + nrL + nbL / 16 * (b->max_read_len > 200 ? 12 : 7) / 10 + 192 + (b->max_read_len > 200 ? 4 : 1) * V2_HB_DW + (b->max_read_len > 200 ? V2_WLX : 0);
 					pdwL = std::min<long long>(pdwL, (g.max_lds - 4096) / 4);
 					const int occL = (int)std::max<long long>(1, std::min<long long>(32, g.max_lds / (4 * pdwL + 256)));
 					pdwL = std::max<long long>(pdwL, (g.max_lds / occL - 256) / 4);
