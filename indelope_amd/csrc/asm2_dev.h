@@ -359,10 +359,14 @@ __device__ __forceinline__ bool bits_equal(const uint32_t *P, int xd, unsigned x
 // Copy nbits bits from (sd, sbit) to (dd, dbit) inside P (bit offsets may exceed 31; they are relative to the dword
 // indices sd / dd).  Lanes take destination dwords; bits of a destination dword outside the range are kept.  Source
 // and destination must not overlap.  Reads P[sd - 1 ..] at most one dword outside the source range (padded).
+// FRESH_LANE: the lane number is taken afresh in every call (k_asm_combine3: the compiler otherwise computes -32 * lane once per
+// kernel, finds no register for it across a region and reloads it from scratch memory -- a wait -- in front of every copy).
+template <bool FRESH_LANE = false>
 __device__ __forceinline__ void copy_bits(uint32_t *P, int dd, int dbit, int sd, int sbit, int nbits)
 {
 	if (nbits <= 0) return;
-	const int lane = lane_id();
+	int lane = lane_id();
+	if (FRESH_LANE) asm volatile("" : "+v"(lane));
 	const int s = sbit - dbit;                                  // source bit of destination bit b is b + s
 	const int d_first = dbit >> 5, d_last = (dbit + nbits - 1) >> 5;
 	for (int d = d_first + lane; d <= d_last; d += 64) {

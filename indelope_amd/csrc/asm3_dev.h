@@ -127,6 +127,56 @@ __device__ __forceinline__ bool allowed3(unsigned qs, unsigned ts, int qreads, i
 	return (qs < 3u && ts > 3u * qs && qreads > 3 * (int)qs) || (ts < 3u && qs > 3u * ts && treads > 3 * (int)ts);
 }
 
+// ------------------------------------------------------------------------------------------------ the next work item
+// The work queue of ihp_common.h (wq_next) taken apart.  A wave that has a region to take over asks for its NEXT one beside the
+// three rounds of loads the take-over makes anyway: the ticket (the shard's counter) beside the record's header, the ticket's
+// region (the cost classes' list) beside the directory, that region's hand-over offset beside the packed bases.  These were
+// three dependent round trips to L2 in front of every take-over, queued behind the stores of the region before.  `stage` says
+// how far the chain has come (a take-over that returns early leaves the rest to v3n_finish, one wait each).
+typedef __attribute__((address_space(1))) int *v3_gint_p;
+struct V3Next {
+	v3_gint_p ctr; int S, s, n_items, cls_end;                     // the shard's counter; item = ticket * S + s; end of every cost class (lane c)
+	int tick_v, rn_v; long long hn_v;                                // in flight (vector registers: the ticket in lane 0)
+	int item, rn; long long hn;                                      // known: rn = -1: the queue is dry
+	int stage;                                                       // 0 nothing asked, 1 ticket, 2 region, 3 offset in flight, 4 all known
+};
+__device__ __forceinline__ void v3n_ticket(V3Next &N)
+{
+	// (an address the compiler cannot call uniform: its atomic optimizer would put a v_readfirstlane -- a wait -- right behind the atomic)
+	v3_gint_p p = N.ctr;
+	asm volatile("" : "+v"(p));
+	if (lane_id() == 0) N.tick_v = __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	N.stage = 1;
+}
+__device__ __forceinline__ void v3n_region(const AsmArgs &a, V3Next &N)
+{
+	// (every load of the chain is unconditional, ONE load from a chosen address, and its answer is first looked at in the NEXT
+	// step: a value that meets a select or a join here would be waited for here)
+	const int lane = lane_id();
+	N.item = uni(N.tick_v) * N.S + N.s;
+	const bool live = N.item < N.n_items;
+	const int *p = (const int *)a.v2_hoff;                             // (no list: any address that can be read)
+	if (a.lpt_cnt) {                                                   // item -> (class, position)
+		const int c = popc64(ballot(lane < a.lpt_nclass && N.item >= N.cls_end));
+		const int pos = N.item - (c ? __builtin_amdgcn_readlane(N.cls_end, c - 1) : 0);
+		p = a.lpt_seg + (live ? (size_t)c * a.lpt_stride + pos : 0);
+	} else if (a.in_list) p = a.in_list + (live ? N.item : 0);
+	N.rn_v = *p;
+	N.stage = 2;
+}
+__device__ __forceinline__ void v3n_offset(const AsmArgs &a, V3Next &N)
+{
+	N.rn = N.item < N.n_items ? (a.lpt_cnt || a.in_list ? uni(N.rn_v) : N.item) : -1;
+	N.hn_v = a.v2_hoff[N.rn >= 0 ? N.rn : 0];
+	N.stage = 3;
+}
+__device__ __forceinline__ void v3n_finish(const AsmArgs &a, V3Next &N)
+{
+	if (N.stage < 2) v3n_region(a, N);
+	if (N.stage < 3) v3n_offset(a, N);
+	if (N.stage < 4) { N.hn = uni(N.hn_v); N.stage = 4; }
+}
+
 // ------------------------------------------------------------------------------------------------ take-over
 // Support extrema and zones of SUP[so .. so + len), one base per lane.
 template <class ST>
@@ -147,10 +197,11 @@ __device__ inline void v3_stats(ST &S, const V3Ctx &C, int c)
 // Hand-over record of k_asm_reads -> directory in S, packed bases in PM, supports counted from the read records in SUP.
 // Returns 1 if the read phase did not take the region, 0 when ready, IHP_E_CAPACITY when it does not fit / is not for this path.
 template <class ST>
-__device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int &n_pre)
+__device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, long long hoff, V3Next &N, int &n_pre)
 {
 	const int lane = lane_id();
-	const uint32_t *H = a.v2_hand + uni(a.v2_hoff[r]);
+	const uint32_t *H = a.v2_hand + hoff;                             // (v2_hoff[r]: asked for beside the bases of the region before this one)
+	v3n_ticket(N);
 	const int n = uni((int)H[0]), nrr = uni((int)H[1]);
 	n_pre = 0;
 	if (n < 0) return 1;
@@ -158,6 +209,7 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 	constexpr int NREC = ST::NREC, SB = (int)sizeof(typename ST::sup_t);
 	if (nrr > 64 * NREC || n > ST::MAXC) return IHP_E_CAPACITY;     // (the records of a region are kept in four registers; ten in the wide build)
 	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
+	v3n_region(a, N);                                                // (the header is here, and so is the ticket)
 	if (lane < n) {
 		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
 		d_poff = (int)a0.x; d_len = (int)a0.y; d_nreads = (int)a0.z; d_slo = (int)a0.w; d_shi = (int)a1.x; d_anchor = (int)a1.y;
@@ -217,10 +269,29 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, int r, int
 	LDS_ORDER();
 	if (ballot(over)) { V3_CNT(C, 8, 1); return IHP_E_CAPACITY; }  // 256 reads on one base: the byte-based passes (u32 supports) take the region
 	// the packed bases as they are, one zero pad dword behind every contig (the scratch area overlapped PM: bases last)
-	for (int c = 0; c < n; ++c) {
-		const int len = bcast(d_len, c), po = bcast(poff, c);
-		const uint32_t *src = H + bcast(d_poff, c);
-		for (int d = lane; d <= (len + 15) >> 4; d += 64) C.PM[po + d] = 16 * d < len ? src[d] : 0u;
+	// Lane <-> dword of PM, 256 dwords a round with their loads in flight together (a loop over the contigs was one dependent
+	// round trip to L2 per contig -- a dozen per region, each as long as a best_match phase).
+	for (int g0 = 0; g0 < ptotal; g0 += 256) {
+		int own[4] = {0, 0, 0, 0};
+		for (int i = 1; i < n; ++i) {
+			const int pi = __builtin_amdgcn_readlane(poff, i);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) own[k] = g0 + 64 * k + lane >= pi ? i : own[k];
+		}
+		int off[4];                                                  // -1: a pad dword (or past the end)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int g = g0 + 64 * k + lane;
+			const int d = g - __builtin_amdgcn_ds_bpermute(own[k] << 2, poff);
+			const int len = __builtin_amdgcn_ds_bpermute(own[k] << 2, d_len), so = __builtin_amdgcn_ds_bpermute(own[k] << 2, d_poff);
+			off[k] = g < ptotal && 16 * d < len ? so + d : -1;
+		}
+		if (g0 == 0) v3n_offset(a, N);                                // (the directory's loads have long brought the next region's number)
+		uint32_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) v[k] = H[off[k] < 0 ? 0 : off[k]];   // every lane loads (the header when it has nothing to fetch): no branch between the loads
+#pragma unroll
+		for (int k = 0; k < 4; ++k) if (g0 + 64 * k + lane < ptotal) C.PM[g0 + 64 * k + lane] = off[k] < 0 ? 0u : v[k];
 	}
 	LDS_ORDER();
 	return 0;
@@ -846,21 +917,21 @@ __device__ inline int v3_insert(ST &S, V3Ctx &C, int ts, int qs, int off, int nc
 		for (int i = lane; i <= nw; i += 64) C.PM[ndw + i] = 0;
 		LDS_ORDER();
 		if (off < 0) {                                               // :180-195
-			copy_bits(C.PM, ndw, 0, qpb >> 4, 2 * (qpb & 15), 2 * aoff);
+			copy_bits<true>(C.PM, ndw, 0, qpb >> 4, 2 * (qpb & 15), 2 * aoff);
 			LDS_ORDER();
-			copy_bits(C.PM, ndw, 2 * aoff, tpb >> 4, 2 * (tpb & 15), 2 * tlen);
+			copy_bits<true>(C.PM, ndw, 2 * aoff, tpb >> 4, 2 * (tpb & 15), 2 * tlen);
 			LDS_ORDER();
-			copy_bits(C.PM, ndw, 2 * (aoff + tlen), qpb >> 4, 2 * ((qpb & 15) + aoff + tlen), 2 * (qlen - aoff - tlen));
+			copy_bits<true>(C.PM, ndw, 2 * (aoff + tlen), qpb >> 4, 2 * ((qpb & 15) + aoff + tlen), 2 * (qlen - aoff - tlen));
 		} else {
-			copy_bits(C.PM, ndw, 0, tpb >> 4, 2 * (tpb & 15), 2 * tlen);
+			copy_bits<true>(C.PM, ndw, 0, tpb >> 4, 2 * (tpb & 15), 2 * tlen);
 			LDS_ORDER();
-			copy_bits(C.PM, ndw, 2 * tlen, qpb >> 4, 2 * ((qpb & 15) + tlen - off), 2 * (newlen - tlen));   // :220-221
+			copy_bits<true>(C.PM, ndw, 2 * tlen, qpb >> 4, 2 * ((qpb & 15) + tlen - off), 2 * (newlen - tlen));   // :220-221
 		}
 		C.bump_pm += nw + 1; C.bump_sup += ncap + SLOT_PAD;
 	} else if (newlen > tlen) {
 		// in place: the new bases behind t's last one; the slot's dwords past the old end may hold anything
 		const int d0 = ndw, b0 = 2 * (nsh + tlen);
-		copy_bits(C.PM, d0, b0, qpb >> 4, 2 * ((qpb & 15) + tlen - off), 2 * (newlen - tlen));
+		copy_bits<true>(C.PM, d0, b0, qpb >> 4, 2 * ((qpb & 15) + tlen - off), 2 * (newlen - tlen));
 		LDS_ORDER();
 		// zero the tail of the last dword and the pad dword (windows read one dword past the end)
 		const int endb = nsh + newlen;

@@ -498,45 +498,18 @@ __device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C,
 	if (err) n_final = 0;
 	const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
 	long long mstop = -0x7fffffffffffffffll - 1;                   // max_stop over reads with mapq > 5 (indelope.nim:213-216)
-	for (long long ri = r0 + lane; ri < r1; ri += 64)
-		if (a.mapq[ri] > a.min_mapq_stop && a.read_stop[ri] > mstop) mstop = a.read_stop[ri];
+	for (long long ri = r0 + lane; ri < r1; ri += 64) {                // (both loads at once: one round trip a step, not two)
+		const int mq = a.mapq[ri]; const long long rs = a.read_stop[ri];
+		mstop = (mq > a.min_mapq_stop) & (rs > mstop) ? rs : mstop;
+	}
 	mstop = -wave_min_ll(-mstop - 1) - 1;
 	const long long seq_base = r0 < r1 ? a.read_off[r0] : 0;
 	const long long origin = a.ref_origin[r];
-	const long long L = a.ref_off[r + 1] - a.ref_off[r];
+	const long long roff = a.ref_off[r], L = a.ref_off[r + 1] - roff;
 	const int width = (int)((double)(a.K + 1) / 2.0 - 1.0);       // :218
-	long long cursor = 0;
-	for (int k = 0; k < n_final; ++k) {
-		const int c = uni((int)S.listA[k]);
-		const int len = uni(S.len[c]), pb = uni(16 * S.dw[c] + S.sh[c]), so = uni(S.so[c]);
-		uint8_t *oseq = a.out_seq + seq_base + cursor; uint32_t *osup = a.out_sup + seq_base + cursor;
-		for (int i = 4 * lane; i < len; i += 256) {                  // four bases per lane: 2-bit codes -> "ACTG" bytes
-			const int b = pb + i;
-			const unsigned c8 = (fsh(C.PM[(b >> 4) + 1], C.PM[b >> 4], 2u * (unsigned)(b & 15))) & 0xffu;
-			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
-			const unsigned w = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
-			unsigned s4[4] = {1u, 1u, 1u, 1u};                           // four supports (the slot is padded: reading past len is fine)
-			if (so >= 0) {
-				if (ST::WIDE) {
-					const unsigned lo = ld32u((const uint32_t *)C.SUP, 2 * (so + i)), hi = ld32u((const uint32_t *)C.SUP, 2 * (so + i) + 4);
-					s4[0] = lo & 0xffffu; s4[1] = lo >> 16; s4[2] = hi & 0xffffu; s4[3] = hi >> 16;
-				} else {
-					const unsigned sv = ld32u((const uint32_t *)C.SUP, so + i);
-					s4[0] = sv & 0xffu; s4[1] = (sv >> 8) & 0xffu; s4[2] = (sv >> 16) & 0xffu; s4[3] = sv >> 24;
-				}
-			}
-			if (i + 4 <= len) {
-				*(u32_unaligned *)(oseq + i) = w;
-				osup[i] = s4[0]; osup[i + 1] = s4[1]; osup[i + 2] = s4[2]; osup[i + 3] = s4[3];
-			} else {
-#pragma unroll
-				for (int j = 0; j < 3; ++j) if (i + j < len) { oseq[i + j] = (uint8_t)(w >> (8 * j)); osup[i + j] = s4[j]; }
-			}
-		}
-		cursor += len;
-	}
 	// The contigs' records and alignment jobs, lane k <-> final contig k (at most 64): one atomic per region for the job slots
 	// (per job it was a dependent round trip to L2 in the one lane that did this, and 200 000 requests to one address).
+	// In front of the contigs' bases: the atomic's answer is then not queued behind a region's worth of stores.
 	long long carry = 0;                                                // bases of the contigs before k0
 	for (int k0 = 0; k0 < n_final; k0 += 64) {
 		const int k = k0 + lane;
@@ -571,10 +544,41 @@ __device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C,
 		const int j = plan_append(a.n_jobs, job);
 		if (job) {
 			AlnJob jb;
-			jb.q_off = seq_base + mycur; jb.t_off = a.ref_off[r] + beg; jb.qlen = len; jb.tlen = rl;
+			jb.q_off = seq_base + mycur; jb.t_off = roff + beg; jb.qlen = len; jb.tlen = rl;
 			jb.out = (int)slot; jb.region = r; jb.flags = ALN_Q_ACGT; jb.pad_ = 0;   // 2-bit packed contigs; enc_base() folds the window
 			a.jobs[j] = jb;
 		}
+	}
+	// the bases and supports of the final contigs (stores only: nothing below waits for them)
+	long long cursor = 0;
+	for (int k = 0; k < n_final; ++k) {
+		const int c = uni((int)S.listA[k]);
+		const int len = uni(S.len[c]), pb = uni(16 * S.dw[c] + S.sh[c]), so = uni(S.so[c]);
+		uint8_t *oseq = a.out_seq + seq_base + cursor; uint32_t *osup = a.out_sup + seq_base + cursor;
+		for (int i = 4 * lane; i < len; i += 256) {                  // four bases per lane: 2-bit codes -> "ACTG" bytes
+			const int b = pb + i;
+			const unsigned c8 = (fsh(C.PM[(b >> 4) + 1], C.PM[b >> 4], 2u * (unsigned)(b & 15))) & 0xffu;
+			const unsigned t = c8 | (c8 << 6), u = t | (t << 12);
+			const unsigned w = __builtin_amdgcn_perm(0u, PK_LUT, u & 0x03030303u);
+			unsigned s4[4] = {1u, 1u, 1u, 1u};                           // four supports (the slot is padded: reading past len is fine)
+			if (so >= 0) {
+				if (ST::WIDE) {
+					const unsigned lo = ld32u((const uint32_t *)C.SUP, 2 * (so + i)), hi = ld32u((const uint32_t *)C.SUP, 2 * (so + i) + 4);
+					s4[0] = lo & 0xffffu; s4[1] = lo >> 16; s4[2] = hi & 0xffffu; s4[3] = hi >> 16;
+				} else {
+					const unsigned sv = ld32u((const uint32_t *)C.SUP, so + i);
+					s4[0] = sv & 0xffu; s4[1] = (sv >> 8) & 0xffu; s4[2] = (sv >> 16) & 0xffu; s4[3] = sv >> 24;
+				}
+			}
+			if (i + 4 <= len) {
+				*(u32_unaligned *)(oseq + i) = w;
+				osup[i] = s4[0]; osup[i + 1] = s4[1]; osup[i + 2] = s4[2]; osup[i + 3] = s4[3];
+			} else {
+#pragma unroll
+				for (int j = 0; j < 3; ++j) if (i + j < len) { oseq[i + j] = (uint8_t)(w >> (8 * j)); osup[i + j] = s4[j]; }
+			}
+		}
+		cursor += len;
 	}
 	if (lane == 0) { a.status[r] = err; a.n_pre[r] = n_pre; a.n_final[r] = n_final; }
 }
@@ -592,7 +596,6 @@ template <int MINW, bool TEAM, int MAXC = V3_MAXC, bool WIDE = false>
 __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_asm_combine3(const AsmArgs a)
 {
 	__shared__ V3StateT<MAXC, WIDE> S;
-	__shared__ int s_item;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_arena[];
 	__shared__ V3Par s_par;                                    // (dropped from the one-wave build: nobody refers to it there)
 	V3Par *const par = TEAM ? &s_par : nullptr;
@@ -621,22 +624,21 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 		cls_end = (int)wave_scan_add(lane < a.lpt_nclass ? (unsigned)a.lpt_cnt[lane] : 0u);
 		n_items = __builtin_amdgcn_readlane(cls_end, 63);
 	}
-	unsigned wq_dead = 0;
-	for (;;) {
-		if (lane == 0) s_item = wq_next(a.work_counter, n_items, (int)blockIdx.x, wq_dead);
-		WAVE_SYNC();
-		int r = __builtin_amdgcn_readfirstlane(s_item);
-		WAVE_SYNC();
-		if (r < 0) break;
-		if (a.lpt_cnt) {                                        // item -> (class, position)
-			const int c = popc64(ballot(lane < a.lpt_nclass && r >= cls_end));
-			const int pos = r - (c ? __builtin_amdgcn_readlane(cls_end, c - 1) : 0);
-			r = uni(a.lpt_seg[(size_t)c * a.lpt_stride + pos]);
-		} else if (a.in_list) r = a.in_list[r];
+	// (the work queue: V3Next, asm3_dev.h -- a region's successor is asked for beside the loads of its take-over)
+	V3Next N;
+	N.S = (int)gridDim.x < WQ_SHARDS ? (int)gridDim.x : WQ_SHARDS; N.s = (int)blockIdx.x % N.S;
+	N.n_items = n_items; N.cls_end = cls_end; N.tick_v = 0; N.rn_v = -1; N.hn_v = 0;
+	N.ctr = (v3_gint_p)(a.work_counter + N.s * 16);
+	v3n_ticket(N);
+	v3n_finish(a, N);
+	int r = N.rn;
+	long long hoff = N.hn;
+	while (r >= 0) {
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
-		int err = v3_take_over(a, S, C, r, n_pre);
-		if (err == 1) continue;                                // the read phase did not take this region
+		N.stage = 0;
+		int err = v3_take_over(a, S, C, hoff, N, n_pre);         // (1: the read phase did not take this region)
+		v3n_finish(a, N);
 		const long long tcA = a.prof ? (long long)clock64() : 0;
 		if (!err) {
 			const int n2 = v3_combine_pass<TEAM>(S, C, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, T);
@@ -646,19 +648,21 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 				if (n3 < 0) err = n3; else n_final = n3;
 			}
 		}
-		if (a.prof && lane == 0) { S.prof[0] += (long long)clock64() - tcR; S.prof[1] += (long long)clock64() - tcA; S.prof[3] += 1; }
-		if (err == IHP_E_CAPACITY && a.out_list) {             // not here: the next, roomier launch (or the byte-based passes) take it
+		if (a.prof && lane == 0 && err != 1) { S.prof[0] += (long long)clock64() - tcR; S.prof[1] += (long long)clock64() - tcA; S.prof[3] += 1; }
+		if (err == 1) {
+		} else if (err == IHP_E_CAPACITY && a.out_list) {       // not here: the next, roomier launch (or the byte-based passes) take it
 			if (lane == 0) { a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
-			continue;
+		} else {
+			region_epilogue3(a, S, C, r, err, n_pre, n_final);
+			if (a.prof && lane == 0) {
+				const long long dt_ = (long long)clock64() - tcR;
+				S.prof[2] += dt_;
+				atomicMax((unsigned long long *)&a.prof[53], ((unsigned long long)dt_ << 20) | (unsigned long long)(r & 0xfffff));   // the longest region of the launch (cycles << 20 | region)
+				atomicAdd((unsigned long long *)&a.prof[54 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], (unsigned long long)dt_);
+				atomicAdd((unsigned long long *)&a.prof[57 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], 1ull);
+			}
 		}
-		region_epilogue3(a, S, C, r, err, n_pre, n_final);
-		if (a.prof && lane == 0) {
-			const long long dt_ = (long long)clock64() - tcR;
-			S.prof[2] += dt_;
-			atomicMax((unsigned long long *)&a.prof[53], ((unsigned long long)dt_ << 20) | (unsigned long long)(r & 0xfffff));   // the longest region of the launch (cycles << 20 | region)
-			atomicAdd((unsigned long long *)&a.prof[54 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], (unsigned long long)dt_);
-			atomicAdd((unsigned long long *)&a.prof[57 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], 1ull);
-		}
+		r = N.rn; hoff = N.hn;
 	}
 	if (TEAM && n_waves > 1) {                                 // the others leave their loop
 		if (lane == 0) par->cmd = 2;
