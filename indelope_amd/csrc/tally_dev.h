@@ -186,16 +186,68 @@ __device__ __forceinline__ unsigned long long to_packed_alphabet(unsigned long l
 // has a base that is not upper-case ACGT (k_prepack's read_bad), so every window of a read is a valid k-mer (:300).
 // Lanes = reads as there; same counts, same first-hit positions.  Returns false (nothing done) when a group of 64 reads
 // does not fit the LDS area.
-__device__ inline bool tally_reads_packed(const uint32_t *pk, const long long *read_off, const uint8_t *mapq,
-                                          long long r0, long long r1, int min_mapq, int K,
-                                          unsigned long long refe, unsigned long long alte, int counts[3],
-                                          uint32_t *lds32, int lds_bytes, int *ref_hit, int *alt_hit)
+// Round 6: no rolling code.  The packed read IS the sequence of its windows -- the window that starts at base p is 2 K bits of the
+// stream from bit 2 p, first base lowest -- so the four k-mer codes are turned into that order once, a window's first sixteen bases
+// are one v_alignbit of two neighbouring dwords, and a position costs that and four 32-bit compares against scalars; only a
+// position at which some read's first sixteen bases match goes on to the rest of the window, the end of the read and the
+// first-hit bookkeeping (one position in six on C2).  It was a 64-bit shift, mask and four 64-bit compares per base with all
+// of the bookkeeping every time: 12 VALU + 11 SALU a base, now 5 + 4.
+// One group of up to 64 packed reads -> LDS: dwords [gb, gb + nd) of pk by the loads that write LDS themselves (global_load_lds:
+// a wave's 64 dwords land at consecutive addresses from a wave-uniform base, no register in between), all of them in flight at
+// once; whoever reads the area waits with WSYNC.  (A dword a lane through a register and a wait per round was eleven dependent
+// round trips to HBM for 64 reads of 150 bases -- most of a job's time; sixteen bytes a lane through registers cost 35 spilled
+// registers in a kernel that keeps eight waves per SIMD.)
+__device__ __forceinline__ void tally_stage_packed(const uint32_t *src, int nd, uint32_t *lds32)
 {
+	typedef __attribute__((address_space(3))) uint32_t *lds_p;
+	typedef const __attribute__((address_space(1))) uint32_t *glb_p;
 	const int lane = lane_id();
-	const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1) : ~0ull;
-	const unsigned long long ref_f = to_packed_alphabet(refe), ref_r = to_packed_alphabet(revcomp_code(refe, K));
-	const unsigned long long alt_f = to_packed_alphabet(alte), alt_r = to_packed_alphabet(revcomp_code(alte, K));
-	for (long long b = r0; b < r1; b += 64) {                   // fits?  (decided before anything is counted)
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (what was read from the area before has been read)
+	for (int i0 = 0; i0 < nd; i0 += 64)
+		if (i0 + lane < nd) __builtin_amdgcn_global_load_lds((glb_p)(src + i0 + lane), (lds_p)(lds32 + i0), 4, 0, 0);
+}
+// A lane's read of the group [b, e): first dword relative to the group's and length; n = 0: not used (:294) or no read
+__device__ __forceinline__ void tally_lane_read(const long long *read_off, const uint8_t *mapq, long long b, long long e, long long gb, int min_mapq, int &d0, int &n)
+{
+	const long long ri = b + lane_id();
+	const long long rc = ri < e ? ri : e - 1;                       // (every lane loads: nothing waits on a branch)
+	const long long o = read_off[rc], o1 = read_off[rc + 1];
+	const bool use = ri < e && !(mapq && mapq[rc] < min_mapq);     // :294
+	d0 = use ? (int)((o >> 4) + ri - gb) : 0; n = use ? (int)(o1 - o) : 0;
+}
+// The first group of a region, ahead of the tally (fill_events: while the k-mer bytes are on their way).  base0 / end0: read_off of
+// the region's first read and of the end of its first group.  False: it does not fit the LDS area.
+__device__ __forceinline__ bool tally_stage_packed_first(const uint32_t *pk, const long long *read_off, const uint8_t *mapq, long long r0, long long r1,
+                                                         long long base0, long long end0, int min_mapq, uint32_t *lds32, int lds_bytes, int &d0, int &n)
+{
+	const long long e = r0 + 64 < r1 ? r0 + 64 : r1;
+	const long long gb = (base0 >> 4) + r0;
+	const int nd = (int)(((end0 >> 4) + e) - gb);
+	if (4 * nd + 8 > lds_bytes) return false;
+	tally_stage_packed(pk + gb, nd, lds32);
+	tally_lane_read(read_off, mapq, r0, e, gb, min_mapq, d0, n);   // (behind the staging loads: its answers are looked at right away)
+	return true;
+}
+__device__ __forceinline__ unsigned long long kmer_stream_order(unsigned long long code, int K)
+{   // code: first base in the highest of its 2 K bits (the rolling order) -> first base in the lowest
+	unsigned long long x = __builtin_bitreverse64(code);            // bases in reverse order, and the two bits of every base swapped
+	x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+	return x >> (64 - 2 * K);
+}
+template <bool KGE16>                                           // K >= 16 (the usual 27): a window's first sixteen bases need no mask
+__device__ inline bool tally_reads_packed_k(const uint32_t *pk, const long long *read_off, const uint8_t *mapq,
+                                            long long r0, long long r1, int min_mapq, int K,
+                                            unsigned long long refe, unsigned long long alte, int counts[3],
+                                            uint32_t *lds32, int lds_bytes, int *ref_hit, int *alt_hit, bool first_staged, int fd0, int fn)
+{   // first_staged: the caller has put the first group into LDS (tally_stage_packed_first; fd0 / fn: what it returned)
+	const int lane = lane_id();
+	const unsigned long long t0 = kmer_stream_order(to_packed_alphabet(refe), K), t1 = kmer_stream_order(to_packed_alphabet(revcomp_code(refe, K)), K);
+	const unsigned long long t2 = kmer_stream_order(to_packed_alphabet(alte), K), t3 = kmer_stream_order(to_packed_alphabet(revcomp_code(alte, K)), K);
+	const unsigned mlo = K >= 16 ? 0xffffffffu : (1u << (2 * K)) - 1u;                       // a window's first sixteen bases ...
+	const unsigned mhi = K <= 16 ? 0u : K >= 32 ? 0xffffffffu : (1u << (2 * K - 32)) - 1u;   // ... and the rest of it
+	const unsigned l0 = (unsigned)t0, l1 = (unsigned)t1, l2 = (unsigned)t2, l3 = (unsigned)t3;
+	const unsigned h0 = (unsigned)(t0 >> 32), h1 = (unsigned)(t1 >> 32), h2 = (unsigned)(t2 >> 32), h3 = (unsigned)(t3 >> 32);
+	for (long long b = first_staged ? r0 + 64 : r0; b < r1; b += 64) {   // fits?  (decided before anything is counted)
 		const long long e = b + 64 < r1 ? b + 64 : r1;
 		const long long nd = ((read_off[e] >> 4) + e) - ((read_off[b] >> 4) + b);
 		if (4 * nd + 8 > lds_bytes) return false;
@@ -203,43 +255,56 @@ __device__ inline bool tally_reads_packed(const uint32_t *pk, const long long *r
 	int nref = 0, nalt = 0, nboth = 0;
 	for (long long b = r0; b < r1; b += 64) {
 		const long long e = b + 64 < r1 ? b + 64 : r1;
-		const long long gb = (read_off[b] >> 4) + b;
-		const int nd = (int)(((read_off[e] >> 4) + e) - gb);
-		WSYNC();
-		for (int i = lane; i < nd; i += 64) lds32[i] = pk[gb + i];
-		WSYNC();
 		const long long ri = b + lane;
-		const bool use = ri < e && !(mapq && mapq[ri] < min_mapq);   // :294
-		int d0 = 0, n = 0;
-		if (use) { const long long o = read_off[ri]; d0 = (int)((o >> 4) + ri - gb); n = (int)(read_off[ri + 1] - o); }
+		int d0 = fd0, n = fn;
+		if (!(first_staged && b == r0)) {
+			const long long gb = (read_off[b] >> 4) + b;
+			const int nd = (int)(((read_off[e] >> 4) + e) - gb);
+			tally_stage_packed(pk + gb, nd, lds32);
+			tally_lane_read(read_off, mapq, b, e, gb, min_mapq, d0, n);
+		}
+		WSYNC();
 		const int nmax = wave_max_i32s(n);
-		unsigned long long f = 0, rfm = 0, afm = 0;
+		const int nq = ((n + 15) >> 4) + 1;                           // dwords 0 .. nq from the read's first are the read's own or the two behind them (staged or slack)
+		unsigned long long rfm = 0, afm = 0;
 		int rpos = -1, apos = -1;
-		for (int j0 = 0; j0 < nmax; j0 += 16) {
-			const unsigned dw = j0 < n ? lds32[d0 + (j0 >> 4)] : 0u;
+		unsigned w0 = lds32[d0], w1 = lds32[d0 + 1];
+		for (int p0 = 0; p0 + K <= nmax; p0 += 16) {                  // window starts p0 .. p0 + 15
+			const int q = (p0 >> 4) + 2;
+			const unsigned w2 = q <= nq ? lds32[d0 + q] : 0u;
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				f = ((f << 2) | (unsigned long long)((dw >> (2 * k)) & 3u)) & mask;
-				const int j = j0 + k;
-				if (j < K - 1) continue;                                  // (wave-uniform) no full window yet
-				const unsigned long long full = ballot(j < n);
-				const unsigned long long hr = full & (ballot(f == ref_f) | ballot(f == ref_r));   // :301-309
-				const unsigned long long ha = full & (ballot(f == alt_f) | ballot(f == alt_r));
-				const int wpos = j - (K - 1);                             // start of this window: the first hit is kept
-				rpos = lane_in_mask(hr & ~rfm) ? wpos : rpos;
-				apos = lane_in_mask(ha & ~afm) ? wpos : apos;
+				unsigned lo = k ? __builtin_amdgcn_alignbit(w1, w0, 2u * (unsigned)k) : w0;
+				if (!KGE16) lo &= mlo;
+				const unsigned long long c0 = ballot(lo == l0), c1 = ballot(lo == l1), c2 = ballot(lo == l2), c3 = ballot(lo == l3);
+				if (!((c0 | c1) | (c2 | c3))) continue;                  // the usual position: nobody's window starts like a k-mer
+				const int p = p0 + k;
+				const unsigned hi = (k ? __builtin_amdgcn_alignbit(w2, w1, 2u * (unsigned)k) : w1) & mhi;
+				const unsigned long long full = ballot(p + K <= n);
+				const unsigned long long hr = full & ((c0 & ballot(hi == h0)) | (c1 & ballot(hi == h1)));   // :301-309
+				const unsigned long long ha = full & ((c2 & ballot(hi == h2)) | (c3 & ballot(hi == h3)));
+				rpos = lane_in_mask(hr & ~rfm) ? p : rpos;                // the first hit is kept
+				apos = lane_in_mask(ha & ~afm) ? p : apos;
 				rfm |= hr; afm |= ha;
 			}
+			w0 = w1; w1 = w2;
 		}
-		const unsigned long long usem = ballot(use);
-		rfm &= usem; afm &= usem;
-		if (ref_hit && ri < e) { ref_hit[ri - r0] = use ? rpos : -1; alt_hit[ri - r0] = use ? apos : -1; }
+		// (a read that is not used, :294, has n = 0 here: no window of it is full, its bits stay clear and its positions -1)
+		if (ref_hit && ri < e) { ref_hit[ri - r0] = rpos; alt_hit[ri - r0] = apos; }
 		nref += popc64(rfm);
 		nalt += popc64(afm);
 		nboth += popc64(rfm & afm);                               // :310-311
 	}
 	counts[0] = nref; counts[1] = nalt; counts[2] = nboth;
 	return true;
+}
+__device__ inline bool tally_reads_packed(const uint32_t *pk, const long long *read_off, const uint8_t *mapq,
+                                          long long r0, long long r1, int min_mapq, int K,
+                                          unsigned long long refe, unsigned long long alte, int counts[3],
+                                          uint32_t *lds32, int lds_bytes, int *ref_hit, int *alt_hit, bool first_staged = false, int fd0 = 0, int fn = 0)
+{
+	if (K >= 16) return tally_reads_packed_k<true>(pk, read_off, mapq, r0, r1, min_mapq, K, refe, alte, counts, lds32, lds_bytes, ref_hit, alt_hit, first_staged, fd0, fn);
+	return tally_reads_packed_k<false>(pk, read_off, mapq, r0, r1, min_mapq, K, refe, alte, counts, lds32, lds_bytes, ref_hit, alt_hit, first_staged, fd0, fn);
 }
 
 __device__ __forceinline__ int distinct_bytes(const char *s, int n)
@@ -340,6 +405,7 @@ __device__ inline void fill_events(const CigSrc cigar, int ntrunc,
 	const int width = (int)((double)(K + 1) / 2.0 - 1.0);                // :218
 	int toff = ctg_rel, qoff = 0, ii = -1;
 	bool staged = false;
+	bool pstaged = false; int pd0 = 0, pn = 0;                          // the packed reads' first group is in LDS (lane: first dword, length)
 	for (int i = 0; i < ntrunc; ++i) {
 		const uint32_t cwi = cigar.word(i), op = cwi & 0xf, len = cwi >> 4;
 		if (op == 0) { toff += (int)len; qoff += (int)len; continue; }
@@ -371,6 +437,7 @@ __device__ inline void fill_events(const CigSrc cigar, int ntrunc,
 			if (lane < K) ak = ctg[qstart + lane];                       // :248
 			// the reads travel to LDS while the k-mer bytes are still on their way
 			if (!pk && !staged && r1 > r0) staged = tally_stage_first(bases, base0, end0, lds32, lds_bytes);
+			if (pk && !pstaged && r1 > r0) pstaged = tally_stage_packed_first(pk, read_off, mapq, r0, r1, base0, end0, P.min_mapq_tally, lds32, lds_bytes, pd0, pn);
 			if (!ballot(lane < K && rk != ak)) {                         // :255-262
 				qstart = e_qs - 3;
 				if (qstart < 0) qstart = 0;
@@ -406,12 +473,14 @@ __device__ inline void fill_events(const CigSrc cigar, int ntrunc,
 					if (hoff + 2 * nr > hit_cap) { hoff = -1; if (lane == 0) atomicExch(hit_overflow, 1); }
 				}
 			}
-			if (!(pk && tally_reads_packed(pk, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
-			                               hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr))) {
+			// (a first group that did not fit has left nothing staged: both kinds of staging are decided before they write)
+			if (!(pk && (pstaged || r1 <= r0) && tally_reads_packed(pk, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
+			                               hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr, pstaged, pd0, pn))) {
 				tally_reads_lds(bases, read_off, mapq, r0, r1, P.min_mapq_tally, K, refe, alte, counts, lds32, lds_bytes,
-				                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr, staged);
+				                hoff >= 0 ? hit_pool + hoff : nullptr, hoff >= 0 ? hit_pool + hoff + nr : nullptr, staged && !pstaged);
 				if (r1 - r0 > 64) staged = false;                        // later groups have overwritten the first one
-			} else staged = false;
+				pstaged = false;
+			} else { staged = false; if (r1 - r0 > 64) pstaged = false; }
 			status = IHP_EV_TALLIED;
 		}
 		DevEvent *o = ev + ii;

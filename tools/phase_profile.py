@@ -41,6 +41,9 @@ def main():
     print("      other                 ", k(d[1] - d[5] - d[4] - d[6] - d[7]))
     print("    epilogue                ", k(d[2] - d[0]))
     print("  events per region: best_match %.1f, candidates %.1f, verify passes %.1f, vote scans %.1f, merges %.1f" % tuple(d[32 + i] / R for i in range(5)))
+    nj = max(int(d[18]) + int(d[19]), 1)
+    print("  tally: %d jobs with events (%d without); cycles per job with events %.1f k, of which the header %.1f k" %
+          (int(d[18]), int(d[19]), d[16] / max(int(d[18]), 1) / 1e3, d[20] / nj / 1e3))
     print("  reads (per region, %.1f reads): set-up %s prep %s target %s query %s insert %s" %
           (nreads / n, k(d[27] * R / n), k(d[12] * R / n), k(d[13] * R / n), k(d[14] * R / n), k(d[15] * R / n)))
 
