@@ -623,12 +623,45 @@ __device__ __forceinline__ void pair_steady_step(PairState &S, const PairEnv &E,
 	"v_pk_min_i16 %[t4], %[XA], 4 op_sel_hi:[1,0]\n\t"                                                             \
 	"v_pk_min_i16 %[t8], %[YA], 8 op_sel_hi:[1,0]\n\t"                                                             \
 	"v_add3_u32 %[t1], %[t4], %[t1], %[t8]\n\t"                                                                    \
-	"v_pk_lshlrev_b16 %[acA], 4, %[acA] op_sel_hi:[0,1]\n\t"                                                       \
-	"v_pk_add_u16 %[acA], %[acA], %[t1]\n\t"                                                                       \
+	"v_pk_mad_u16 %[acA], %[acA], 16, %[t1] op_sel_hi:[1,0,1]\n\t"  /* the traceback nibble behind the group's earlier ones */ \
 	"v_cndmask_b32_e64 %[t2], %[GA], %[t2], %[sp]\n\t"   /* H[en0] = H[en0-1] + u (:318), the others += v */       \
 	"v_cndmask_b32_e64 %[t4], %[VA], %[UA], %[sp]\n\t"                                                             \
 	"v_pk_lshrrev_b16 %[t4], 8, %[t4] op_sel_hi:[0,1]\n\t"                                                         \
 	"v_pk_add_u16 %[GA], %[t4], %[t2]\n\t"                                                                         \
+	"s_and_b64 %[inT], " LM ", %[hi]\n\t"
+// The same for a diagonal whose en0 is the one of the diagonal before (the second of a steady pair): the cell en0 had an H of its own
+// on that diagonal, u and v are exact differences of H, so H[en0-1] + u (:318) and H[en0] + v are one number -- three instructions
+// less (the neighbour's H and the two selects).
+#define IHP_PS_VEC_SAME_EN(ZW, WAIT, RM, LM, PRE)                                                                         \
+	"v_mov_b32_dpp %[t0], %[XA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+	"v_mov_b32_dpp %[t1], %[VA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+	PRE                                                                                                            \
+	WAIT "\n\t"                                                                                                    \
+	"v_perm_b32 %[t3], %[TA1], %[TA0], " ZW "\n\t"                                                                 \
+	"v_cndmask_b32_e64 %[ZA], %[ZA], %[t3], " RM "\n\t"  /* the refreshed scores (:214-228) */                     \
+	"v_pk_add_u16 %[t0], %[t0], %[t1]\n\t"               /* a = x' + v' */                                         \
+	"v_pk_add_u16 %[t3], %[YA], %[UA]\n\t"               /* b = y + u */                                           \
+	"v_pk_sub_i16 %[t4], %[ZA], %[t0] clamp\n\t"         /* s1: negative <=> a > z */                              \
+	"v_pk_max_u16 %[t5], %[ZA], %[t0]\n\t"                                                                         \
+	"v_pk_sub_i16 %[t8], %[t5], %[t3] clamp\n\t"         /* s2: negative <=> b > max(z, a) */                      \
+	"v_pk_max_u16 %[t5], %[t5], %[t3]\n\t"                                                                         \
+	"v_pk_min_u16 %[t5], %[t5], %[Mp]\n\t"               /* z */                                                   \
+	"v_pk_sub_i16 %[VA], %[t5], %[UA]\n\t"               /* v = z - u */                                           \
+	"v_pk_sub_i16 %[UA], %[t5], %[t1]\n\t"               /* u = z - v' */                                          \
+	"v_pk_sub_i16 %[t5], %[t5], %[Qp]\n\t"                                                                         \
+	"v_pk_sub_i16 %[t0], %[t0], %[t5]\n\t"                                                                         \
+	"v_pk_sub_i16 %[t3], %[t3], %[t5]\n\t"                                                                         \
+	"v_pk_max_i16 %[XA], %[t0], 0\n\t"                                                                             \
+	"v_pk_max_i16 %[YA], %[t3], 0\n\t"                                                                             \
+	"v_pk_lshrrev_b16 %[t1], 15, %[t8] op_sel_hi:[0,1]\n\t"                                                        \
+	"v_pk_lshrrev_b16 %[t4], 14, %[t4] op_sel_hi:[0,1]\n\t"                                                        \
+	"v_and_or_b32 %[t1], %[t4], %[k22], %[t1]\n\t"                                                                 \
+	"v_pk_min_i16 %[t4], %[XA], 4 op_sel_hi:[1,0]\n\t"                                                             \
+	"v_pk_min_i16 %[t8], %[YA], 8 op_sel_hi:[1,0]\n\t"                                                             \
+	"v_add3_u32 %[t1], %[t4], %[t1], %[t8]\n\t"                                                                    \
+	"v_pk_mad_u16 %[acA], %[acA], 16, %[t1] op_sel_hi:[1,0,1]\n\t"  /* the traceback nibble behind the group's earlier ones */ \
+	"v_pk_lshrrev_b16 %[t4], 8, %[VA] op_sel_hi:[0,1]\n\t"  /* every H += v, H[en0] too: en0 is the lane it was on the diagonal before, */ \
+	"v_pk_add_u16 %[GA], %[t4], %[GA]\n\t"             /* whose H it has, and H[en0-1] + u (:318) is the same number */ \
 	"s_and_b64 %[inT], " LM ", %[hi]\n\t"
 // one alignment behind the joint test (labels 3..7 are local to the instance: every branch is forward).  ZS2: more terms of
 // the vouching limit (the tail's t* + qlen - 1), with the lane of the new maximum in %[i].
@@ -723,7 +756,7 @@ __device__ __forceinline__ int pair_steady_pairs_asm(PairState &S, const PairEnv
 		"s_lshl_b64 %[ge], %[ge], 1\n\t"
 		"s_add_i32 %[r], %[r], 1\n\t"
 		// ---- the second: it closes a traceback group when r & 2; en0 grows behind it
-		IHP_PS_VEC("%[t7]", "s_waitcnt lgkmcnt(0)", "%[ge]", "%[ge]", "")
+		IHP_PS_VEC_SAME_EN("%[t7]", "s_waitcnt lgkmcnt(0)", "%[ge]", "%[ge]", "")
 		"s_bitcmp1_b32 %[r], 1\n\t"
 		"s_cbranch_scc0 2f\n\t"
 		"global_store_dword %[vof], %[acA], %[pb]\n\t"
@@ -828,7 +861,7 @@ __device__ __forceinline__ int pair_tail_run_asm(PairState &S, const PairEnv &E,
 		"12:\n\t"
 		// ---- an odd one: it closes a traceback group when r & 2; en0 grows behind it
 		"ds_read_b32 %[t6], %[qp]\n\t"
-		IHP_PS_VEC("%[t7]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[lo]", "")
+		IHP_PS_VEC_SAME_EN("%[t7]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[lo]", "")
 		"s_bitcmp1_b32 %[r], 1\n\t"
 		"s_cbranch_scc0 2f\n\t"
 		"global_store_dword %[vof], %[acA], %[pb]\n\t"
@@ -908,7 +941,7 @@ __device__ __forceinline__ int pair_early_run_asm(PairState &S, const PairEnv &E
 	"s_lshl_b64 %[sp], %[sp], 1\n\t"                                                                               \
 	"s_lshl_b64 %[hi], %[hi], 1\n\t"                                                                               \
 	"s_or_b64 %[hi], %[hi], 1\n\t"
-#define IHP_PE_ASM(EVEN_EXTRA) \
+#define IHP_PE_ASM(EVEN_EXTRA, VEC_ODD) \
 	asm volatile( \
 		"s_waitcnt lgkmcnt(0)\n\t" \
 		"s_min_i32 %[zsm], %[zs0], %[zs1]\n\t" \
@@ -928,7 +961,7 @@ __device__ __forceinline__ int pair_early_run_asm(PairState &S, const PairEnv &E
 		"ds_read_b32 %[t7], %[qp] offset:4\n" \
 		"12:\n\t" \
 		"ds_read_b32 %[t6], %[qp]\n\t" \
-		IHP_PS_VEC("%[t7]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[rf]", IHP_PE_PRE) \
+		VEC_ODD("%[t7]", "s_waitcnt lgkmcnt(1)", "%[rf]", "%[rf]", IHP_PE_PRE) \
 		"s_bitcmp1_b32 %[r], 1\n\t" \
 		"s_cbranch_scc0 2f\n\t" \
 		"global_store_dword %[vof], %[acA], %[pb]\n\t" \
@@ -953,7 +986,8 @@ __device__ __forceinline__ int pair_early_run_asm(PairState &S, const PairEnv &E
 		: [acB] "v"(S.accB), [TA0] "v"(S.TA0), [TA1] "v"(S.TA1), [Qv] "v"(Qv), [Mp] "s"(Mp), [Qp] "s"(Qp), [k22] "s"(k22), [inc0] "s"(inc0), [inc1] "s"(inc1), \
 		  [lim] "s"(lim), [st] "s"(st), [zq] "s"(zq), [c1] "s"(c1), [zd] "s"(zd), [pb] "s"(pbase) \
 		: "vcc", "scc", "memory");
-	if (GROW) { IHP_PE_ASM(IHP_PE_UP) } else { IHP_PE_ASM("s_lshl_b64 %[rf], %[rf], 1\n\t") }
+	// (GROW: en0 = r is a new cell on every diagonal; otherwise the odd diagonals keep the en0 of the even one before them)
+	if (GROW) { IHP_PE_ASM(IHP_PE_UP, IHP_PS_VEC) } else { IHP_PE_ASM("s_lshl_b64 %[rf], %[rf], 1\n\t", IHP_PS_VEC_SAME_EN) }
 #undef IHP_PE_ASM
 	S.qptr -= stat ? r + 1 - r_in : r - r_in;
 	(void)qp;
@@ -999,8 +1033,7 @@ __device__ __forceinline__ int pair_early_run_asm(PairState &S, const PairEnv &E
 	"v_pk_min_i16 %[t4], " X ", 4 op_sel_hi:[1,0]\n\t"                                                             \
 	"v_pk_min_i16 %[t8], " Y ", 8 op_sel_hi:[1,0]\n\t"                                                             \
 	"v_add3_u32 %[t1], %[t4], %[t1], %[t8]\n\t"                                                                    \
-	"v_pk_lshlrev_b16 " AC ", 4, " AC " op_sel_hi:[0,1]\n\t"                                                       \
-	"v_pk_add_u16 " AC ", " AC ", %[t1]\n\t"
+	"v_pk_mad_u16 " AC ", " AC ", 16, %[t1] op_sel_hi:[1,0,1]\n\t"
 #define IHP_PH_DIAG(ZWA, ZWB)                                                                                     \
 	"v_readlane_b32 %[ex], %[XA], 63\n\t"                /* the block edge of slot B: slot A's lane 63 of diagonal r - 1 */ \
 	"v_readlane_b32 %[ev], %[VA], 63\n\t"                                                                          \
@@ -1124,6 +1157,7 @@ __device__ __forceinline__ int pair_hasb_run_asm(PairState &S, const PairEnv &E,
 #undef IHP_PH_EZ
 #undef IHP_PH_NEXT
 #undef IHP_PS_VEC
+#undef IHP_PS_VEC_SAME_EN
 #undef IHP_PS_PER
 #undef IHP_PS_EZ
 #undef IHP_PS_ZS2_NONE

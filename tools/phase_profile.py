@@ -44,6 +44,9 @@ def main():
     nj = max(int(d[18]) + int(d[19]), 1)
     print("  tally: %d jobs with events (%d without); cycles per job with events %.1f k, of which the header %.1f k" %
           (int(d[18]), int(d[19]), d[16] / max(int(d[18]), 1) / 1e3, d[20] / nj / 1e3))
+    na = max(int(d[11]), 1)
+    print("  ksw2 pair sweep, cycles per alignment (%d): set-up %.1f k, sweep %.1f k (early diagonals %.1f k, tail %.1f k), traceback %.1f k" %
+          (na, d[8] / na / 1e3, d[9] / na / 1e3, d[60] / na / 1e3, d[61] / na / 1e3, d[10] / na / 1e3))
     print("  reads (per region, %.1f reads): set-up %s prep %s target %s query %s insert %s" %
           (nreads / n, k(d[27] * R / n), k(d[12] * R / n), k(d[13] * R / n), k(d[14] * R / n), k(d[15] * R / n)))
 
