@@ -128,11 +128,13 @@ __device__ __forceinline__ bool allowed3(unsigned qs, unsigned ts, int qreads, i
 }
 
 // ------------------------------------------------------------------------------------------------ the next work item
-// The work queue of ihp_common.h (wq_next) taken apart.  A wave that has a region to take over asks for its NEXT one beside the
-// three rounds of loads the take-over makes anyway: the ticket (the shard's counter) beside the record's header, the ticket's
-// region (the cost classes' list) beside the directory, that region's hand-over offset beside the packed bases.  These were
-// three dependent round trips to L2 in front of every take-over, queued behind the stores of the region before.  `stage` says
-// how far the chain has come (a take-over that returns early leaves the rest to v3n_finish, one wait each).
+// The work queue of ihp_common.h (wq_next) taken apart.  A wave asks for its NEXT region beside the three rounds of loads the
+// EPILOGUE of the current one makes anyway: the ticket (the shard's counter) beside the region's read range, the ticket's region
+// (the cost classes' list) beside the reads' stops, that region's hand-over offset beside the reference offsets.  These were three
+// dependent round trips to L2 in front of every take-over, queued behind the stores of the region before.  (Asked for at the
+// START of a region -- beside the take-over's loads -- the ticket binds a region to a wave a whole region early: with two
+// regions per wave, a batch of 10 000, that is a static schedule, and the launch's tail grew by a fifth.)  `stage` says how far
+// the chain has come (a region without an epilogue leaves all of it to v3n_finish, one wait each).
 typedef __attribute__((address_space(1))) int *v3_gint_p;
 struct V3Next {
 	v3_gint_p ctr; int S, s, n_items, cls_end;                     // the shard's counter; item = ticket * S + s; end of every cost class (lane c)
@@ -197,11 +199,10 @@ __device__ inline void v3_stats(ST &S, const V3Ctx &C, int c)
 // Hand-over record of k_asm_reads -> directory in S, packed bases in PM, supports counted from the read records in SUP.
 // Returns 1 if the read phase did not take the region, 0 when ready, IHP_E_CAPACITY when it does not fit / is not for this path.
 template <class ST>
-__device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, long long hoff, V3Next &N, int &n_pre)
+__device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, long long hoff, int &n_pre)
 {
 	const int lane = lane_id();
-	const uint32_t *H = a.v2_hand + hoff;                             // (v2_hoff[r]: asked for beside the bases of the region before this one)
-	v3n_ticket(N);
+	const uint32_t *H = a.v2_hand + hoff;                             // (v2_hoff[r]: asked for in the epilogue of the region before this one)
 	const int n = uni((int)H[0]), nrr = uni((int)H[1]);
 	n_pre = 0;
 	if (n < 0) return 1;
@@ -209,7 +210,6 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, long long 
 	constexpr int NREC = ST::NREC, SB = (int)sizeof(typename ST::sup_t);
 	if (nrr > 64 * NREC || n > ST::MAXC) return IHP_E_CAPACITY;     // (the records of a region are kept in four registers; ten in the wide build)
 	int d_poff = 0, d_len = 0, d_nreads = 0, d_slo = 0, d_shi = 0, d_anchor = 0;
-	v3n_region(a, N);                                                // (the header is here, and so is the ticket)
 	if (lane < n) {
 		const uint4 a0 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane), a1 = *(const uint4 *)(H + V2_HDR + V2_DIRW * lane + 4);
 		d_poff = (int)a0.x; d_len = (int)a0.y; d_nreads = (int)a0.z; d_slo = (int)a0.w; d_shi = (int)a1.x; d_anchor = (int)a1.y;
@@ -286,7 +286,6 @@ __device__ inline int v3_take_over(const AsmArgs &a, ST &S, V3Ctx &C, long long 
 			const int len = __builtin_amdgcn_ds_bpermute(own[k] << 2, d_len), so = __builtin_amdgcn_ds_bpermute(own[k] << 2, d_poff);
 			off[k] = g < ptotal && 16 * d < len ? so + d : -1;
 		}
-		if (g0 == 0) v3n_offset(a, N);                                // (the directory's loads have long brought the next region's number)
 		uint32_t v[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) v[k] = H[off[k] < 0 ? 0 : off[k]];   // every lane loads (the header when it has nothing to fetch): no branch between the loads

@@ -492,17 +492,20 @@ __global__ __launch_bounds__(64, MINW) void k_asm_reads(const ReadArgs a)
 
 // Final contigs of one region from the packed representation (asm3_dev.h) -> output slots, alignment jobs; see region_epilogue.
 template <class ST>
-__device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C, int r, int err, int n_pre, int &n_final)
+__device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C, int r, int err, int n_pre, int &n_final, V3Next &N)
 {
 	const int lane = lane_id();
 	if (err) n_final = 0;
+	v3n_ticket(N);                                                   // (the wave's next region: asm3_dev.h, V3Next)
 	const long long r0 = a.region_read_off[r], r1 = a.region_read_off[r + 1];
 	long long mstop = -0x7fffffffffffffffll - 1;                   // max_stop over reads with mapq > 5 (indelope.nim:213-216)
+	if (r0 < r1) v3n_region(a, N);                                   // (r0 is here, and so is the ticket)
 	for (long long ri = r0 + lane; ri < r1; ri += 64) {                // (both loads at once: one round trip a step, not two)
 		const int mq = a.mapq[ri]; const long long rs = a.read_stop[ri];
 		mstop = (mq > a.min_mapq_stop) & (rs > mstop) ? rs : mstop;
 	}
 	mstop = -wave_min_ll(-mstop - 1) - 1;
+	if (N.stage == 2) v3n_offset(a, N);
 	const long long seq_base = r0 < r1 ? a.read_off[r0] : 0;
 	const long long origin = a.ref_origin[r];
 	const long long roff = a.ref_off[r], L = a.ref_off[r + 1] - roff;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 		cls_end = (int)wave_scan_add(lane < a.lpt_nclass ? (unsigned)a.lpt_cnt[lane] : 0u);
 		n_items = __builtin_amdgcn_readlane(cls_end, 63);
 	}
-	// (the work queue: V3Next, asm3_dev.h -- a region's successor is asked for beside the loads of its take-over)
+	// (the work queue: V3Next, asm3_dev.h -- a region's successor is asked for beside the loads of its epilogue)
 	V3Next N;
 	N.S = (int)gridDim.x < WQ_SHARDS ? (int)gridDim.x : WQ_SHARDS; N.s = (int)blockIdx.x % N.S;
 	N.n_items = n_items; N.cls_end = cls_end; N.tick_v = 0; N.rn_v = -1; N.hn_v = 0;
@@ -637,8 +640,7 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 		int n_pre = 0, n_final = 0;
 		const long long tcR = a.prof ? (long long)clock64() : 0;
 		N.stage = 0;
-		int err = v3_take_over(a, S, C, hoff, N, n_pre);         // (1: the read phase did not take this region)
-		v3n_finish(a, N);
+		int err = v3_take_over(a, S, C, hoff, n_pre);            // (1: the read phase did not take this region)
 		const long long tcA = a.prof ? (long long)clock64() : 0;
 		if (!err) {
 			const int n2 = v3_combine_pass<TEAM>(S, C, S.listA, n_pre, S.listB, 0, a.combine_min_overlap, T);
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 		} else if (err == IHP_E_CAPACITY && a.out_list) {       // not here: the next, roomier launch (or the byte-based passes) take it
 			if (lane == 0) { a.n_final[r] = 0; a.out_list[atomicAdd(a.n_out, 1)] = r; }
 		} else {
-			region_epilogue3(a, S, C, r, err, n_pre, n_final);
+			region_epilogue3(a, S, C, r, err, n_pre, n_final, N);
 			if (a.prof && lane == 0) {
 				const long long dt_ = (long long)clock64() - tcR;
 				S.prof[2] += dt_;
@@ -662,6 +664,8 @@ __global__ __launch_bounds__(TEAM ? 64 * V3_MAXW : 64) __attribute__((amdgpu_wav
 				atomicAdd((unsigned long long *)&a.prof[57 + (n_pre >= 19 ? 0 : n_pre >= 13 ? 1 : 2)], 1ull);
 			}
 		}
+		if (N.stage == 0) v3n_ticket(N);                          // (a region without an epilogue)
+		v3n_finish(a, N);
 		r = N.rn; hoff = N.hn;
 	}
 	if (TEAM && n_waves > 1) {                                 // the others leave their loop
