@@ -1901,7 +1901,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 				else hipLaunchKernelGGL((k_prepack_fast<2, true>), dim3(b->grid_pack), dim3(64), 0, s, pa);
 			}
 			else if (pf == 1) hipLaunchKernelGGL(k_prepack_fast<1>, dim3(b->grid_pack), dim3(64), 0, s, pa);
-			else if (pf == 2) hipLaunchKernelGGL(k_prepack_fast<2>, dim3(b->grid_pack), dim3(64), 0, s, pa);
+			// (88 registers: 20 waves of this build are resident on a CU, and its waves all do the same work -- a grid of 32 per CU ran as
+			// one full round and one of twelve waves)
+			else if (pf == 2) hipLaunchKernelGGL(k_prepack_fast<2>, dim3(std::min(b->grid_pack, g.cus * 20)), dim3(64), 0, s, pa);
 			else if (pf == 3) hipLaunchKernelGGL(k_prepack_fast<3>, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			else if (pf == 4) hipLaunchKernelGGL(k_prepack_fast<4>, dim3(b->grid_pack), dim3(64), 0, s, pa);
 			else hipLaunchKernelGGL(k_prepack, dim3(b->grid_pack), dim3(64), 0, s, pa);

@@ -40,6 +40,8 @@ def main():
     print("      trims                 ", k(d[7]))
     print("      other                 ", k(d[1] - d[5] - d[4] - d[6] - d[7]))
     print("    epilogue                ", k(d[2] - d[0]))
+    print("    by contigs at the take-over: >= 19: %d regions, %.1f k cycles each; 13-18: %d, %.1f k; <= 12: %d, %.1f k; the longest region of the launch %.1f k (region %d)" %
+          (int(d[57]), d[54] / max(int(d[57]), 1) / 1e3, int(d[58]), d[55] / max(int(d[58]), 1) / 1e3, int(d[59]), d[56] / max(int(d[59]), 1) / 1e3, (int(p[53]) >> 20) / 1e3, int(p[53]) & 0xfffff))
     print("  events per region: best_match %.1f, candidates %.1f, verify passes %.1f, vote scans %.1f, merges %.1f" % tuple(d[32 + i] / R for i in range(5)))
     nj = max(int(d[18]) + int(d[19]), 1)
     print("  tally: %d jobs with events (%d without); cycles per job with events %.1f k, of which the header %.1f k" %
