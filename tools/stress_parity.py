@@ -70,6 +70,8 @@ def main():
             o1, _ = synth.generate(n_regions=int(rng.integers(1, 40)), read_len=cfg["read_len"], n_reads=(8, 120), err_rate=1e-3, config_id=5000 + it)
             b = concat_batches([o1, b, o1.slice(0, max(1, o1.n_regions // 2))])
         kw = dict(K=K)
+        if os.environ.get("IHP_STRESS_NO_FALLBACK"):                # (replaying a refusal: does it come from the fallback's scratch?)
+            kw["fallback"] = 0
         if rng.random() < 0.5:
             kw.update(min_reads=3, min_ctg_len=73)
         if WIDE_PARAMS and rng.random() < 0.7:                     # the parameters the CLI leaves at their defaults, too
