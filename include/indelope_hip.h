@@ -532,7 +532,7 @@ int  ihp_batch_fallback_ms(ihp_batch *b, float *ms);
  * forwarded at run time (arena / slot overflow) to the 2nd/3rd/4th assembly pass, [23] regions the packed pass handed
  * back to the byte-based class-1 kernel, [28] regions sent on to the roomy combine launch, [29] regions the read phase
  * filed under the second (larger-arena) combine launch, [30] under the third, [21] 1 if the last run left the retry
- * launches out, [31] runs of this batch repeated in full because of that, [22] ksw2 kernel mode; [32..39] event counts of the combine kernel
+ * launches out (bit 0 the assembly retry launches, 1 the roomy ksw2 launch, 2 the roomy launch of the alignment fallback), [31] runs of this batch repeated in full because of that, [47] items of the alignment fallback that took its roomy launch, [22] ksw2 kernel mode; [32..39] event counts of the combine kernel
  * (best_match calls, exact candidates, verification passes, vote scans, merges, filter passes, query-phase target looks, trims that read supports). */
 int  ihp_batch_profile(ihp_batch *b, int64_t out[64]);
 /* The same with the caller's capacity: the first min(cap, 64) counters.  (ihp_batch_profile writes 64 int64 since round 3;
@@ -569,6 +569,7 @@ int  ihp_debug_limits(const int64_t limits[4]);
  *   "verbose" 1     a line on stderr per run: the combine tiers (waves per CU, arenas, grids) it was launched with
  *   "ksw_p_cap" n   bytes of traceback scratch per wave of the main ksw2 launch (0 = library sizing): jobs that need more take the
  *                   roomy launch behind it
+ *   "fb_p_cap" n    the same for the main launch of the alignment fallback: items that need more take ITS roomy launch
  *   "comb_waves" n  waves per workgroup of the combine kernel, 1 / 2 / 4 (0 = by the tier's occupancy): wave 0 runs the region,
  *                   the others take shares of its best_match calls
  *   "no_rich" 1     read-rich regions (assembly classes 2-4) stay with the byte-based passes instead of the packed path

@@ -72,6 +72,7 @@ struct Knobs {
 	int no_hint = 0;       // 1: every combine launch with its full grid whatever the last batch needed
 	int no_spec = 0;       // 1: the retry launches are always enqueued (default: left out when the last batch needed none, checked at the wait)
 	int ksw_p_cap = 0;     // bytes: caps the traceback scratch per wave of the MAIN ksw2 launch (its jobs that need more go to the roomy launch)
+	int fb_p_cap = 0;      // the same for the MAIN launch of the alignment fallback (items that need more go to its roomy launch)
 	int comb_waves = 0;    // waves per workgroup of k_asm_combine3 (1, 2, 4; 0 = by the tier's occupancy): wave 0 runs the region, the others share its best_match calls
 	int verbose = 0;       // 1: a line on stderr per run with the combine tiers it was launched with
 	int tally_rec_cap = 0; // test hook: records k_tally_prep may write (the other jobs with events take k_tally's own header path)
@@ -551,7 +552,7 @@ extern "C" int ihp_debug_set(const char *key, int64_t value)
 {
 	if (!key) { g_knob = Knobs(); g_hints.clear(); return 0; }
 	struct { const char *name; int *field; } tab[] = {
-		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"tally_rec_cap", &g_knob.tally_rec_cap}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"fb_skip", &g_knob.fb_skip}, {"prepack_fast", &g_knob.prepack_fast},
+		{"asm_v1", &g_knob.asm_v1}, {"no_rich", &g_knob.no_rich}, {"no_hint", &g_knob.no_hint}, {"no_spec", &g_knob.no_spec}, {"spec_fail", &g_knob.spec_fail}, {"comb_minw", &g_knob.comb_minw}, {"tally_minw", &g_knob.tally_minw}, {"tally_rec_cap", &g_knob.tally_rec_cap}, {"verbose", &g_knob.verbose}, {"comb_waves", &g_knob.comb_waves}, {"ksw_p_cap", &g_knob.ksw_p_cap}, {"fb_p_cap", &g_knob.fb_p_cap}, {"tally_pk", &g_knob.tally_pk}, {"lpt", &g_knob.lpt}, {"ksw_pair", &g_knob.ksw_pair}, {"fb_duo", &g_knob.fb_duo}, {"fb_skip", &g_knob.fb_skip}, {"prepack_fast", &g_knob.prepack_fast},
 		{"asm_waves", &g_knob.asm_waves}, {"asmr_waves", &g_knob.asmr_waves}, {"comb_occ", &g_knob.comb_occ},
 		{"ksw_waves", &g_knob.ksw_waves}, {"tally_waves", &g_knob.tally_waves}, {"v2_arena", &g_knob.v2_arena},
 		{"v2_pdw", &g_knob.v2_pdw}, {"profile", &g_knob.profile}, {"strict_ksw", &g_knob.strict_ksw},
@@ -1003,8 +1004,8 @@ extern "C" int ihp_kmer_tally(int32_t n_reads, const uint8_t *bases, const int64
 }
 
 // ------------------------------------------------------- the batched region path
-enum { WQ_SETS = 25 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles); [24] the wide combine launch (regions of more than 255 reads)
-enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_NRECS = 25 /* 2 */, M_WORDS = 32,
+enum { WQ_SETS = 26 };      // work-queue counter sets: 11 assembly launches, ksw2, tally, fallback; [14] holds the combine cost-class counters; [15] the read-rich k_asm_reads launch; [16] the third combine tier; [17] the roomy ksw2 launch; [18] the pair launch of ksw2; [19..23] the zero block of the ksw2 plan (jobs per contig length, pairs, singles); [24] the wide combine launch (regions of more than 255 reads); [25] the roomy fallback launch
+enum { M_CIG = 0, M_EV = 2, M_NJOBS = 4, M_CNT_ASM = 5, M_KSW_OVF = 6, M_CNT_TALLY = 7, M_OVF = 8, M_NRETRY = 11, M_CNT_RETRY = 12, M_NRETRY2 = 13, M_CNT_ASM2 = 14, M_NRETRY3 = 15, M_CNT_ASM3 = 16, M_NFB = 17, M_OVF_HIT = 18, M_NRETRY0 = 19, M_HIT = 20, M_NRETRYC = 22, M_NTIERB = 23, M_NTIERC = 24, M_NRECS = 25 /* 2 */, M_FB_OVF = 27, M_WORDS = 32,
        M_SLAB_BAD = 48, M_HIST = 49, M_MANYC = 60 };   // M_MANYC: regions with more contigs than the first tier's short table holds   // (behind the stamps, inside the report block: raised by k_slab_expand when a compact slab's lengths do not add up)
 struct ihp_batch {
 	ihp_params P;
@@ -1045,7 +1046,7 @@ struct ihp_batch {
 	unsigned long long hint_key = 0;                       // the batch's shape (HintTable)
 	long long cig_pool_cap = 0, cig_bump_cap = 0, ev_pool_cap = 0, njobs_cap = 0;
 	// alignment fallback (indelope.nim:312-372)
-	DBuf fb_items, fb_p_scratch, fb_cig_tmp;
+	DBuf fb_items, fb_p_scratch, fb_cig_tmp, fb_ovf;       // fb_ovf: items the main fallback launch could not hold (its roomy launch shares the roomy ksw2 launch's scratch)
 	DBuf pack_cnt, pack_slab;                              // result compaction (ihp_batch_fetch)
 	DBuf tally_recs, tally_ovf; int tally_rec_cap = 0;     // k_tally_prep -> k_tally (TallyRec)
 	DBuf hit_pool; long long hit_cap = 0;                  // first-hit k-mer positions per (tallied event, read)
@@ -1060,7 +1061,8 @@ struct ihp_batch {
 	int *queues_dev() const { return (int *)((char *)misc.p + Z_QUEUES); }
 	int *hitcnt_dev() const { return (int *)((char *)misc.p + z_hitcnt()); }
 	int grid_fb = 0, lds_fb = 0, fb_cig_cap = 0, max_region_reads = 0;
-	size_t fb_p_cap = 0;
+	size_t fb_p_cap = 0, fb_p_cap_big = 0; int fb_cig_cap_big = 0;
+	static constexpr int FB_OVF_CAP = 1 << 16;
 	// outputs
 	DBuf status, n_pre, n_final, ctg_start, ctg_nreads, ctg_seq_off, ctg_len, aln_flags, aln_ref_len, aln_ref_start;
 	DBuf out_seq, out_sup, jobs, ez, cig_off, cig_pool, ev_off, n_ev, ev_pool, summary;
@@ -1072,6 +1074,7 @@ struct ihp_batch {
 	bool spec_skipped = false;                             // the run left out the retry launches (nobody needed them in the last batch): checked when it is waited for
 	bool force_full = false;
 	bool ksw_skipped = false;                              // the run left out the roomy ksw2 launch (no job needed it in the last batch): checked at the wait
+	bool fb_roomy_skipped = false;                         // the same for the roomy launch of the alignment fallback
 	DBuf ksw_ovf, p_scratch_big, cig_tmp_big;              // jobs the main ksw2 launch could not hold, and the roomy launch's scratch
 	size_t p_cap_big = 0; int cig_cap_big = 0, grid_kovf = 0;
 	bool tier_wide = false;                                // the first combine tier runs the build with the full contig table (many regions with more than COMB_MAXC_A contigs)
@@ -1153,6 +1156,7 @@ static int alloc_work(ihp_batch *b)
 		AL(fb_items, sizeof(FbItem) * (size_t)b->ev_pool_cap);
 		AL(fb_p_scratch, b->fb_p_cap * b->grid_fb);
 		AL(fb_cig_tmp, sizeof(uint32_t) * (size_t)b->fb_cig_cap * b->grid_fb);
+		AL(fb_ovf, sizeof(int) * (size_t)ihp_batch::FB_OVF_CAP);
 	}
 	AL(prof, sizeof(long long) * 64);
 	AL(status, sizeof(int) * R); AL(n_pre, sizeof(int) * R); AL(n_final, sizeof(int) * R);
@@ -1175,7 +1179,7 @@ static int alloc_work(ihp_batch *b)
 static void release_work(ihp_batch *b)
 {
 	DBuf *bufs[] = {&b->retry_list0, &b->retry_listc, &b->lpt_seg, &b->v2_hand, &b->arena_seq, &b->arena_sup, &b->lds_sup, &b->lds_sup2, &b->lds_sup3, &b->retry_list, &b->retry_list2, &b->retry_list3,
-	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->ksw_ovf, &b->ksw_plan, &b->p_scratch_pair, &b->cig_tmp_pair, &b->p_scratch_big, &b->cig_tmp_big, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->prof,
+	                &b->corr2, &b->corr, &b->p_scratch, &b->cig_tmp, &b->ksw_ovf, &b->ksw_plan, &b->p_scratch_pair, &b->cig_tmp_pair, &b->p_scratch_big, &b->cig_tmp_big, &b->fb_items, &b->fb_p_scratch, &b->fb_cig_tmp, &b->fb_ovf, &b->prof,
 	                &b->status, &b->n_pre, &b->n_final, &b->ctg_start, &b->ctg_nreads, &b->ctg_seq_off, &b->ctg_len, &b->aln_flags,
 	                &b->aln_ref_len, &b->aln_ref_start, &b->out_seq, &b->out_sup, &b->jobs, &b->ez, &b->cig_off, &b->cig_pool,
 	                &b->ev_off, &b->n_ev, &b->ev_pool, &b->hit_pool, &b->pack_cnt, &b->pack_slab, &b->tally_recs, &b->tally_ovf};
@@ -1683,6 +1687,20 @@ static int batch_upload_common(const ihp_params *p, const ihp_batch_in *in, cons
 		}
 		b->lds_fb = (int)std::min<size_t>(lneed + 64, (size_t)g.max_lds - 2048);
 		b->grid_fb = grid_for(1 << 30, std::max(1, std::min(16, g.max_lds / (b->lds_fb + 256))));
+		// the roomy launch for the items that do not fit that (a read of an event on a contig far longer than its window): the roomy
+		// ksw2 launch's few workgroups and its scratch, cut for the longest contig the assembly can leave (up to 256 MB each)
+		{
+			const int tbig = std::max(qmax, tmax);
+			const int wb = p->fb_bw < 0 ? std::max(ql, tbig) : p->fb_bw;
+			const int ncb = (std::min(std::min(ql, tbig), wb + 1) + 15) / 16 + 1;
+			size_t pb = ((size_t)(ql + tbig) * ncb + 1) * 16 + 64;
+			if (ksw_duo_ok(FP, std::min(ql, 64 * DUO_NS_MAX), tbig, tbig)) pb = std::max(pb, ksw_duo_p_bytes(std::min(ql, 64 * DUO_NS_MAX), tbig));
+			b->fb_p_cap_big = std::min<size_t>(pb, (size_t)256 << 20);
+			b->fb_cig_cap_big = ql + tbig + 16;
+			const size_t pall = std::max(b->p_cap_big, b->fb_p_cap_big);
+			b->grid_kovf = (int)std::max<size_t>(1, std::min<size_t>((size_t)(b->grid_kovf > 0 ? b->grid_kovf : 16), ((size_t)512 << 20) / pall));
+		}
+		if (g_knob.fb_p_cap > 0) b->fb_p_cap = std::min(b->fb_p_cap, (size_t)g_knob.fb_p_cap);
 	}
 	lap("sizing");
 	static_assert(sizeof(int) * M_WORDS <= ihp_batch::Z_TIMES, "misc counters overlap the stamps");
@@ -1776,8 +1794,9 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	// failure returns with nothing in the stream
 	const bool ksw_roomy = b->R > 0 && b->n_reads > 0 && !(have_hint && !g_knob.no_spec && !b->force_full && H.n_kovf == 0 && H.clean_k >= CLEAN_MIN);
 	if (ksw_roomy) {
-		if (!b->p_scratch_big.p) { int rcb = b->p_scratch_big.alloc(b->p_cap_big * b->grid_kovf); if (rcb) return rcb; }
-		if (!b->cig_tmp_big.p) { int rcb = b->cig_tmp_big.alloc(sizeof(uint32_t) * (size_t)b->cig_cap_big * b->grid_kovf); if (rcb) { b->p_scratch_big.release(); return rcb; } }
+		// (shared with the roomy launch of the alignment fallback, which runs behind the tally)
+		if (!b->p_scratch_big.p) { int rcb = b->p_scratch_big.alloc(std::max(b->p_cap_big, b->fb_p_cap_big) * std::max(1, b->grid_kovf)); if (rcb) return rcb; }
+		if (!b->cig_tmp_big.p) { int rcb = b->cig_tmp_big.alloc(sizeof(uint32_t) * (size_t)std::max(b->cig_cap_big, b->fb_cig_cap_big) * std::max(1, b->grid_kovf)); if (rcb) { b->p_scratch_big.release(); return rcb; } }
 	}
 	// counters, stamps, work queues and per-region hit counts are zero: cleared at upload and by the previous run's k_summary
 	int *wq = b->queues_dev();
@@ -1793,7 +1812,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	int *misc = b->misc.as<int>();
 	unsigned long long *tm = b->timing ? b->times_dev() : nullptr;
 	HIPC(hipEventRecord(b->ev[0], s));
-	bool spec_skipped_run = false, ksw_skipped_run = false;
+	bool spec_skipped_run = false, ksw_skipped_run = false, fb_roomy_skipped_run = false;
 	if (b->R > 0) {
 		AsmArgs a;
 		a.n_regions = b->R;
@@ -2181,8 +2200,23 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 		a.cig_tmp = b->fb_cig_tmp.as<uint32_t>(); a.cig_cap = b->fb_cig_cap;
 		a.overflow = misc + M_OVF; a.work_counter = wq + 9 * WQ_WORDS;
 		a.duo = (g_knob.fb_duo ? 1 : 0) | (g_knob.fb_skip ? 2 : 0);
+		a.in_list = nullptr; a.n_in = nullptr; a.ovf_list = b->fb_ovf.as<int>(); a.ovf_n = misc + M_FB_OVF; a.ovf_cap = ihp_batch::FB_OVF_CAP;
 		hipLaunchKernelGGL(k_fallback, dim3(b->grid_fb), dim3(64), b->lds_fb, s, a);
 		HIPC(hipGetLastError());
+		// the roomy launch for what that one put on its list: enqueued with the roomy ksw2 launch (same scratch, same streak:
+		// the wait checks the list's length and repeats the run in full when this launch was left out and an item needed it)
+		const bool fb_roomy = ksw_roomy && b->p_scratch_big.p && b->cig_tmp_big.p;
+		fb_roomy_skipped_run = !fb_roomy;
+		if (fb_roomy) {
+			FbArgs r2 = a;
+			r2.t_start = nullptr; r2.in_list = b->fb_ovf.as<int>(); r2.n_in = misc + M_FB_OVF; r2.ovf_list = nullptr; r2.ovf_n = nullptr;
+			r2.lds_budget = g.max_lds - 2048 - 64;
+			r2.p_scratch = b->p_scratch_big.as<uint8_t>(); r2.p_cap = std::max(b->p_cap_big, b->fb_p_cap_big);
+			r2.cig_tmp = b->cig_tmp_big.as<uint32_t>(); r2.cig_cap = std::max(b->cig_cap_big, b->fb_cig_cap_big);
+			r2.work_counter = wq + 25 * WQ_WORDS;
+			hipLaunchKernelGGL(k_fallback, dim3(std::max(1, b->grid_kovf)), dim3(64), (size_t)g.max_lds - 2048, s, r2);
+			HIPC(hipGetLastError());
+		}
 	}
 	HIPC(hipEventRecord(b->ev[5], s));
 	if (b->R > 0) {
@@ -2204,6 +2238,7 @@ extern "C" int ihp_batch_run(ihp_batch *b)
 	if (b->fetch_flags & IHP_FETCH_EAGER) { const int rcp = pack_counts_enqueue(b); if (rcp) return rcp; }
 	b->spec_skipped = spec_skipped_run;
 	b->ksw_skipped = ksw_skipped_run;
+	b->fb_roomy_skipped = fb_roomy_skipped_run;
 	b->acc_pending = b->timing;
 	b->dirty = false;                                      // k_summary is in the stream: it leaves `misc` clear for the next run
 	return 0;
@@ -2231,6 +2266,7 @@ static bool spec_failed(const ihp_batch *b)
 {
 	if (!b->ran) return false;
 	if (b->spec_skipped && (b->report[M_NRETRYC] > 0 || b->report[M_NRETRY0] > 0 || g_knob.spec_fail)) return true;
+	if (b->fb_roomy_skipped && b->report[M_FB_OVF] > 0) return true;
 	return b->ksw_skipped && (b->report[M_KSW_OVF] > 0 || g_knob.spec_fail);
 }
 static int run_again_in_full(ihp_batch *b)
@@ -2247,7 +2283,7 @@ static void hint_refresh(const ihp_batch *b)
 	if (!b->ran || b->R <= 0 || !b->hint_key) return;
 	TierHint h;
 	h.n_b = b->report[M_NTIERB]; h.n_c = b->report[M_NTIERC]; h.n_big = b->report[M_NRETRYC];
-	h.n_back = b->report[M_NRETRY0]; h.n_kovf = b->report[M_KSW_OVF];
+	h.n_back = b->report[M_NRETRY0]; h.n_kovf = b->report[M_KSW_OVF] + b->report[M_FB_OVF];   // (what needs the roomy ksw2 / fallback launches)
 	// the streaks count RUNS, not waits: sync, fetch, pack and summary all confirm the same run
 	const int step = b->hint_counted ? 0 : 1;
 	b->hint_counted = true;
@@ -2363,7 +2399,8 @@ static int batch_profile64(ihp_batch *b, int64_t out[64])
 	out[29] = b->report[M_NTIERB];                    // regions the read phase filed under the second (larger-arena) combine launch
 	out[30] = b->report[M_NTIERC];                    // ... and under the third
 	out[31] = b->n_reruns;                            // runs of this batch repeated in full because a run without the retry launches met a region that needed them
-	out[21] = (b->spec_skipped ? 1 : 0) | (b->ksw_skipped ? 2 : 0);   // the last run left out: 1 the assembly retry launches, 2 the roomy ksw2 launch
+	out[21] = (b->spec_skipped ? 1 : 0) | (b->ksw_skipped ? 2 : 0) | (b->fb_roomy_skipped ? 4 : 0);   // the last run left out: 1 the assembly retry launches, 2 the roomy ksw2 launch, 4 the fallback's
+	out[47] = b->report[M_FB_OVF];                    // items the alignment fallback's main launch handed to its roomy launch
 	return 0;
 }
 

@@ -502,7 +502,7 @@ __device__ inline void region_epilogue3(const AsmArgs &a, ST &S, const V3Ctx &C,
 	if (r0 < r1) v3n_region(a, N);                                   // (r0 is here, and so is the ticket)
 	for (long long ri = r0 + lane; ri < r1; ri += 64) {                // (both loads at once: one round trip a step, not two)
 		const int mq = a.mapq[ri]; const long long rs = a.read_stop[ri];
-		mstop = (mq > a.min_mapq_stop) & (rs > mstop) ? rs : mstop;
+		mstop = ((mq > a.min_mapq_stop) & (rs > mstop)) ? rs : mstop;
 	}
 	mstop = -wave_min_ll(-mstop - 1) - 1;
 	if (N.stage == 2) v3n_offset(a, N);
@@ -1208,6 +1208,11 @@ struct FbArgs {
 	int *work_counter;
 	unsigned long long *t_start;               // optional: see mark_start()
 	int duo;                                   // 1: items that fit it take the two-target sweep (ksw_duo.h)
+	// An item whose alignments need more LDS or traceback scratch than this launch gives a wave -- a read of an event on a contig far
+	// longer than its reference window -- is put on ovf_list (when there is one); a second launch of this kernel -- in_list = that
+	// list, a few workgroups with all the LDS and a large scratch each -- takes it.  Without ovf_list, or past ovf_cap, overflow[1].
+	const int *in_list; const int *n_in;       // work item -> item index (null: the items themselves)
+	int *ovf_list, *ovf_n; int ovf_cap;
 };
 
 // count_flanked_cigar (indelope.nim:185-199) over Ez.cigar (ksw2.nim:22-33); wave-uniform
@@ -1236,16 +1241,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	mark_start(a.t_start);
 	const int n_items = *a.n_items;
 	const long long total = (long long)n_items * a.max_region_reads;
-	const int n = total > 0x7fffffff ? 0x7fffffff : (int)total;
+	int n = total > 0x7fffffff ? 0x7fffffff : (int)total;
+	if (a.in_list) { n = *a.n_in; n = n < a.ovf_cap ? n : a.ovf_cap; }
 	uint8_t *p = a.p_scratch + (size_t)blockIdx.x * a.p_cap;
 	uint32_t *ct = a.cig_tmp + (size_t)blockIdx.x * a.cig_cap;
 	unsigned wq_dead = 0;
 	for (;;) {
 		if (lane == 0) s_item = wq_next(a.work_counter, n, (int)blockIdx.x, wq_dead);
 		WSYNC();
-		const int j = uni(s_item);
+		int j = uni(s_item);
 		WSYNC();
 		if (j < 0) break;
+		if (a.in_list) j = uni(a.in_list[j]);
+		auto punt = [&]() {                                              // not in this launch: the roomy one, or IHP_E_CAPACITY
+			if (lane != 0) return;
+			const int k = a.ovf_list ? atomicAdd(a.ovf_n, 1) : a.ovf_cap;
+			if (k < a.ovf_cap) a.ovf_list[k] = j; else atomicExch(&a.overflow[1], 1);
+		};
 		// item j = read * n_events + event: the queue deals items to its shards by j % 64, and "read i of every event"
 		// in one shard would put all the reads that start right of their event (skipped at once) together
 		const int i = j / n_items, f = j - i * n_items;
@@ -1285,7 +1297,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		ncol_ = ((ncol_ < w + 1 ? ncol_ : w + 1) + 15) / 16 + 1;
 		const size_t pneed = ((size_t)(rl + tmax - 1 > 0 ? rl + tmax - 1 : 0) * ncol_ + 1) * 16;
 		if (rl > 0 && tmax > 0 && (pneed > a.p_cap || rl + tmax + 8 > a.cig_cap)) {
-			if (lane == 0) atomicExch(&a.overflow[1], 1);
+			punt();
 			continue;
 		}
 		const uint8_t *qy = a.bases + off + lo;
@@ -1332,7 +1344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			cnt[side] = o.n_cigar > 0 ? count_flanked_cigar_dev(ct, o.n_cigar, o.max_q) : 0;   // :343-344
 			WSYNC();
 		}
-		if (over) { if (lane == 0) atomicExch(&a.overflow[1], 1); continue; }
+		if (over) { punt(); continue; }
 		const int rn = cnt[0], an = cnt[1];
 		if (lane == 0) {
 			if (rn == 1 && an > 1) atomicAdd(&E->ref_support, 1);      // :353-354

@@ -330,3 +330,53 @@ def test_compact_slab_with_the_reads_two_bits_each(hip, oracle, which):
             hip.batch_free(h)
     finally:
         s2.free()
+
+
+# ------------------------------------------------------------------------------------------------ the fallback's roomy launch
+def test_fallback_items_that_do_not_fit_the_main_launch_take_the_roomy_one(hip, oracle):
+    """A read of an event whose alignments need more traceback scratch than the alignment fallback's launch gives a wave used to
+    refuse its batch (IHP_E_CAPACITY: met by the randomised runs with 960-base reads on a contig far longer than its window).  Now
+    k_fallback puts such an item on a list and a second launch of it -- the roomy ksw2 launch's few workgroups, all the LDS, a large
+    scratch -- votes for it (indelope.nim:336-356 all the same).  ihp_debug_set("fb_p_cap", n) cuts the main launch's scratch so that
+    EVERY item goes that way; a batch that follows three clean runs of its shape (the roomy launches are then left out) is run
+    again in full when it turns out to need them."""
+    b, _ = synth.generate(48, n_reads=(24, 64), err_rate=1e-3, config_id=67, dup_frac=0.5)
+    b = b.with_trim_bounds()
+    exp = oracle.run_regions(b)
+    assert int((exp.events["aligned"] == 1).sum()) > 5                      # the fallback has work
+    hip.debug_set(fb_p_cap=1024)
+    try:
+        got = hip.run_regions(b)
+        _same(got, exp)
+        h = hip.batch_upload(b)
+        try:
+            hip.batch_run(h)
+            _same(hip.batch_fetch(h), exp)
+            prof = hip.batch_profile(h)
+            assert int(prof[47]) > 100 and int(prof[31]) == 0                 # every item took the roomy launch; no hint yet: it was enqueued, no repeat
+        finally:
+            hip.batch_free(h)
+    finally:
+        hip.debug_set(fb_p_cap=0)
+    # behind a streak of clean runs of the same shape the roomy launches are left out; the next batch that needs them pays one repeat
+    clean, _ = synth.generate(48, n_reads=(24, 64), err_rate=1e-3, config_id=68, dup_frac=0.0)
+    clean = clean.with_trim_bounds()
+    hc = hip.batch_upload(clean)
+    try:
+        for _ in range(4):
+            hip.batch_run(hc)
+            hip.batch_sync(hc)
+    finally:
+        hip.batch_free(hc)
+    hip.debug_set(fb_p_cap=1024)
+    try:
+        h = hip.batch_upload(b)
+        try:
+            hip.batch_run(h)
+            _same(hip.batch_fetch(h), exp)
+            prof = hip.batch_profile(h)
+            assert int(prof[31]) == 1 and int(prof[47]) > 100                 # left out, found wanting, run again in full
+        finally:
+            hip.batch_free(h)
+    finally:
+        hip.debug_set(fb_p_cap=0)
